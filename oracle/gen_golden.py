@@ -1,0 +1,623 @@
+#!/usr/bin/env python3
+"""Golden-vector generator — TEST INFRASTRUCTURE, not product code.
+
+Imports the *unmodified* reference (pyLabFEA v4.4.2, /root/reference/src) in the
+build container and dumps inputs/outputs of the hot-path functions as small
+``.npz`` fixtures under ``tests/golden/``.  The reference never travels to the GPU
+box; only these numeric fixtures do.
+
+Run (build container only):
+
+    MPLBACKEND=Agg PYTHONPATH=oracle/_refshim:/root/reference/src \
+        python oracle/gen_golden.py [--only material,element,mesh,solve,svc]
+
+Reference entry points exercised (file:line relative to /root/reference/src/pylabfea):
+  material.py:207 response, :348 calc_yf, :414 ML_full_yf, :576 calc_seq,
+  :678 calc_seqB, :704 calc_fgrad, :974 get_sflow, :1009 epl_dot, :1057 C_tan,
+  :2401 elasticity, :2466 plasticity, :3062 calc_properties
+  model.py:262 Element.__init__, :365 calc_Kel, :439 calc_Bmat, :758 mesh,
+  :954 setupK, :979 solve, :1473 calc_global
+  basic.py:107 sig_princ, :304 sig_dev, :328 eps_eq
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+os.environ.setdefault('MPLBACKEND', 'Agg')
+import pylabfea as FE  # noqa: E402  (the reference)
+
+assert FE.__version__ == '4.4.2'
+
+
+# ----------------------------------------------------------------------------
+# material definitions shared by several fixtures
+# ----------------------------------------------------------------------------
+MATERIALS = {
+    # name: (elasticity kwargs, plasticity kwargs)
+    'j2': (dict(E=200.e3, nu=0.3), dict(sy=150., khard=500., sdim=6)),
+    'j2_k0': (dict(E=200.e3, nu=0.3), dict(sy=150., khard=0., sdim=6)),
+    'hill6': (dict(E=200.e3, nu=0.3),
+              dict(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)),
+    'hill6_dp': (dict(E=200.e3, nu=0.3),
+                 dict(sy=120., hill=[1.2, 0.9, 1.1, 1.3, 0.7, 1.0], khard=250., sdim=6,
+                      drucker=0.15)),
+    'hill6_rv': (dict(E=200.e3, nu=0.3),
+                 dict(sy=50., rv=[1.2, 1.0, 0.8, 1.0, 1.0, 1.0], sdim=6)),
+    'workhard': (dict(E=300.e3, nu=0.3), dict(sy=150., khard=2000.)),
+    'cubic': (dict(C11=170.e3, C12=124.e3, C44=75.e3), dict(sy=80., khard=300., sdim=6,
+                                                             hill=[1.1, 0.9, 1.0, 1.2, 1.0, 0.9])),
+}
+
+
+def make_material(name):
+    el, pl = MATERIALS[name]
+    m = FE.Material(name=name)
+    m.elasticity(**el)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m.plasticity(**{k: (list(v) if isinstance(v, list) else v) for k, v in pl.items()})
+    return m
+
+
+def mat_params(m):
+    """Flat parameter record consumed by both the oracle and the product tests."""
+    d0 = m.lhs if m.lhs is not None else np.ones(3) * m.drucker
+    return dict(CV=np.array(m.CV, dtype=float), E=float(m.E), nu=float(m.nu),
+                sy=float(m.sy), khard=float(m.khard), hill=np.array(m.hill, dtype=float),
+                dp=np.array(d0, dtype=float), sdim=int(m.sdim),
+                hill_6p=bool(m.hill_6p), hill_3p=bool(m.hill_3p))
+
+
+def element_CV(m, planestress):
+    """CV exactly as Model.Element.__init__ builds it (model.py:272-303)."""
+    fe = FE.Model(dim=2, planestress=planestress)
+    fe.geom([1.], LY=1.)
+    fe.assign([m])
+    fe.mesh(NX=1, NY=1)
+    return np.array(fe.element[0].CV, dtype=float)
+
+
+# ----------------------------------------------------------------------------
+# 1. material-level fixtures
+# ----------------------------------------------------------------------------
+def rand_unit6(rng, n):
+    v = rng.normal(size=(n, 6))
+    return v / np.linalg.norm(v, axis=1)[:, None]
+
+
+def gen_response_inputs(m, CV, rng, n, twod):
+    """Seeded inputs covering the four branches of Material.response."""
+    sig = np.zeros((n, 6))
+    epl = np.zeros((n, 6))
+    deps = np.zeros((n, 6))
+    for i in range(n):
+        kind = i % 8
+        d = rng.normal(size=6)
+        if twod:
+            d[3] = d[4] = 0.
+        d /= np.linalg.norm(d)
+        # plastic pre-strain (deviatoric-ish), half of the samples
+        if i % 2 == 1:
+            e = rng.normal(size=6) * 2.e-3
+            if twod:
+                e[3] = e[4] = 0.
+            e[0:3] -= e[0:3].mean()
+            epl[i] = e
+        sflow = m.get_sflow(epl[i])
+        seq_d = m.calc_seq(d)
+        if abs(seq_d) < 1e-3:
+            d[0] += 1.
+            seq_d = m.calc_seq(d)
+        if kind == 0:      # deep elastic, small step
+            sig[i] = d / seq_d * sflow * rng.uniform(0.0, 0.5)
+            deps[i] = rand_unit6(rng, 1)[0] * rng.uniform(1e-6, 2e-4)
+        elif kind == 1:    # inside, step crosses surface (split branch)
+            sig[i] = d / seq_d * sflow * rng.uniform(0.3, 0.9)
+            deps[i] = d * rng.uniform(4e-4, 4e-3)
+        elif kind == 2:    # on surface, small outward step (1-step branch)
+            sig[i] = d / seq_d * sflow * rng.uniform(0.9995, 1.0005)
+            deps[i] = (d + 0.3 * rand_unit6(rng, 1)[0]) * rng.uniform(1e-6, 5e-5)
+        elif kind == 3:    # on surface, large step (50 sub-steps + scale-back)
+            sig[i] = d / seq_d * sflow * rng.uniform(0.999, 1.003)
+            deps[i] = (d + 0.5 * rand_unit6(rng, 1)[0]) * rng.uniform(3e-4, 5e-3)
+        elif kind == 4:    # on surface, unloading / neutral
+            sig[i] = d / seq_d * sflow * rng.uniform(0.99, 1.0)
+            deps[i] = -d * rng.uniform(1e-5, 1e-3) + 0.2 * rand_unit6(rng, 1)[0] * 1e-4
+        elif kind == 5:    # slightly inside (fy0 in (-0.15*?,0)) large step
+            sig[i] = d / seq_d * (sflow - rng.uniform(0.0, 0.14))
+            deps[i] = rand_unit6(rng, 1)[0] * rng.uniform(1e-4, 3e-3)
+        elif kind == 6:    # zero initial state, big step (first plastic increment)
+            sig[i] = 0.
+            epl[i] = 0.
+            deps[i] = d * rng.uniform(5e-4, 6e-3)
+        else:              # generic random
+            sig[i] = d / seq_d * sflow * rng.uniform(0.0, 1.02)
+            deps[i] = rand_unit6(rng, 1)[0] * 10 ** rng.uniform(-6, -2.3)
+        if twod:
+            sig[i, 3] = sig[i, 4] = 0.
+            deps[i, 3] = deps[i, 4] = 0.
+    return sig, epl, deps
+
+
+def run_response(m, sig, epl, deps, CV):
+    n = len(sig)
+    fy = np.zeros(n)
+    so = np.zeros((n, 6))
+    dp = np.zeros((n, 6))
+    ct = np.zeros((n, 36))
+    ns = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        m.msg['nsteps'] = -1
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            f, s, d, c = m.response(sig[i], epl[i], deps[i], CV)
+        fy[i] = f
+        so[i] = s
+        dp[i] = d
+        ct[i] = np.asarray(c).reshape(36)
+        ns[i] = m.msg['nsteps']
+    return fy, so, dp, ct, ns
+
+
+def gen_material():
+    t0 = time.time()
+    for name in MATERIALS:
+        m = make_material(name)
+        rng = np.random.default_rng(abs(hash(name)) % 1000 if False else sum(map(ord, name)))
+        rec = {('par_' + k): v for k, v in mat_params(m).items()}
+        # --- batch evaluations on random Voigt stresses
+        N = 1000
+        sig = rng.normal(size=(N, 6)) * np.array([120., 120., 120., 60., 60., 60.])
+        sig[:50, 3:] = 0.           # axis-aligned
+        sig[50:60] *= 1.e-3          # tiny
+        epl = rng.normal(size=(N, 6)) * 3.e-3
+        epl[:, 0:3] -= epl[:, 0:3].mean(axis=1)[:, None]
+        epl[::3] = 0.
+        rec['b_sig'] = sig
+        rec['b_epl'] = epl
+        rec['b_seq'] = m.calc_seq(sig)
+        rec['b_fgrad'] = m.calc_fgrad(sig)
+        rec['b_yf'] = np.array([m.calc_yf(sig[i], epl=epl[i]) for i in range(N)])
+        rec['b_sflow'] = np.array([m.get_sflow(epl[i]) for i in range(N)])
+        rec['b_peeq'] = FE.eps_eq(epl)
+        rec['b_sdev'] = FE.sig_dev(sig)
+        # C_tan / epl_dot on a subset
+        nsub = 100
+        CV = np.array(m.CV)
+        ctan = np.zeros((nsub, 36))
+        pdot = np.zeros((nsub, 6))
+        dd = rng.normal(size=(nsub, 6)) * 1.e-3
+        for i in range(nsub):
+            ctan[i] = m.C_tan(sig[i], CV, epl=epl[i]).reshape(36)
+            pdot[i] = m.epl_dot(sig[i], epl[i], CV, dd[i])
+        rec['b_deps'] = dd
+        rec['b_ctan'] = ctan
+        rec['b_pdot'] = pdot
+        # --- response, plane strain (material CV), plane stress CV, 3-d inputs
+        for tag, CVr, twod in (('pe', element_CV(m, False), True),
+                               ('ps', element_CV(m, True), True),
+                               ('3d', np.array(m.CV), False)):
+            n = 240
+            s, e, d = gen_response_inputs(m, CVr, rng, n, twod)
+            fy, so, dp, ct, ns = run_response(m, s, e, d, CVr)
+            rec['r%s_CV' % tag] = CVr
+            rec['r%s_sig' % tag] = s
+            rec['r%s_epl' % tag] = e
+            rec['r%s_deps' % tag] = d
+            rec['r%s_fy' % tag] = fy
+            rec['r%s_sig_out' % tag] = so
+            rec['r%s_depl' % tag] = dp
+            rec['r%s_ct' % tag] = ct
+            rec['r%s_nsteps' % tag] = ns
+        np.savez_compressed(os.path.join(OUT, 'material_%s.npz' % name), **rec)
+        nb = {t: np.bincount(np.minimum(rec['r%s_nsteps' % t], 49) // 49 +
+                             (rec['r%s_nsteps' % t] < 0).astype(int) * 0)
+              for t in ('pe', 'ps', '3d')}
+        print('material', name, 'done', '%.1fs' % (time.time() - t0), nb)
+    # SURVEY anchor values
+    m = make_material('j2')
+    f, s, d, c = m.response(np.array([10, 80, 30, 0, 0, 5.]), np.zeros(6),
+                            np.array([-2e-4, 8e-4, 0, 0, 0, 2e-4]), m.CV)
+    assert abs(f - (-0.17118857254814657)) < 1e-12
+
+
+# ----------------------------------------------------------------------------
+# 2. element fixtures: B matrices, Kel, dense K
+# ----------------------------------------------------------------------------
+def gen_element():
+    rec = {}
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    m2 = FE.Material()
+    m2.elasticity(C11=170.e3, C12=124.e3, C44=75.e3)
+    k = 0
+    for mat in (m, m2):
+        for ps in (False, True):
+            for (lx, ly, lz) in ((1., 1., 1.), (0.25, 0.5, 2.), (4. / 3., 0.7, 1.)):
+                fe = FE.Model(dim=2, planestress=ps)
+                fe.geom([lx], LY=ly, LZ=lz)
+                fe.assign([mat])
+                fe.mesh(NX=1, NY=1)
+                el = fe.element[0]
+                rec['e%d_par' % k] = np.array([lx, ly, lz, float(ps), mat.E, mat.nu])
+                rec['e%d_CV' % k] = np.array(el.CV)
+                rec['e%d_B' % k] = np.array(el.Bmat)          # (4,6,8)
+                rec['e%d_Kel' % k] = np.array(el.Kel)
+                rec['e%d_gp' % k] = np.array([el.gpx, el.gpy])
+                # Kel with a non-trivial symmetric tangent
+                rng = np.random.default_rng(k)
+                a = rng.normal(size=(6, 6))
+                D = np.array(el.CV) + 1.e3 * (a + a.T)
+                el.elstiff = D
+                el.calc_Kel()
+                rec['e%d_D' % k] = D
+                rec['e%d_KelD' % k] = np.array(el.Kel)
+                k += 1
+    rec['n'] = k
+    # dense K + pattern on small meshes
+    for (nx, ny, ps) in ((3, 2, False), (8, 8, False), (5, 4, True)):
+        fe = FE.Model(dim=2, planestress=ps)
+        fe.geom([2., 1.], LY=1.5)
+        fe.assign([m, m2])
+        fe.mesh(NX=nx, NY=ny)
+        K = fe.setupK()
+        rec['K_%dx%d' % (nx, ny)] = K
+        rec['Kconn_%dx%d' % (nx, ny)] = np.array([el.nodes for el in fe.element], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, 'element.npz'), **rec)
+    print('element done')
+
+
+# ----------------------------------------------------------------------------
+# 3. mesh integer products
+# ----------------------------------------------------------------------------
+def mesh_record(fe):
+    mat_index = {id(mm): i for i, mm in enumerate(fe.mat)}
+    return dict(
+        npos=np.array(fe.npos), conn=np.array([el.nodes for el in fe.element], dtype=np.int64),
+        mat_id=np.array([mat_index[id(el.Mat)] for el in fe.element], dtype=np.int64),
+        lxy=np.array([[el.Lelx, el.Lely] for el in fe.element]),
+        noleft=np.array(fe.noleft, dtype=np.int64), noright=np.array(fe.noright, dtype=np.int64),
+        nobot=np.array(fe.nobot, dtype=np.int64), notop=np.array(fe.notop, dtype=np.int64),
+        noinner=np.array(fe.noinner, dtype=np.int64),
+        dims=np.array([fe.NnodeX, fe.NnodeY, fe.Nnode, fe.Nel, fe.Ndof], dtype=np.int64))
+
+
+def gen_mesh():
+    rec = {}
+    ma = FE.Material(num=1)
+    ma.elasticity(E=100.e3, nu=0.35)
+    mb = FE.Material(num=2)
+    mb.elasticity(E=300.e3, nu=0.3)
+    cases = []
+    for n in (4, 18, 32):
+        fe = FE.Model(dim=2)
+        fe.geom([4.], LY=4.)
+        fe.assign([ma])
+        fe.mesh(NX=n, NY=n)
+        cases.append(('sq%d' % n, fe))
+    fe = FE.Model(dim=2, planestress=True)
+    fe.geom([2, 1, 2, 1, 2], LY=4.)
+    fe.assign([ma, mb, ma, mb, ma])
+    fe.mesh(NX=16, NY=4)
+    cases.append(('lam16x4', fe))
+    fe = FE.Model(dim=2)
+    fe.geom([2, 1, 2, 1, 2], LY=4.)
+    fe.assign([ma, mb, ma, mb, ma])
+    fe.mesh(NX=13, NY=3)          # non-proportional: largest section absorbs the remainder
+    cases.append(('lam13x3', fe))
+    fe = FE.Model(dim=2)
+    fe.geom([2., 2.], LY=4.)
+    fe.assign([ma, mb])
+    fe.mesh(NX=4, NY=4)
+    cases.append(('lam4x4', fe))
+    NX = NY = 18
+    el = np.ones((NX, NY))
+    el[6:12, 6:12] = 2
+    fe = FE.Model(dim=2)
+    fe.geom(sect=2, LX=4., LY=4.)
+    fe.assign([ma, mb])
+    fe.mesh(elmts=el, NX=NX, NY=NY)
+    cases.append(('incl18', fe))
+    rec['inclusion_elmts'] = el
+    for name, fe in cases:
+        for k, v in mesh_record(fe).items():
+            rec['%s_%s' % (name, k)] = v
+    rec['names'] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, 'mesh.npz'), **rec)
+    print('mesh done')
+
+
+# ----------------------------------------------------------------------------
+# 4. model-level traces of Model.solve
+# ----------------------------------------------------------------------------
+class ResponseRecorder(object):
+    """Wraps Material.response to log the number of calls per solve."""
+
+    def __init__(self, mat):
+        self.mat = mat
+        self.n = 0
+        self.orig = mat.response
+
+        def wrapped(sig, epl, deps, CV, maxit=50):
+            self.n += 1
+            return self.orig(sig, epl, deps, CV, maxit)
+        mat.response = wrapped
+
+
+def solve_record(fe, prefix, rec, tsolve=None):
+    rec[prefix + '_u'] = np.array(fe.u)
+    rec[prefix + '_f'] = np.array(fe.f)
+    rec[prefix + '_sgl'] = np.array(fe.sgl)
+    rec[prefix + '_egl'] = np.array(fe.egl)
+    rec[prefix + '_epgl'] = np.array(fe.epgl)
+    rec[prefix + '_sig'] = np.array([el.sig for el in fe.element])
+    rec[prefix + '_eps'] = np.array([el.eps for el in fe.element])
+    rec[prefix + '_epl'] = np.array([el.epl for el in fe.element])
+    rec[prefix + '_elstiff'] = np.array([np.asarray(el.elstiff).reshape(36) for el in fe.element])
+    rec[prefix + '_nsteps'] = np.array(fe.nsteps)
+    rec[prefix + '_niter'] = np.array(fe.niter, dtype=np.int64)
+    rec[prefix + '_co_nconv'] = np.array(fe.co_nconv, dtype=np.int64)
+    g = fe.glob
+    rec[prefix + '_globbc'] = np.array([g['ebc1'], g['ebc2'], g['sbc1'], g['sbc2'],
+                                        g['ebc12'], g['sbc12'], g['ebc21'], g['sbc21']], dtype=float)
+    rec[prefix + '_glob'] = np.array([g['sig'], g['eps'], g['epl']])
+    if tsolve is not None:
+        rec[prefix + '_tsolve'] = np.array(tsolve)
+
+
+def tension_model(mat, n, eps, planestress=False, L=4.):
+    fe = FE.Model(dim=2, planestress=planestress)
+    fe.geom([L], LY=L)
+    fe.assign([mat])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    fe.mesh(NX=n, NY=n)
+    return fe
+
+
+def inclusion_elmts(n):
+    el = np.ones((n, n))
+    a, b = int(n / 3), 2 * int(n / 3)
+    el[a:b, a:b] = 2
+    return el
+
+
+def gen_solve():
+    rec = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # config 1: 32x32 elastic (BASELINE.json configs[0])
+        m = FE.Material()
+        m.elasticity(E=200.e3, nu=0.3)
+        fe = tension_model(m, 32, 0.001)
+        t = time.time()
+        fe.solve()
+        solve_record(fe, 'el32', rec, time.time() - t)
+        print('el32', rec['el32_tsolve'], fe.glob['sig'][1])
+
+        # 8x8 and 12x12 J2 / Hill uniaxial tension (homogeneous)
+        for name, n, eps, ms in (('j2_8', 8, 0.002, None), ('hill6_8', 8, 0.002, None),
+                                 ('hill6_12', 12, 0.003, 8)):
+            mat = make_material(name.split('_')[0])
+            rr = ResponseRecorder(mat)
+            fe = tension_model(mat, n, eps)
+            t = time.time()
+            fe.solve(min_step=ms)
+            dt = time.time() - t
+            solve_record(fe, name, rec, dt)
+            rec[name + '_ncalls'] = np.array(rr.n)
+            print(name, '%.1fs' % dt, fe.nsteps, fe.niter, rr.n, fe.sgl[-1][1])
+
+        # soft elastic inclusion in plastic matrix (heterogeneous, exercises divergence)
+        for name, n, eps, ms in (('incl_j2_9', 9, 0.002, None), ('incl_hill6_12', 12, 0.0015, 6)):
+            mat = make_material(name.split('_')[1])
+            soft = FE.Material(num=2)
+            soft.elasticity(E=1.e3, nu=0.27)
+            fe = FE.Model(dim=2, planestress=False)
+            fe.geom(sect=2, LX=4., LY=4.)
+            fe.assign([mat, soft])
+            fe.bcleft(0.)
+            fe.bcbot(0.)
+            fe.bcright(0., 'force')
+            fe.bctop(eps * fe.leny, 'disp')
+            fe.mesh(elmts=inclusion_elmts(n), NX=n, NY=n)
+            rr = ResponseRecorder(mat)
+            t = time.time()
+            fe.solve(min_step=ms)
+            dt = time.time() - t
+            solve_record(fe, name, rec, dt)
+            rec[name + '_ncalls'] = np.array(rr.n)
+            print(name, '%.1fs' % dt, fe.nsteps, fe.niter, rr.n)
+
+        # tests/test_basic.py: laminate elastic 16x4 plane stress (test_model a)
+        mat1 = FE.Material()
+        mat1.elasticity(E=100.e3, nu=0.35)
+        mat2 = FE.Material()
+        mat2.elasticity(E=300.e3, nu=0.3)
+        fe = FE.Model(dim=2, planestress=True)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([mat1, mat2, mat1, mat2, mat1])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.1 * fe.leny, 'disp')
+        fe.mesh(NX=16, NY=4)
+        fe.solve()
+        solve_record(fe, 'lam16x4', rec)
+
+        # tests/test_basic.py:test_bcnode 18x18 inclusion, free sides, corner node fixed
+        NX = NY = 18
+        el = inclusion_elmts(18)
+        ma = FE.Material(num=1)
+        ma.elasticity(E=100.e3, nu=0.27)
+        mb = FE.Material(num=2)
+        mb.elasticity(E=3.e3, nu=0.3)
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom(sect=2, LX=4., LY=4.)
+        fe.assign([ma, mb])
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bcleft(0., 'force')
+        fe.bctop(0.01 * fe.leny, 'disp')
+        fe.mesh(elmts=el, NX=NX, NY=NY)
+        hh = [no in fe.nobot for no in fe.noleft]
+        noc = np.nonzero(hh)[0]
+        fe.bcnode(noc, 0., 'disp', 'x')
+        fe.solve()
+        solve_record(fe, 'bcnode18', rec)
+        rec['bcnode18_noc'] = np.array(noc)
+
+        # calc_properties harness (2x2 plane stress, 4 load cases) for the sdim=6 materials
+        for name, eps, ms in (('workhard', 0.1, None), ('hill6', 0.05, None), ('j2', 0.01, 5)):
+            mat = make_material(name)
+            t = time.time()
+            mat.calc_properties(eps=eps, sigeps=True, min_step=ms)
+            for lc in ('stx', 'sty', 'et2', 'ect'):
+                p = 'prop_%s_%s' % (name, lc)
+                rec[p + '_sig'] = np.array(mat.sigeps[lc]['sig'])
+                rec[p + '_eps'] = np.array(mat.sigeps[lc]['eps'])
+                rec[p + '_epl'] = np.array(mat.sigeps[lc]['epl'])
+                rec[p + '_ys'] = np.array([mat.prop[lc]['ys'], mat.propJ2[lc]['ys']])
+                rec[p + '_seq'] = np.array(mat.prop[lc]['seq'])
+                rec[p + '_seqJ2'] = np.array(mat.propJ2[lc]['seq'])
+                rec[p + '_peeq'] = np.array(mat.propJ2[lc]['peeq'])
+            rec['prop_%s_args' % name] = np.array([eps, -1 if ms is None else ms], dtype=float)
+            print('calc_properties', name, '%.1fs' % (time.time() - t))
+
+        # re-entrant solve (checkpoint/resume semantics): two successive loads
+        mat = make_material('j2')
+        fe = tension_model(mat, 6, 0.0012)
+        fe.solve()
+        fe.bctop(0.002 * fe.leny, 'disp')
+        fe.solve()
+        solve_record(fe, 'resume_j2_6', rec)
+
+    np.savez_compressed(os.path.join(OUT, 'solve.npz'), **rec)
+    print('solve done')
+
+
+# ----------------------------------------------------------------------------
+# 5. SVC yield function fixtures
+# ----------------------------------------------------------------------------
+def svc_params(mat):
+    svm = mat.svm_yf
+    return dict(sv=np.array(svm.support_vectors_), dual=np.array(svm.dual_coef_[0, :]),
+                intercept=np.array(svm.intercept_[0]), gamma=np.array(mat.gam_yf, dtype=float),
+                scale_seq=np.array(mat.scale_seq, dtype=float),
+                dev_only=np.array(bool(mat.dev_only)), CV=np.array(mat.CV), E=np.array(mat.E),
+                nu=np.array(mat.nu), sy=np.array(mat.sy), khard=np.array(float(mat.khard)),
+                hill=np.array(mat.hill), sdim=np.array(mat.sdim), Ndof=np.array(mat.Ndof))
+
+
+def gen_svc():
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cases = {}
+        # config 4 material: examples/train_hill.py:25-49
+        mat_h = FE.Material(name='Hill-reference', num=1)
+        mat_h.elasticity(E=200.e3, nu=0.3)
+        mat_h.plasticity(sy=50., rv=[1.2, 1.0, 0.8, 1.0, 1.0, 1.0], sdim=6)
+        ml = FE.Material('ML-Hill-p1', num=2)
+        t = time.time()
+        ml.train_SVC(C=2.0, gamma=1.0, mat_ref=mat_h, Nseq=25, Nlc=300, Fe=0.1, Ce=0.99,
+                     gridsearch=False)
+        print('train_hill SVC: %d SVs, %.1fs' % (len(ml.svm_yf.support_vectors_), time.time() - t))
+        cases['hill'] = (ml, mat_h)
+        # tests/test_ml.py:37-52 (test_ml_shear) material
+        mat_s = FE.Material(name='Hill-shear')
+        mat_s.elasticity(E=200.e3, nu=0.3)
+        mat_s.plasticity(sy=150., hill=[1.4, 1., 0.7, 1.2, .8, 1.], sdim=6)
+        mls = FE.Material('Hill-ML')
+        mls.train_SVC(C=2, gamma=0.5, mat_ref=mat_s, Nseq=4, Nlc=300, Fe=0.7, Ce=0.95)
+        mls.dev_only = False
+        print('test_ml_shear SVC: %d SVs' % len(mls.svm_yf.support_vectors_))
+        cases['shear'] = (mls, mat_s)
+
+        for name, (ml, ref) in cases.items():
+            rec = {('par_' + k): v for k, v in svc_params(ml).items()}
+            rng = np.random.default_rng(7 + len(name))
+            N = 400
+            sy = ml.sy
+            u = rand_unit6(rng, N)
+            sig = u * (sy * rng.uniform(0.2, 1.6, size=N))[:, None]
+            sig[:40, 3:5] = 0.
+            rec['b_sig'] = sig
+            rec['b_yf'] = ml.calc_yf(sig)
+            rec['b_fgrad'] = ml.calc_fgrad(sig)
+            rec['b_seq'] = ml.calc_seq(sig)
+            nf = 120
+            fyf = np.zeros(nf)
+            for i in range(nf):
+                fyf[i] = ml.ML_full_yf(sig[i], verb=False)
+            rec['b_full_yf'] = fyf
+            # response through element CVs
+            for tag, ps in (('pe', False), ('ps', True)):
+                CVr = element_CV(ml, ps)
+                n = 64
+                s, e, d = gen_response_inputs(ml, CVr, rng, n, True)
+                e[:] = 0.
+                t = time.time()
+                fy, so, dp, ct, ns = run_response(ml, s, e, d, CVr)
+                print('svc', name, tag, 'response %.1fs' % (time.time() - t), np.bincount(ns))
+                rec['r%s_CV' % tag] = CVr
+                rec['r%s_sig' % tag] = s
+                rec['r%s_epl' % tag] = e
+                rec['r%s_deps' % tag] = d
+                rec['r%s_fy' % tag] = fy
+                rec['r%s_sig_out' % tag] = so
+                rec['r%s_depl' % tag] = dp
+                rec['r%s_ct' % tag] = ct
+                rec['r%s_nsteps' % tag] = ns
+            np.savez_compressed(os.path.join(OUT, 'svc_%s.npz' % name), **rec)
+
+        # tests/test_ml.py:test_ml_shear model (6x3 plane stress simple shear)
+        mls = cases['shear'][0]
+        fem = FE.Model(dim=2, planestress=True)
+        fem.geom([2], LY=2.)
+        fem.assign([mls])
+        fem.bcbot(0., bctype='disp', bcdir='y')
+        fem.bcbot(0., bctype='disp', bcdir='x')
+        fem.bcleft(0., bctype='force')
+        fem.bcright(0., bctype='force')
+        fem.bctop(0.006 * fem.leny, bctype='disp', bcdir='x')
+        fem.bctop(0., bctype='disp', bcdir='y')
+        fem.mesh(NX=6, NY=3)
+        t = time.time()
+        fem.solve()
+        fem.calc_global()
+        rec = {}
+        solve_record(fem, 'shear6x3', rec, time.time() - t)
+        print('shear6x3 %.1fs' % rec['shear6x3_tsolve'], fem.glob['sig'][5], fem.element[3].epl[5])
+        np.savez_compressed(os.path.join(OUT, 'svc_solve.npz'), **rec)
+    print('svc done')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='material,element,mesh,solve,svc')
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    todo = args.only.split(',')
+    if 'material' in todo:
+        gen_material()
+    if 'element' in todo:
+        gen_element()
+    if 'mesh' in todo:
+        gen_mesh()
+    if 'solve' in todo:
+        gen_solve()
+    if 'svc' in todo:
+        gen_svc()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,624 @@
+/*
+ * plfx_oracle.c — CPU oracle for the pyLabFEA hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference algorithm; every function cites the reference
+ * lines it follows (paths relative to /root/reference/src/pylabfea).  Deliberately
+ * un-optimised and written in the order of the Python statements so that it can be
+ * audited side by side with the reference.  Pinned by tests/test_oracle_golden.py against
+ * vectors dumped from the imported reference (oracle/gen_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#include "plfx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define YF_TOLERANCE 5.e-3 /* basic.py:26 */
+
+/* ------------------------------------------------------------------ small linear algebra */
+static void matvec6(const double A[36], const double x[6], double y[6])
+{
+    for (int i = 0; i < 6; i++) {
+        double s = 0.;
+        for (int j = 0; j < 6; j++) s += A[i * 6 + j] * x[j];
+        y[i] = s;
+    }
+}
+
+static double dot6(const double a[6], const double b[6])
+{
+    double s = 0.;
+    for (int i = 0; i < 6; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* Gauss-Jordan inverse with partial pivoting of the leading n x n block (n <= 3) */
+static void inv_block(const double *A, int lda, int n, double *Ai /* n*n */)
+{
+    double w[3][6];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            w[i][j] = A[i * lda + j];
+            w[i][n + j] = (i == j) ? 1. : 0.;
+        }
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(w[r][c]) > fabs(w[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 2 * n; j++) {
+                double t = w[c][j];
+                w[c][j] = w[p][j];
+                w[p][j] = t;
+            }
+        double d = w[c][c];
+        for (int j = 0; j < 2 * n; j++) w[c][j] /= d;
+        for (int r = 0; r < n; r++)
+            if (r != c) {
+                double f = w[r][c];
+                for (int j = 0; j < 2 * n; j++) w[r][j] -= f * w[c][j];
+            }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ai[i * n + j] = w[i][n + j];
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix: G = V diag(w) V^T */
+static void jacobi3(const double G[9], double w[3], double V[9])
+{
+    double A[9];
+    memcpy(A, G, sizeof(A));
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+        if (off == 0.) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double apq = A[p * 3 + q];
+                if (apq == 0.) continue;
+                double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2. * apq);
+                double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+                double c = 1. / sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < 3; k++) { /* A <- A J */
+                    double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - s * akq;
+                    A[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) { /* A <- J^T A */
+                    double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - s * aqk;
+                    A[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0];
+    w[1] = A[4];
+    w[2] = A[8];
+}
+
+/* minimum-norm least-squares solution of a(3x6) x = b, as numpy.linalg.lstsq(rcond=None):
+ * singular values <= eps*max(M,N)*s_max are treated as zero (material.py:331). */
+static void lstsq_3x6(const double a[18], const double b[3], double x[6])
+{
+    double G[9], w[3], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0.;
+            for (int k = 0; k < 6; k++) s += a[i * 6 + k] * a[j * 6 + k];
+            G[i * 3 + j] = s;
+        }
+    jacobi3(G, w, V);
+    double wmax = fmax(fmax(w[0], w[1]), w[2]);
+    double smax = wmax > 0. ? sqrt(wmax) : 0.;
+    double cut = 2.220446049250313e-16 * 6. * smax;
+    double y[3] = {0., 0., 0.};
+    for (int k = 0; k < 3; k++) {
+        double sk = w[k] > 0. ? sqrt(w[k]) : 0.;
+        if (sk <= cut || sk == 0.) continue;
+        double proj = V[0 * 3 + k] * b[0] + V[1 * 3 + k] * b[1] + V[2 * 3 + k] * b[2];
+        for (int i = 0; i < 3; i++) y[i] += V[i * 3 + k] * proj / w[k];
+    }
+    for (int j = 0; j < 6; j++) x[j] = a[0 * 6 + j] * y[0] + a[1 * 6 + j] * y[1] + a[2 * 6 + j] * y[2];
+}
+
+/* ------------------------------------------------------------------ basic.py helpers */
+void plfo_sig_dev(const double sig[6], double out[6]) /* basic.py:316-324 */
+{
+    double p = (sig[0] + sig[1] + sig[2]) / 3.;
+    out[0] = sig[0] - p;
+    out[1] = sig[1] - p;
+    out[2] = sig[2] - p;
+    out[3] = sig[3];
+    out[4] = sig[4];
+    out[5] = sig[5];
+}
+
+double plfo_eps_eq(const double e[6]) /* basic.py:350-352 */
+{
+    double n = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    double s = e[3] * e[3] + e[4] * e[4] + e[5] * e[5];
+    return sqrt(2. * (n + 0.5 * s) / 3.);
+}
+
+/* ------------------------------------------------------------------ material.py */
+double plfo_calc_seq(const plfo_material *m, const double sig[6]) /* material.py:636-673 */
+{
+    double hp[6] = {1., 1., 1., 1., 1., 1.};
+    double d0[3] = {0., 0., 0.};
+    if (m->kind != PLFO_ELASTIC) { /* self.sy is not None */
+        for (int i = 0; i < 6; i++) hp[i] = m->hill[i];
+        for (int i = 0; i < 3; i++) d0[i] = m->dp[i];
+    }
+    double I1 = (sig[0] * d0[0] + sig[1] * d0[1] + sig[2] * d0[2]) / 3.;
+    double I2 = hp[0] * (sig[0] - sig[1]) * (sig[0] - sig[1]) +
+                hp[1] * (sig[1] - sig[2]) * (sig[1] - sig[2]) +
+                hp[2] * (sig[2] - sig[0]) * (sig[2] - sig[0]) +
+                6. * hp[3] * sig[3] * sig[3] + 6. * hp[4] * sig[4] * sig[4] +
+                6. * hp[5] * sig[5] * sig[5];
+    I2 *= 0.5;
+    return sqrt(I2) + I1;
+}
+
+double plfo_get_sflow(const plfo_material *m, const double epl[6]) /* material.py:992-997 */
+{
+    return m->sy + plfo_eps_eq(epl) * m->khard;
+}
+
+static double svc_decision(const plfo_material *m, const double sig[6]) /* material.py:398-405, 2330-2340 */
+{
+    double s[6], x[6];
+    if (m->dev_only)
+        plfo_sig_dev(sig, s);
+    else
+        memcpy(s, sig, sizeof(s));
+    for (int i = 0; i < 6; i++) x[i] = s[i] / m->scale_seq;
+    double f = 0.;
+    for (int k = 0; k < m->nsv; k++) {
+        const double *v = m->sv + (size_t)k * m->ndof;
+        double hh = 0.;
+        for (int i = 0; i < 6; i++) hh += (x[i] - v[i]) * (x[i] - v[i]);
+        f += m->dual[k] * exp(-m->gamma * hh);
+    }
+    return f + m->intercept;
+}
+
+double plfo_calc_yf(const plfo_material *m, const double sig[6], const double epl[6]) /* material.py:378-411 */
+{
+    if (m->kind == PLFO_SVC6) return svc_decision(m, sig);
+    return plfo_calc_seq(m, sig) - plfo_get_sflow(m, epl);
+}
+
+void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]) /* material.py:765-845 */
+{
+    if (m->kind == PLFO_SVC6) {
+        double s[6], x[6], dK[6] = {0., 0., 0., 0., 0., 0.};
+        if (m->dev_only)
+            plfo_sig_dev(sig, s);
+        else
+            memcpy(s, sig, sizeof(s));
+        for (int i = 0; i < 6; i++) x[i] = s[i] / m->scale_seq;
+        for (int k = 0; k < m->nsv; k++) { /* grad_rbf, material.py:768-778 */
+            const double *v = m->sv + (size_t)k * m->ndof;
+            double hv[6], hh = 0.;
+            for (int i = 0; i < 6; i++) {
+                hv[i] = x[i] - v[i];
+                hh += hv[i] * hv[i];
+            }
+            double kk = exp(-m->gamma * hh);
+            for (int i = 0; i < 6; i++) dK[i] += m->dual[k] * (kk * (-2. * m->gamma * hv[i]));
+        }
+        for (int i = 0; i < 6; i++) a[i] = dK[i] / m->scale_seq; /* material.py:807 */
+        return;
+    }
+    double h0 = m->hill[0], h1 = m->hill[1], h2 = m->hill[2];
+    double d3[3] = {m->dp[0] / 3., m->dp[1] / 3., m->dp[2] / 3.}; /* ones*drucker/3 (:833); the lhs variant cannot
+                                                                    * run in the reference (`if self.lhs:` on an array, :642) */
+    double seq = plfo_calc_seq(m, sig);
+    double sd[6];
+    plfo_sig_dev(sig, sd);
+    a[0] = ((h0 + h2) * sd[0] - h0 * sd[1] - h2 * sd[2]) / (2. * seq) + d3[0];
+    a[1] = ((h1 + h0) * sd[1] - h0 * sd[0] - h1 * sd[2]) / (2. * seq) + d3[1];
+    a[2] = ((h2 + h1) * sd[2] - h2 * sd[0] - h1 * sd[1]) / (2. * seq) + d3[2];
+    a[3] = 3. * m->hill[3] * sd[3] / seq;
+    a[4] = 3. * m->hill[4] * sd[4] / seq;
+    a[5] = 3. * m->hill[5] * sd[5] / seq;
+}
+
+/* ---- scipy.optimize.brentq (scipy 1.15.3, scipy/optimize/Zeros/brentq.c; Brent 1973) */
+double plfo_brentq(plfo_fn f, void *ctx, double xa, double xb, double xtol, double rtol,
+                   int maxiter, int *converged)
+{
+    double xpre = xa, xcur = xb;
+    double xblk = 0., fpre, fcur, fblk = 0., spre = 0., scur = 0., sbis;
+    double delta, stry, dpre, dblk;
+    *converged = 1;
+    fpre = f(xpre, ctx);
+    fcur = f(xcur, ctx);
+    if (fpre == 0.) return xpre;
+    if (fcur == 0.) return xcur;
+    if (signbit(fpre) == signbit(fcur)) {
+        *converged = 0;
+        return 0.;
+    }
+    for (int i = 0; i < maxiter; i++) {
+        if (fpre != 0. && fcur != 0. && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2.;
+        sbis = (xblk - xcur) / 2.;
+        if (fcur == 0. || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            double lim = fmin(fabs(spre), 3. * fabs(sbis) - delta);
+            if (2. * fabs(stry) < lim) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0. ? delta : -delta);
+        fcur = f(xcur, ctx);
+    }
+    *converged = 0;
+    return xcur;
+}
+
+typedef struct {
+    const plfo_material *m;
+    const double *su;
+    const double *epl;
+} yloc_ctx;
+
+static double yloc_scalar(double x, void *vctx) /* material.py:547-574 find_yloc_scalar */
+{
+    yloc_ctx *c = (yloc_ctx *)vctx;
+    double s[6];
+    for (int i = 0; i < 6; i++) s[i] = x * c->su[i];
+    return plfo_calc_yf(c->m, s, c->epl);
+}
+
+double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double epl_in[6],
+                       int *status) /* material.py:414-516, ld=None */
+{
+    static const double zero6[6] = {0., 0., 0., 0., 0., 0.};
+    const double *epl = epl_in ? epl_in : zero6;
+    int st = 0;
+    double seq = plfo_calc_seq(m, sig);
+    double sflow = plfo_get_sflow(m, epl);
+    double yf;
+    if (seq < 0.01) {
+        yf = seq - 0.85 * sflow; /* :445-448 */
+    } else {
+        double su[6];
+        for (int i = 0; i < 6; i++) su[i] = sig[i] / seq; /* :452 */
+        double x0 = sflow;
+        if (su[0] * su[1] < -1.e-5) x0 *= 0.5; /* :468-473 (tresca off) */
+        double x1 = x0;
+        yloc_ctx c = {m, su, epl};
+        while (yloc_scalar(x0, &c) >= 0. && x0 > 0.01) x0 *= 0.98; /* :475-480 */
+        while (yloc_scalar(x1, &c) < 0. && x1 < 5. * sflow) x1 *= 1.02; /* :481-486 */
+        double f0 = yloc_scalar(x0, &c), f1 = yloc_scalar(x1, &c);
+        if (f0 * f1 > 0.) { /* :495-499 */
+            if (status) *status = 1;
+            return seq - 0.85 * sflow;
+        }
+        int conv;
+        double xs = plfo_brentq(yloc_scalar, &c, x0, x1, 1.e-5, 4. * 2.220446049250313e-16, 100, &conv);
+        if (conv && xs < 4. * sflow) {
+            yf = seq - xs * plfo_calc_seq(m, su); /* :507 */
+        } else {
+            yf = seq - 0.85 * sflow; /* :510 */
+            st = 2;
+        }
+    }
+    if (status) *status = st;
+    return yf;
+}
+
+void plfo_epl_dot(const plfo_material *m, const double sig[6], const double epl[6],
+                  const double Cel[36], const double deps[6], double pdot[6]) /* material.py:1032-1055 */
+{
+    double ds[6], st[6];
+    matvec6(Cel, deps, ds);
+    for (int i = 0; i < 6; i++) st[i] = sig[i] + ds[i];
+    double yfun = plfo_calc_yf(m, st, epl);
+    if (yfun <= YF_TOLERANCE) { /* ABSOLUTE tolerance, material.py:1041 */
+        for (int i = 0; i < 6; i++) pdot[i] = 0.;
+        return;
+    }
+    double a[6], ca[6];
+    plfo_calc_fgrad(m, sig, a);
+    matvec6(Cel, a, ca);
+    double hh = dot6(a, ca) + m->khard;
+    double cd[6];
+    matvec6(Cel, deps, cd);
+    double lam = dot6(a, cd) / hh;
+    for (int i = 0; i < 6; i++) pdot[i] = lam * a[i];
+}
+
+void plfo_C_tan(const plfo_material *m, const double sig[6], const double Cel[36], double Ct[36]) /* material.py:1076-1086 */
+{
+    double a[6], ca[6];
+    plfo_calc_fgrad(m, sig, a);
+    matvec6(Cel, a, ca);
+    double hh = dot6(a, ca) + m->khard;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) Ct[i * 6 + j] = Cel[i * 6 + j] - ca[i] * ca[j] / hh;
+}
+
+static double resp_yf(const plfo_material *m, const double s[6], const double e[6])
+{
+    if (m->kind == PLFO_SVC6) return plfo_ML_full_yf(m, s, e, NULL); /* material.py:249-252 */
+    return plfo_calc_yf(m, s, e);
+}
+
+int plfo_response(const plfo_material *m, const double sig_in[6], const double epl[6],
+                  const double deps[6], const double CV[36],
+                  double *fy, double sig[6], double depl[6], double Ct[36]) /* material.py:207-346 */
+{
+    const int maxit = 50;
+    double dsig[6], tmp[6], fy1;
+    int niter = 0;
+    memcpy(sig, sig_in, 6 * sizeof(double)); /* :241 copy */
+    for (int i = 0; i < 6; i++) depl[i] = 0.;
+    double toler = YF_TOLERANCE * plfo_get_sflow(m, epl); /* :243 */
+    matvec6(CV, deps, dsig);                              /* :244 */
+    double st_scal = 1.;
+    for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsig[i];
+    fy1 = resp_yf(m, tmp, epl); /* :249-252 */
+    if (fy1 < toler) {
+        for (int i = 0; i < 6; i++) sig[i] += dsig[i];
+        memcpy(Ct, CV, 36 * sizeof(double));
+    } else {
+        double deps_r[6];
+        double fy0 = plfo_calc_yf(m, sig, epl); /* :259 */
+        if (fy0 < -0.15) {
+            if (m->kind == PLFO_SVC6) fy0 = plfo_ML_full_yf(m, sig, NULL, NULL); /* :265 */
+            st_scal += fy0 / plfo_calc_seq(m, dsig);                             /* :266 */
+            double deps_el[6], ds_el[6];
+            for (int i = 0; i < 6; i++) deps_el[i] = deps[i] * (1. - st_scal);
+            matvec6(CV, deps_el, ds_el);
+            for (int i = 0; i < 6; i++) sig[i] += ds_el[i];
+            for (int i = 0; i < 36; i++) Ct[i] = CV[i] * (1. - st_scal);
+            for (int i = 0; i < 6; i++) deps_r[i] = deps[i] - deps_el[i];
+        } else {
+            memcpy(deps_r, deps, sizeof(deps_r));
+            for (int i = 0; i < 36; i++) Ct[i] = 0.;
+        }
+        double ddepl[6], T[36], eplt[6];
+        plfo_epl_dot(m, sig, epl, CV, deps_r, ddepl); /* :277 */
+        plfo_C_tan(m, sig, CV, T);                    /* :278 */
+        for (int i = 0; i < 6; i++) eplt[i] = epl[i] + depl[i] + ddepl[i];
+        matvec6(T, deps_r, dsig);
+        for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsig[i];
+        fy1 = resp_yf(m, tmp, eplt); /* :282-285 */
+        int nsteps;
+        if (fy1 > toler) {
+            for (int i = 0; i < 6; i++) deps_r[i] /= maxit;
+            nsteps = maxit;
+        } else {
+            nsteps = 1;
+        }
+        for (niter = 0; niter < nsteps; niter++) { /* :295 */
+            plfo_epl_dot(m, sig, epl, CV, deps_r, ddepl);
+            plfo_C_tan(m, sig, CV, T);
+            for (int i = 0; i < 6; i++) eplt[i] = epl[i] + depl[i] + ddepl[i];
+            matvec6(T, deps_r, dsig);
+            for (int i = 0; i < 6; i++) sig[i] += dsig[i];
+            fy1 = resp_yf(m, sig, eplt);
+            if (fy1 > toler) { /* :310-342 radial scale-back */
+                double SV[36];
+                for (int i = 0; i < 36; i++) SV[i] = 0.;
+                int nb = (CV[2 * 6 + 2] > 1.) ? 3 : 2;
+                double hh[9];
+                inv_block(CV, 6, nb, hh);
+                for (int i = 0; i < nb; i++)
+                    for (int j = 0; j < nb; j++) SV[i * 6 + j] = hh[i * nb + j];
+                for (int i = 3; i < 6; i++)
+                    if (CV[i * 6 + i] > 1.) SV[i * 6 + i] = 1. / CV[i * 6 + i];
+                double sq = plfo_calc_seq(m, sig);
+                for (int i = 0; i < 6; i++) dsig[i] = sig[i] * fy1 / sq;
+                for (int i = 0; i < 6; i++) sig[i] -= dsig[i];
+                double sd[6];
+                matvec6(SV, dsig, sd);
+                for (int i = 0; i < 6; i++) ddepl[i] += sd[i];
+                for (int i = 0; i < 6; i++) eplt[i] = epl[i] + depl[i] + ddepl[i];
+                double a[18] = {deps_r[0], 0., 0., 0., deps_r[2], deps_r[1],
+                                0., deps_r[1], 0., deps_r[2], 0., deps_r[0],
+                                0., 0., deps_r[2], deps_r[1], deps_r[0], 0.};
+                double x[6];
+                lstsq_3x6(a, dsig, x);
+                T[0 * 6 + 0] -= x[0];
+                T[0 * 6 + 1] -= x[5];
+                T[0 * 6 + 2] -= x[4];
+                T[1 * 6 + 0] -= x[5];
+                T[1 * 6 + 1] -= x[1];
+                T[1 * 6 + 2] -= x[3];
+                T[2 * 6 + 0] -= x[4];
+                T[2 * 6 + 1] -= x[3];
+                T[2 * 6 + 2] -= x[2];
+                fy1 = resp_yf(m, sig, eplt);
+            }
+            for (int i = 0; i < 36; i++) Ct[i] += T[i] * st_scal / nsteps; /* :343 */
+            for (int i = 0; i < 6; i++) depl[i] += ddepl[i];                /* :344 */
+        }
+        niter = nsteps - 1; /* Python leaves niter at the last loop index (:345) */
+    }
+    *fy = fy1;
+    return niter;
+}
+
+/* ------------------------------------------------------------------ batched drivers */
+void plfo_seq_batch(const plfo_material *m, int n, const double *sig, double *seq)
+{
+    for (int i = 0; i < n; i++) seq[i] = plfo_calc_seq(m, sig + 6 * (size_t)i);
+}
+
+void plfo_fgrad_batch(const plfo_material *m, int n, const double *sig, double *a)
+{
+    for (int i = 0; i < n; i++) plfo_calc_fgrad(m, sig + 6 * (size_t)i, a + 6 * (size_t)i);
+}
+
+void plfo_yf_batch(const plfo_material *m, int n, const double *sig, const double *epl, double *yf)
+{
+    for (int i = 0; i < n; i++) yf[i] = plfo_calc_yf(m, sig + 6 * (size_t)i, epl + 6 * (size_t)i);
+}
+
+void plfo_full_yf_batch(const plfo_material *m, int n, const double *sig, const double *epl,
+                        double *yf, int *status)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++)
+        yf[i] = plfo_ML_full_yf(m, sig + 6 * (size_t)i, epl ? epl + 6 * (size_t)i : NULL,
+                                status ? status + i : NULL);
+}
+
+void plfo_response_batch(const plfo_material *mats, int n, const int *mat_id,
+                         const double *sig, const double *epl, const double *deps,
+                         const double *CV, double *fy, double *sig_out, double *depl,
+                         double *ct, int *nsteps, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) {
+        int mid = mat_id ? mat_id[i] : 0;
+        size_t o = 6 * (size_t)i;
+        if (mats[mid].kind == PLFO_ELASTIC) { /* model.py:1341 skips elastic materials */
+            fy[i] = 0.;
+            nsteps[i] = 0;
+            continue;
+        }
+        nsteps[i] = plfo_response(&mats[mid], sig + o, epl + o, deps + o, CV + 36 * (size_t)mid,
+                                  fy + i, sig_out + o, depl + o, ct + 36 * (size_t)i);
+    }
+}
+
+/* ------------------------------------------------------------------ model.py element */
+void plfo_calc_Bmat(double lx, double ly, double x, double y, int planestress,
+                    const double CV[36], double E, double nu, double B[48]) /* model.py:475-501 */
+{
+    for (int i = 0; i < 48; i++) B[i] = 0.;
+    double xi1 = 2. * x / lx - 1.;
+    double xi2 = 2. * y / ly - 1.;
+    double hxm = 0.125 * (1. - xi1) / ly;
+    double hym = 0.125 * (1. - xi2) / lx;
+    double hxp = 0.125 * (1. + xi1) / ly;
+    double hyp = 0.125 * (1. + xi2) / lx;
+    B[0 * 8 + 0] = -hym;
+    B[0 * 8 + 2] = -hyp;
+    B[0 * 8 + 4] = hym;
+    B[0 * 8 + 6] = hyp;
+    B[1 * 8 + 1] = -hxm;
+    B[1 * 8 + 3] = hxm;
+    B[1 * 8 + 5] = -hxp;
+    B[1 * 8 + 7] = hxp;
+    B[5 * 8 + 0] = -hxm;
+    B[5 * 8 + 1] = -hym;
+    B[5 * 8 + 2] = hxm;
+    B[5 * 8 + 3] = -hyp;
+    B[5 * 8 + 4] = -hxp;
+    B[5 * 8 + 5] = hym;
+    B[5 * 8 + 6] = hxp;
+    B[5 * 8 + 7] = hyp;
+    if (planestress) { /* :498-501 */
+        for (int j = 0; j < 8; j++) {
+            double h0 = 0., h1 = 0.;
+            for (int k = 0; k < 6; k++) {
+                h0 += CV[0 * 6 + k] * B[k * 8 + j];
+                h1 += CV[1 * 6 + k] * B[k * 8 + j];
+            }
+            B[2 * 8 + j] = -nu * (h0 + h1) / E;
+        }
+    }
+}
+
+static void gauss_point(double lx, double ly, int i, double *x, double *y) /* model.py:339-346 */
+{
+    double cpos = sqrt(1. / 3.);
+    double sx = ((i / 2) % 2 == 0) ? 1. : -1.;
+    double sy = (i % 2 == 0) ? 1. : -1.;
+    *x = 0.5 * (1. + sx * cpos) * lx;
+    *y = 0.5 * (1. + sy * cpos) * ly;
+}
+
+void plfo_calc_Kel(double lx, double ly, double thick, int planestress, const double CV[36],
+                   double E, double nu, const double D[36], double Kel[64]) /* model.py:365-370 */
+{
+    double Jac = lx * ly * thick * 4.; /* model.py:316-322, 340 */
+    double sum[64];
+    for (int i = 0; i < 64; i++) sum[i] = 0.;
+    for (int g = 0; g < 4; g++) {
+        double x, y, B[48], DB[48];
+        gauss_point(lx, ly, g, &x, &y);
+        plfo_calc_Bmat(lx, ly, x, y, planestress, CV, E, nu, B);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 8; j++) {
+                double s = 0.;
+                for (int k = 0; k < 6; k++) s += D[i * 6 + k] * B[k * 8 + j];
+                DB[i * 8 + j] = s;
+            }
+        for (int i = 0; i < 8; i++)
+            for (int j = 0; j < 8; j++) {
+                double s = 0.;
+                for (int k = 0; k < 6; k++) s += B[k * 8 + i] * DB[k * 8 + j];
+                sum[i * 8 + j] += s;
+            }
+    }
+    for (int i = 0; i < 64; i++) Kel[i] = Jac * 1. * sum[i];
+}
+
+void plfo_strain(double lx, double ly, int planestress, const double CV[36], double E, double nu,
+                 const double ue[8], double eps[6]) /* model.py:387-411 */
+{
+    for (int i = 0; i < 6; i++) eps[i] = 0.;
+    for (int g = 0; g < 4; g++) {
+        double x, y, B[48];
+        gauss_point(lx, ly, g, &x, &y);
+        plfo_calc_Bmat(lx, ly, x, y, planestress, CV, E, nu, B);
+        for (int i = 0; i < 6; i++) {
+            double s = 0.;
+            for (int j = 0; j < 8; j++) s += B[i * 8 + j] * ue[j];
+            eps[i] += 1. * s;
+        }
+    }
+}

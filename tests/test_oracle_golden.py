@@ -1,0 +1,57 @@
+"""CPU oracle (oracle/plfx_oracle.c) pinned against golden vectors dumped from the imported
+reference (oracle/gen_golden.py -> tests/golden/*.npz).  Tolerances are relative FP64 round-off."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+MATS = ['j2', 'j2_k0', 'hill6', 'hill6_dp', 'hill6_rv', 'workhard', 'cubic']
+
+
+def rel(a, b, floor=1e-300):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b) / (np.abs(b) + floor))
+
+
+@pytest.fixture(scope='module', params=MATS)
+def gold(request, golden_dir):
+    z = np.load(os.path.join(golden_dir, 'material_%s.npz' % request.param))
+    return z, O.Material.from_golden(z)
+
+
+def test_seq_fgrad_yf(gold):
+    z, m = gold
+    assert rel(O.calc_seq(m, z['b_sig']), z['b_seq'], 1e-9) < 1e-13
+    assert np.max(np.abs(O.calc_fgrad(m, z['b_sig']) - z['b_fgrad'])) < 1e-12
+    assert np.max(np.abs(O.calc_yf(m, z['b_sig'], z['b_epl']) - z['b_yf'])) < 1e-10
+
+
+@pytest.mark.parametrize('tag', ['pe', 'ps', '3d'])
+def test_response(gold, tag):
+    z, m = gold
+    CV = z['r%s_CV' % tag]
+    fy, so, dp, ct, ns = O.response(m, CV, z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+    assert np.array_equal(ns, z['r%s_nsteps' % tag])
+    sc = float(m.c.sy)
+    assert np.max(np.abs(fy - z['r%s_fy' % tag])) < 1e-8 * sc
+    assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-9 * sc
+    assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-12
+    assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-7 * CV[0, 0]
+
+
+def test_element(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'element.npz'))
+    for k in range(int(z['n'])):
+        lx, ly, lz, ps, E, nu = z['e%d_par' % k]
+        CV = z['e%d_CV' % k]
+        gp = z['e%d_gp' % k]
+        for g in range(4):
+            B = O.calc_Bmat(lx, ly, gp[0, g], gp[1, g], ps > 0, CV, E, nu)
+            assert np.max(np.abs(B - z['e%d_B' % k][g])) < 1e-15
+        K = O.calc_Kel(lx, ly, lz, ps > 0, CV, E, nu, CV)
+        assert rel(K, z['e%d_Kel' % k], 1e-6) < 1e-12
+        K = O.calc_Kel(lx, ly, lz, ps > 0, CV, E, nu, z['e%d_D' % k])
+        assert rel(K, z['e%d_KelD' % k], 1e-6) < 1e-12
