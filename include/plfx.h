@@ -1,0 +1,165 @@
+/*
+ * plfx.h — C-ABI of libplfx.so, the MI355X (gfx950) engine for pyLabFEA's hot path.
+ *
+ * The reference (pyLabFEA v4.4.2, pure Python) has no FFI: its boundary is the Python object
+ * API Model.solve() -> Element.* -> Material.response().  Every entry point below replaces the
+ * reference function cited next to it (paths relative to /root/reference/src/pylabfea) and is
+ * what a ctypes binding inside the reference would call (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host arrays are caller-owned, C-contiguous,
+ *     `double` / `int32_t`, and are not retained after the call returns (copied to HBM).
+ *   - Voigt order (11,22,33,23,13,12), engineering shear strains; 6x6 matrices row-major [36].
+ *   - host-side per-point arrays are AoS ([n*6], [n*36]) exactly like the NumPy arrays of the
+ *     reference; the SoA layout in HBM is private to the library (DESIGN.md "Data layout").
+ *   - every function returns 0 on success, <0 on error (plfx_last_error gives the text);
+ *     soft failures of the reference (warnings.warn) are returned as counters/flags.
+ *   - one context per host thread; a context is bound to one GPU and one HIP stream.
+ */
+#ifndef PLFX_H
+#define PLFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plfx_ctx plfx_ctx;
+
+/* yield-function kinds */
+enum {
+    PLFX_ELASTIC = 0, /* Material.sy is None: no response() call (model.py:1341) */
+    PLFX_HILL6 = 1,   /* analytic Hill-6p on the full Voigt stress, J2 = all ones (material.py:650-661) */
+    PLFX_PRINC3 = 2,  /* sdim=3: Hill-3p/J2 on principal stresses (material.py:662-670)  [not yet built] */
+    PLFX_SVC6 = 3     /* RBF-SVC yield function on 6 stress features (material.py:398-405, 765-807) */
+};
+
+/* error codes */
+enum {
+    PLFX_OK = 0,
+    PLFX_ERR_HIP = -1,      /* HIP runtime failure (no device, OOM, launch error) */
+    PLFX_ERR_ARG = -2,      /* invalid argument */
+    PLFX_ERR_STATE = -3,    /* call order violated (e.g. solve before set_mesh) */
+    PLFX_ERR_UNSUPPORTED = -4
+};
+
+/* One material as seen by an element: mirrors Material.elasticity/plasticity (material.py:2401-2594)
+ * plus the trained SVC parameters (svm_yf.support_vectors_, dual_coef_, intercept_, gam_yf, scale_seq). */
+typedef struct plfx_material {
+    int32_t kind;      /* PLFX_* */
+    int32_t sdim;      /* 6 (3 reserved) */
+    double CV[36];     /* ELEMENT elastic matrix, i.e. after the plane-stress/strain choice of
+                          Element.__init__ (model.py:272-303); must be symmetric */
+    double E, nu;      /* used by the plane-stress B-matrix row (model.py:498-501) */
+    double sy, khard;  /* material.py:2512-2513 */
+    double hill[6];    /* material.py:2573 */
+    double drucker;    /* material.py:2514 (d0 = ones*drucker) */
+    int32_t nsv;       /* SVC: number of support vectors */
+    int32_t nfeat;     /* SVC: features per support vector (6) */
+    int32_t dev_only;  /* SVC: deviatoric features (material.py:2336) */
+    int32_t _pad;
+    double gamma, intercept, scale_seq;
+    const double *sv;   /* [nsv*nfeat] row-major */
+    const double *dual; /* [nsv] */
+} plfx_material;
+
+/* ---------------------------------------------------------------- context */
+int plfx_create(int device, plfx_ctx **out);
+void plfx_destroy(plfx_ctx *ctx);
+const char *plfx_last_error(plfx_ctx *ctx);
+const char *plfx_version(void);
+/* name[<=len], number of CUs, bytes of HBM */
+int plfx_device_info(plfx_ctx *ctx, char *name, int len, int *cus, int64_t *hbm_bytes);
+/* HIP stream the library launches on (for hipEvent timing by the caller) */
+void *plfx_stream(plfx_ctx *ctx);
+int plfx_sync(plfx_ctx *ctx);
+
+/* ---------------------------------------------------------------- materials */
+/* replaces the parameter set-up consumed by Material.response (material.py:2401-2594) */
+int plfx_set_materials(plfx_ctx *ctx, int nmat, const plfx_material *mats);
+
+/* ---------------------------------------------------------------- batched point evaluations
+ * Material.calc_seq (material.py:576), calc_fgrad (:704), calc_yf (:348), ML_full_yf (:414),
+ * response (:207) on N points; also the kernel-level parity entry points. */
+int plfx_seq_batch(plfx_ctx *ctx, int mat, int n, const double *sig, double *seq);
+int plfx_fgrad_batch(plfx_ctx *ctx, int mat, int n, const double *sig, double *fgrad);
+int plfx_yf_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const double *epl, double *yf);
+/* ld: NULL or one loading direction [6] shared by all points (model.py:1052); status[n]: 0 ok,
+ * 1 bracket failure, 2 root not accepted (both fall back to seq-0.85*sflow as the reference) */
+int plfx_full_yf_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const double *epl,
+                       const double *ld, double *yf, int32_t *status);
+int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig,
+                        const double *epl, const double *deps, double *fy, double *sig_out,
+                        double *depl, double *ct /* [n*36] */, int32_t *nsteps);
+
+/* ---------------------------------------------------------------- mesh (Model.mesh products, model.py:758-952)
+ * conn[nel*4]: Q4 connectivity in the reference's node order; mat_id[nel]; lxy[nel*2] element
+ * sizes (Lelx, Lely).  Elements are rectangles aligned with the axes (model.py:262).
+ * The element range [el_begin, el_end) is the part owned by this rank (x-strip shard);
+ * pass 0, nel for a single GPU. */
+int plfx_set_mesh(plfx_ctx *ctx, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
+                  const double *lxy, double thick, int planestress, int el_begin, int el_end);
+/* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
+int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);
+/* element stiffness of element e from its current tangent (Element.calc_Kel, model.py:365), [64] */
+int plfx_get_kel(plfx_ctx *ctx, int e, double *Kel);
+
+/* ---------------------------------------------------------------- state (el.sig/eps/epl/elstiff, Model.u/f/du)
+ * which: 0 sig, 1 eps, 2 epl, 3 res_sig, 4 res_depl  -> [nel_owned*6];  5 elstiff -> [nel_owned*36];
+ *        6 u, 7 f, 8 du -> [ndof];  9 fyn (fy/sflow of the last sweep) -> [nel_owned];
+ *        10 max_steps (stat_nlin) -> [nel_owned] as double */
+int plfx_state_get(plfx_ctx *ctx, int which, double *out);
+int plfx_state_set(plfx_ctx *ctx, int which, const double *in);
+/* solve() first-call initialisation (model.py:1212-1234): zero u,f,sig,eps,epl; elstiff = CV */
+int plfx_state_reset(plfx_ctx *ctx);
+/* gather entries of u (which=6), f (7) or du (8) at idx[n] */
+int plfx_gather(plfx_ctx *ctx, int which, int n, const int32_t *idx, double *out);
+
+/* ---------------------------------------------------------------- assembly (Model.setupK, model.py:954-977) */
+int plfx_assemble(plfx_ctx *ctx);
+/* export the assembled matrix as CSR (scalar rows, sorted columns).  Call with NULL arrays to get nnz. */
+int plfx_get_csr(plfx_ctx *ctx, int64_t *nnz, int32_t *rowptr, int32_t *colidx, double *val);
+
+/* ---------------------------------------------------------------- boundary conditions + solve
+ * calc_BC (model.py:1070-1206) reduced to data: presc_idx[n] DOFs with displacement BC (ascending or
+ * not), du_presc[n] the value written to du (first application), w[n] the multiplicity-weighted
+ * value that enters the right-hand side (the reference re-applies a DOF shared by two edges),
+ * fext[ndof] consistent nodal forces (or NULL).  Builds rhs = P (fext - K w) and the free mask. */
+int plfx_apply_bc(plfx_ctx *ctx, int n, const int32_t *presc_idx, const double *du_presc,
+                  const double *w, const double *fext);
+/* Kred + np.linalg.solve (model.py:1028-1033, 1291, 1335) as Jacobi-PCG on the free DOFs.
+ * warm != 0 starts from the previous du on the free DOFs.  Result in du (state 8). */
+int plfx_solve(plfx_ctx *ctx, double rtol, int maxit, int warm, int *iters, double *relres);
+
+/* ---------------------------------------------------------------- non-linear driver pieces */
+/* material sweep (model.py:1340-1359) over owned elements with the current du:
+ * response + |elstiff - Ct|_F > 1e-3 test + tangent refresh (averaging when nit >= 15).
+ * changed: any tangent updated; conv: all fy/sflow <= yf_tolerance*1.0001 */
+int plfx_sweep(plfx_ctx *ctx, int nit, int *changed, int *conv);
+/* calc_scf statistics (model.py:1036-1067): sum of entries, sum of squares about the mean, min, count.
+ * sld[6] loading direction for SVC materials. */
+int plfx_scf_stats(plfx_ctx *ctx, const double *sld, double *sum, double *sumsq_c, double *minv,
+                   int64_t *count, double mean_in, int pass);
+/* end-of-load-step update (model.py:1383-1392): u += du, f += K du, sig/epl/eps update */
+int plfx_update_state(plfx_ctx *ctx);
+/* calc_global element sums (model.py:1500-1511): out[18] = sum(sig*Vel), sum(eps*Vel), sum(epl*Vel) */
+int plfx_global_sums(plfx_ctx *ctx, double *out18);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * RCCL communicator for the per-CG-step all-reduce of the global vector.  id is the 128-byte
+ * ncclUniqueId created on rank 0 by plfx_comm_unique_id and broadcast by the caller. */
+int plfx_comm_unique_id(char id[128]);
+int plfx_comm_init(plfx_ctx *ctx, const char id[128], int rank, int nranks);
+
+/* ---------------------------------------------------------------- instrumentation */
+/* accumulated HIP-event time (ms) and launch count of a named kernel family since the last reset:
+ * which: 0 sweep, 1 spmv(+dot), 2 cg vector update, 3 assemble */
+int plfx_timing_get(plfx_ctx *ctx, int which, double *ms, int64_t *launches);
+int plfx_timing_reset(plfx_ctx *ctx);
+int plfx_timing_enable(plfx_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLFX_H */

@@ -1,0 +1,481 @@
+// plfx_device.hpp — device-side constitutive math for gfx950 (MI355X).
+//
+// One thread owns one material point: the 6-component stress / plastic strain / strain
+// increment and the 21-entry symmetric tangent live in VGPRs; per-material constants
+// (elastic matrix, compliance, Hill coefficients, SVC support vectors) are staged in LDS and
+// read with wave-uniform (broadcast) addresses when the points of a wave share a material.
+//
+// What is computed follows pyLabFEA v4.4.2 (paths relative to /root/reference/src/pylabfea):
+//   material.py:207-346 response   :348-412 calc_yf    :414-516 ML_full_yf   :576-676 calc_seq
+//   material.py:704-858 calc_fgrad :974-1007 get_sflow :1009-1055 epl_dot    :1057-1086 C_tan
+//   basic.py:304 sig_dev, :328 eps_eq, :26 yf_tolerance
+// How it is computed is not: the tangent T = C - (Ca)(Ca)^T/h is never formed (only its action and
+// its weighted sum), the principal-stress eigen-solve that the reference computes and discards on
+// the Hill-6p branch is skipped, and the 3x6 min-norm least-squares of the scale-back step is solved
+// in closed form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plfx {
+
+constexpr double YF_TOL = 5.e-3;       // basic.py:26
+constexpr double SPLIT_THRESHOLD = -0.15;  // material.py:260
+constexpr int MAXIT = 50;              // material.py:207
+
+// symmetric 6x6 stored as 21 entries, upper triangle row-major
+__host__ __device__ constexpr int sym_idx(int i, int j)
+{
+    return (i <= j) ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j));
+}
+
+// Per-material record in device memory (and staged in LDS by the kernels).
+struct MatDev {
+    double CV[21];   // element elastic matrix (symmetric)
+    double SV[21];   // compliance used by the scale-back step (material.py:315-320)
+    double hill[6];
+    double sy, khard, d0;  // d0 = drucker (calc_seq adds d0*tr(sig)/3, calc_fgrad adds d0/3)
+    double E, nu;
+    double gamma, intercept, scale_seq;
+    const double *sv;    // device pointer [nsv*6]
+    const double *dual;  // device pointer [nsv]
+    int32_t kind, sdim, nsv, dev_only;
+};
+
+// y = C x for a symmetric 21-entry matrix
+__device__ __forceinline__ void symv(const double *C, const double *x, double *y)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = 0.;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s = fma(C[sym_idx(i, j)], x[j], s);
+        y[i] = s;
+    }
+}
+
+__device__ __forceinline__ double dot6(const double *a, const double *b)
+{
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 6; i++) s = fma(a[i], b[i], s);
+    return s;
+}
+
+// basic.py:350-352
+__device__ __forceinline__ double eps_eq(const double *e)
+{
+    double n = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    double s = e[3] * e[3] + e[4] * e[4] + e[5] * e[5];
+    return sqrt(2. * (n + 0.5 * s) / 3.);
+}
+
+// material.py:650-673 (Hill-6p on the Voigt stress; J2 when hill == 1)
+__device__ __forceinline__ double hill_seq(const MatDev &m, const double *s)
+{
+    double d01 = s[0] - s[1], d12 = s[1] - s[2], d20 = s[2] - s[0];
+    double I2 = m.hill[0] * d01 * d01 + m.hill[1] * d12 * d12 + m.hill[2] * d20 * d20 +
+                6. * m.hill[3] * s[3] * s[3] + 6. * m.hill[4] * s[4] * s[4] +
+                6. * m.hill[5] * s[5] * s[5];
+    double I1 = (s[0] + s[1] + s[2]) * m.d0 / 3.;
+    return sqrt(0.5 * I2) + I1;
+}
+
+__device__ __forceinline__ double sflow_of(const MatDev &m, const double *epl)
+{
+    return m.sy + eps_eq(epl) * m.khard;  // material.py:997
+}
+
+// material.py:826-845 analytic normal
+__device__ __forceinline__ void hill_fgrad(const MatDev &m, const double *s, double *a)
+{
+    double seq = hill_seq(m, s);
+    double p = (s[0] + s[1] + s[2]) / 3.;
+    double s0 = s[0] - p, s1 = s[1] - p, s2 = s[2] - p;
+    double h0 = m.hill[0], h1 = m.hill[1], h2 = m.hill[2];
+    double d3 = m.d0 / 3.;
+    a[0] = ((h0 + h2) * s0 - h0 * s1 - h2 * s2) / (2. * seq) + d3;
+    a[1] = ((h1 + h0) * s1 - h0 * s0 - h1 * s2) / (2. * seq) + d3;
+    a[2] = ((h2 + h1) * s2 - h2 * s0 - h1 * s1) / (2. * seq) + d3;
+    a[3] = 3. * m.hill[3] * s[3] / seq;
+    a[4] = 3. * m.hill[4] * s[4] / seq;
+    a[5] = 3. * m.hill[5] * s[5] / seq;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RBF-SVC yield function (material.py:398-405 decision function, :765-807 gradient).
+// sv/dual point to LDS when the kernel staged them, to global memory otherwise; every lane reads
+// the same address (broadcast), so the loop is FP64-VALU bound (software exp).
+__device__ __forceinline__ void svc_features(const MatDev &m, const double *s, double *x)
+{
+    double p = m.dev_only ? (s[0] + s[1] + s[2]) / 3. : 0.;  // material.py:2336
+    double inv = 1. / m.scale_seq;
+    // the reference divides (x = sig/scale_seq); keep the division for bit-fidelity of x
+    (void)inv;
+    x[0] = (s[0] - p) / m.scale_seq;
+    x[1] = (s[1] - p) / m.scale_seq;
+    x[2] = (s[2] - p) / m.scale_seq;
+    x[3] = s[3] / m.scale_seq;
+    x[4] = s[4] / m.scale_seq;
+    x[5] = s[5] / m.scale_seq;
+}
+
+__device__ inline double svc_decision_x(const MatDev &m, const double *sv, const double *dual,
+                                        const double *x)
+{
+    double f = 0.;
+    const int n = m.nsv;
+    const double g = -m.gamma;
+    for (int k = 0; k < n; k++) {
+        const double *v = sv + 6 * k;
+        double hh = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double d = x[i] - v[i];
+            hh = fma(d, d, hh);
+        }
+        f = fma(dual[k], exp(g * hh), f);
+    }
+    return f + m.intercept;
+}
+
+__device__ inline double svc_decision(const MatDev &m, const double *sv, const double *dual,
+                                      const double *s)
+{
+    double x[6];
+    svc_features(m, s, x);
+    return svc_decision_x(m, sv, dual, x);
+}
+
+__device__ inline void svc_fgrad(const MatDev &m, const double *sv, const double *dual,
+                                 const double *s, double *a)
+{
+    double x[6], acc[6] = {0., 0., 0., 0., 0., 0.};
+    svc_features(m, s, x);
+    const int n = m.nsv;
+    const double g = -m.gamma;
+    for (int k = 0; k < n; k++) {
+        const double *v = sv + 6 * k;
+        double hv[6], hh = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            hv[i] = x[i] - v[i];
+            hh = fma(hv[i], hv[i], hh);
+        }
+        double w = dual[k] * exp(g * hh);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = fma(w, hv[i], acc[i]);
+    }
+    double sc = -2. * m.gamma / m.scale_seq;  // (-2 gamma)(x - sv) / scale_seq, material.py:775,807
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = acc[i] * sc;
+}
+
+// Yield-function policy: analytic Hill-6p / J2.
+struct YfHill {
+    const MatDev &m;
+    __device__ YfHill(const MatDev &mm) : m(mm) {}
+    __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
+    // calc_yf(sig, epl)
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        return hill_seq(m, s) - sflow_of(m, epl);
+    }
+    // yield function used for the convergence tests inside response()
+    __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
+    __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const { hill_fgrad(m, s, a); }
+};
+
+// scipy.optimize.brentq (scipy 1.15.3, Brent 1973) specialised to f(x) = decision(x*su)
+template <class F>
+__device__ inline double brentq_dev(F f, double xa, double xb, double fa, double fb, double xtol,
+                                    double rtol, int maxiter, bool &converged)
+{
+    double xpre = xa, xcur = xb, xblk = 0., fpre = fa, fcur = fb, fblk = 0.;
+    double spre = 0., scur = 0., sbis, delta, stry, dpre, dblk;
+    converged = true;
+    if (fpre == 0.) return xpre;
+    if (fcur == 0.) return xcur;
+    for (int i = 0; i < maxiter; i++) {
+        if (fpre != 0. && fcur != 0. && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2.;
+        sbis = (xblk - xcur) / 2.;
+        if (fcur == 0. || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            double lim = fmin(fabs(spre), 3. * fabs(sbis) - delta);
+            if (2. * fabs(stry) < lim) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0. ? delta : -delta);
+        fcur = f(xcur);
+    }
+    converged = false;
+    return xcur;
+}
+
+// Yield-function policy: RBF-SVC (ML_yf).  calc_seq of an ML material is J2 (hill = ones).
+struct YfSvc {
+    const MatDev &m;
+    const double *sv;
+    const double *dual;
+    __device__ YfSvc(const MatDev &mm, const double *s, const double *d) : m(mm), sv(s), dual(d) {}
+    __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        (void)epl;
+        return svc_decision(m, sv, dual, s);
+    }
+    // ML_full_yf (material.py:414-516): distance to the yield locus along the ray through s
+    // (ld == nullptr) or along the loading direction ld.
+    __device__ inline double full_ld(const double *s, const double *epl, const double *ld,
+                                     int *status) const
+    {
+        double seqv = hill_seq(m, s);
+        double sflow = sflow_of(m, epl);
+        if (status) *status = 0;
+        if (seqv < 0.01 && ld == nullptr) return seqv - 0.85 * sflow;
+        double su[6];
+        if (ld == nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) su[i] = s[i] / seqv;
+        } else {
+            double hh = sqrt(dot6(ld, ld));  // material.py:455-462
+            if (hh < 1.e-3) {
+                su[0] = sqrt(1.5);
+#pragma unroll
+                for (int i = 1; i < 6; i++) su[i] = 0.;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) su[i] = ld[i] * sqrt(1.5) / hh;
+            }
+        }
+        // x*su scaled into feature space once: features are linear in the stress
+        double xu[6];
+        svc_features(m, su, xu);
+        auto f = [&](double x) {
+            double xs[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                // reference: features of (x*su) = (x*su - p)/scale; reproduce that order
+                xs[i] = x * su[i];
+            }
+            return svc_decision(m, sv, dual, xs);
+        };
+        (void)xu;
+        double x0 = sflow;
+        if (su[0] * su[1] < -1.e-5) x0 *= 0.5;  // material.py:468-473
+        double x1 = x0;
+        double f0 = f(x0);
+        double f1 = f0;
+        while (f0 >= 0. && x0 > 0.01) {  // material.py:475-480
+            x0 *= 0.98;
+            f0 = f(x0);
+        }
+        while (f1 < 0. && x1 < 5. * sflow) {  // material.py:481-486
+            x1 *= 1.02;
+            f1 = f(x1);
+        }
+        if (f0 * f1 > 0.) {  // material.py:495-499
+            if (status) *status = 1;
+            return seqv - 0.85 * sflow;
+        }
+        bool conv;
+        double xs = brentq_dev(f, x0, x1, f0, f1, 1.e-5, 4. * 2.220446049250313e-16, 100, conv);
+        if (conv && xs < 4. * sflow) return seqv - xs * hill_seq(m, su);  // material.py:507
+        if (status) *status = 2;
+        return seqv - 0.85 * sflow;  // material.py:510
+    }
+    __device__ __forceinline__ double full(const double *s, const double *epl) const
+    {
+        return full_ld(s, epl, nullptr, nullptr);
+    }
+    // material.py:265: fy0 re-evaluated as full yield function with epl = 0
+    __device__ __forceinline__ double full0(const double *s, double fy0) const
+    {
+        (void)fy0;
+        const double z[6] = {0., 0., 0., 0., 0., 0.};
+        return full_ld(s, z, nullptr, nullptr);
+    }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const { svc_fgrad(m, sv, dual, s, a); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Material.response (material.py:207-346) for one point.  In/out: sig (updated to the end of the
+// step).  Out: fy, depl, Ct (21 symmetric entries).  Returns msg['nsteps'] (last loop index).
+template <class YF>
+__device__ inline int response_point(const MatDev &m, const YF &yf, double *sig, const double *epl,
+                                     const double *deps, double &fy, double *depl, double *Ct)
+{
+    const double *CV = m.CV;
+    double dsig[6], tmp[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) depl[i] = 0.;
+    const double sflow0 = sflow_of(m, epl);
+    const double toler = YF_TOL * sflow0;  // :243
+    symv(CV, deps, dsig);                  // :244
+#pragma unroll
+    for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsig[i];
+    double fy1 = yf.full(tmp, epl);  // :249-252
+    if (fy1 < toler) {               // purely elastic step :253-256
+#pragma unroll
+        for (int i = 0; i < 6; i++) sig[i] = tmp[i];
+#pragma unroll
+        for (int i = 0; i < 21; i++) Ct[i] = CV[i];
+        fy = fy1;
+        return 0;
+    }
+    double deps_r[6];
+    double st_scal = 1.;
+    double fy0 = yf.plain(sig, epl);  // :259
+    if (fy0 < SPLIT_THRESHOLD) {      // :260-270 split into elastic + plastic part
+        fy0 = yf.full0(sig, fy0);
+        st_scal += fy0 / yf.seq(dsig);
+        const double wel = 1. - st_scal;
+        double de[6], ds[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) de[i] = deps[i] * wel;
+        symv(CV, de, ds);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            sig[i] += ds[i];
+            deps_r[i] = deps[i] - de[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) deps_r[i] = deps[i];
+    }
+    // R accumulates sum_it [ (Ca)(Ca)^T/h + corr3 ]; Ct = CV - (st_scal/nsteps) R at the end
+    // (:343 with T = CV - (Ca)(Ca)^T/h - corr3 and the elastic share CV*(1-st_scal) of :269).
+    double R[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) R[i] = 0.;
+
+    double a[6], ca[6], dsr[6], ddepl[6], eplt[6];
+    int nsteps = 1;
+    // trial step with the full remaining increment (:277-293)
+    {
+        symv(CV, deps_r, dsr);
+        yf.fgrad(sig, a);
+        symv(CV, a, ca);
+        const double hh = dot6(a, ca) + m.khard;
+#pragma unroll
+        for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
+        const double yfun = yf.plain(tmp, epl);  // epl_dot :1032
+        const double lam = (yfun <= YF_TOL) ? 0. : dot6(a, dsr) / hh;
+        const double cd = dot6(ca, deps_r) / hh;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            eplt[i] = epl[i] + lam * a[i];
+            tmp[i] = sig[i] + (dsr[i] - ca[i] * cd);
+        }
+        fy1 = yf.full(tmp, eplt);
+        if (fy1 > toler) {
+            nsteps = MAXIT;
+#pragma unroll
+            for (int i = 0; i < 6; i++) deps_r[i] /= MAXIT;
+            symv(CV, deps_r, dsr);
+        }
+    }
+    for (int it = 0; it < nsteps; it++) {  // :295
+        yf.fgrad(sig, a);
+        symv(CV, a, ca);
+        const double hh = dot6(a, ca) + m.khard;
+#pragma unroll
+        for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
+        const double yfun = yf.plain(tmp, epl);  // NB entry epl, absolute tolerance (:299, :1041)
+        const double lam = (yfun <= YF_TOL) ? 0. : dot6(a, dsr) / hh;
+        const double cd = dot6(ca, deps_r) / hh;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            ddepl[i] = lam * a[i];
+            sig[i] += dsr[i] - ca[i] * cd;
+            eplt[i] = epl[i] + depl[i] + ddepl[i];
+        }
+        fy1 = yf.full(sig, eplt);
+        const double ih = 1. / hh;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) R[sym_idx(i, j)] = fma(ca[i] * ih, ca[j], R[sym_idx(i, j)]);
+        if (fy1 > toler) {  // radial scale-back :310-342
+            const double sq = yf.seq(sig);
+            const double fr = fy1 / sq;
+            double dsg[6], sd[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                dsg[i] = sig[i] * fr;
+                sig[i] -= dsg[i];
+            }
+            symv(m.SV, dsg, sd);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                ddepl[i] += sd[i];
+                eplt[i] = epl[i] + depl[i] + ddepl[i];
+            }
+            // min-norm solution of the 3x6 system (:325-337): x = A^T G^{-1} b,
+            // G = |d|^2 I + d d^T - diag(d^2), d = deps_r[0:3], b = dsg[0:3]
+            const double d0 = deps_r[0], d1 = deps_r[1], d2 = deps_r[2];
+            const double n2 = d0 * d0 + d1 * d1 + d2 * d2;
+            if (n2 > 0.) {
+                const double g01 = d0 * d1, g02 = d0 * d2, g12 = d1 * d2;
+                const double c00 = n2 * n2 - g12 * g12, c01 = g02 * g12 - g01 * n2,
+                             c02 = g01 * g12 - g02 * n2;
+                const double c11 = n2 * n2 - g02 * g02, c12 = g01 * g02 - g12 * n2,
+                             c22 = n2 * n2 - g01 * g01;
+                const double det = n2 * c00 + g01 * c01 + g02 * c02;
+                const double y0 = (c00 * dsg[0] + c01 * dsg[1] + c02 * dsg[2]) / det;
+                const double y1 = (c01 * dsg[0] + c11 * dsg[1] + c12 * dsg[2]) / det;
+                const double y2 = (c02 * dsg[0] + c12 * dsg[1] + c22 * dsg[2]) / det;
+                R[sym_idx(0, 0)] += d0 * y0;            // x0
+                R[sym_idx(1, 1)] += d1 * y1;            // x1
+                R[sym_idx(2, 2)] += d2 * y2;            // x2
+                R[sym_idx(1, 2)] += d2 * y1 + d1 * y2;  // x3
+                R[sym_idx(0, 2)] += d2 * y0 + d0 * y2;  // x4
+                R[sym_idx(0, 1)] += d1 * y0 + d0 * y1;  // x5
+            }
+            fy1 = yf.full(sig, eplt);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) depl[i] += ddepl[i];  // :344
+    }
+    const double w = st_scal / nsteps;
+#pragma unroll
+    for (int i = 0; i < 21; i++) Ct[i] = fma(-w, R[i], CV[i]);
+    fy = fy1;
+    return nsteps - 1;  // :345
+}
+
+}  // namespace plfx

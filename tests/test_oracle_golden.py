@@ -55,3 +55,25 @@ def test_element(golden_dir):
         assert rel(K, z['e%d_Kel' % k], 1e-6) < 1e-12
         K = O.calc_Kel(lx, ly, lz, ps > 0, CV, E, nu, z['e%d_D' % k])
         assert rel(K, z['e%d_KelD' % k], 1e-6) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['hill', 'shear'])
+def test_svc(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))
+    m = O.Material.from_golden(z)
+    sig = z['b_sig']
+    assert np.max(np.abs(O.calc_yf(m, sig) - z['b_yf'])) < 1e-10
+    assert np.max(np.abs(O.calc_fgrad(m, sig) - z['b_fgrad'])) < 1e-12
+    nf = len(z['b_full_yf'])
+    fyf, st = O.ML_full_yf(m, sig[:nf])
+    # brentq stops within xtol=1e-5 (stress units); identical iterates up to exp() round-off
+    assert np.max(np.abs(fyf - z['b_full_yf'])) < 1e-7
+    for tag in ('pe', 'ps'):
+        CV = z['r%s_CV' % tag]
+        fy, so, dp, ct, ns = O.response(m, CV, z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+        assert np.array_equal(ns, z['r%s_nsteps' % tag])
+        sc = float(m.c.sy)
+        assert np.max(np.abs(fy - z['r%s_fy' % tag])) < 1e-6 * sc
+        assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sc
+        assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
+        assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
