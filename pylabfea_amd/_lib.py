@@ -1,0 +1,346 @@
+"""ctypes binding of libplfx.so (the C-ABI declared in include/plfx.h).
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no MI355X is visible,
+every entry point raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C pylabfea_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libplfx.so')
+
+# yield-function kinds (include/plfx.h)
+ELASTIC, HILL6, PRINC3, SVC6 = 0, 1, 2, 3
+
+# state ids of plfx_state_get/_set
+ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS = range(11)
+
+# timing families
+T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE = range(4)
+
+
+class PlfxError(RuntimeError):
+    pass
+
+
+class CMaterial(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('sdim', C.c_int32), ('CV', C.c_double * 36),
+                ('E', C.c_double), ('nu', C.c_double), ('sy', C.c_double), ('khard', C.c_double),
+                ('hill', C.c_double * 6), ('drucker', C.c_double), ('nsv', C.c_int32),
+                ('nfeat', C.c_int32), ('dev_only', C.c_int32), ('_pad', C.c_int32),
+                ('gamma', C.c_double), ('intercept', C.c_double), ('scale_seq', C.c_double),
+                ('sv', C.c_void_p), ('dual', C.c_void_p)]
+
+
+# every symbol include/plfx.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = [
+    'plfx_create', 'plfx_destroy', 'plfx_last_error', 'plfx_version', 'plfx_device_info',
+    'plfx_stream', 'plfx_sync', 'plfx_set_materials', 'plfx_seq_batch', 'plfx_fgrad_batch',
+    'plfx_yf_batch', 'plfx_full_yf_batch', 'plfx_response_batch', 'plfx_set_mesh', 'plfx_get_bmat',
+    'plfx_get_kel', 'plfx_state_get', 'plfx_state_set', 'plfx_state_reset', 'plfx_gather',
+    'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
+    'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
+    'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable',
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libplfx.so; raises PlfxError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PlfxError('libplfx.so not found at %s - build it first (__graft_entry__.build()); '
+                        'pylabfea_amd has no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.plfx_last_error.restype = C.c_char_p
+    lib.plfx_version.restype = C.c_char_p
+    lib.plfx_stream.restype = C.c_void_p
+    lib.plfx_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None):
+    """Build a plfx_material record.  svc = dict(sv, dual, gamma, intercept, scale_seq, dev_only).
+    Returns (struct, keepalive) - keepalive holds the arrays the struct points to."""
+    m = CMaterial()
+    m.kind = int(kind)
+    m.sdim = 6
+    cv = _f64(CV).reshape(36)
+    for i in range(36):
+        m.CV[i] = cv[i]
+    m.E, m.nu = float(E), float(nu)
+    m.sy = 0. if sy is None else float(sy)
+    m.khard = 0. if khard is None else float(khard)
+    h = np.ones(6) if hill is None else np.asarray(hill, dtype=float)
+    for i in range(6):
+        m.hill[i] = h[i] if i < len(h) else 1.
+    m.drucker = float(drucker or 0.)
+    keep = []
+    if svc is not None:
+        sv = _f64(svc['sv'])
+        dual = _f64(svc['dual']).reshape(-1)
+        keep = [sv, dual]
+        m.nsv, m.nfeat = sv.shape
+        m.dev_only = int(bool(svc.get('dev_only', False)))
+        m.gamma = float(svc['gamma'])
+        m.intercept = float(svc['intercept'])
+        m.scale_seq = float(svc['scale_seq'])
+        m.sv = sv.ctypes.data
+        m.dual = dual.ctypes.data
+    return m, keep
+
+
+class Context(object):
+    """One libplfx context = one GPU + one HIP stream.  Thin, typed wrapper over the C-ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.plfx_create(int(device), C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.plfx_last_error(self.h).decode() if self.h else 'plfx_create failed'
+            if self.h:
+                self.lib.plfx_destroy(self.h)
+                self.h = C.c_void_p()
+            raise PlfxError('libplfx: %s' % msg)
+        self.nmat = 0
+        self.nel = 0
+        self.nel_owned = 0
+        self.ndof = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.plfx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, soft=False):
+        if rc < 0 or (rc > 0 and not soft):
+            raise PlfxError('libplfx error %d: %s' % (rc, self.lib.plfx_last_error(self.h).decode()))
+        return rc
+
+    # -- info
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        hbm = C.c_int64()
+        self._chk(self.lib.plfx_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value
+
+    def stream(self):
+        return self.lib.plfx_stream(self.h)
+
+    def sync(self):
+        self._chk(self.lib.plfx_sync(self.h))
+
+    # -- materials
+    def set_materials(self, records):
+        """records: list of (CMaterial, keepalive)"""
+        arr = (CMaterial * len(records))()
+        self._keep = []
+        for i, (m, keep) in enumerate(records):
+            arr[i] = m
+            self._keep.append(keep)
+        self._chk(self.lib.plfx_set_materials(self.h, len(records), arr))
+        self.nmat = len(records)
+
+    # -- batched point evaluation (host AoS arrays)
+    def seq(self, mat, sig):
+        sig = _f64(sig).reshape(-1, 6)
+        out = np.empty(len(sig))
+        self._chk(self.lib.plfx_seq_batch(self.h, int(mat), len(sig), _dp(sig), _dp(out)))
+        return out
+
+    def fgrad(self, mat, sig):
+        sig = _f64(sig).reshape(-1, 6)
+        out = np.empty_like(sig)
+        self._chk(self.lib.plfx_fgrad_batch(self.h, int(mat), len(sig), _dp(sig), _dp(out)))
+        return out
+
+    def yf(self, mat, sig, epl=None):
+        sig = _f64(sig).reshape(-1, 6)
+        epl = np.zeros_like(sig) if epl is None else _f64(epl).reshape(-1, 6)
+        out = np.empty(len(sig))
+        self._chk(self.lib.plfx_yf_batch(self.h, int(mat), len(sig), _dp(sig), _dp(epl), _dp(out)))
+        return out
+
+    def full_yf(self, mat, sig, epl=None, ld=None):
+        sig = _f64(sig).reshape(-1, 6)
+        epl = np.zeros_like(sig) if epl is None else _f64(epl).reshape(-1, 6)
+        ldp = None if ld is None else _f64(ld).reshape(6)
+        out = np.empty(len(sig))
+        st = np.zeros(len(sig), dtype=np.int32)
+        self._chk(self.lib.plfx_full_yf_batch(self.h, int(mat), len(sig), _dp(sig), _dp(epl), _dp(ldp),
+                                              _dp(out), _dp(st)))
+        return out, st
+
+    def response(self, sig, epl, deps, mat_id=None):
+        sig = _f64(sig).reshape(-1, 6)
+        n = len(sig)
+        epl = _f64(epl).reshape(-1, 6)
+        deps = _f64(deps).reshape(-1, 6)
+        mid = None if mat_id is None else _i32(mat_id)
+        fy = np.empty(n)
+        so = np.empty((n, 6))
+        dp = np.empty((n, 6))
+        ct = np.empty((n, 36))
+        ns = np.empty(n, dtype=np.int32)
+        self._chk(self.lib.plfx_response_batch(self.h, n, _dp(mid), _dp(sig), _dp(epl), _dp(deps),
+                                               _dp(fy), _dp(so), _dp(dp), _dp(ct), _dp(ns)))
+        return fy, so, dp, ct, ns
+
+    # -- mesh / state
+    def set_mesh(self, conn, mat_id, lxy, nnode, thick, planestress, el_begin=0, el_end=None):
+        conn = _i32(conn).reshape(-1, 4)
+        nel = len(conn)
+        mat_id = _i32(mat_id)
+        lxy = _f64(lxy).reshape(nel, 2)
+        if el_end is None:
+            el_end = nel
+        self._chk(self.lib.plfx_set_mesh(self.h, nel, int(nnode), _dp(conn), _dp(mat_id), _dp(lxy),
+                                         C.c_double(thick), int(bool(planestress)), int(el_begin),
+                                         int(el_end)))
+        self.nel = nel
+        self.nel_owned = el_end - el_begin
+        self.ndof = 2 * int(nnode)
+
+    def get_bmat(self, e):
+        B = np.empty((4, 6, 8))
+        self._chk(self.lib.plfx_get_bmat(self.h, int(e), _dp(B)))
+        return B
+
+    def get_kel(self, e):
+        K = np.empty((8, 8))
+        self._chk(self.lib.plfx_get_kel(self.h, int(e), _dp(K)))
+        return K
+
+    def state_get(self, which):
+        if which in (ST_U, ST_F, ST_DU):
+            out = np.empty(self.ndof)
+        elif which in (ST_FYN, ST_MAXSTEPS):
+            out = np.empty(self.nel_owned)
+        elif which == ST_ELSTIFF:
+            out = np.empty((self.nel_owned, 36))
+        else:
+            out = np.empty((self.nel_owned, 6))
+        self._chk(self.lib.plfx_state_get(self.h, int(which), _dp(out)))
+        return out
+
+    def state_set(self, which, arr):
+        arr = _f64(arr)
+        self._chk(self.lib.plfx_state_set(self.h, int(which), _dp(arr)))
+
+    def state_reset(self):
+        self._chk(self.lib.plfx_state_reset(self.h))
+
+    def gather(self, which, idx):
+        idx = _i32(idx)
+        out = np.empty(len(idx))
+        self._chk(self.lib.plfx_gather(self.h, int(which), len(idx), _dp(idx), _dp(out)))
+        return out
+
+    # -- assembly / solve
+    def assemble(self):
+        self._chk(self.lib.plfx_assemble(self.h))
+
+    def get_csr(self):
+        """Assembled global matrix as scipy.sparse.csr_matrix."""
+        import scipy.sparse as sp
+        nnz = C.c_int64()
+        self._chk(self.lib.plfx_get_csr(self.h, C.byref(nnz), None, None, None))
+        rowptr = np.empty(self.ndof + 1, dtype=np.int32)
+        col = np.empty(nnz.value, dtype=np.int32)
+        val = np.empty(nnz.value)
+        self._chk(self.lib.plfx_get_csr(self.h, C.byref(nnz), _dp(rowptr), _dp(col), _dp(val)))
+        return sp.csr_matrix((val, col, rowptr), shape=(self.ndof, self.ndof))
+
+    def apply_bc(self, idx, du_presc, w, fext=None):
+        idx = _i32(idx)
+        du_presc = _f64(du_presc)
+        w = _f64(w)
+        fx = None if fext is None else _f64(fext)
+        self._chk(self.lib.plfx_apply_bc(self.h, len(idx), _dp(idx), _dp(du_presc), _dp(w), _dp(fx)))
+
+    def solve(self, rtol=1e-12, maxit=100000, warm=False):
+        it = C.c_int()
+        rr = C.c_double()
+        rc = self._chk(self.lib.plfx_solve(self.h, C.c_double(rtol), int(maxit), int(bool(warm)),
+                                           C.byref(it), C.byref(rr)), soft=True)
+        return it.value, rr.value, rc == 0
+
+    def sweep(self, nit):
+        ch = C.c_int()
+        cv = C.c_int()
+        self._chk(self.lib.plfx_sweep(self.h, int(nit), C.byref(ch), C.byref(cv)))
+        return bool(ch.value), bool(cv.value)
+
+    def scf_stats(self, sld):
+        """returns (count, min, sum) of the calc_scf list entries"""
+        sld = _f64(sld).reshape(6)
+        s = C.c_double()
+        mn = C.c_double()
+        cnt = C.c_int64()
+        self._chk(self.lib.plfx_scf_stats(self.h, _dp(sld), C.byref(s), None, C.byref(mn), C.byref(cnt),
+                                          C.c_double(0.), 0))
+        return cnt.value, mn.value, s.value
+
+    def scf_sumsq(self, mean):
+        s2 = C.c_double()
+        self._chk(self.lib.plfx_scf_stats(self.h, None, None, C.byref(s2), None, None, C.c_double(mean), 1))
+        return s2.value
+
+    def update_state(self):
+        self._chk(self.lib.plfx_update_state(self.h))
+
+    def global_sums(self):
+        out = np.empty(18)
+        self._chk(self.lib.plfx_global_sums(self.h, _dp(out)))
+        return out.reshape(3, 6)
+
+    # -- multi-GPU
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.plfx_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, uid, rank, nranks):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._chk(self.lib.plfx_comm_init(self.h, buf, int(rank), int(nranks)))
+
+    # -- instrumentation
+    def timing_enable(self, on=True):
+        self._chk(self.lib.plfx_timing_enable(self.h, int(bool(on))))
+
+    def timing_reset(self):
+        self._chk(self.lib.plfx_timing_reset(self.h))
+
+    def timing_get(self, which):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._chk(self.lib.plfx_timing_get(self.h, int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

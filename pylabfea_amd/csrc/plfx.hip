@@ -1,0 +1,1330 @@
+// plfx.hip — host side of libplfx.so: context, HBM residency, C-ABI (include/plfx.h).
+//
+// HBM layout (FP64 / int32, everything resident for the life of the mesh):
+//   per owned element e (SoA, component-major [c*nel + e]): sig[6] epl[6] eps[6] res_sig[6]
+//     res_depl[6] elstiff[21, symmetric] M[6] (compact stiffness generator) fyn max_steps cls
+//   connectivity conn[nel_total*4] (global element ids), per node: block-ELL matrix
+//     val[nslot][2x2][nnode], col[nslot][nnode], contrib[nslot][nq][nnode] (assembly gather lists)
+//   per DOF (interleaved x,y per node = double2): u f du rhs dinv diag is_presc + PCG vectors
+//     x r z q p0 p1
+#include "../../include/plfx.h"
+#include "plfx_kernels.hpp"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace plfx;
+
+#define PLFX_VERSION "0.1.0-r1"
+
+namespace {
+
+struct EvPair {
+    hipEvent_t a, b;
+    int which;
+    bool pending;
+};
+
+struct Timing {
+    bool on = false;
+    std::vector<EvPair> ring;
+    size_t head = 0;
+    double ms[8] = {0};
+    int64_t n[8] = {0};
+};
+
+// minimal RCCL surface (dlopen'ed so the library loads on hosts without RCCL in the path)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int (*fn_ncclGetUniqueId)(ncclUniqueId *);
+typedef int (*fn_ncclCommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*fn_ncclCommDestroy)(ncclComm_t);
+struct Rccl {
+    void *h = nullptr;
+    fn_ncclGetUniqueId GetUniqueId = nullptr;
+    fn_ncclCommInitRank CommInitRank = nullptr;
+    fn_ncclAllReduce AllReduce = nullptr;
+    fn_ncclCommDestroy CommDestroy = nullptr;
+};
+Rccl g_rccl;
+bool load_rccl()
+{
+    if (g_rccl.h) return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return false;
+    g_rccl.GetUniqueId = (fn_ncclGetUniqueId)dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (fn_ncclCommInitRank)dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.AllReduce = (fn_ncclAllReduce)dlsym(g_rccl.h, "ncclAllReduce");
+    g_rccl.CommDestroy = (fn_ncclCommDestroy)dlsym(g_rccl.h, "ncclCommDestroy");
+    return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
+}
+constexpr int NCCL_FLOAT64 = 8;  // ncclDouble
+constexpr int NCCL_SUM = 0;
+
+template <class T>
+struct DBuf {  // device buffer
+    T *p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct plfx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    int lds_doubles = 0;  // dynamic LDS budget (doubles) for SVC staging
+
+    // materials
+    int nmat = 0;
+    std::vector<MatDev> hmat;
+    MatDev *dmat = nullptr;
+    std::vector<double *> dsv;  // owned device copies of sv/dual
+    bool has_svc = false;
+    int svc_lds_need = 0;
+
+    // mesh
+    int nel_total = 0, nnode = 0, ndof = 0, e0 = 0, nel = 0;  // nel = owned
+    int planestress = 0;
+    double thick = 1.;
+    int ncls = 0;
+    std::vector<ClassDev> hcls;
+    std::vector<int32_t> hcls_id;  // per total element
+    std::vector<int32_t> hconn;
+    std::vector<double> hlxy;
+    ClassDev *dcls = nullptr;
+    int32_t *dconn = nullptr, *dcls_id = nullptr;  // dcls_id: owned elements only
+    int nslot = 0, nq = 0;
+    int32_t *dcol = nullptr, *dcontrib = nullptr;
+    std::vector<int32_t> hcol;
+    double *dval = nullptr;
+    int n_begin = 0, n_end = 0;  // node range touched by owned elements
+    bool nonlin = false;
+
+    // element state (owned)
+    double *sig = nullptr, *epl = nullptr, *eps = nullptr, *res_sig = nullptr, *res_depl = nullptr;
+    double *elstiff = nullptr, *Mel = nullptr, *fyn = nullptr, *scf_hh = nullptr;
+    int32_t *max_steps = nullptr, *scf_mult = nullptr;
+    // dof vectors
+    double *u = nullptr, *f = nullptr, *du = nullptr, *rhs = nullptr, *dinv = nullptr, *diag = nullptr,
+           *is_presc = nullptr, *dup = nullptr, *wv = nullptr, *fext = nullptr;
+    double *x = nullptr, *r = nullptr, *z = nullptr, *q = nullptr, *p[2] = {nullptr, nullptr};
+    // scalars / partials
+    double *part = nullptr;  // [8][MAXPART]
+    double *part_g = nullptr;
+    CgScalars *sc = nullptr;
+    int *flags = nullptr;
+    double *small = nullptr;  // [64] scratch outputs
+    int32_t *idx_tmp = nullptr;
+    double *val_tmp = nullptr;
+    size_t tmp_cap = 0;
+    bool assembled = false, bc_set = false;
+    int grid_nodes = 0, grid_el = 0;
+
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    Timing tim;
+};
+
+namespace {
+
+int fail(plfx_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(c, PLFX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+template <class T>
+int dalloc(plfx_ctx *c, T **p, size_t n)
+{
+    if (*p) {
+        hipFree(*p);
+        *p = nullptr;
+    }
+    if (n == 0) n = 1;
+    HIPCHK(c, hipMalloc((void **)p, n * sizeof(T)));
+    HIPCHK(c, hipMemsetAsync(*p, 0, n * sizeof(T), c->stream));
+    return 0;
+}
+
+template <class T>
+void dfree(T *&p)
+{
+    if (p) hipFree(p);
+    p = nullptr;
+}
+
+int grid_for(size_t n, int cap = MAXPART)
+{
+    size_t g = (n + BLOCK - 1) / BLOCK;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// round the grid to a multiple of 8 (XCD count) when large enough, for xcd_tile()
+int grid_xcd(size_t n)
+{
+    int g = grid_for(n);
+    if (g >= 16) g &= ~7;
+    return g;
+}
+
+void tim_begin(plfx_ctx *c, int which, EvPair **out)
+{
+    *out = nullptr;
+    Timing &t = c->tim;
+    if (!t.on) return;
+    if (t.ring.empty()) {
+        t.ring.resize(2048);
+        for (auto &e : t.ring) {
+            hipEventCreate(&e.a);
+            hipEventCreate(&e.b);
+            e.pending = false;
+        }
+    }
+    EvPair &e = t.ring[t.head];
+    if (e.pending) {  // recycle: resolve the old measurement first
+        hipEventSynchronize(e.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e.a, e.b);
+        t.ms[e.which] += ms;
+        t.n[e.which]++;
+        e.pending = false;
+    }
+    e.which = which;
+    hipEventRecord(e.a, c->stream);
+    *out = &e;
+    t.head = (t.head + 1) % t.ring.size();
+}
+
+void tim_end(plfx_ctx *c, EvPair *e)
+{
+    if (!e) return;
+    hipEventRecord(e->b, c->stream);
+    e->pending = true;
+}
+
+void tim_flush(plfx_ctx *c)
+{
+    Timing &t = c->tim;
+    for (auto &e : t.ring)
+        if (e.pending) {
+            hipEventSynchronize(e.b);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e.a, e.b);
+            t.ms[e.which] += ms;
+            t.n[e.which]++;
+            e.pending = false;
+        }
+}
+
+// 6x6 symmetric (row-major 36) -> 21
+void pack_sym(const double *A, double *S)
+{
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) S[sym_idx(i, j)] = A[i * 6 + j];
+}
+
+// inverse of the leading n x n block (n = 2 or 3) by Gauss-Jordan with partial pivoting
+bool inv_small(const double *A, int lda, int n, double *Ai)
+{
+    double w[3][6];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            w[i][j] = A[i * lda + j];
+            w[i][n + j] = (i == j) ? 1. : 0.;
+        }
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++)
+            if (std::fabs(w[r][col]) > std::fabs(w[piv][col])) piv = r;
+        if (w[piv][col] == 0.) return false;
+        if (piv != col)
+            for (int j = 0; j < 2 * n; j++) std::swap(w[col][j], w[piv][j]);
+        const double d = w[col][col];
+        for (int j = 0; j < 2 * n; j++) w[col][j] /= d;
+        for (int r = 0; r < n; r++)
+            if (r != col) {
+                const double fct = w[r][col];
+                for (int j = 0; j < 2 * n; j++) w[r][j] -= fct * w[col][j];
+            }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ai[i * n + j] = w[i][n + j];
+    return true;
+}
+
+// Gauss point i of the Q4 element (model.py:339-346)
+void gauss_point(double lx, double ly, int i, double *x, double *y)
+{
+    const double cpos = std::sqrt(1. / 3.);
+    const double sx = ((i / 2) % 2 == 0) ? 1. : -1.;
+    const double sy = (i % 2 == 0) ? 1. : -1.;
+    *x = 0.5 * (1. + sx * cpos) * lx;
+    *y = 0.5 * (1. + sy * cpos) * ly;
+}
+
+// shape-function derivative factors at (x,y): bx[a] = B[0][2a], by[a] = B[1][2a+1] (model.py:475-497)
+void shape_b(double lx, double ly, double x, double y, double bx[4], double by[4])
+{
+    const double xi1 = 2. * x / lx - 1.;
+    const double xi2 = 2. * y / ly - 1.;
+    const double hxm = 0.125 * (1. - xi1) / ly;
+    const double hym = 0.125 * (1. - xi2) / lx;
+    const double hxp = 0.125 * (1. + xi1) / ly;
+    const double hyp = 0.125 * (1. + xi2) / lx;
+    bx[0] = -hym;
+    bx[1] = -hyp;
+    bx[2] = hym;
+    bx[3] = hyp;
+    by[0] = -hxm;
+    by[1] = hxm;
+    by[2] = -hxp;
+    by[3] = hxp;
+}
+
+ClassDev make_class(const plfx_ctx *c, int mat, double lx, double ly)
+{
+    ClassDev k;
+    memset(&k, 0, sizeof(k));
+    k.mat = mat;
+    k.lx = lx;
+    k.ly = ly;
+    k.vel = lx * ly * c->thick;       // model.py:316
+    const double jac = 4. * k.vel;    // model.py:322, 340 (wght = 1)
+    k.kappa = 0.;
+    if (c->planestress) {             // model.py:498-501 with the plane-stress CV of :277-283
+        const MatDev &m = c->hmat[mat];
+        const double c11 = m.CV[sym_idx(0, 0)], c12 = m.CV[sym_idx(0, 1)];
+        k.kappa = -m.nu * (c11 + c12) / m.E;
+    }
+    for (int g = 0; g < 4; g++) {
+        double x, y, bx[4], by[4];
+        gauss_point(lx, ly, g, &x, &y);
+        shape_b(lx, ly, x, y, bx, by);
+        for (int a = 0; a < 4; a++) {
+            k.bxs[a] += bx[a];
+            k.bys[a] += by[a];
+            for (int b = 0; b < 4; b++) {
+                k.Sxx[a * 4 + b] += jac * bx[a] * bx[b];
+                k.Sxy[a * 4 + b] += jac * bx[a] * by[b];
+                k.Syy[a * 4 + b] += jac * by[a] * by[b];
+            }
+        }
+    }
+    return k;
+}
+
+void free_mesh(plfx_ctx *c)
+{
+    dfree(c->dcls);
+    dfree(c->dconn);
+    dfree(c->dcls_id);
+    dfree(c->dcol);
+    dfree(c->dcontrib);
+    dfree(c->dval);
+    dfree(c->sig);
+    dfree(c->epl);
+    dfree(c->eps);
+    dfree(c->res_sig);
+    dfree(c->res_depl);
+    dfree(c->elstiff);
+    dfree(c->Mel);
+    dfree(c->fyn);
+    dfree(c->scf_hh);
+    dfree(c->max_steps);
+    dfree(c->scf_mult);
+    dfree(c->u);
+    dfree(c->f);
+    dfree(c->du);
+    dfree(c->rhs);
+    dfree(c->dinv);
+    dfree(c->diag);
+    dfree(c->is_presc);
+    dfree(c->dup);
+    dfree(c->wv);
+    dfree(c->fext);
+    dfree(c->x);
+    dfree(c->r);
+    dfree(c->z);
+    dfree(c->q);
+    dfree(c->p[0]);
+    dfree(c->p[1]);
+    c->assembled = c->bc_set = false;
+}
+
+void free_materials(plfx_ctx *c)
+{
+    for (double *p : c->dsv) hipFree(p);
+    c->dsv.clear();
+    dfree(c->dmat);
+    c->hmat.clear();
+    c->nmat = 0;
+}
+
+int ensure_tmp(plfx_ctx *c, size_t n)
+{
+    if (n <= c->tmp_cap) return 0;
+    dfree(c->idx_tmp);
+    dfree(c->val_tmp);
+    int rc = dalloc(c, &c->idx_tmp, n);
+    if (rc) return rc;
+    rc = dalloc(c, &c->val_tmp, 4 * n);
+    if (rc) return rc;
+    c->tmp_cap = n;
+    return 0;
+}
+
+size_t dyn_lds_bytes(const plfx_ctx *c) { return c->has_svc ? (size_t)c->svc_lds_need * 8 : 0; }
+
+int plain_spmv(plfx_ctx *c, const double *in, double *out)
+{
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<0>), dim3(c->grid_nodes), dim3(BLOCK), 0, c->stream, c->nnode, 0,
+                       c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)in, nullptr, nullptr,
+                       (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
+    HIPCHK(c, hipGetLastError());
+    if (c->nranks > 1) {
+        if (g_rccl.AllReduce(out, out, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
+            return fail(c, PLFX_ERR_HIP, "ncclAllReduce failed");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *plfx_version(void) { return PLFX_VERSION; }
+
+int plfx_create(int device, plfx_ctx **out)
+{
+    if (!out) return PLFX_ERR_ARG;
+    *out = nullptr;
+    plfx_ctx *c = new plfx_ctx();
+    *out = c;  // returned even on failure so that plfx_last_error works
+    c->device = device;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(c, PLFX_ERR_HIP, "no HIP device available (%s); libplfx has no CPU fallback",
+                    hipGetErrorString(e));
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipGetDeviceProperties(&c->prop, device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // 160 KiB LDS per CU on gfx950; leave room for the static material/class tables
+    size_t lds = std::max((size_t)c->prop.sharedMemPerBlock, (size_t)c->prop.maxSharedMemoryPerMultiProcessor);
+    lds = std::min(lds, (size_t)160 * 1024);
+    const size_t reserve = sizeof(MatDev) * MAXMAT + sizeof(ClassDev) * MAXCLS + 1024;
+    c->lds_doubles = lds > reserve ? (int)((lds - reserve) / 8) : 0;
+    int rc;
+    if ((rc = dalloc(c, &c->part, (size_t)8 * MAXPART))) return rc;
+    if ((rc = dalloc(c, &c->part_g, (size_t)18 * MAXPART))) return rc;
+    if ((rc = dalloc(c, &c->sc, 1))) return rc;
+    if ((rc = dalloc(c, &c->flags, 4))) return rc;
+    if ((rc = dalloc(c, &c->small, 64))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PLFX_OK;
+}
+
+void plfx_destroy(plfx_ctx *c)
+{
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (auto &e : c->tim.ring) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    free_mesh(c);
+    free_materials(c);
+    dfree(c->part);
+    dfree(c->part_g);
+    dfree(c->sc);
+    dfree(c->flags);
+    dfree(c->small);
+    dfree(c->idx_tmp);
+    dfree(c->val_tmp);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *plfx_last_error(plfx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int plfx_device_info(plfx_ctx *c, char *name, int len, int *cus, int64_t *hbm)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    if (name && len > 0) {
+        snprintf(name, len, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    }
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)c->prop.totalGlobalMem;
+    return PLFX_OK;
+}
+
+void *plfx_stream(plfx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int plfx_sync(plfx_ctx *c)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ materials
+int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    if (nmat < 1 || nmat > MAXMAT || !mats) return fail(c, PLFX_ERR_ARG, "nmat must be in 1..%d", MAXMAT);
+    free_materials(c);
+    c->has_svc = false;
+    c->svc_lds_need = 0;
+    c->nonlin = false;
+    c->hmat.resize(nmat);
+    for (int k = 0; k < nmat; k++) {
+        const plfx_material &s = mats[k];
+        MatDev &m = c->hmat[k];
+        memset(&m, 0, sizeof(m));
+        if (s.kind == PLFX_PRINC3 || s.sdim == 3)
+            return fail(c, PLFX_ERR_UNSUPPORTED, "material %d: sdim=3 (principal-stress) flow rules are not built yet", k);
+        if (s.kind != PLFX_ELASTIC && s.kind != PLFX_HILL6 && s.kind != PLFX_SVC6)
+            return fail(c, PLFX_ERR_ARG, "material %d: unknown kind %d", k, s.kind);
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++)
+                if (std::fabs(s.CV[i * 6 + j] - s.CV[j * 6 + i]) >
+                    1e-9 * (std::fabs(s.CV[i * 6 + j]) + std::fabs(s.CV[j * 6 + i]) + 1e-300))
+                    return fail(c, PLFX_ERR_ARG, "material %d: CV must be symmetric", k);
+        pack_sym(s.CV, m.CV);
+        // compliance of the scale-back step (material.py:315-320)
+        double SV[36] = {0.};
+        const int nb = (s.CV[2 * 6 + 2] > 1.) ? 3 : 2;
+        double hh[9];
+        if (!inv_small(s.CV, 6, nb, hh)) return fail(c, PLFX_ERR_ARG, "material %d: singular CV block", k);
+        for (int i = 0; i < nb; i++)
+            for (int j = 0; j < nb; j++) SV[i * 6 + j] = hh[i * nb + j];
+        for (int i = 3; i < 6; i++)
+            if (s.CV[i * 6 + i] > 1.) SV[i * 6 + i] = 1. / s.CV[i * 6 + i];
+        // symmetrise round-off of the Gauss-Jordan inverse
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) SV[i * 6 + j] = SV[j * 6 + i] = 0.5 * (SV[i * 6 + j] + SV[j * 6 + i]);
+        pack_sym(SV, m.SV);
+        for (int i = 0; i < 6; i++) m.hill[i] = (s.kind == PLFX_ELASTIC) ? 1. : s.hill[i];
+        m.sy = s.sy;
+        m.khard = s.khard;
+        m.d0 = (s.kind == PLFX_ELASTIC) ? 0. : s.drucker;
+        m.E = s.E;
+        m.nu = s.nu;
+        m.kind = s.kind;
+        m.sdim = 6;
+        if (s.kind != PLFX_ELASTIC) c->nonlin = true;
+        if (s.kind == PLFX_SVC6) {
+            if (s.nsv < 1 || s.nfeat != 6 || !s.sv || !s.dual)
+                return fail(c, PLFX_ERR_ARG, "material %d: SVC needs nsv>=1, nfeat==6, sv and dual", k);
+            double *dsv = nullptr, *ddu = nullptr;
+            HIPCHK(c, hipMalloc((void **)&dsv, (size_t)s.nsv * 6 * 8));
+            c->dsv.push_back(dsv);
+            HIPCHK(c, hipMalloc((void **)&ddu, (size_t)s.nsv * 8));
+            c->dsv.push_back(ddu);
+            HIPCHK(c, hipMemcpy(dsv, s.sv, (size_t)s.nsv * 6 * 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(ddu, s.dual, (size_t)s.nsv * 8, hipMemcpyHostToDevice));
+            m.sv = dsv;
+            m.dual = ddu;
+            m.nsv = s.nsv;
+            m.dev_only = s.dev_only;
+            m.gamma = s.gamma;
+            m.intercept = s.intercept;
+            m.scale_seq = s.scale_seq;
+            if (!c->has_svc && s.nsv * 7 <= c->lds_doubles) c->svc_lds_need = s.nsv * 7;
+            c->has_svc = true;
+        }
+    }
+    c->nmat = nmat;
+    int rc = dalloc(c, &c->dmat, (size_t)nmat);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->has_svc) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
+        const int bytes = (int)dyn_lds_bytes(c);
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_point_eval, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_scf_elements, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ batched point evaluation
+static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, const double *epl,
+                      const double *ld, double *out, int32_t *status)
+{
+    if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
+    if (mat < 0 || mat >= c->nmat || n < 0 || !sig || !out) return fail(c, PLFX_ERR_ARG, "bad argument");
+    if (n == 0) return PLFX_OK;
+    const int wout = (what == 1) ? 6 : 1;
+    double *dsig = nullptr, *depl = nullptr, *dout = nullptr, *dld = nullptr;
+    int32_t *dst = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dsig, (size_t)n * 48));
+    HIPCHK(c, hipMalloc((void **)&dout, (size_t)n * 8 * wout));
+    HIPCHK(c, hipMemcpyAsync(dsig, sig, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    if (epl) {
+        HIPCHK(c, hipMalloc((void **)&depl, (size_t)n * 48));
+        HIPCHK(c, hipMemcpyAsync(depl, epl, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    }
+    if (ld) {
+        HIPCHK(c, hipMalloc((void **)&dld, 48));
+        HIPCHK(c, hipMemcpyAsync(dld, ld, 48, hipMemcpyHostToDevice, c->stream));
+    }
+    if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
+    hipLaunchKernelGGL(k_point_eval, dim3(grid_for(n)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                       c->dmat, c->nmat, c->svc_lds_need, what, mat, n, dsig, depl, dld, dout, dst);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)n * 8 * wout, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, dst, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(dsig);
+    hipFree(dout);
+    if (depl) hipFree(depl);
+    if (dld) hipFree(dld);
+    if (dst) hipFree(dst);
+    return PLFX_OK;
+}
+
+int plfx_seq_batch(plfx_ctx *c, int mat, int n, const double *sig, double *seq)
+{
+    return point_eval(c, 0, mat, n, sig, nullptr, nullptr, seq, nullptr);
+}
+int plfx_fgrad_batch(plfx_ctx *c, int mat, int n, const double *sig, double *a)
+{
+    return point_eval(c, 1, mat, n, sig, nullptr, nullptr, a, nullptr);
+}
+int plfx_yf_batch(plfx_ctx *c, int mat, int n, const double *sig, const double *epl, double *yf)
+{
+    return point_eval(c, 2, mat, n, sig, epl, nullptr, yf, nullptr);
+}
+int plfx_full_yf_batch(plfx_ctx *c, int mat, int n, const double *sig, const double *epl,
+                       const double *ld, double *yf, int32_t *status)
+{
+    return point_eval(c, 3, mat, n, sig, epl, ld, yf, status);
+}
+
+int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double *sig,
+                        const double *epl, const double *deps, double *fy, double *sig_out,
+                        double *depl, double *ct, int32_t *nsteps)
+{
+    if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
+    if (n < 0 || !sig || !epl || !deps || !fy || !sig_out || !depl || !ct || !nsteps)
+        return fail(c, PLFX_ERR_ARG, "null argument");
+    if (n == 0) return PLFX_OK;
+    if (mat_id)
+        for (int i = 0; i < n; i++)
+            if (mat_id[i] < 0 || mat_id[i] >= c->nmat) return fail(c, PLFX_ERR_ARG, "mat_id[%d] out of range", i);
+    double *d_in = nullptr, *d_out = nullptr;
+    int32_t *d_mid = nullptr, *d_ns = nullptr;
+    const size_t N = n;
+    HIPCHK(c, hipMalloc((void **)&d_in, N * 18 * 8));
+    HIPCHK(c, hipMalloc((void **)&d_out, N * (1 + 6 + 6 + 36) * 8));
+    HIPCHK(c, hipMalloc((void **)&d_ns, N * 4));
+    HIPCHK(c, hipMemcpyAsync(d_in, sig, N * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_in + 6 * N, epl, N * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_in + 12 * N, deps, N * 48, hipMemcpyHostToDevice, c->stream));
+    if (mat_id) {
+        HIPCHK(c, hipMalloc((void **)&d_mid, N * 4));
+        HIPCHK(c, hipMemcpyAsync(d_mid, mat_id, N * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    double *d_fy = d_out, *d_so = d_out + N, *d_dp = d_out + 7 * N, *d_ct = d_out + 13 * N;
+    EvPair *ev;
+    tim_begin(c, 0, &ev);
+    hipLaunchKernelGGL(k_response_batch, dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                       c->dmat, c->nmat, c->svc_lds_need, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N,
+                       d_fy, d_so, d_dp, d_ct, d_ns);
+    tim_end(c, ev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fy, d_fy, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sig_out, d_so, N * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(depl, d_dp, N * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ct, d_ct, N * 288, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nsteps, d_ns, N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_in);
+    hipFree(d_out);
+    hipFree(d_ns);
+    if (d_mid) hipFree(d_mid);
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ mesh
+int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
+                  const double *lxy, double thick, int planestress, int el_begin, int el_end)
+{
+    if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
+    if (nel < 1 || nnode < 4 || !conn || !mat_id || !lxy) return fail(c, PLFX_ERR_ARG, "bad mesh arguments");
+    if (el_begin < 0 || el_end > nel || el_begin >= el_end) return fail(c, PLFX_ERR_ARG, "bad owned element range");
+    free_mesh(c);
+    c->nel_total = nel;
+    c->nnode = nnode;
+    c->ndof = 2 * nnode;
+    c->e0 = el_begin;
+    c->nel = el_end - el_begin;
+    c->thick = thick;
+    c->planestress = planestress ? 1 : 0;
+    for (int e = 0; e < nel; e++) {
+        if (mat_id[e] < 0 || mat_id[e] >= c->nmat) return fail(c, PLFX_ERR_ARG, "mat_id[%d] out of range", e);
+        for (int a = 0; a < 4; a++)
+            if (conn[4 * e + a] < 0 || conn[4 * e + a] >= nnode)
+                return fail(c, PLFX_ERR_ARG, "conn[%d][%d] out of range", e, a);
+    }
+    c->hconn.assign(conn, conn + (size_t)4 * nel);
+    c->hlxy.assign(lxy, lxy + (size_t)2 * nel);
+    // element classes (material, lx, ly)
+    c->hcls.clear();
+    c->hcls_id.resize(nel);
+    {
+        int last = -1;
+        for (int e = 0; e < nel; e++) {
+            const double lx = lxy[2 * e], ly = lxy[2 * e + 1];
+            int found = -1;
+            if (last >= 0 && c->hcls[last].mat == mat_id[e] && c->hcls[last].lx == lx && c->hcls[last].ly == ly)
+                found = last;
+            else
+                for (size_t k = 0; k < c->hcls.size(); k++)
+                    if (c->hcls[k].mat == mat_id[e] && c->hcls[k].lx == lx && c->hcls[k].ly == ly) {
+                        found = (int)k;
+                        break;
+                    }
+            if (found < 0) {
+                if ((int)c->hcls.size() >= MAXCLS)
+                    return fail(c, PLFX_ERR_UNSUPPORTED, "more than %d (material, lx, ly) element classes", MAXCLS);
+                c->hcls.push_back(make_class(c, mat_id[e], lx, ly));
+                found = (int)c->hcls.size() - 1;
+            }
+            c->hcls_id[e] = found;
+            last = found;
+        }
+    }
+    c->ncls = (int)c->hcls.size();
+
+    // node -> owned elements adjacency, neighbour slots, assembly gather lists
+    const int nown = c->nel;
+    std::vector<int32_t> deg(nnode + 1, 0);
+    for (int e = el_begin; e < el_end; e++)
+        for (int a = 0; a < 4; a++) deg[conn[4 * e + a] + 1]++;
+    for (int i = 0; i < nnode; i++) deg[i + 1] += deg[i];
+    std::vector<int32_t> adj(deg[nnode]);  // packed (local element, local node) in ascending element order
+    {
+        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
+        for (int e = el_begin; e < el_end; e++)
+            for (int a = 0; a < 4; a++) adj[fill[conn[4 * e + a]]++] = (e - el_begin) * 4 + a;
+    }
+    int nslot = 0, nq = 0, nb = nnode, ne = 0;
+    std::vector<std::vector<int32_t>> nbrs;  // only to size; recomputed below to limit memory
+    // pass 1: sizes
+    {
+        std::vector<int32_t> tmp;
+        for (int i = 0; i < nnode; i++) {
+            const int a0 = deg[i], a1 = deg[i + 1];
+            if (a1 == a0) continue;
+            nb = std::min(nb, i);
+            ne = std::max(ne, i + 1);
+            nq = std::max(nq, a1 - a0);
+            tmp.clear();
+            for (int k = a0; k < a1; k++) {
+                const int e = adj[k] >> 2;
+                for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            nslot = std::max(nslot, (int)tmp.size());
+        }
+    }
+    if (nslot == 0) return fail(c, PLFX_ERR_ARG, "no owned elements");
+    c->nslot = nslot;
+    c->nq = nq;
+    c->n_begin = nb;
+    c->n_end = ne;
+    c->hcol.assign((size_t)nslot * nnode, -1);
+    std::vector<int32_t> hcontrib((size_t)nslot * nq * nnode, -1);
+    {
+        std::vector<int32_t> tmp;
+        for (int i = 0; i < nnode; i++) {
+            const int a0 = deg[i], a1 = deg[i + 1];
+            if (a1 == a0) continue;
+            tmp.clear();
+            for (int k = a0; k < a1; k++) {
+                const int e = adj[k] >> 2;
+                for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            for (size_t s = 0; s < tmp.size(); s++) {
+                c->hcol[s * nnode + i] = tmp[s];
+                int qn = 0;
+                for (int k = a0; k < a1; k++) {  // ascending element order = reference's addition order
+                    const int e = adj[k] >> 2, a = adj[k] & 3;
+                    for (int b = 0; b < 4; b++)
+                        if (conn[4 * (e + el_begin) + b] == tmp[s])
+                            hcontrib[((size_t)s * nq + qn++) * nnode + i] = e * 16 + a * 4 + b;
+                }
+            }
+        }
+    }
+    if ((size_t)nown * 16 > 0x7fffffffULL) return fail(c, PLFX_ERR_UNSUPPORTED, "too many elements for int32 gather codes");
+
+    int rc;
+#define ALLOC(ptr, n) if ((rc = dalloc(c, &(ptr), (size_t)(n)))) return rc
+    ALLOC(c->dcls, c->ncls);
+    ALLOC(c->dconn, (size_t)4 * nel);
+    ALLOC(c->dcls_id, nown);
+    ALLOC(c->dcol, (size_t)nslot * nnode);
+    ALLOC(c->dcontrib, (size_t)nslot * nq * nnode);
+    ALLOC(c->dval, (size_t)nslot * 4 * nnode);
+    ALLOC(c->sig, (size_t)6 * nown);
+    ALLOC(c->epl, (size_t)6 * nown);
+    ALLOC(c->eps, (size_t)6 * nown);
+    ALLOC(c->res_sig, (size_t)6 * nown);
+    ALLOC(c->res_depl, (size_t)6 * nown);
+    ALLOC(c->elstiff, (size_t)21 * nown);
+    ALLOC(c->Mel, (size_t)6 * nown);
+    ALLOC(c->fyn, nown);
+    ALLOC(c->scf_hh, nown);
+    ALLOC(c->max_steps, nown);
+    ALLOC(c->scf_mult, nown);
+    const size_t nd = c->ndof;
+    ALLOC(c->u, nd);
+    ALLOC(c->f, nd);
+    ALLOC(c->du, nd);
+    ALLOC(c->rhs, nd);
+    ALLOC(c->dinv, nd);
+    ALLOC(c->diag, nd);
+    ALLOC(c->is_presc, nd);
+    ALLOC(c->dup, nd);
+    ALLOC(c->wv, nd);
+    ALLOC(c->fext, nd);
+    ALLOC(c->x, nd);
+    ALLOC(c->r, nd);
+    ALLOC(c->z, nd);
+    ALLOC(c->q, nd);
+    ALLOC(c->p[0], nd);
+    ALLOC(c->p[1], nd);
+#undef ALLOC
+    HIPCHK(c, hipMemcpyAsync(c->dcls, c->hcls.data(), sizeof(ClassDev) * c->ncls, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dconn, conn, (size_t)16 * nel, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dcls_id, c->hcls_id.data() + el_begin, (size_t)4 * nown, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dcol, c->hcol.data(), c->hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dcontrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->grid_nodes = grid_xcd(nnode);
+    c->grid_el = grid_xcd(nown);
+    return plfx_state_reset(c);
+}
+
+int plfx_get_bmat(plfx_ctx *c, int e, double *B)
+{
+    if (!c || c->hcls.empty()) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (e < 0 || e >= c->nel_total || !B) return fail(c, PLFX_ERR_ARG, "bad argument");
+    const ClassDev &k = c->hcls[c->hcls_id[e]];
+    for (int g = 0; g < 4; g++) {
+        double x, y, bx[4], by[4];
+        gauss_point(k.lx, k.ly, g, &x, &y);
+        shape_b(k.lx, k.ly, x, y, bx, by);
+        double *Bg = B + 48 * g;
+        for (int i = 0; i < 48; i++) Bg[i] = 0.;
+        for (int a = 0; a < 4; a++) {
+            Bg[0 * 8 + 2 * a] = bx[a];
+            Bg[1 * 8 + 2 * a + 1] = by[a];
+            Bg[5 * 8 + 2 * a] = by[a];
+            Bg[5 * 8 + 2 * a + 1] = bx[a];
+            Bg[2 * 8 + 2 * a] = k.kappa * bx[a];
+            Bg[2 * 8 + 2 * a + 1] = k.kappa * by[a];
+        }
+    }
+    return PLFX_OK;
+}
+
+int plfx_get_kel(plfx_ctx *c, int e, double *Kel)
+{
+    if (!c || !c->Mel) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (e < c->e0 || e >= c->e0 + c->nel || !Kel) return fail(c, PLFX_ERR_ARG, "element not owned");
+    double M[6];
+    const int le = e - c->e0;
+    for (int k = 0; k < 6; k++)
+        HIPCHK(c, hipMemcpy(&M[k], c->Mel + (size_t)k * c->nel + le, 8, hipMemcpyDeviceToHost));
+    const ClassDev &k = c->hcls[c->hcls_id[e]];
+    for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) {
+            const double sxx = k.Sxx[a * 4 + b], sxy = k.Sxy[a * 4 + b], syx = k.Sxy[b * 4 + a], syy = k.Syy[a * 4 + b];
+            Kel[(2 * a) * 8 + 2 * b] = M[0] * sxx + M[2] * (sxy + syx) + M[5] * syy;
+            Kel[(2 * a) * 8 + 2 * b + 1] = M[1] * sxy + M[2] * sxx + M[4] * syy + M[5] * syx;
+            Kel[(2 * a + 1) * 8 + 2 * b] = M[1] * syx + M[4] * syy + M[2] * sxx + M[5] * sxy;
+            Kel[(2 * a + 1) * 8 + 2 * b + 1] = M[3] * syy + M[4] * (syx + sxy) + M[5] * sxx;
+        }
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ state
+int plfx_state_reset(plfx_ctx *c)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    const size_t ne = c->nel, nd = c->ndof;
+    HIPCHK(c, hipMemsetAsync(c->sig, 0, 48 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->epl, 0, 48 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->eps, 0, 48 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->res_sig, 0, 48 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->res_depl, 0, 48 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->fyn, 0, 8 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->max_steps, 0, 4 * ne, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->u, 0, 8 * nd, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->f, 0, 8 * nd, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->du, 0, 8 * nd, c->stream));
+    hipLaunchKernelGGL(k_init_tangent, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
+                       c->dmat, c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel);
+    HIPCHK(c, hipGetLastError());
+    c->assembled = false;
+    return PLFX_OK;
+}
+
+static int state_ptr(plfx_ctx *c, int which, double **p, size_t *comps, size_t *n, bool *soa)
+{
+    *soa = true;
+    *n = c->nel;
+    switch (which) {
+    case 0: *p = c->sig; *comps = 6; break;
+    case 1: *p = c->eps; *comps = 6; break;
+    case 2: *p = c->epl; *comps = 6; break;
+    case 3: *p = c->res_sig; *comps = 6; break;
+    case 4: *p = c->res_depl; *comps = 6; break;
+    case 5: *p = c->elstiff; *comps = 21; break;
+    case 6: *p = c->u; *comps = 1; *n = c->ndof; *soa = false; break;
+    case 7: *p = c->f; *comps = 1; *n = c->ndof; *soa = false; break;
+    case 8: *p = c->du; *comps = 1; *n = c->ndof; *soa = false; break;
+    case 9: *p = c->fyn; *comps = 1; *soa = false; break;
+    default: return fail(c, PLFX_ERR_ARG, "unknown state id %d", which);
+    }
+    return 0;
+}
+
+int plfx_state_get(plfx_ctx *c, int which, double *out)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (!out) return fail(c, PLFX_ERR_ARG, "null output");
+    if (which == 10) {
+        std::vector<int32_t> t(c->nel);
+        HIPCHK(c, hipMemcpyAsync(t.data(), c->max_steps, (size_t)4 * c->nel, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int e = 0; e < c->nel; e++) out[e] = t[e];
+        return PLFX_OK;
+    }
+    double *p;
+    size_t comps, n;
+    bool soa;
+    int rc = state_ptr(c, which, &p, &comps, &n, &soa);
+    if (rc) return rc;
+    if (!soa) {
+        HIPCHK(c, hipMemcpyAsync(out, p, 8 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return PLFX_OK;
+    }
+    std::vector<double> t(comps * n);
+    HIPCHK(c, hipMemcpyAsync(t.data(), p, 8 * comps * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (comps == 6) {
+        for (size_t e = 0; e < n; e++)
+            for (int k = 0; k < 6; k++) out[6 * e + k] = t[(size_t)k * n + e];
+    } else {  // symmetric 21 -> full 36
+        for (size_t e = 0; e < n; e++)
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) out[36 * e + 6 * i + j] = t[(size_t)sym_idx(i, j) * n + e];
+    }
+    return PLFX_OK;
+}
+
+int plfx_state_set(plfx_ctx *c, int which, const double *in)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (!in) return fail(c, PLFX_ERR_ARG, "null input");
+    if (which == 10) return fail(c, PLFX_ERR_ARG, "max_steps is read-only");
+    double *p;
+    size_t comps, n;
+    bool soa;
+    int rc = state_ptr(c, which, &p, &comps, &n, &soa);
+    if (rc) return rc;
+    if (!soa) {
+        HIPCHK(c, hipMemcpyAsync(p, in, 8 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return PLFX_OK;
+    }
+    std::vector<double> t(comps * n);
+    if (comps == 6) {
+        for (size_t e = 0; e < n; e++)
+            for (int k = 0; k < 6; k++) t[(size_t)k * n + e] = in[6 * e + k];
+    } else {
+        for (size_t e = 0; e < n; e++)
+            for (int i = 0; i < 6; i++)
+                for (int j = i; j < 6; j++) t[(size_t)sym_idx(i, j) * n + e] = in[36 * e + 6 * i + j];
+    }
+    HIPCHK(c, hipMemcpyAsync(p, t.data(), 8 * comps * n, hipMemcpyHostToDevice, c->stream));
+    if (which == 5) {
+        hipLaunchKernelGGL(k_refresh_M, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
+                           c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PLFX_OK;
+}
+
+int plfx_gather(plfx_ctx *c, int which, int n, const int32_t *idx, double *out)
+{
+    if (!c || !c->u) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (n < 0 || !idx || !out) return fail(c, PLFX_ERR_ARG, "bad argument");
+    if (n == 0) return PLFX_OK;
+    const double *src = which == 6 ? c->u : which == 7 ? c->f : which == 8 ? c->du : nullptr;
+    if (!src) return fail(c, PLFX_ERR_ARG, "gather supports u(6), f(7), du(8)");
+    for (int k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "idx[%d] out of range", k);
+    int rc = ensure_tmp(c, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->idx_tmp, idx, (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->idx_tmp, src, c->val_tmp);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->val_tmp, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ assembly
+int plfx_assemble(plfx_ctx *c)
+{
+    if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    EvPair *ev;
+    tim_begin(c, 3, &ev);
+    hipLaunchKernelGGL(k_assemble, dim3(grid_for(c->nnode), c->nslot), dim3(BLOCK), 0, c->stream,
+                       c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel, c->dcontrib, c->dcls_id,
+                       c->Mel, c->dcol, c->dval, c->diag);
+    tim_end(c, ev);
+    HIPCHK(c, hipGetLastError());
+    if (c->nranks > 1) {  // Jacobi needs the full diagonal
+        if (g_rccl.AllReduce(c->diag, c->diag, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
+            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(diag) failed");
+    }
+    c->assembled = true;
+    return PLFX_OK;
+}
+
+int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
+    const int nn = c->nnode, ns = c->nslot;
+    int64_t cnt = 0;
+    for (int i = 0; i < nn; i++) {
+        int k = 0;
+        for (int s = 0; s < ns; s++)
+            if (c->hcol[(size_t)s * nn + i] >= 0) k++;
+        cnt += 4 * (int64_t)k;
+    }
+    if (nnz) *nnz = cnt;
+    if (!rowptr || !colidx || !val) return PLFX_OK;
+    std::vector<double> hv((size_t)ns * 4 * nn);
+    HIPCHK(c, hipMemcpyAsync(hv.data(), c->dval, hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t pos = 0;
+    for (int i = 0; i < nn; i++)
+        for (int rr = 0; rr < 2; rr++) {
+            rowptr[2 * i + rr] = (int32_t)pos;
+            for (int s = 0; s < ns; s++) {
+                const int j = c->hcol[(size_t)s * nn + i];
+                if (j < 0) continue;
+                for (int cc = 0; cc < 2; cc++) {
+                    colidx[pos] = 2 * j + cc;
+                    val[pos] = hv[((size_t)s * 4 + rr * 2 + cc) * nn + i];
+                    pos++;
+                }
+            }
+        }
+    rowptr[2 * nn] = (int32_t)pos;
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ BC + solve
+int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc, const double *w,
+                  const double *fext)
+{
+    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
+    if (n < 0 || (n > 0 && (!idx || !du_presc || !w))) return fail(c, PLFX_ERR_ARG, "bad argument");
+    for (int k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "presc_idx[%d] out of range", k);
+    const size_t nd = c->ndof;
+    int rc = ensure_tmp(c, std::max(n, 1));
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->is_presc, 0, 8 * nd, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dup, 0, 8 * nd, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wv, 0, 8 * nd, c->stream));
+    if (n > 0) {
+        std::vector<double> ones(n, 1.);
+        HIPCHK(c, hipMemcpyAsync(c->idx_tmp, idx, (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->val_tmp, du_presc, (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->val_tmp + n, w, (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->val_tmp + 2 * (size_t)n, ones.data(), (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
+        const dim3 g((n + BLOCK - 1) / BLOCK);
+        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp, c->dup);
+        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp + n, c->wv);
+        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp + 2 * (size_t)n, c->is_presc);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // `ones` goes out of scope
+    }
+    if (fext) HIPCHK(c, hipMemcpyAsync(c->fext, fext, 8 * nd, hipMemcpyHostToDevice, c->stream));
+    rc = plain_spmv(c, c->wv, c->q);  // K w
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bc_finish, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd,
+                       fext ? c->fext : nullptr, c->q, c->diag, c->is_presc, c->rhs, c->dinv);
+    HIPCHK(c, hipGetLastError());
+    if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bc_set = true;
+    return PLFX_OK;
+}
+
+int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
+{
+    if (!c || !c->bc_set) return c ? fail(c, PLFX_ERR_STATE, "apply_bc first") : PLFX_ERR_STATE;
+    if (maxit < 1) maxit = 1;
+    const size_t nd = c->ndof;
+    const int nn = c->nnode;
+    const int gn = c->grid_nodes;
+    double *P_pq = c->part, *P_rz[2] = {c->part + MAXPART, c->part + 2 * MAXPART},
+           *P_rr[2] = {c->part + 3 * MAXPART, c->part + 4 * MAXPART}, *P_bb = c->part + 5 * MAXPART;
+    const bool multi = c->nranks > 1;
+    // x0
+    hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
+    int rc = 0;
+    if (warm) {
+        rc = plain_spmv(c, c->x, c->q);
+        if (rc) return rc;
+    }
+    // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1")
+    hipLaunchKernelGGL(k_cg_init, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->rhs,
+                       warm ? (const double2 *)c->q : nullptr, (const double2 *)c->dinv,
+                       (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
+    hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
+    // beta of the first iteration must be 0: rz_old = +inf, p_old = 0
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(BLOCK), 0, c->stream, P_rz[0], (size_t)gn, (double)INFINITY);
+    HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
+    HIPCHK(c, hipGetLastError());
+
+    const int chunk = 50;
+    int it = 0, done = 0;
+    CgScalars hs;
+    while (it < maxit && !done) {
+        const int stop = std::min(maxit, it + chunk);
+        for (; it < stop; it++) {
+            const int cur = it & 1;  // partial slot written by this iteration's update kernel
+            const int prev = cur ^ 1;
+            double *pold = c->p[prev], *pnew = c->p[cur];
+            EvPair *ev;
+            tim_begin(c, 1, &ev);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<1>), dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->n_begin, c->n_end,
+                               c->nslot, c->dcol, c->dval, (const double2 *)pold, (const double2 *)c->z,
+                               (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn,
+                               P_pq, c->sc, it);
+            tim_end(c, ev);
+            if (multi) {
+                hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->n_begin,
+                                   c->n_end, (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew,
+                                   (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, c->sc);
+                if (g_rccl.AllReduce(c->q, c->q, nd, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
+                    return fail(c, PLFX_ERR_HIP, "ncclAllReduce(q) failed");
+                hipLaunchKernelGGL(k_dot_pq, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
+                                   (const double2 *)c->q, P_pq, c->sc);
+            }
+            tim_begin(c, 2, &ev);
+            hipLaunchKernelGGL(k_cg_update, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
+                               (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
+                               (double2 *)c->r, (double2 *)c->z, P_pq, gn, P_rz[prev], P_rr[prev], gn,
+                               P_rz[cur], P_rr[cur], c->sc);
+            tim_end(c, ev);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        done = hs.done;
+    }
+    if (!done) {
+        // the convergence test of iteration `it` has not run yet: evaluate the last residual
+        hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[(it - 1) & 1], gn, c->sc);
+        HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
+    HIPCHK(c, hipGetLastError());
+    if (iters) *iters = done ? hs.iters : it;
+    if (relres) {
+        const double bb = hs.thresh2 / (rtol * rtol);
+        *relres = (bb > 0. && hs.rr_final >= 0.) ? std::sqrt(hs.rr_final / bb) : 0.;
+    }
+    return done ? PLFX_OK : 1;  // 1 = iteration limit reached (soft failure, like co_nconv)
+}
+
+// ------------------------------------------------------------------------------ non-linear driver pieces
+int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, 16, c->stream));
+    EvPair *ev;
+    tim_begin(c, 0, &ev);
+    hipLaunchKernelGGL(k_sweep, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream, c->dmat,
+                       c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
+                       (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel, c->res_sig,
+                       c->res_depl, c->fyn, c->max_steps, nit, c->flags);
+    tim_end(c, ev);
+    HIPCHK(c, hipGetLastError());
+    int h[4];
+    HIPCHK(c, hipMemcpyAsync(h, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (changed) *changed = h[0];
+    if (conv) *conv = h[1] ? 0 : 1;
+    return PLFX_OK;
+}
+
+int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c, double *minv,
+                   int64_t *count, double mean_in, int pass)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    const int g = grid_for(c->nel, 256);
+    if (pass == 0) {
+        if (!sld) return fail(c, PLFX_ERR_ARG, "sld required");
+        HIPCHK(c, hipMemcpyAsync(c->small + 32, sld, 48, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                           c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
+                           c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
+                           c->small + 32, c->scf_hh, c->scf_mult);
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult,
+                       mean_in, pass, c->part_g);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> h((size_t)3 * g);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->part_g, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double s = 0., cnt = 0., mn = 1.e300;
+    for (int b = 0; b < g; b++) {
+        s += h[b];
+        cnt += h[g + b];
+        mn = std::min(mn, h[2 * (size_t)g + b]);
+    }
+    if (pass == 0) {
+        if (sum) *sum = s;
+        if (count) *count = (int64_t)(cnt + 0.5);
+        if (minv) *minv = mn;
+    } else if (sumsq_c) {
+        *sumsq_c = s;
+    }
+    return PLFX_OK;
+}
+
+int plfx_update_state(plfx_ctx *c)
+{
+    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
+    const size_t nd = c->ndof;
+    int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    hipLaunchKernelGGL(k_update_state, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
+                       c->dmat, c->dcls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
+                       (const double2 *)c->u, c->sig, c->epl, c->eps, c->elstiff, c->res_sig,
+                       c->res_depl, c->nonlin ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    return PLFX_OK;
+}
+
+int plfx_global_sums(plfx_ctx *c, double *out18)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (!out18) return fail(c, PLFX_ERR_ARG, "null output");
+    const int g = grid_for(c->nel, 256);
+    hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
+                       c->sig, c->eps, c->epl, c->part_g);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out18, c->small, 18 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ multi-GPU
+int plfx_comm_unique_id(char id[128])
+{
+    if (!id) return PLFX_ERR_ARG;
+    if (!load_rccl()) return PLFX_ERR_UNSUPPORTED;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != 0) return PLFX_ERR_HIP;
+    memcpy(id, u.internal, 128);
+    return PLFX_OK;
+}
+
+int plfx_comm_init(plfx_ctx *c, const char id[128], int rank, int nranks)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    if (!id || rank < 0 || rank >= nranks) return fail(c, PLFX_ERR_ARG, "bad rank/nranks");
+    if (!load_rccl()) return fail(c, PLFX_ERR_UNSUPPORTED, "librccl.so not found");
+    ncclUniqueId u;
+    memcpy(u.internal, id, 128);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (g_rccl.CommInitRank(&c->comm, nranks, u, rank) != 0) return fail(c, PLFX_ERR_HIP, "ncclCommInitRank failed");
+    c->rank = rank;
+    c->nranks = nranks;
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ instrumentation
+int plfx_timing_enable(plfx_ctx *c, int on)
+{
+    if (!c) return PLFX_ERR_STATE;
+    c->tim.on = on != 0;
+    return PLFX_OK;
+}
+
+int plfx_timing_reset(plfx_ctx *c)
+{
+    if (!c) return PLFX_ERR_STATE;
+    tim_flush(c);
+    for (int i = 0; i < 8; i++) {
+        c->tim.ms[i] = 0.;
+        c->tim.n[i] = 0;
+    }
+    return PLFX_OK;
+}
+
+int plfx_timing_get(plfx_ctx *c, int which, double *ms, int64_t *launches)
+{
+    if (!c || which < 0 || which >= 8) return PLFX_ERR_ARG;
+    tim_flush(c);
+    if (ms) *ms = c->tim.ms[which];
+    if (launches) *launches = c->tim.n[which];
+    return PLFX_OK;
+}
+
+}  // extern "C"

@@ -109,9 +109,7 @@ __device__ __forceinline__ void hill_fgrad(const MatDev &m, const double *s, dou
 __device__ __forceinline__ void svc_features(const MatDev &m, const double *s, double *x)
 {
     double p = m.dev_only ? (s[0] + s[1] + s[2]) / 3. : 0.;  // material.py:2336
-    double inv = 1. / m.scale_seq;
     // the reference divides (x = sig/scale_seq); keep the division for bit-fidelity of x
-    (void)inv;
     x[0] = (s[0] - p) / m.scale_seq;
     x[1] = (s[1] - p) / m.scale_seq;
     x[2] = (s[2] - p) / m.scale_seq;
@@ -282,19 +280,12 @@ struct YfSvc {
                 for (int i = 0; i < 6; i++) su[i] = ld[i] * sqrt(1.5) / hh;
             }
         }
-        // x*su scaled into feature space once: features are linear in the stress
-        double xu[6];
-        svc_features(m, su, xu);
-        auto f = [&](double x) {
+        auto f = [&](double x) {  // find_yloc_scalar (material.py:547-574): calc_yf(x*su)
             double xs[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                // reference: features of (x*su) = (x*su - p)/scale; reproduce that order
-                xs[i] = x * su[i];
-            }
+            for (int i = 0; i < 6; i++) xs[i] = x * su[i];
             return svc_decision(m, sv, dual, xs);
         };
-        (void)xu;
         double x0 = sflow;
         if (su[0] * su[1] < -1.e-5) x0 *= 0.5;  // material.py:468-473
         double x1 = x0;

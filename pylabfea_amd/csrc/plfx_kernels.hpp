@@ -1,0 +1,854 @@
+// plfx_kernels.hpp — HIP kernels of libplfx (gfx950 / MI355X).
+//
+// Kernels (one wavefront = 64 lanes, blocks of 256 threads = 4 waves, one per SIMD):
+//   k_response_batch  Material.response on N independent points (AoS in/out; façade + parity entry)
+//   k_point_eval      calc_seq / calc_fgrad / calc_yf / ML_full_yf on N points
+//   k_sweep           model.py:1340-1359: strain gather + response + tangent test/refresh, SoA state
+//   k_assemble        model.py:954-977 as a deterministic gather into the block-ELL matrix
+//   k_spmv            q = K p (block-ELL, one thread per node = two rows) [+ fused p update + p.q]
+//   k_cg_update       x,r,z update + r.z, r.r partials
+//   k_update_state    model.py:1383-1392
+// All reductions are two-stage with a fixed grid and are summed in index order, so results are
+// bitwise reproducible run to run.
+#pragma once
+#include "plfx_device.hpp"
+
+namespace plfx {
+
+constexpr int BLOCK = 256;
+constexpr int MAXMAT = 16;
+constexpr int MAXCLS = 16;
+constexpr int MAXPART = 1024;  // max blocks of a reducing kernel (partials per scalar)
+
+// Element class = (material, lx, ly): everything the element routines need besides the state.
+// B-matrix structure (model.py:475-501): B[0][2a] = B[5][2a+1] = bx_a, B[1][2a+1] = B[5][2a] = by_a,
+// plane stress adds B[2][j] = kappa (B[0][j] + B[1][j]) with kappa = -nu (C11+C12)/E.
+struct ClassDev {
+    double bxs[4], bys[4];             // sum over the 4 Gauss points (strain operator, model.py:387-411)
+    double Sxx[16], Sxy[16], Syy[16];  // Jac * sum_gp b?_a b?_b  (stiffness integrals, model.py:365-370)
+    double kappa, vel, lx, ly;
+    int32_t mat, _pad;
+};
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum in fixed order; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *sh /* [BLOCK/64] */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; i++) t += sh[i];
+    }
+    return t;
+}
+
+// every block sums the same partial array in the same order -> identical scalar on all blocks
+__device__ __forceinline__ double sum_partials(const double *part, int n, double *sh)
+{
+    double v = 0.;
+    for (int i = threadIdx.x; i < n; i += BLOCK) v += part[i];
+    double t = block_sum(v, sh);
+    __shared__ double bc;
+    if (threadIdx.x == 0) bc = t;
+    __syncthreads();
+    t = bc;
+    __syncthreads();
+    return t;
+}
+
+// XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
+// contiguous range of tiles so that the neighbour columns a tile gathers are in the same L2.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    const int per = nb >> 3;
+    if (per == 0 || (nb & 7)) return b;
+    return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ void stage_materials(MatDev *smat, const MatDev *gmat, int nmat)
+{
+    const int words = nmat * (int)(sizeof(MatDev) / 8);
+    const double *src = reinterpret_cast<const double *>(gmat);
+    double *dst = reinterpret_cast<double *>(smat);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+}
+
+// stage the support vectors of the first SVC material into dynamic LDS (if they fit)
+__device__ __forceinline__ void stage_svc(const MatDev *smat, int nmat, double *lds, int lds_doubles,
+                                          int &svc_mat, const double *&sv, const double *&dual)
+{
+    svc_mat = -1;
+    sv = dual = nullptr;
+    for (int k = 0; k < nmat; k++)
+        if (smat[k].kind == 3 && smat[k].nsv * 7 <= lds_doubles) {
+            svc_mat = k;
+            break;
+        }
+    if (svc_mat < 0) return;
+    const int n = smat[svc_mat].nsv;
+    for (int i = threadIdx.x; i < 6 * n; i += blockDim.x) lds[i] = smat[svc_mat].sv[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[6 * n + i] = smat[svc_mat].dual[i];
+    sv = lds;
+    dual = lds + 6 * n;
+}
+
+// dispatch response on the material kind
+__device__ inline int response_any(const MatDev &m, const double *sv, const double *dual,
+                                   double *sig, const double *epl, const double *deps, double &fy,
+                                   double *depl, double *Ct)
+{
+    if (m.kind == 3) {
+        YfSvc yf(m, sv ? sv : m.sv, dual ? dual : m.dual);
+        return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
+    }
+    YfHill yf(m);
+    return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
+}
+
+extern __shared__ double dyn_lds[];
+
+// ---------------------------------------------------------------------------------------------
+// Material.response on n points, host-layout (AoS) arrays.
+__global__ void __launch_bounds__(BLOCK)
+k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
+                 const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
+                 double *sig_out, double *depl_out, double *ct_out, int32_t *nsteps)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    int svc_mat;
+    const double *sv, *dual;
+    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    __syncthreads();
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const int mid = mat_id ? mat_id[i] : 0;
+        const MatDev &m = smat[mid];
+        double sig[6], epl[6], deps[6], depl[6], Ct[21], f = 0.;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            sig[c] = sig_in[6 * (size_t)i + c];
+            epl[c] = epl_in[6 * (size_t)i + c];
+            deps[c] = deps_in[6 * (size_t)i + c];
+        }
+        int ns = 0;
+        if (m.kind == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) depl[c] = 0.;
+#pragma unroll
+            for (int c = 0; c < 21; c++) Ct[c] = m.CV[c];
+        } else {
+            const bool staged = (mid == svc_mat);
+            ns = response_any(m, staged ? sv : nullptr, staged ? dual : nullptr, sig, epl, deps, f,
+                              depl, Ct);
+        }
+        fy[i] = f;
+        nsteps[i] = ns;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            sig_out[6 * (size_t)i + c] = sig[c];
+            depl_out[6 * (size_t)i + c] = depl[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) ct_out[36 * (size_t)i + r * 6 + c] = Ct[sym_idx(r, c)];
+    }
+}
+
+// what: 0 calc_seq, 1 calc_fgrad, 2 calc_yf, 3 ML_full_yf (SVC) / calc_yf (analytic)
+__global__ void __launch_bounds__(BLOCK)
+k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, int n,
+             const double *sig_in, const double *epl_in, const double *ld, double *out,
+             int32_t *status)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    int svc_mat;
+    const double *sv, *dual;
+    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    __syncthreads();
+    const MatDev &m = smat[mat];
+    const bool svc = (m.kind == 3);
+    const double *psv = (mat == svc_mat) ? sv : m.sv;
+    const double *pdu = (mat == svc_mat) ? dual : m.dual;
+    double ldv[6];
+    if (ld) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) ldv[c] = ld[c];
+    }
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        double s[6], e[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            s[c] = sig_in[6 * (size_t)i + c];
+            e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
+        }
+        if (what == 0) {
+            out[i] = hill_seq(m, s);
+        } else if (what == 1) {
+            double a[6];
+            if (svc)
+                svc_fgrad(m, psv, pdu, s, a);
+            else
+                hill_fgrad(m, s, a);
+#pragma unroll
+            for (int c = 0; c < 6; c++) out[6 * (size_t)i + c] = a[c];
+        } else if (what == 2) {
+            out[i] = svc ? svc_decision(m, psv, pdu, s) : hill_seq(m, s) - sflow_of(m, e);
+        } else {
+            int st = 0;
+            if (svc) {
+                YfSvc yf(m, psv, pdu);
+                out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
+            } else {
+                out[i] = hill_seq(m, s) - sflow_of(m, e);
+            }
+            if (status) status[i] = st;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element strain from nodal values: (sum_gp B) u_e   (model.py:387-411)
+__device__ __forceinline__ void class_strain(const ClassDev &c, const double2 *u2, int n0, int n1,
+                                             int n2, int n3, double *e)
+{
+    const double2 u0 = u2[n0], u1 = u2[n1], u2_ = u2[n2], u3 = u2[n3];
+    const double ex = c.bxs[0] * u0.x + c.bxs[1] * u1.x + c.bxs[2] * u2_.x + c.bxs[3] * u3.x;
+    const double ey = c.bys[0] * u0.y + c.bys[1] * u1.y + c.bys[2] * u2_.y + c.bys[3] * u3.y;
+    const double gxy = c.bys[0] * u0.x + c.bxs[0] * u0.y + c.bys[1] * u1.x + c.bxs[1] * u1.y +
+                       c.bys[2] * u2_.x + c.bxs[2] * u2_.y + c.bys[3] * u3.x + c.bxs[3] * u3.y;
+    e[0] = ex;
+    e[1] = ey;
+    e[2] = c.kappa * (ex + ey);
+    e[3] = 0.;
+    e[4] = 0.;
+    e[5] = gxy;
+}
+
+// compact element stiffness generator M = [X Y S]^T D [X Y S], X = e0 + kappa e2, Y = e1 + kappa e2,
+// S = e5: the six numbers from which every 2x2 block of B^T D B follows (see k_assemble).
+__device__ __forceinline__ void tangent_to_M(const double *D, double kappa, double *M)
+{
+    const double k = kappa;
+    M[0] = D[sym_idx(0, 0)] + k * (2. * D[sym_idx(0, 2)] + k * D[sym_idx(2, 2)]);                  // XX
+    M[1] = D[sym_idx(0, 1)] + k * (D[sym_idx(0, 2)] + D[sym_idx(1, 2)] + k * D[sym_idx(2, 2)]);    // XY
+    M[2] = D[sym_idx(0, 5)] + k * D[sym_idx(2, 5)];                                                // XS
+    M[3] = D[sym_idx(1, 1)] + k * (2. * D[sym_idx(1, 2)] + k * D[sym_idx(2, 2)]);                  // YY
+    M[4] = D[sym_idx(1, 5)] + k * D[sym_idx(2, 5)];                                                // YS
+    M[5] = D[sym_idx(5, 5)];                                                                       // SS
+}
+
+// Material sweep over the owned elements (model.py:1340-1359).  SoA state: component c of element
+// e at [c*nel + e].  flags[0] |= changed, flags[1] |= not converged.
+__global__ void __launch_bounds__(BLOCK)
+k_sweep(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int lds_doubles, int nel,
+        int e_off, const int32_t *conn, const int32_t *cls, const double2 *du2,
+        const double *sig, const double *epl, double *elstiff, double *Mel, double *res_sig,
+        double *res_depl, double *fyn, int32_t *max_steps, int nit, int *flags)
+{
+    __shared__ MatDev smat[MAXMAT];
+    __shared__ ClassDev scls[MAXCLS];
+    stage_materials(smat, gmat, nmat);
+    {
+        const int words = ncls * (int)(sizeof(ClassDev) / 8);
+        const double *src = reinterpret_cast<const double *>(gcls);
+        double *dst = reinterpret_cast<double *>(scls);
+        for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    int svc_mat;
+    const double *sv, *dual;
+    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    __syncthreads();
+    int changed = 0, nconv = 0;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nel; t += nb) {
+        const int e = t * BLOCK + threadIdx.x;
+        if (e >= nel) continue;
+        const ClassDev &c = scls[cls[e]];
+        const MatDev &m = smat[c.mat];
+        if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
+            fyn[e] = 0.;
+            continue;
+        }
+        const size_t ge = (size_t)e + e_off;  // global element id (connectivity is global)
+        double deps[6], s[6], ep[6], depl[6], Ct[21], fy;
+        class_strain(c, du2, conn[ge * 4 + 0], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            s[k] = sig[(size_t)k * nel + e];
+            ep[k] = epl[(size_t)k * nel + e];
+        }
+        const bool staged = (c.mat == svc_mat);
+        const int ns = response_any(m, staged ? sv : nullptr, staged ? dual : nullptr, s, ep, deps,
+                                    fy, depl, Ct);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            res_sig[(size_t)k * nel + e] = s[k];
+            res_depl[(size_t)k * nel + e] = depl[k];
+        }
+        const double f = fy / sflow_of(m, ep);  // model.py:1345
+        fyn[e] = f;
+        if (!(f <= YF_TOL * 1.0001)) nconv = 1;  // model.py:1361
+        // Frobenius norm of the tangent change over the full 6x6 (model.py:1346)
+        double hh = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                const double d = elstiff[(size_t)sym_idx(i, j) * nel + e] - Ct[sym_idx(i, j)];
+                hh += (i == j ? 1. : 2.) * d * d;
+            }
+        hh = sqrt(hh);
+        if (hh > 1.e-3) {  // model.py:1348-1355
+            if (nit >= 15) {
+#pragma unroll
+                for (int k = 0; k < 21; k++) Ct[k] = 0.5 * (Ct[k] + elstiff[(size_t)k * nel + e]);
+            }
+#pragma unroll
+            for (int k = 0; k < 21; k++) elstiff[(size_t)k * nel + e] = Ct[k];
+            double M[6];
+            tangent_to_M(Ct, c.kappa, M);
+#pragma unroll
+            for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+            changed = 1;
+        }
+        if (ns > max_steps[e]) max_steps[e] = ns;  // stat_nlin['max_steps'] (model.py:1356)
+    }
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+    if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// elstiff = CV, M from CV for all owned elements (model.py:1219-1221)
+__global__ void __launch_bounds__(BLOCK)
+k_init_tangent(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t *cls,
+               double *elstiff, double *Mel)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= nel) return;
+    const ClassDev &c = gcls[cls[e]];
+    const MatDev &m = gmat[c.mat];
+    double D[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) {
+        D[k] = m.CV[k];
+        elstiff[(size_t)k * nel + e] = D[k];
+    }
+    double M[6];
+    tangent_to_M(D, c.kappa, M);
+#pragma unroll
+    for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+}
+
+// recompute M from elstiff (after plfx_state_set of the tangent)
+__global__ void __launch_bounds__(BLOCK)
+k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *elstiff, double *Mel)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= nel) return;
+    double D[21], M[6];
+#pragma unroll
+    for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
+    tangent_to_M(D, gcls[cls[e]].kappa, M);
+#pragma unroll
+    for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Assembly (model.py:954-977) as a gather: thread (node i, slot s) sums the <= nq element
+// contributions of block K[i, col(s)] in ascending element order.  contrib code = e*16 + a*4 + b
+// (e local owned-element index, a/b local node numbers), -1 = none.
+// val layout: [(s*4 + r*2 + c) * nnode + i]
+__global__ void __launch_bounds__(BLOCK)
+k_assemble(const ClassDev *gcls, int ncls, int nnode, int nslot, int nq, int nel,
+           const int32_t *contrib, const int32_t *cls, const double *Mel, const int32_t *col,
+           double *val, double *diag)
+{
+    __shared__ ClassDev scls[MAXCLS];
+    {
+        const int words = ncls * (int)(sizeof(ClassDev) / 8);
+        const double *src = reinterpret_cast<const double *>(gcls);
+        double *dst = reinterpret_cast<double *>(scls);
+        for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int s = blockIdx.y;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        double k00 = 0., k01 = 0., k10 = 0., k11 = 0.;
+        for (int q = 0; q < nq; q++) {
+            const int code = contrib[((size_t)s * nq + q) * nnode + i];
+            if (code < 0) continue;
+            const int e = code >> 4, a = (code >> 2) & 3, b = code & 3;
+            const ClassDev &c = scls[cls[e]];
+            const double Mxx = Mel[e], Mxy = Mel[(size_t)nel + e], Mxs = Mel[(size_t)2 * nel + e],
+                         Myy = Mel[(size_t)3 * nel + e], Mys = Mel[(size_t)4 * nel + e],
+                         Mss = Mel[(size_t)5 * nel + e];
+            const double sxx = c.Sxx[a * 4 + b], sxy = c.Sxy[a * 4 + b], syx = c.Sxy[b * 4 + a],
+                         syy = c.Syy[a * 4 + b];
+            k00 += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
+            k01 += Mxy * sxy + Mxs * sxx + Mys * syy + Mss * syx;
+            k10 += Mxy * syx + Mys * syy + Mxs * sxx + Mss * sxy;
+            k11 += Myy * syy + Mys * (syx + sxy) + Mss * sxx;
+        }
+        val[((size_t)s * 4 + 0) * nnode + i] = k00;
+        val[((size_t)s * 4 + 1) * nnode + i] = k01;
+        val[((size_t)s * 4 + 2) * nnode + i] = k10;
+        val[((size_t)s * 4 + 3) * nnode + i] = k11;
+        if (col[(size_t)s * nnode + i] == i) {
+            diag[2 * (size_t)i] = k00;
+            diag[2 * (size_t)i + 1] = k11;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-ELL SpMV, one thread per node (two rows).
+// MODE 0: q = K p                                   (plain; used for K w, K du, residual)
+// MODE 1: PCG step: beta = rz_new/rz_old from the partial sums of the previous update kernel,
+//         p_new = z + beta p_old (written to pnew), q = K p_new, partial sums of p_new . q.
+struct CgScalars {
+    double thresh2;  // (rtol * |b|)^2
+    int32_t done;    // sticky convergence flag
+    int32_t iters;   // iteration count at convergence
+    double rr_final;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv(int nnode, int n_begin, int n_end, int nslot, const int32_t *col, const double *val,
+       const double2 *p, const double2 *z, double2 *pnew, double2 *q, const double *part_rz_new,
+       const double *part_rz_old, const double *part_rr, int npart_prev, double *part_pq,
+       CgScalars *sc, int it)
+{
+    __shared__ double sh[BLOCK / 64];
+    double beta = 0.;
+    if (MODE == 1) {
+        if (sc->done) return;
+        const double rr = sum_partials(part_rr, npart_prev, sh);
+        if (rr <= sc->thresh2) {  // all blocks take the same decision from the same partials
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                sc->done = 1;
+                sc->iters = it;
+                sc->rr_final = rr;
+            }
+            return;
+        }
+        const double rzn = sum_partials(part_rz_new, npart_prev, sh);
+        const double rzo = sum_partials(part_rz_old, npart_prev, sh);
+        beta = rzn / rzo;
+    }
+    double acc_pq = 0.;
+    const int nb = gridDim.x;
+    const int span = n_end - n_begin;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < span; t += nb) {
+        const int i = n_begin + t * BLOCK + threadIdx.x;
+        if (i >= n_end) continue;
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < nslot; s++) {
+            const int j = col[(size_t)s * nnode + i];
+            if (j < 0) continue;
+            double2 pj;
+            if (MODE == 1) {
+                const double2 zj = z[j], po = p[j];
+                pj.x = fma(beta, po.x, zj.x);
+                pj.y = fma(beta, po.y, zj.y);
+            } else {
+                pj = p[j];
+            }
+            const double v00 = val[((size_t)s * 4 + 0) * nnode + i];
+            const double v01 = val[((size_t)s * 4 + 1) * nnode + i];
+            const double v10 = val[((size_t)s * 4 + 2) * nnode + i];
+            const double v11 = val[((size_t)s * 4 + 3) * nnode + i];
+            qx = fma(v00, pj.x, fma(v01, pj.y, qx));
+            qy = fma(v10, pj.x, fma(v11, pj.y, qy));
+        }
+        q[i] = make_double2(qx, qy);
+        if (MODE == 1) {
+            const double2 zi = z[i], po = p[i];
+            double2 pn;
+            pn.x = fma(beta, po.x, zi.x);
+            pn.y = fma(beta, po.y, zi.y);
+            pnew[i] = pn;
+            acc_pq = fma(pn.x, qx, fma(pn.y, qy, acc_pq));
+        }
+    }
+    if (MODE == 1) {
+        const double t = block_sum(acc_pq, sh);
+        if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
+    }
+}
+
+// partial sums of p.q over all nodes (multi-GPU: after the all-reduce of q), and the p update for
+// nodes outside the rank's own SpMV range
+__global__ void __launch_bounds__(BLOCK)
+k_dot_pq(int nnode, const double2 *p, const double2 *q, double *part_pq, const CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    double acc = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 a = p[i], b = q[i];
+        acc = fma(a.x, b.x, fma(a.y, b.y, acc));
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
+}
+
+// p_new = z + beta p_old for nodes outside [n_begin, n_end) (multi-GPU only)
+__global__ void __launch_bounds__(BLOCK)
+k_p_update_outside(int nnode, int n_begin, int n_end, const double2 *p, const double2 *z,
+                   double2 *pnew, double2 *q, const double *part_rz_new, const double *part_rz_old,
+                   const double *part_rr, int npart_prev, const CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    const double rr = sum_partials(part_rr, npart_prev, sh);
+    if (rr <= sc->thresh2) return;
+    const double rzn = sum_partials(part_rz_new, npart_prev, sh);
+    const double rzo = sum_partials(part_rz_old, npart_prev, sh);
+    const double beta = rzn / rzo;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        if (i >= n_begin && i < n_end) continue;
+        const double2 zi = z[i], po = p[i];
+        pnew[i] = make_double2(fma(beta, po.x, zi.x), fma(beta, po.y, zi.y));
+        q[i] = make_double2(0., 0.);
+    }
+}
+
+// alpha = rz/pq;  x += alpha p;  r -= alpha q (free DOFs only);  z = dinv r;  partials r.z, r.r
+__global__ void __launch_bounds__(BLOCK)
+k_cg_update(int nnode, const double2 *p, const double2 *q, const double2 *dinv, double2 *x,
+            double2 *r, double2 *z, const double *part_pq, int npart_pq, const double *part_rz,
+            const double *part_rr_prev, int npart_prev, double *part_rz_out, double *part_rr_out,
+            const CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    // same decision as the k_spmv<1> of this iteration (it set sc->done only if rr <= thresh2,
+    // and that write is visible here because it happened in an earlier kernel)
+    const double pq = sum_partials(part_pq, npart_pq, sh);
+    const double rz = sum_partials(part_rz, npart_prev, sh);
+    (void)part_rr_prev;
+    const double alpha = rz / pq;
+    double a_rz = 0., a_rr = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 pi = p[i], qi = q[i], di = dinv[i];
+        double2 xi = x[i], ri = r[i], zi;
+        xi.x = fma(alpha, pi.x, xi.x);
+        xi.y = fma(alpha, pi.y, xi.y);
+        ri.x = (di.x != 0.) ? fma(-alpha, qi.x, ri.x) : 0.;
+        ri.y = (di.y != 0.) ? fma(-alpha, qi.y, ri.y) : 0.;
+        zi.x = di.x * ri.x;
+        zi.y = di.y * ri.y;
+        x[i] = xi;
+        r[i] = ri;
+        z[i] = zi;
+        a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
+        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+    }
+    const double t1 = block_sum(a_rz, sh);
+    const double t2 = block_sum(a_rr, sh);
+    if (threadIdx.x == 0) {
+        part_rz_out[blockIdx.x] = t1;
+        part_rr_out[blockIdx.x] = t2;
+    }
+}
+
+// r = mask (b - q), z = dinv r, partial r.z, r.r   (initial residual; q = K x0)
+__global__ void __launch_bounds__(BLOCK)
+k_cg_init(int nnode, const double2 *b, const double2 *q, const double2 *dinv, double2 *r, double2 *z,
+          double *part_rz_out, double *part_rr_out, double *part_bb_out)
+{
+    __shared__ double sh[BLOCK / 64];
+    double a_rz = 0., a_rr = 0., a_bb = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 bi = b[i], di = dinv[i];
+        double2 ri, zi;
+        const double2 qi = q ? q[i] : make_double2(0., 0.);
+        ri.x = (di.x != 0.) ? bi.x - qi.x : 0.;
+        ri.y = (di.y != 0.) ? bi.y - qi.y : 0.;
+        zi.x = di.x * ri.x;
+        zi.y = di.y * ri.y;
+        r[i] = ri;
+        z[i] = zi;
+        a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
+        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+        const double bx = (di.x != 0.) ? bi.x : 0., by = (di.y != 0.) ? bi.y : 0.;
+        a_bb = fma(bx, bx, fma(by, by, a_bb));
+    }
+    const double t1 = block_sum(a_rz, sh);
+    const double t2 = block_sum(a_rr, sh);
+    const double t3 = block_sum(a_bb, sh);
+    if (threadIdx.x == 0) {
+        part_rz_out[blockIdx.x] = t1;
+        part_rr_out[blockIdx.x] = t2;
+        part_bb_out[blockIdx.x] = t3;
+    }
+}
+
+// finalise set-up scalars on one block: thresh2 = rtol^2 * max(bb, tiny), reset flags
+__global__ void k_cg_setup(const double *part_bb, int npart, double rtol, CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    const double bb = sum_partials(part_bb, npart, sh);
+    if (threadIdx.x == 0) {
+        sc->thresh2 = rtol * rtol * bb;
+        sc->done = 0;
+        sc->iters = -1;
+        sc->rr_final = -1.;
+    }
+}
+
+// final rr for reporting when the iteration limit was hit
+__global__ void k_cg_final(const double *part_rr, int npart, CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    const double rr = sum_partials(part_rr, npart, sh);
+    if (threadIdx.x == 0 && !sc->done) sc->rr_final = rr;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_fill(double *a, size_t n, double v)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) a[i] = v;
+}
+
+// y[idx[k]] = v[k]
+__global__ void __launch_bounds__(BLOCK) k_scatter(int n, const int32_t *idx, const double *v, double *y)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) y[idx[k]] = v[k];
+}
+
+__global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, const double *y, double *v)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) v[k] = y[idx[k]];
+}
+
+// rhs = fext - K w (q holds K w);  dinv = free ? 1/|diag| : 0
+__global__ void __launch_bounds__(BLOCK)
+k_bc_finish(size_t ndof, const double *fext, const double *kw, const double *diag,
+            const double *is_presc, double *rhs, double *dinv)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        const bool free_dof = (is_presc[i] == 0.);
+        rhs[i] = free_dof ? (fext ? fext[i] : 0.) - kw[i] : 0.;
+        const double d = fabs(diag[i]);
+        dinv[i] = free_dof ? (d > 1e-300 ? 1. / d : 1.) : 0.;
+    }
+}
+
+// du = x (free) + du_presc (prescribed)
+__global__ void __launch_bounds__(BLOCK)
+k_compose_du(size_t ndof, const double *x, const double *dup, const double *is_presc, double *du)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
+        du[i] = (is_presc[i] != 0.) ? dup[i] : x[i];
+}
+
+// x0 = warm ? du on free DOFs : 0
+__global__ void __launch_bounds__(BLOCK)
+k_x0(size_t ndof, const double *du, const double *is_presc, int warm, double scale, double *x)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
+        x[i] = (warm && is_presc[i] == 0.) ? scale * du[i] : 0.;
+}
+
+// u += du ; f += q  (q = K du)     (model.py:1383-1384)
+__global__ void __launch_bounds__(BLOCK)
+k_axpy_uf(size_t ndof, const double *du, const double *q, double *u, double *f)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        u[i] += du[i];
+        f[i] += q[i];
+    }
+}
+
+// element state update at the end of a load step (model.py:1385-1392); u already updated
+__global__ void __launch_bounds__(BLOCK)
+k_update_state(const MatDev *gmat, const ClassDev *gcls, int nel, int e_off, const int32_t *conn,
+               const int32_t *cls, const double2 *du2, const double2 *u2, double *sig, double *epl,
+               double *eps, const double *elstiff, const double *res_sig, const double *res_depl,
+               int nonlin)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= nel) return;
+    const ClassDev &c = gcls[cls[e]];
+    const MatDev &m = gmat[c.mat];
+    const size_t ge = (size_t)e + e_off;
+    const int n0 = conn[ge * 4], n1 = conn[ge * 4 + 1], n2 = conn[ge * 4 + 2], n3 = conn[ge * 4 + 3];
+    if (m.kind != 0 && nonlin) {  // el.res_sig is set (model.py:1390-1391)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            epl[(size_t)k * nel + e] += res_depl[(size_t)k * nel + e];
+            sig[(size_t)k * nel + e] = res_sig[(size_t)k * nel + e];
+        }
+    } else {  // el.sig += elstiff @ deps ; depl = 0 for elastic materials (model.py:1387-1388)
+        double de[6], D[21], ds[6];
+        class_strain(c, du2, n0, n1, n2, n3, de);
+#pragma unroll
+        for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
+        symv(D, de, ds);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sig[(size_t)k * nel + e] += ds[k];
+    }
+    double et[6];
+    class_strain(c, u2, n0, n1, n2, n3, et);  // el.eps = el.eps_t() (model.py:1392)
+#pragma unroll
+    for (int k = 0; k < 6; k++) eps[(size_t)k * nel + e] = et[k];
+}
+
+// calc_global sums (model.py:1500-1507): partials of sum(x*Vel) for the 18 components
+__global__ void __launch_bounds__(BLOCK)
+k_global_partials(const ClassDev *gcls, int nel, const int32_t *cls, const double *sig,
+                  const double *eps, const double *epl, double *part /* [18][gridDim.x] */)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0.;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
+        const double v = gcls[cls[e]].vel;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            acc[k] = fma(sig[(size_t)k * nel + e], v, acc[k]);
+            acc[6 + k] = fma(eps[(size_t)k * nel + e], v, acc[6 + k]);
+            acc[12 + k] = fma(epl[(size_t)k * nel + e], v, acc[12 + k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        const double t = block_sum(acc[k], sh);
+        if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+__global__ void k_reduce_rows(const double *part, int nrows, int npart, double *out)
+{
+    __shared__ double sh[BLOCK / 64];
+    for (int k = 0; k < nrows; k++) {
+        const double t = sum_partials(part + (size_t)k * npart, npart, sh);
+        if (threadIdx.x == 0) out[k] = t;
+    }
+}
+
+// calc_scf per element (model.py:1036-1054): hh value and multiplicity (0, 1 or 2 appends)
+__global__ void __launch_bounds__(BLOCK)
+k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int lds_doubles, int nel,
+               int e_off, const int32_t *conn, const int32_t *cls, const double2 *du2,
+               const double *sig, const double *epl, const double *elstiff, const double *sld,
+               double *hh_out, int32_t *mult_out)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    int svc_mat;
+    const double *sv, *dual;
+    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    __syncthreads();
+    (void)ncls;
+    double ld[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ld[k] = sld[k];
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
+        const ClassDev &c = gcls[cls[e]];
+        const MatDev &m = smat[c.mat];
+        const size_t ge = (size_t)e + e_off;
+        double de[6], D[21], ds[6];
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], de);
+#pragma unroll
+        for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
+        symv(D, de, ds);
+        int mult = 0;
+        double hh = 0.;
+        if (m.kind != 0) {
+            const double sref = hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
+            if (sref > 0.1) {
+                double s[6], ep[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    s[k] = sig[(size_t)k * nel + e];
+                    ep[k] = epl[(size_t)k * nel + e];
+                }
+                double yf0;
+                if (m.kind == 3) {
+                    const bool st = (c.mat == svc_mat);
+                    YfSvc yf(m, st ? sv : m.sv, st ? dual : m.dual);
+                    yf0 = yf.plain(s, ep);  // branch test on the decision function (model.py:1046-1048)
+                    if (yf0 < SPLIT_THRESHOLD) {
+                        yf0 = yf.full_ld(s, ep, ld, nullptr);  // model.py:1049-1052
+                        hh = fmin(1., -yf0 / sref);
+                        mult = 2;  // appended twice (model.py:1054 and :1058)
+                    } else {
+                        hh = fmin(1., sqrt(1.5) * sflow_of(m, ep) / sref);
+                        mult = 1;
+                    }
+                } else {
+                    yf0 = hill_seq(m, s) - sflow_of(m, ep);
+                    if (yf0 < SPLIT_THRESHOLD) {
+                        hh = fmin(1., -yf0 / sref);
+                        mult = 2;
+                    } else {
+                        hh = fmin(1., sqrt(1.5) * sflow_of(m, ep) / sref);
+                        mult = 1;
+                    }
+                }
+            }
+        }
+        hh_out[e] = hh;
+        mult_out[e] = mult;
+    }
+}
+
+// pass 0: sum(mult*hh), min(hh | mult>0), count ; pass 1: sum(mult*(hh-mean)^2)
+__global__ void __launch_bounds__(BLOCK)
+k_scf_reduce(int nel, const double *hh, const int32_t *mult, double mean, int pass,
+             double *part /* [3][gridDim.x] */)
+{
+    __shared__ double sh[BLOCK / 64];
+    __shared__ double shmin[BLOCK / 64];
+    double s = 0., cnt = 0., mn = 1.e300;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
+        const int m = mult[e];
+        if (m == 0) continue;
+        const double h = hh[e];
+        if (pass == 0) {
+            s += m * h;
+            cnt += m;
+            mn = fmin(mn, h);
+        } else {
+            s += m * (h - mean) * (h - mean);
+        }
+    }
+    const double ts = block_sum(s, sh);
+    const double tc = block_sum(cnt, sh);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shmin[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = shmin[0];
+        for (int i = 1; i < BLOCK / 64; i++) t = fmin(t, shmin[i]);
+        part[blockIdx.x] = ts;
+        part[gridDim.x + blockIdx.x] = tc;
+        part[2 * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+}  // namespace plfx
