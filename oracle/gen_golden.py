@@ -351,6 +351,42 @@ class ResponseRecorder(object):
         mat.response = wrapped
 
 
+class SolveTracer(object):
+    """Captures every linear solve of Model.solve by patching numpy.linalg.solve and reading the
+    locals of the calling frame (calc_BC's ``ind`` list, the right-hand side, the BC increments and
+    the load-step / iteration counters live there, model.py:1290-1335)."""
+
+    def __init__(self):
+        self.rows = []
+        self.ind = None
+        self.du = []
+
+    def __enter__(self):
+        self._orig = np.linalg.solve
+
+        def traced(a, b):
+            x = self._orig(a, b)
+            fr = sys._getframe(1)
+            if fr.f_code.co_name == 'solve' and 'ind' in fr.f_locals:
+                L = fr.f_locals
+                if self.ind is None:
+                    self.ind = np.array(L['ind'], dtype=np.int64)
+                dbcr, dbct = L.get('dbcr'), L.get('dbct')
+                self.rows.append([L.get('il', -1), L.get('nit', -1), dbcr[0], dbcr[1], dbct[0], dbct[1],
+                                  float(np.linalg.norm(b)), float(np.sum(b)), float(np.linalg.norm(x)),
+                                  float(L.get('scale_bc', np.nan)) if 'scale_bc' in L else np.nan])
+            return x
+        np.linalg.solve = traced
+        return self
+
+    def __exit__(self, *a):
+        np.linalg.solve = self._orig
+
+    def store(self, rec, prefix):
+        rec[prefix + '_trace'] = np.array(self.rows, dtype=float)
+        rec[prefix + '_ind'] = self.ind
+
+
 def solve_record(fe, prefix, rec, tsolve=None):
     rec[prefix + '_u'] = np.array(fe.u)
     rec[prefix + '_f'] = np.array(fe.f)
@@ -400,8 +436,10 @@ def gen_solve():
         m.elasticity(E=200.e3, nu=0.3)
         fe = tension_model(m, 32, 0.001)
         t = time.time()
-        fe.solve()
+        with SolveTracer() as tr:
+            fe.solve()
         solve_record(fe, 'el32', rec, time.time() - t)
+        tr.store(rec, 'el32')
         print('el32', rec['el32_tsolve'], fe.glob['sig'][1])
 
         # 8x8 and 12x12 J2 / Hill uniaxial tension (homogeneous)
@@ -411,9 +449,11 @@ def gen_solve():
             rr = ResponseRecorder(mat)
             fe = tension_model(mat, n, eps)
             t = time.time()
-            fe.solve(min_step=ms)
+            with SolveTracer() as tr:
+                fe.solve(min_step=ms)
             dt = time.time() - t
             solve_record(fe, name, rec, dt)
+            tr.store(rec, name)
             rec[name + '_ncalls'] = np.array(rr.n)
             print(name, '%.1fs' % dt, fe.nsteps, fe.niter, rr.n, fe.sgl[-1][1])
 
@@ -432,9 +472,11 @@ def gen_solve():
             fe.mesh(elmts=inclusion_elmts(n), NX=n, NY=n)
             rr = ResponseRecorder(mat)
             t = time.time()
-            fe.solve(min_step=ms)
+            with SolveTracer() as tr:
+                fe.solve(min_step=ms)
             dt = time.time() - t
             solve_record(fe, name, rec, dt)
+            tr.store(rec, name)
             rec[name + '_ncalls'] = np.array(rr.n)
             print(name, '%.1fs' % dt, fe.nsteps, fe.niter, rr.n)
 
@@ -451,8 +493,10 @@ def gen_solve():
         fe.bcright(0., 'force')
         fe.bctop(0.1 * fe.leny, 'disp')
         fe.mesh(NX=16, NY=4)
-        fe.solve()
+        with SolveTracer() as tr:
+            fe.solve()
         solve_record(fe, 'lam16x4', rec)
+        tr.store(rec, 'lam16x4')
 
         # tests/test_basic.py:test_bcnode 18x18 inclusion, free sides, corner node fixed
         NX = NY = 18
@@ -472,8 +516,10 @@ def gen_solve():
         hh = [no in fe.nobot for no in fe.noleft]
         noc = np.nonzero(hh)[0]
         fe.bcnode(noc, 0., 'disp', 'x')
-        fe.solve()
+        with SolveTracer() as tr:
+            fe.solve()
         solve_record(fe, 'bcnode18', rec)
+        tr.store(rec, 'bcnode18')
         rec['bcnode18_noc'] = np.array(noc)
 
         # calc_properties harness (2x2 plane stress, 4 load cases) for the sdim=6 materials

@@ -1,0 +1,417 @@
+"""``Material`` façade: the reference's constitutive API for the hot path, evaluated by libplfx on
+the MI355X.
+
+Mirrors pylabfea.Material (reference /root/reference/src/pylabfea/material.py) for the methods on
+the path named by BASELINE.json: ``elasticity`` (:2401), ``plasticity`` (:2466), ``response`` (:207),
+``calc_yf`` (:348), ``ML_full_yf`` (:414), ``calc_seq`` (:576), ``calc_fgrad`` (:704), ``get_sflow``
+(:974), ``epl_dot`` (:1009), ``C_tan`` (:1057) and the test harness ``calc_properties`` (:3062).
+Same names, argument meaning and error behaviour; arguments are never mutated.
+
+Out of scope here: SVC *training*, data import, plotting, texture/work-hardening
+features.  A trained SVC enters through :meth:`Material.set_svc` / :meth:`Material.from_sklearn`.
+Not built yet: sdim=3 (principal-stress) flow rules, Tresca and Barlat equivalent stresses.
+"""
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .basic import eps_eq, sig_eq_j2, yf_tolerance
+
+_point_ctx = None      # shared context for point evaluations
+_point_key = None
+
+
+def _ctx():
+    global _point_ctx
+    if _point_ctx is None:
+        _point_ctx = _lib.Context(0)
+    return _point_ctx
+
+
+class Material(object):
+    """Material card: elastic constants, plastic parameters, optional trained SVC yield function.
+
+    Attributes follow the reference (``sy, khard, hill, drucker, E, nu, C11, C12, C44, CV, sdim,
+    ML_yf, dev_only, scale_seq, gam_yf, msg, prop, propJ2, sigeps`` ...).
+    """
+
+    def __init__(self, name='Material', num=1):
+        self.name = name
+        self.num = num
+        self.E = self.nu = self.CV = self.C11 = self.C12 = self.C44 = None
+        self.sy = None          # elasticity only unless sy is set (material.py:159)
+        self.sy0 = None
+        self.khard = None
+        self.drucker = None
+        self.lhs = None
+        self.hill = None
+        self.hill_3p = False
+        self.hill_6p = False
+        self.tresca = False
+        self.barlat = False
+        self.sdim = None
+        self.ML_yf = False
+        self.ML_grad = False
+        self.dev_only = False
+        self.scale_seq = None
+        self.gam_yf = None
+        self.C_yf = None
+        self.Ndof = 2
+        self.svc = None         # dict(sv, dual, intercept) of the trained SVC
+        self.msg = {'yield_fct': None, 'gradient': None, 'nsteps': 0, 'equiv': None}
+        lcs = ('stx', 'sty', 'et2', 'ect')
+        self.prop = {k: {'ys': None, 'seq': None, 'eeq': None, 'peeq': None, 'style': None, 'name': None}
+                     for k in lcs}
+        self.propJ2 = {k: {'ys': None, 'seq': None, 'eeq': None, 'peeq': None} for k in lcs}
+        self.sigeps = {k: {'sig': None, 'eps': None, 'epl': None} for k in lcs}
+        self._version = 0
+
+    # ------------------------------------------------------------------ definition
+    def elasticity(self, C11=None, C12=None, C44=None, CV=None, E=None, nu=None):
+        """Define elastic properties (material.py:2401-2464)."""
+        if E is not None:
+            if nu is None:
+                raise ValueError('Error: Inconsistent definition of material parameters: Only E provided')
+            if (C11 is not None) or (C12 is not None) or (C44 is not None):
+                raise ValueError('Error: Inconsistent definition of material parameters: E provided together with C_ij')
+            hh = E / ((1. + nu) * (1. - 2. * nu))
+            self.C11 = (1. - nu) * hh
+            self.C12 = nu * hh
+            self.C44 = (0.5 - nu) * hh
+            self.E = E
+            self.nu = nu
+        elif C11 is not None:
+            if nu is not None:
+                raise ValueError('Error: Inconsistent definition of material parameters: nu provided together with C_ij')
+            if (C12 is None) or (C44 is None):
+                raise ValueError('Error: Inconsistent definition of material parameters: C_12 or C_44 values missing')
+            self.C11, self.C12, self.C44 = C11, C12, C44
+            self.nu = C12 / (C11 + C12)
+            self.E = 2 * C44 * (1 + self.nu)
+        elif CV is not None:
+            self.CV = np.array(CV, dtype=float)
+            self.C11 = self.CV[0, 0]
+            self.C12 = self.CV[0, 1]
+            self.C44 = self.CV[3, 3]
+            self.nu = self.C12 / (self.C11 + self.C12)
+            self.E = 2 * self.C44 * (1 + self.nu)
+        else:
+            raise ValueError('elasticity: Inconsistent definition of material parameters')
+        if CV is None:
+            M = np.zeros((6, 6))
+            M[0, 0] = M[1, 1] = M[2, 2] = self.C11
+            M[0, 1] = M[0, 2] = M[1, 2] = self.C12
+            M[1, 0] = M[2, 0] = M[2, 1] = self.C12
+            M[3, 3] = M[4, 4] = M[5, 5] = self.C44
+            self.CV = M
+        self._version += 1
+
+    def plasticity(self, sy=None, sdim=6, drucker=0., khard=0., tresca=False, barlat=None,
+                   barlat_exp=None, hill=None, hill_3p=None, hill_6p=None, rv=None, lhs=None):
+        """Define plastic parameters (material.py:2466-2594)."""
+        if sy < 0.:
+            raise ValueError('Initial yield strength cannot be negative.')
+        if khard < 0.:
+            warnings.warn('Strain softening not supported. khard is set to 0.')
+            khard = 0.
+        if lhs is not None:
+            # the reference stores lhs but calc_seq evaluates `if self.lhs:` on the array
+            # (material.py:642), which raises for any 3-vector: the option cannot run there either
+            raise NotImplementedError('lhs (Liu-Huang-Stout asymmetry) is not supported')
+        if sdim != 3 and sdim != 6:
+            raise ValueError('{} in plasticity: sdim must be either 3 or 6'.format(self.name))
+        if sdim == 3:
+            raise NotImplementedError('sdim=3 (principal-stress flow rule) is not built yet in pylabfea_amd')
+        if tresca:
+            raise NotImplementedError('Tresca equivalent stress is not built yet in pylabfea_amd')
+        if barlat is not None:
+            raise NotImplementedError('Barlat Yld2004-18p is not built yet in pylabfea_amd '
+                                      '(the reference has no flow rule for it either, material.py:822)')
+        if self.sdim is not None and self.sdim != sdim:
+            print('plasticity: Parameter sdim is changed. New value:', sdim)
+        self.sdim = sdim
+        self.sy0 = sy
+        self.sy = sy
+        self.khard = khard
+        self.drucker = drucker
+        self.lhs = None
+        if hill is None and rv is None:
+            hill = np.ones(sdim)
+        elif hill is None:
+            hill = np.ones(sdim)
+            if len(rv) != sdim:
+                raise ValueError(f'plasticity: wrong dimension of yield stress ratios, must be {sdim}')
+            rinv = 1. / np.array(rv, dtype=float)
+            hill[0] = rinv[0] ** 2 + rinv[1] ** 2 - rinv[2] ** 2
+            hill[1] = rinv[1] ** 2 + rinv[2] ** 2 - rinv[0] ** 2
+            hill[2] = rinv[2] ** 2 + rinv[0] ** 2 - rinv[1] ** 2
+            hill[3] = rinv[3] ** 2
+            hill[4] = rinv[4] ** 2
+            hill[5] = rinv[5] ** 2
+        elif rv is not None:
+            warnings.warn('plasticity: Both, hill and rv, have been provided. Using Hill parameters.')
+        hill = list(hill)
+        lh = len(hill)
+        if hill_6p is None and hill_3p is None:
+            hill_6p = (lh == 6)
+            hill_3p = not hill_6p
+            if hill_3p and hill[0] == 1. and hill[1] == 1. and hill[2] == 1.:
+                hill_3p = False
+        if hill_6p and lh != 6:
+            raise ValueError('plasticity: When hill_6p is set True, 6 Hill parameters must be provided')
+        if hill_3p and lh != 3:
+            raise ValueError('plasticity: When hill_3p is set True, only 3 Hill parameters can be provided')
+        if hill_3p:  # sdim == 6 here
+            print('Material', self.name)
+            warnings.warn('plasticity: 3 Hill parameters are provided, but sdim=6; shear parameters set to 1')
+            hill_3p = False
+            hill_6p = True
+            hill.extend([1., 1., 1.])
+        if lh == 3 and len(hill) == 3:
+            hill.extend([1., 1., 1.])
+        self.hill_6p = bool(hill_6p)
+        self.hill_3p = bool(hill_3p)
+        self.hill = np.array(hill, dtype=float)
+        self.tresca = False
+        self.barlat = False
+        self._version += 1
+
+    def set_svc(self, support_vectors, dual_coef, intercept, gamma, scale_seq, dev_only=False, C=None):
+        """Install a trained RBF-SVC yield function (what ``train_SVC`` leaves in ``svm_yf``,
+        ``gam_yf`` and ``scale_seq``; material.py:398-405, 797-807).  ``dual_coef``/``intercept`` are
+        scikit-learn's public ``dual_coef_[0]`` / ``intercept_[0]``."""
+        if self.sy is None:
+            raise ValueError('set_svc: call elasticity() and plasticity(sy=..., sdim=6) first')
+        sv = np.ascontiguousarray(support_vectors, dtype=float)
+        if sv.ndim != 2 or sv.shape[1] != 6:
+            raise ValueError('set_svc: support vectors must have shape (nsv, 6) (sdim=6 features)')
+        dual = np.ascontiguousarray(dual_coef, dtype=float).reshape(-1)
+        if len(dual) != len(sv):
+            raise ValueError('set_svc: dual_coef and support_vectors differ in length')
+        self.svc = dict(sv=sv, dual=dual, intercept=float(intercept))
+        self.gam_yf = float(gamma)
+        self.C_yf = C
+        self.scale_seq = float(scale_seq)
+        self.dev_only = bool(dev_only)
+        self.ML_yf = True
+        self.Ndof = 6
+        if self.khard:
+            # calc_fgrad of an ML material resets self.khard to 0 on every call (material.py:812-814)
+            warnings.warn('set_svc: khard of an ML material is reset to 0 by the reference flow rule')
+            self.khard = 0.
+        self._version += 1
+
+    @classmethod
+    def from_sklearn(cls, svm, scale_seq, E, nu, sy, name='ML-material', dev_only=False):
+        """Build an ML material from a fitted ``sklearn.svm.SVC`` (RBF kernel, 6 stress features)."""
+        m = cls(name=name)
+        m.elasticity(E=E, nu=nu)
+        m.plasticity(sy=sy, sdim=6)
+        gamma = svm._gamma if hasattr(svm, '_gamma') else svm.gamma
+        m.set_svc(svm.support_vectors_, svm.dual_coef_[0, :], svm.intercept_[0], gamma, scale_seq,
+                  dev_only=dev_only, C=getattr(svm, 'C', None))
+        return m
+
+    # ------------------------------------------------------------------ records for libplfx
+    def _record(self, CV, ana=False):
+        """plfx_material record of this material with the element matrix CV."""
+        if self.sy is None:
+            return _lib.pack_material(_lib.ELASTIC, CV, E=self.E, nu=self.nu)
+        if self.ML_yf and not ana:
+            svc = dict(sv=self.svc['sv'], dual=self.svc['dual'], intercept=self.svc['intercept'],
+                       gamma=self.gam_yf, scale_seq=self.scale_seq, dev_only=self.dev_only)
+            return _lib.pack_material(_lib.SVC6, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
+                                      hill=self.hill, drucker=self.drucker, svc=svc)
+        return _lib.pack_material(_lib.HILL6, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
+                                  hill=self.hill, drucker=self.drucker)
+
+    def _load(self, CV=None, ana=False):
+        """Make this material (with element matrix CV) material 0 of the shared point context."""
+        global _point_key
+        cv = np.asarray(self.CV if CV is None else CV, dtype=float)
+        if cv.shape != (6, 6):
+            raise ValueError('CV must be a (6,6) array')
+        key = (id(self), self._version, bool(ana), cv.tobytes(), self.khard, self.sy)
+        ctx = _ctx()
+        if key != _point_key:
+            ctx.set_materials([self._record(cv, ana=ana)])
+            _point_key = key
+        return ctx
+
+    @staticmethod
+    def _voigt(sig, name):
+        """(3,),(6,),(N,3),(N,6) -> (N,6) Voigt (principal stresses padded with zero shear)."""
+        s = np.asarray(sig, dtype=float)
+        sh = s.shape
+        single = sh in ((3,), (6,))
+        if single:
+            s = s[None, :]
+        if s.ndim != 2 or s.shape[1] not in (3, 6):
+            raise TypeError('Unknown format of stress in %s' % name)
+        if s.shape[1] == 3:
+            s = np.concatenate((s, np.zeros((len(s), 3))), axis=1)
+        return np.ascontiguousarray(s), single
+
+    # ------------------------------------------------------------------ constitutive functions
+    def calc_seq(self, sig):
+        """Generalised (Hill/Drucker) equivalent stress (material.py:576-676)."""
+        s, single = self._voigt(sig, 'calc_seq')
+        if self.sy is None:
+            seq = sig_eq_j2(s)  # elastic material: J2 (material.py:637-640)
+        else:
+            seq = self._load(ana=True).seq(0, s)
+            self.msg['equiv'] = '6-parameter Hill, full Voigt stress'
+        return seq[0] if single else seq
+
+    def get_sflow(self, epl):
+        """Scalar flow stress for a plastic strain tensor or PEEQ (material.py:974-1007)."""
+        peeq = epl if type(epl) in (float, np.float64) else eps_eq(epl)
+        return self.sy + peeq * self.khard
+
+    def calc_yf(self, sig, epl=None, ana=False, pred=False, **kw):
+        """Yield function: analytic ``calc_seq - sflow`` or the SVC decision function (material.py:348-412)."""
+        s, single = self._voigt(sig, 'calc_yf')
+        if epl is None:
+            e = np.zeros((len(s), 6))
+        elif type(epl) in (float, np.float64):
+            e = np.tile(epl * np.array([1., -0.5, -0.5, 0., 0., 0.]), (len(s), 1))
+        else:
+            e = np.asarray(epl, dtype=float)
+            if e.ndim == 1:
+                e = np.tile(e, (len(s), 1))
+        if self.ML_yf and not ana:
+            f = self._load().yf(0, s, e)
+            if pred:
+                f = np.where(f > 0., 1., -1.)
+                self.msg['yield_fct'] = 'ML_yf-predict'
+            else:
+                self.msg['yield_fct'] = 'ML_yf-decision-fct'
+        else:
+            f = self._load(ana=True).yf(0, s, e)
+            self.msg['yield_fct'] = 'analytical'
+        return f[0] if single else f
+
+    def ML_full_yf(self, sig, epl=None, ld=None, verb=True, **kw):
+        """Distance of a stress to the ML yield locus along its ray / the loading direction
+        (material.py:414-516).  Accepts a single stress like the reference, or (N,6)."""
+        if not self.ML_yf:
+            raise AttributeError('ML_full_yf: material has no trained ML yield function')
+        s = np.asarray(sig, dtype=float)
+        if s.shape not in ((3,), (6,)) and not (s.ndim == 2 and s.shape[1] == 6):
+            raise ValueError('Only individual stress tensors supported in material.ML_full_yf. '
+                             'Shape of argument is {}'.format(s.shape))
+        s, single = self._voigt(s, 'ML_full_yf')
+        e = None
+        if epl is not None:
+            e = np.asarray(epl, dtype=float)
+            if e.ndim == 1:
+                e = np.tile(e, (len(s), 1))
+        f, st = self._load().full_yf(0, s, e, ld)
+        if verb and np.any(st != 0):
+            warnings.warn('ML_full_yf: Could not bracket / locate the yield locus for %d stress(es); '
+                          'conservative estimate seq-0.85*sflow returned' % int(np.sum(st != 0)))
+        return f[0] if single else f
+
+    def calc_fgrad(self, sig, epl=None, seq=None, ana=False, **kw):
+        """Gradient of the yield function w.r.t. stress (material.py:704-858)."""
+        s0 = np.asarray(sig, dtype=float)
+        if epl is not None and np.shape(epl) != s0.shape:
+            raise ValueError('Parameter sig and epl must have the same shape.')
+        if s0.shape not in ((6,),) and not (s0.ndim == 2 and s0.shape[1] == 6):
+            raise ValueError('Unknown format of stress in calc_fgrad')
+        s, single = self._voigt(s0, 'calc_fgrad')
+        if self.ML_yf and not ana:
+            a = self._load().fgrad(0, s)
+            self.khard = 0.  # side effect of the reference (material.py:812-814, no work-hardening data)
+            self.msg['gradient'] = 'gradient to ML_yf'
+        else:
+            a = self._load(ana=True).fgrad(0, s)
+            h = self.hill
+            self.msg['gradient'] = ('analytical, J2 isotropic, full stress' if np.all(h == 1.)
+                                    else 'analytical, 6-parameter Hill, full stress')
+        return a[0] if single else a
+
+    def response(self, sig, epl, deps, CV, maxit=50):
+        """Elastic-predictor / plastic-corrector update of one material point (material.py:207-346).
+        Returns ``fy1, sig, depl, grad_stiff``; ``msg['nsteps']`` is set as in the reference."""
+        sig = np.asarray(sig, dtype=float)
+        sh = sig.shape
+        if sh != (6,) and sh != (3,):
+            raise ValueError('Only individual stress tensors supported in material.response. '
+                             'Shape of argument is {}'.format(sh))
+        if sh == (3,):
+            raise NotImplementedError('response: principal-stress (sdim=3) states are not built yet')
+        if maxit != 50:
+            raise NotImplementedError('response: the device kernel is compiled for maxit=50 (reference default)')
+        if self.sy is None:
+            raise AttributeError('response called for a purely elastic material')
+        fy, so, dp, ct, ns = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
+                                                     np.asarray(deps, dtype=float)[None, :])
+        self.msg['nsteps'] = int(ns[0])
+        return fy[0], so[0], dp[0], ct[0].reshape(6, 6)
+
+    def response_batch(self, sig, epl, deps, CV):
+        """``response`` on (N,6) arrays in one launch (extension; same numbers point by point)."""
+        fy, so, dp, ct, ns = self._load(CV).response(sig, epl, deps)
+        return fy, so, dp, ct.reshape(-1, 6, 6), ns
+
+    def epl_dot(self, sig, epl, Cel, deps, **kw):
+        """Plastic strain increment relaxing the stress to the yield locus (material.py:1009-1055)."""
+        sig = np.asarray(sig, dtype=float)
+        Cel = np.asarray(Cel, dtype=float)
+        deps = np.asarray(deps, dtype=float)
+        yfun = self.calc_yf(sig + Cel @ deps, epl=epl)
+        if yfun <= yf_tolerance:
+            return np.zeros(6)
+        a = self.calc_fgrad(sig, epl=np.asarray(epl, dtype=float))
+        hh = a @ Cel @ a + self.khard
+        return (a @ Cel @ deps / hh) * a
+
+    def C_tan(self, sig, Cel, epl=None):
+        """Continuum tangent stiffness (material.py:1057-1086)."""
+        Cel = np.asarray(Cel, dtype=float)
+        a = self.calc_fgrad(np.asarray(sig, dtype=float))
+        ca = Cel @ a
+        return Cel - np.outer(ca, ca) / (a @ ca + self.khard)
+
+    # ------------------------------------------------------------------ harness
+    def calc_properties(self, size=2, Nel=2, verb=False, eps=0.005, min_step=None, sigeps=False,
+                        load_cases=['stx', 'sty', 'et2', 'ect']):
+        """Stress-strain curves of a 2x2 plane-stress model under four load cases
+        (material.py:3062-3166); the harness of the reference's plasticity tests."""
+        from .model import Model
+
+        def calc_strength(vbc1, nbc1, vbc2, nbc2, sel):
+            fe = Model(dim=2, planestress=True)
+            fe.geom([size], LY=size)
+            fe.assign([self])
+            fe.bcleft(0.)
+            fe.bcbot(0.)
+            fe.bcright(vbc1, nbc1)
+            fe.bctop(vbc2, nbc2)
+            fe.mesh(NX=Nel, NY=Nel)
+            fe.solve(verb=verb, min_step=min_step)
+            seq = self.calc_seq(fe.sgl)
+            eeq = eps_eq(fe.egl)
+            peeq = eps_eq(fe.epgl)
+            iys = np.nonzero(peeq < 1.e-2)
+            self.prop[sel].update(ys=seq[iys[0][-1]], seq=seq, eeq=eeq, peeq=peeq)
+            seq = sig_eq_j2(fe.sgl)
+            iys = np.nonzero(peeq < 1.e-6)
+            self.propJ2[sel].update(ys=seq[iys[0][-1]], seq=seq, eeq=eeq, peeq=peeq)
+            if sigeps:
+                self.sigeps[sel].update(sig=fe.sgl, eps=fe.egl, epl=fe.epgl)
+
+        cases = {'stx': (eps * size, 'disp', 0., 'force', '-r', 'uniax-x'),
+                 'sty': (0., 'force', eps * size, 'disp', '-b', 'uniax-y'),
+                 'et2': (0.4 * eps * size, 'disp', 0.4 * eps * size, 'disp', '-k', 'equibiax'),
+                 'ect': (-0.8 * eps * size, 'disp', 0.8 * eps * size, 'disp', '-m', 'shear')}
+        for case in load_cases:
+            if case not in cases:
+                warnings.warn('calc_properties: Load case not supported: {}'.format(case))
+                continue
+            v1, n1, v2, n2, style, label = cases[case]
+            calc_strength(v1, n1, v2, n2, case)
+            self.prop[case]['style'] = style
+            self.prop[case]['name'] = label

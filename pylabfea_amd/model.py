@@ -1,0 +1,761 @@
+"""``Model`` façade: the reference's FE-model API with the hot path running in libplfx on the MI355X.
+
+Mirrors pylabfea.Model (reference /root/reference/src/pylabfea/model.py) for 2-d models with linear
+Q4 elements: ``geom`` (:514), ``assign`` (:553), ``bcleft/bcright/bcbot/bctop/bcnode`` (:577-757),
+``mesh`` (:758), ``setupK`` (:954), ``solve`` (:979), ``bcval`` (:1452), ``calc_global`` (:1473) and
+the per-element results ``element[i].sig/eps/epl``.  Index generation (node numbering, connectivity,
+boundary sets, free-DOF list) is bit-identical to the reference; the load-step / K-iteration control
+flow of ``solve`` is restated here in Python and every O(Nel) / O(Ndof) operation is one C-ABI call:
+
+    assemble (setupK) -> apply_bc (calc_BC) -> solve (Kred + np.linalg.solve, here Jacobi-PCG on the
+    block-ELL matrix) -> sweep (Material.response per element + tangent refresh) -> update_state.
+
+Out of scope: 1-d models, quadratic elements (the reference raises NotImplementedError for 2-d
+quadratic, model.py:361), user-supplied node positions, plotting.
+"""
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .basic import eps_eq, sig_eq_j2, yf_tolerance
+
+
+class _ElementView(object):
+    """Read-only view of one element's results (``Model.element[i]``), backed by the arrays that
+    ``Model`` downloads from HBM after ``solve``."""
+
+    def __init__(self, model, i):
+        self.Model = model
+        self.index = i
+
+    @property
+    def nodes(self):
+        return [int(n) for n in self.Model._conn[self.index]]
+
+    @property
+    def Mat(self):
+        return self.Model.mat[self.Model._mat_id[self.index]]
+
+    @property
+    def Lelx(self):
+        return float(self.Model._lxy[self.index, 0])
+
+    @property
+    def Lely(self):
+        return float(self.Model._lxy[self.index, 1])
+
+    @property
+    def Vel(self):
+        return self.Lelx * self.Lely * self.Model.thick
+
+    @property
+    def Jac(self):
+        return 4. * self.Vel
+
+    @property
+    def CV(self):
+        return self.Model._element_CV(self.Mat)
+
+    @property
+    def sig(self):
+        return self.Model._state('sig')[self.index]
+
+    @property
+    def eps(self):
+        return self.Model._state('eps')[self.index]
+
+    @property
+    def epl(self):
+        return self.Model._state('epl')[self.index]
+
+    @property
+    def elstiff(self):
+        return self.Model._state('elstiff')[self.index].reshape(6, 6)
+
+    @property
+    def res_sig(self):
+        return self.Model._state('res_sig')[self.index]
+
+    @property
+    def res_depl(self):
+        return self.Model._state('res_depl')[self.index]
+
+    @property
+    def Bmat(self):
+        B = self.Model._engine.get_bmat(self.index)
+        return [B[g] for g in range(4)]
+
+    @property
+    def Kel(self):
+        return self.Model._engine.get_kel(self.index)
+
+    @property
+    def stat_nlin(self):
+        return {'max_iter': 0, 'max_steps': int(self.Model._state('max_steps')[self.index]), 'max_dstiff': None}
+
+    def node_num(self):
+        ind = []
+        for j in self.nodes:
+            ind.extend([2 * j, 2 * j + 1])
+        return ind
+
+    def eps_t(self):
+        return sum(B @ self.Model.u[self.node_num()] for B in self.Bmat)
+
+    def deps(self):
+        return sum(B @ self.Model.du[self.node_num()] for B in self.Bmat)
+
+    def dsig(self):
+        return self.elstiff @ self.deps()
+
+
+class _ElementList(object):
+    def __init__(self, model, n):
+        self._m = model
+        self._n = n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [_ElementView(self._m, k) for k in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError('element index out of range')
+        return _ElementView(self._m, i)
+
+    def __iter__(self):
+        for k in range(self._n):
+            yield _ElementView(self._m, k)
+
+
+class Model(object):
+    """Finite-element model (2-d, Q4) with the reference's attributes: ``dim, planestress, Nsec, LS,
+    lenx, leny, thick, nonlin, mat, Nnode, NnodeX, NnodeY, Nel, Ndof, npos, noleft, noright, nobot,
+    notop, noinner, element, u, f, du, sgl, egl, epgl, glob, nsteps, niter, co_nconv``.
+
+    Extra knobs (not in the reference): ``device`` (GPU ordinal), ``cg_rtol`` / ``cg_maxit`` for the
+    iterative solve that replaces the dense LU, ``solver_stats`` (PCG iterations of every solve).
+    """
+
+    def __init__(self, dim=1, planestress=False, device=0):
+        if dim not in (1, 2):
+            raise ValueError('dim must be either 1 or 2')
+        if dim == 1:
+            raise NotImplementedError('pylabfea_amd builds the 2-d Q4 path only (dim=2)')
+        self.dim = dim
+        self.planestress = planestress
+        self.device = device
+        self.bcl = np.zeros(dim)
+        self.bcb = np.zeros(dim)
+        self.bct = np.zeros(dim)
+        self.bcr = np.zeros(dim)
+        self.bcn = np.zeros(dim)
+        self.noset = None
+        self.ubctop = [False, False]
+        self.ubcright = [False, False]
+        self.ubcleft = [True, False]
+        self.ubcbot = [False, True]
+        self.ubcn = [False, False]
+        self.nonlin = False
+        self.sgl = np.zeros((1, 6))
+        self.egl = np.zeros((1, 6))
+        self.epgl = np.zeros((1, 6))
+        self.u = None
+        self.f = None
+        self.du = None
+        self.Nnode = None
+        self.glob = {'ebc1': None, 'ebc2': None, 'sbc1': None, 'sbc2': None,
+                     'eps': np.zeros(6), 'sig': np.zeros(6), 'epl': np.zeros(6)}
+        self.cg_rtol = 1.e-12
+        self.cg_maxit = 200000
+        self.solver_stats = []
+        self._engine = None
+        self._cache = {}
+        self._shard = None  # (rank, nranks, uid)
+
+    # ------------------------------------------------------------------ pre-processing
+    def geom(self, sect=1, LX=None, LY=1., LZ=1.):
+        """Geometry and sections (model.py:514-551)."""
+        if type(sect) == list:
+            self.Nsec = len(sect)
+            self.LS = np.array(sect)
+            self.lenx = sum(sect)
+        elif type(sect) == int:
+            if sect < 1:
+                raise ValueError('At least one section must be defined.')
+            if LX is None:
+                raise ValueError('LX must be given if sect is of type int')
+            self.lenx = LX
+            self.Nsec = sect
+            self.LS = np.ones(sect) * self.lenx / sect
+        else:
+            raise TypeError('Sect must be either list or int, not {}'.format(type(sect)))
+        self.leny = LY
+        self.thick = LZ
+
+    def assign(self, mats):
+        """Assign a material to each section (model.py:553-575)."""
+        if len(mats) != self.Nsec:
+            raise ValueError('Numer of materials ({}) does not match number of sections ({})'
+                             .format(len(mats), self.Nsec))
+        self.mat = mats
+        self.nonlin = False
+        for mat in mats:
+            if mat.sy is not None:
+                self.nonlin = True
+
+    @staticmethod
+    def _dir(bcdir, who):
+        if (isinstance(bcdir, str) and bcdir.lower() == 'x') or bcdir == 0:
+            return 0
+        if (isinstance(bcdir, str) and bcdir.lower() == 'y') or bcdir == 1:
+            return 1
+        raise ValueError('{}: Unknown value for direction: {}'.format(who, bcdir))
+
+    def bcleft(self, val=0., bctype='disp', bcdir='x'):
+        """BC on lhs nodes (model.py:577-611)."""
+        j = self._dir(bcdir, 'bcleft')
+        self.bcl[j] = val
+        if bctype.lower() == 'disp':
+            self.ubcleft[j] = True
+        elif bctype.lower() == 'force':
+            self.ubcleft[j] = False
+            if np.abs(val) > 1.e-6:
+                raise ValueError('Finite force values at left boundary not supported.')
+        else:
+            raise ValueError('bcleft: Unknown BC: %s' % bctype)
+
+    def bcright(self, val, bctype, bcdir='x'):
+        """BC on rhs nodes (model.py:613-645)."""
+        j = self._dir(bcdir, 'bcright')
+        self.bcr[j] = val
+        if bctype.lower() == 'disp':
+            self.ubcright[j] = True
+        elif bctype.lower() == 'force':
+            self.ubcright[j] = False
+        else:
+            raise TypeError('bcright: Unknown BC: {}'.format(bctype))
+
+    def bcbot(self, val=0., bctype='disp', bcdir='y'):
+        """BC on bottom nodes (model.py:647-683)."""
+        j = self._dir(bcdir, 'bcbot')
+        self.bcb[j] = val
+        if bctype.lower() == 'disp':
+            self.ubcbot[j] = True
+        elif bctype.lower() == 'force':
+            self.ubcbot[j] = False
+            if np.abs(val) > 1.e-6:
+                raise ValueError('Finite force values at bottom boundary not supported.')
+        else:
+            raise ValueError('bcbot: Unknown BC: {}'.format(bctype))
+
+    def bctop(self, val, bctype, bcdir='y'):
+        """BC on top nodes (model.py:685-717)."""
+        j = self._dir(bcdir, 'bctop')
+        self.bct[j] = val
+        if bctype.lower() == 'disp':
+            self.ubctop[j] = True
+        elif bctype.lower() == 'force':
+            self.ubctop[j] = False
+        else:
+            raise TypeError('bctop: Unknown BC: {}'.format(bctype))
+
+    def bcnode(self, node, val, bctype, bcdir):
+        """BC on a freely defined node set (model.py:719-757)."""
+        # the reference keeps `node` as given (int, list or 1-element array); normalise to ints
+        self.noset = [int(n) for n in np.ravel(node)]
+        j = self._dir(bcdir, 'bcnode')
+        self.bcn[j] = val
+        if bctype.lower() == 'disp':
+            self.ubcn[j] = True
+        elif bctype.lower() == 'force':
+            self.ubcn[j] = False
+        else:
+            raise TypeError('bcnode: Unknown BC: {}'.format(bctype))
+
+    def mesh(self, elmts=None, nodes=None, NX=10, NY=1, SF=1):
+        """Structured Q4 mesh (model.py:758-952): node ``j*NnodeY + k`` (x-index slow), element
+        ``j*NY + k``, connectivity ``[n1, n1+1, n1+NnodeY, n1+NnodeY+1]``; laminate sections or an
+        ``elmts`` material-id array.  All integer products equal the reference's bit for bit."""
+        if SF != 1:
+            raise NotImplementedError('Error: Quadrilateral elements with quadratic shape function not yet implemented')
+        if nodes is not None:
+            raise NotImplementedError('mesh: user-supplied node positions are not supported')
+        self.shapefact = SF
+        if elmts is not None:
+            el = np.array(elmts, dtype=int)
+            if len(el.shape) != self.dim:
+                raise ValueError('Cannot use a {}-shaped mesh with a {}-dimemsional model'.format(el.shape, self.dim))
+            NX, NY = el.shape
+        if NX < self.Nsec:
+            raise TypeError('Error: Number of elements is smaller than number of sections')
+        if self.u is not None:
+            warnings.warn('Warning: Solution of previous steps is deleted')
+            self.u = None
+            self.f = None
+        self.NnodeX = NX + 1
+        self.NnodeY = NY + 1
+        self.Nnode = self.NnodeX * self.NnodeY
+        self.Ndof = self.Nnode * 2
+        self.Nel = NX * NY
+        nrow = self.NnodeY
+        npos = np.zeros(self.Ndof)
+        jj, kk = np.meshgrid(np.arange(self.NnodeX), np.arange(nrow), indexing='ij')
+        inode = (jj * nrow + kk)
+        dy = self.leny / NY
+        npos[2 * inode.ravel() + 1] = (kk * dy).ravel()
+        if elmts is None:
+            # elements per section: proportional, the largest section absorbs the remainder (:826-830)
+            hh = self.LS / self.lenx
+            nes = [int(x) for x in np.round(hh * NX)]
+            if np.sum(nes) != NX:
+                im = np.argmax(self.LS)
+                nes[im] = nes[im] - np.sum(nes) + NX
+            xcol = np.zeros(self.NnodeX)
+            mat_col = np.zeros(NX, dtype=np.int64)
+            dx_col = np.zeros(NX)
+            c0 = 0
+            for i in range(self.Nsec):
+                dx = self.LS[i] / nes[i]
+                j0 = 0 if i == 0 else 1
+                jl = np.arange(j0, nes[i] + 1)
+                # x-position uses the section's own dx times the global column index (:847)
+                xcol[c0 + jl] = (jl + c0) * dx
+                mat_col[c0:c0 + nes[i]] = i
+                dx_col[c0:c0 + nes[i]] = dx
+                c0 += nes[i]
+            npos[2 * inode.ravel()] = np.repeat(xcol, nrow)
+            mat_id = np.repeat(mat_col, NY)
+            lxy = np.stack((np.repeat(dx_col, NY), np.full(self.Nel, dy)), axis=1)
+        else:
+            dx = self.lenx / NX
+            npos[2 * inode.ravel()] = (jj * dx).ravel()
+            mat_id = (el - 1).ravel().astype(np.int64)
+            if mat_id.min() < 0 or mat_id.max() >= len(self.mat):
+                raise IndexError('mesh: material number in elmts out of range')
+            lxy = np.stack((np.full(self.Nel, dx), np.full(self.Nel, dy)), axis=1)
+        self.npos = npos
+        # boundary node lists in the reference's append order (:897-911): j outer, k inner
+        self.noleft = [int(n) for n in inode[0, :]]
+        self.noright = [int(n) for n in inode[-1, :]]
+        self.nobot = [int(n) for n in inode[:, 0]]
+        self.notop = [int(n) for n in inode[:, -1]]
+        self.noinner = [int(n) for n in inode[1:-1, 1:-1].ravel()]
+        ih = np.arange(self.Nel)
+        n1 = (ih // NY) * nrow + ih % NY
+        self._conn = np.stack((n1, n1 + 1, n1 + nrow, n1 + nrow + 1), axis=1).astype(np.int64)
+        self._mat_id = mat_id
+        self._lxy = lxy
+        self._NX, self._NY = NX, NY
+        self.element = _ElementList(self, self.Nel)
+        self._drop_engine()
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _drop_engine(self):
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+        self._cache = {}
+
+    def _element_CV(self, mat):
+        """Element elastic matrix (Element.__init__, model.py:272-303)."""
+        if self.planestress:
+            hh = mat.E / (1 - mat.nu * mat.nu)
+            C12 = mat.nu * hh
+            C11 = hh
+            return np.array([[C11, C12, 0., 0., 0., 0.],
+                             [C12, C11, 0., 0., 0., 0.],
+                             [0., 0., 0., 0., 0., 0.],
+                             [0., 0., 0., 0., 0., 0.],
+                             [0., 0., 0., 0., 0., 0.],
+                             [0., 0., 0., 0., 0., mat.C44]])
+        return np.array(mat.CV, dtype=float)
+
+    def distribute(self, rank, nranks, uid):
+        """Shard the elements into ``nranks`` x-strips (contiguous element-column blocks); this
+        process owns strip ``rank`` on GPU ``self.device``.  ``uid`` is the RCCL unique id created on
+        rank 0 (``_lib.Context.comm_unique_id``) and broadcast by the caller."""
+        self._shard = (int(rank), int(nranks), uid)
+        self._drop_engine()
+
+    def strip_range(self, rank, nranks):
+        """Owned element range of x-strip ``rank``: whole element columns, balanced."""
+        NX, NY = self._NX, self._NY
+        c0 = (NX * rank) // nranks
+        c1 = (NX * (rank + 1)) // nranks
+        return c0 * NY, c1 * NY
+
+    def _ensure_engine(self):
+        vers = tuple(m._version for m in self.mat)
+        if self._engine is not None and self._mat_versions == vers:
+            return self._engine
+        if self._engine is not None and self.u is not None:
+            raise RuntimeError('materials were modified after the model was solved; call mesh() again')
+        self._drop_engine()
+        eng = _lib.Context(self.device)
+        eng.set_materials([m._record(self._element_CV(m)) for m in self.mat])
+        e0, e1 = 0, self.Nel
+        if self._shard is not None:
+            rank, nranks, uid = self._shard
+            eng.comm_init(uid, rank, nranks)
+            e0, e1 = self.strip_range(rank, nranks)
+        eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+        self._e0, self._e1 = e0, e1
+        self._engine = eng
+        self._mat_versions = vers
+        plastic = any(m.sy is not None for m in self.mat)
+        if plastic != self.nonlin:
+            raise RuntimeError('plasticity of a material changed after assign(); call assign() again')
+        return eng
+
+    def _state(self, name):
+        """Element results downloaded from HBM on first access after a solve."""
+        if name not in self._cache:
+            ids = {'sig': _lib.ST_SIG, 'eps': _lib.ST_EPS, 'epl': _lib.ST_EPL, 'elstiff': _lib.ST_ELSTIFF,
+                   'res_sig': _lib.ST_RES_SIG, 'res_depl': _lib.ST_RES_DEPL, 'max_steps': _lib.ST_MAXSTEPS,
+                   'fyn': _lib.ST_FYN}
+            a = self._ensure_engine().state_get(ids[name])
+            if self._shard is not None:  # place the owned strip into a full-size array
+                full = np.zeros((self.Nel,) + a.shape[1:])
+                full[self._e0:self._e1] = a
+                a = full
+            self._cache[name] = a
+        return self._cache[name]
+
+    # ------------------------------------------------------------------ assembly
+    def setupK(self):
+        """Assemble the system stiffness matrix (model.py:954-977).  Returned as a
+        ``scipy.sparse.csr_matrix`` (the reference returns the same matrix as a dense array)."""
+        eng = self._ensure_engine()
+        eng.assemble()
+        return eng.get_csr()
+
+    # ------------------------------------------------------------------ boundary conditions
+    def _bc_data(self, bcl0, bcb0, dbcr, dbct, dbcn):
+        """calc_BC (model.py:1070-1206) as data: prescribed DOFs (in order of first application),
+        value written to du, multiplicity-weighted value for the right-hand side, external forces."""
+        nd = self.Ndof
+        first = np.full(nd, np.nan)
+        w = np.zeros(nd)
+        fext = np.zeros(nd)
+        any_force = False
+
+        def disp(nodes, k, val, who):
+            idx = 2 * np.asarray(nodes, dtype=np.int64) + k
+            new = np.isnan(first[idx])
+            if not np.all(new):
+                old = first[idx[~new]]
+                if np.any(old != val):
+                    warnings.warn('Inconsistent BC at {} nodes ({} vs {}).'.format(who, old[old != val][0], val))
+            first[idx[new]] = val
+            w[idx] += val  # a DOF shared by two edges enters the rhs twice (:1115-1122, 1163-1170)
+
+        for k in range(2):
+            if self.ubcleft[k]:
+                disp(self.noleft, k, bcl0[k], 'left')
+        for k in range(2):
+            if self.ubcbot[k]:
+                disp(self.nobot, k, bcb0[k], 'bottom')
+        for k in range(2):
+            if self.ubcright[k]:
+                disp(self.noright, k, dbcr[k], 'right')
+            else:
+                nodes = np.asarray(self.noright, dtype=np.int64)
+                hh = np.full(len(nodes), 1. / (self.NnodeY - 1))
+                hy = self.npos[2 * nodes + 1]
+                hh[(hy < 1.e-3) | (hy > self.leny - 1.e-3)] *= 0.5
+                fext[2 * nodes + k] += dbcr[k] * hh
+                any_force = any_force or dbcr[k] != 0.
+        for k in range(2):
+            if self.ubctop[k]:
+                disp(self.notop, k, dbct[k], 'top')
+            else:
+                nodes = np.asarray(self.notop, dtype=np.int64)
+                hh = np.full(len(nodes), 1. / (self.NnodeX - 1))
+                hx = self.npos[2 * nodes]
+                hh[(hx < 1.e-3) | (hx > self.lenx - 1.e-3)] *= 0.5
+                fext[2 * nodes + k] += dbct[k] * hh
+                any_force = any_force or dbct[k] != 0.
+        if self.noset is not None:
+            if dbcn is None:
+                raise ValueError('No BC for selected node set given.')
+            for k in range(2):
+                if self.ubcn[k]:
+                    disp(self.noset, k, dbcn[k], 'node set')
+                else:
+                    for j in self.noset:
+                        fext[2 * int(j) + k] += dbcn[k]
+                    any_force = any_force or dbcn[k] != 0.
+        presc = np.nonzero(~np.isnan(first))[0]
+        return presc, first[presc], w[presc], (fext if any_force else None)
+
+    def free_dofs(self):
+        """The reference's ``ind`` list (ascending free DOFs) for the current BC flags."""
+        z = np.zeros(2)
+        presc = self._bc_data(z, z, z, z, z if self.noset is not None else None)[0]
+        mask = np.ones(self.Ndof, dtype=bool)
+        mask[presc] = False
+        return np.nonzero(mask)[0]
+
+    def _solve_lin(self, eng, bc, warm):
+        eng.apply_bc(*bc)
+        it, rr, ok = eng.solve(self.cg_rtol, self.cg_maxit, warm)
+        self.solver_stats.append((it, rr))
+        if not ok:
+            warnings.warn('PCG reached the iteration limit (relres={:.2e})'.format(rr))
+
+    def _calc_scf(self, eng, sld):
+        """Load-step scaling factor (model.py:1036-1067) from per-element values reduced on the GPU."""
+        cnt, mn, s = eng.scf_stats(sld)
+        if self._shard is not None:
+            cnt, mn, s = self._allreduce_scf(cnt, mn, s)
+        if cnt == 0:
+            return 1.
+        mean = s / cnt
+        s2 = eng.scf_sumsq(mean)
+        if self._shard is not None:
+            s2 = self._allreduce_sum(s2)
+        std = np.sqrt(s2 / cnt)
+        if std < 0.1:
+            scf = mn
+        else:
+            scf = np.maximum(1.e-3, mean - std)
+        if scf < 1.e-3:
+            scf = 1.e-3
+        return float(scf)
+
+    # collectives of the host-side scalars (only in sharded runs; torch.distributed is the plumbing)
+    def _allreduce_sum(self, x):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        if dist.get_backend() == 'nccl':
+            t = t.cuda(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        r = t.cpu().numpy()
+        return r if np.ndim(x) else float(r[0])
+
+    def _allreduce_scf(self, cnt, mn, s):
+        import torch
+        import torch.distributed as dist
+        r = self._allreduce_sum(np.array([cnt, s], dtype=np.float64))
+        t = torch.tensor([mn], dtype=torch.float64)
+        if dist.get_backend() == 'nccl':
+            t = t.cuda(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(round(r[0])), float(t.cpu()[0]), float(r[1])
+
+    def _allreduce_flags(self, change, conv):
+        r = self._allreduce_sum(np.array([float(change), float(not conv)]))
+        return r[0] > 0., not (r[1] > 0.)
+
+    # ------------------------------------------------------------------ solution
+    def solve(self, min_step=None, verb=False):
+        """Solve the (non-linear) boundary-value problem (model.py:979-1450).
+
+        Same load-step control as the reference: elastic predictor, load-step scaling ``calc_scf``
+        (first 10 steps), up to 16 stiffness iterations with halving of the increment (first 6 steps),
+        state update, homogenisation.  Results: ``u, f, sgl, egl, epgl, glob, nsteps, niter,
+        co_nconv`` and ``element[i].sig/eps/epl``."""
+        if self.Nnode is None:
+            raise AttributeError('Attributes for mesh not set, but required by solver.')
+        eng = self._ensure_engine()
+        self._cache = {}
+        dim = 2
+        if self.u is None:
+            eng.state_reset()
+            self.sgl = np.zeros((1, 6))
+            self.egl = np.zeros((1, 6))
+            self.epgl = np.zeros((1, 6))
+            bcr0 = np.zeros(dim)
+            bct0 = np.zeros(dim)
+            self.bct_mem = np.zeros(dim)
+            self.bcr_mem = np.zeros(dim)
+            if self.noset is not None:
+                bcn0 = np.zeros(dim)
+                self.bcn_mem = np.zeros(dim)
+            first_call = True
+        else:  # resume from the previous solution (model.py:1235-1239)
+            bcr0 = self.bcr_mem
+            bct0 = self.bct_mem
+            if self.noset is not None:
+                bcn0 = self.bcn_mem
+            first_call = False
+        bcl0 = self.bcl
+        bcb0 = self.bcb
+        eng.assemble()
+        # loading direction for the ML yield-point search (model.py:1245-1258)
+        sld = np.zeros(6)
+        if np.abs(self.bcr[0]) > 1.e-6:
+            sld[0] = np.sign(self.bcr[0])
+        if np.abs(self.bct[1]) > 1.e-6:
+            sld[1] = np.sign(self.bct[1])
+        if np.abs(self.bcr[1]) > 1.e-6:
+            sld[5] = np.sign(self.bcr[1])
+        if np.abs(self.bct[0]) > 1.e-6:
+            sld[5] = np.sign(self.bct[0])
+        if np.linalg.norm(sld) < 1.e-3:
+            warnings.warn('solve: inconsistent BC sld={}, bct={}, bcr={}'.format(sld, self.bct, self.bcr))
+            sld[0] = 1.
+        il = 0
+        nit = 0
+        niter = []
+        co_nconv = []
+        bc_inc = True
+        nconv = 0
+        warm = not first_call
+        dbcn = None
+        while bc_inc:
+            max_dbct = self.bct - bct0
+            max_dbcr = self.bcr - bcr0
+            if min_step is not None:
+                sc = np.maximum(1, min_step - il)
+                max_dbct /= sc
+                max_dbcr /= sc
+            dbcr = max_dbcr
+            dbct = max_dbct
+            if self.noset is not None:
+                max_dbcn = self.bcn - bcn0
+                if min_step is not None:
+                    max_dbcn /= np.maximum(1, min_step - il)
+                dbcn = max_dbcn  # alias, exactly as in the reference (model.py:1285)
+            # elastic predictor with the stiffness of the previous step (model.py:1290-1291)
+            self._solve_lin(eng, self._bc_data(bcl0, bcb0, dbcr, dbct, dbcn), warm)
+            warm = True
+            if self.nonlin:
+                scale_bc = self._calc_scf(eng, sld) if il < 10 else 1.
+                dbcr = max_dbcr * scale_bc
+                dbct = max_dbct * scale_bc
+                nit = 0
+                change = True
+                conv = False
+                if verb:
+                    print('***Load step #', il)
+                    print('scaling factor', scale_bc)
+                while (change or not conv) and nit <= 15:
+                    if il < 6 and nit > 1:
+                        # reduce the load increment to reach convergence (model.py:1308-1330)
+                        hs = 0.5
+                        for k in range(dim):
+                            for (mx, tot, cur0, d) in ((max_dbcr, self.bcr, bcr0, dbcr),
+                                                       (max_dbct, self.bct, bct0, dbct)):
+                                if mx[k] >= 0:
+                                    hh = np.minimum(tot[k] - cur0[k], d[k] * hs)
+                                    d[k] = np.maximum(0.05 * mx[k], hh)
+                                else:
+                                    hh = np.maximum(tot[k] - cur0[k], d[k] * hs)
+                                    d[k] = np.minimum(0.05 * mx[k], hh)
+                            if self.noset is not None:
+                                if max_dbcn[k] >= 0:
+                                    hh = np.minimum(self.bcn[k] - bcn0[k], dbcn[k] * hs)
+                                    dbcn[k] = np.maximum(0.05 * max_dbcn[k], hh)
+                                else:
+                                    hh = np.maximum(self.bcn[k] - bcn0[k], dbcn[k] * hs)
+                                    dbcn[k] = np.minimum(0.05 * max_dbcn[k], hh)
+                    eng.assemble()  # updated tangent stiffness (model.py:1333)
+                    self._solve_lin(eng, self._bc_data(bcl0, bcb0, dbcr, dbct, dbcn), True)
+                    change, conv = eng.sweep(nit)  # material response of every element (model.py:1340-1361)
+                    if self._shard is not None:
+                        change, conv = self._allreduce_flags(change, conv)
+                    if verb:
+                        if not conv:
+                            print('\n  ###  Warning: No convergence of plasticity algorithm in trial step #', nit)
+                        print('+++Inner trial step #', nit)
+                        print('load increment right:', dbcr)
+                        print('load increment top:', dbct)
+                        if self.noset is not None:
+                            print('load increment set:', dbcn)
+                    if not conv:
+                        nconv += 1
+                    nit += 1
+            # update internal variables with the results of the load step (model.py:1383-1392)
+            eng.update_state()
+            il += 1
+            niter.append(nit - 1)
+            co_nconv.append(nconv)
+            bcr0 += dbcr
+            hl0 = np.abs(bcr0[0] - self.bcr[0]) > 1.e-6 and np.abs(self.bcr[0]) > 1.e-9
+            hl1 = np.abs(bcr0[1] - self.bcr[1]) > 1.e-6 and np.abs(self.bcr[1]) > 1.e-9
+            bct0 += dbct
+            hr0 = np.abs(bct0[0] - self.bct[0]) > 1.e-6 and np.abs(self.bct[0]) > 1.e-9
+            hr1 = np.abs(bct0[1] - self.bct[1]) > 1.e-6 and np.abs(self.bct[1]) > 1.e-9
+            if self.noset is not None:
+                bcn0 += dbcn
+                hr0 = hr0 or (np.abs(bcn0[0] - self.bcn[0]) > 1.e-6 and np.abs(self.bcn[0]) > 1.e-9)
+                hr1 = hr1 or (np.abs(bcn0[1] - self.bcn[1]) > 1.e-6 and np.abs(self.bcn[1]) > 1.e-9)
+            bc_inc = bool(hr0 or hr1 or hl0 or hl1)
+            self._calc_global_device(eng)
+            self.sgl = np.append(self.sgl, [self.glob['sig']], axis=0)
+            self.egl = np.append(self.egl, [self.glob['eps']], axis=0)
+            self.epgl = np.append(self.epgl, [self.glob['epl']], axis=0)
+            if verb:
+                print('Iteration step #', nit)
+                print('Load increment ', il, 'total', self.ubctop, 'top ', bct0, '/', self.bct, '; last step ', dbct)
+                print('Load increment ', il, 'total', self.ubcright, 'rhs', bcr0, '/', self.bcr, '; last step ', dbcr)
+                print('Global strain: ', np.around(self.glob['eps'], decimals=5))
+                print('Global stress: ', np.around(self.glob['sig'], decimals=3))
+                print('Global plastic strain: ', np.around(self.glob['epl'], decimals=6))
+                print('----------------------------')
+        self.bct_mem = bct0
+        self.bcr_mem = bcr0
+        if self.noset is not None:
+            self.bcn_mem = bcn0
+        self.nsteps = il
+        self.niter = niter
+        self.co_nconv = co_nconv
+        self.u = eng.state_get(_lib.ST_U)
+        self.f = eng.state_get(_lib.ST_F)
+        self.du = eng.state_get(_lib.ST_DU)
+        self._cache = {}
+
+    # ------------------------------------------------------------------ homogenisation
+    def bcval(self, nodes):
+        """Average displacement and total force at a node set (model.py:1452-1471)."""
+        idx = 2 * np.asarray(nodes, dtype=np.int64)
+        n = len(idx)
+        return (np.sum(self.u[idx]) / n, np.sum(self.u[idx + 1]) / n, np.sum(self.f[idx]), np.sum(self.f[idx + 1]))
+
+    def _glob_from(self, bv, sums):
+        (uxl, uyl, fxl, fyl), (uxr, uyr, fxr, fyr), (uxb, uyb, fxb, fyb), (uxt, uyt, fxt, fyt) = bv
+        g = self.glob
+        g['ebc1'] = (uxr - uxl) / self.lenx
+        g['sbc1'] = 0.5 * (fxr - fxl) / (self.leny * self.thick)
+        g['ebc21'] = (uyr - uyl) / self.lenx
+        g['sbc21'] = 0.5 * (fyr - fyl) / (self.leny * self.thick)
+        g['ebc2'] = (uyt - uyb) / self.leny
+        g['sbc2'] = 0.5 * (fyt - fyb) / (self.lenx * self.thick)
+        g['ebc12'] = (uxt - uxb) / self.leny
+        g['sbc12'] = 0.5 * (fxt - fxb) / (self.lenx * self.thick)
+        Vm = self.lenx * self.leny * self.thick
+        g['sig'] = sums[0] / Vm
+        g['eps'] = sums[1] / Vm
+        g['epl'] = sums[2] / Vm
+
+    def _calc_global_device(self, eng):
+        """calc_global during solve: boundary DOFs gathered from HBM, element sums reduced on the GPU."""
+        bv = []
+        for nodes in (self.noleft, self.noright, self.nobot, self.notop):
+            idx = 2 * np.asarray(nodes, dtype=np.int64)
+            n = len(idx)
+            both = np.concatenate((idx, idx + 1))
+            uu = eng.gather(_lib.ST_U, both)
+            ff = eng.gather(_lib.ST_F, both)
+            bv.append((np.sum(uu[:n]) / n, np.sum(uu[n:]) / n, np.sum(ff[:n]), np.sum(ff[n:])))
+        sums = eng.global_sums()
+        if self._shard is not None:
+            sums = self._allreduce_sum(sums.ravel()).reshape(3, 6)
+        self._glob_from(bv, sums)
+
+    def calc_global(self):
+        """Global quantities from boundary nodes and element averages (model.py:1473-1511)."""
+        eng = self._ensure_engine()
+        self._calc_global_device(eng)
+
+    def plot(self, *args, **kw):
+        raise NotImplementedError('plotting is out of scope of pylabfea_amd (SURVEY.md §2); '
+                                  'use the reference package on the arrays u, npos, element[i].sig')

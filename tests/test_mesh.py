@@ -1,0 +1,122 @@
+"""Index generation of the façade (Model.mesh) against the reference's products — bit-exact for
+node numbering, connectivity, boundary sets and material ids; exact for node positions."""
+import os
+
+import numpy as np
+import pytest
+
+import pylabfea_amd as FE
+
+
+def build(name, z):
+    ma = FE.Material(num=1)
+    ma.elasticity(E=100.e3, nu=0.35)
+    mb = FE.Material(num=2)
+    mb.elasticity(E=300.e3, nu=0.3)
+    if name.startswith('sq'):
+        n = int(name[2:])
+        fe = FE.Model(dim=2)
+        fe.geom([4.], LY=4.)
+        fe.assign([ma])
+        fe.mesh(NX=n, NY=n)
+    elif name == 'lam16x4':
+        fe = FE.Model(dim=2, planestress=True)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([ma, mb, ma, mb, ma])
+        fe.mesh(NX=16, NY=4)
+    elif name == 'lam13x3':
+        fe = FE.Model(dim=2)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([ma, mb, ma, mb, ma])
+        fe.mesh(NX=13, NY=3)
+    elif name == 'lam4x4':
+        fe = FE.Model(dim=2)
+        fe.geom([2., 2.], LY=4.)
+        fe.assign([ma, mb])
+        fe.mesh(NX=4, NY=4)
+    elif name == 'incl18':
+        fe = FE.Model(dim=2)
+        fe.geom(sect=2, LX=4., LY=4.)
+        fe.assign([ma, mb])
+        fe.mesh(elmts=z['inclusion_elmts'], NX=18, NY=18)
+    return fe
+
+
+@pytest.mark.parametrize('name', ['sq4', 'sq18', 'sq32', 'lam16x4', 'lam13x3', 'lam4x4', 'incl18'])
+def test_mesh_products(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, 'mesh.npz'))
+    fe = build(name, z)
+    g = lambda k: z['%s_%s' % (name, k)]
+    assert np.array_equal(np.array([fe.NnodeX, fe.NnodeY, fe.Nnode, fe.Nel, fe.Ndof]), g('dims'))
+    assert np.array_equal(fe._conn, g('conn'))
+    # the fixture identifies materials by object (a material may serve several sections)
+    last = {id(m): i for i, m in enumerate(fe.mat)}
+    assert np.array_equal(np.array([last[id(fe.mat[k])] for k in fe._mat_id]), g('mat_id'))
+    for k in ('noleft', 'noright', 'nobot', 'notop', 'noinner'):
+        assert np.array_equal(np.array(getattr(fe, k), dtype=np.int64), g(k)), k
+    assert np.array_equal(fe.npos, g('npos'))          # exact floats
+    assert np.array_equal(fe._lxy, g('lxy'))
+    assert fe.element[3].nodes == list(g('conn')[3])
+
+
+def test_api_errors():
+    with pytest.raises(ValueError):
+        FE.Model(dim=3)
+    fe = FE.Model(dim=2)
+    with pytest.raises(AttributeError):
+        fe.solve()
+    with pytest.raises(ValueError):
+        fe.geom(sect=0, LX=1.)
+    fe.geom([1., 1.], LY=1.)
+    m = FE.Material()
+    with pytest.raises(ValueError):
+        m.elasticity(E=1.)
+    m.elasticity(E=100.e3, nu=0.35)
+    assert abs(m.C11 - 160493.8271604938) < 1e-5      # reference tests/test_basic.py:test_material
+    assert abs(m.C12 - 86419.75308641973) < 1e-5
+    assert abs(m.C44 - 37037.03703703704) < 1e-5
+    with pytest.raises(ValueError):
+        fe.assign([m])
+    with pytest.raises(ValueError):
+        m.plasticity(sy=-1.)
+    with pytest.raises(ValueError):
+        fe.bcleft(1., 'force')
+    with pytest.raises(TypeError):
+        fe.bcright(0., 'bogus')
+
+
+def test_free_dofs_match_reference_ind(golden_dir):
+    """calc_BC's free-DOF list `ind` (captured from the reference's solve frame)."""
+    z = np.load(os.path.join(golden_dir, 'solve.npz'))
+    if 'el32_ind' not in z:
+        pytest.skip('fixture without traces')
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    fe = FE.Model(dim=2)
+    fe.geom([4.], LY=4.)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.001 * fe.leny, 'disp')
+    fe.mesh(NX=32, NY=32)
+    assert np.array_equal(fe.free_dofs(), z['el32_ind'])
+    # test_bcnode configuration: free sides, corner node fixed in x
+    ma = FE.Material(num=1)
+    ma.elasticity(E=100.e3, nu=0.27)
+    mb = FE.Material(num=2)
+    mb.elasticity(E=3.e3, nu=0.3)
+    el = np.ones((18, 18))
+    el[6:12, 6:12] = 2
+    fe = FE.Model(dim=2)
+    fe.geom(sect=2, LX=4., LY=4.)
+    fe.assign([ma, mb])
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bcleft(0., 'force')
+    fe.bctop(0.01 * fe.leny, 'disp')
+    fe.mesh(elmts=el, NX=18, NY=18)
+    noc = np.nonzero([no in fe.nobot for no in fe.noleft])[0]
+    assert list(noc) == [0]
+    fe.bcnode(noc, 0., 'disp', 'x')
+    assert np.array_equal(fe.free_dofs(), z['bcnode18_ind'])
