@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of pyLabFEA's hot path on MI355X (see DESIGN.md "Measurement").
+
+Metric (BASELINE.json): integration-point (= element) updates per second of the
+elastic-plastic load-step loop, with the wall-clock per load step beside it.
+
+Workload (N=1 default): BASELINE.json configs[2] — 1024x1024 Q4 mesh, Hill-48 plasticity
+(sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100, sdim=6), plane strain, uniaxial tension in y to
+eps=0.005 in 50 increments (``Model.solve(min_step=50)``).  One *step* = one load increment of that
+schedule: elastic predictor solve + K-iterations of {assemble, PCG solve, material sweep} + state
+update + homogenisation, everything resident in HBM.  The first PREROLL increments (elastic regime)
+are run untimed as set-up so that warm-up and timed steps lie in the plastic regime.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: the elements are sharded into N x-strips (one rank per GPU); every rank keeps full-length DOF
+vectors and the global vector is all-reduced over RCCL at each CG step (strong scaling: the mesh is
+fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PREROLL = 6          # untimed elastic increments before warm-up (part of set-up)
+HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def hill_material(FE):
+    mat = FE.Material(name='Hill-48')
+    mat.elasticity(E=200.e3, nu=0.3)
+    mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+    return mat
+
+
+def tension_model(FE, mat, n, eps, device=0):
+    fe = FE.Model(dim=2, planestress=False, device=device)
+    fe.geom([4.], LY=4.)
+    fe.assign([mat])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    fe.mesh(NX=n, NY=n)
+    return fe
+
+
+def cpu_baseline(n, steps, warmup):
+    """Same hot path on the host cores: the pinned CPU oracle (oracle/solve_ref.py: OpenMP sweep,
+    sparse assembly, sparse direct solve) on a bounded sample of the same workload."""
+    import pylabfea_amd as FE
+    from oracle.solve_ref import RefSolver
+    mat = hill_material(FE)
+    fe = tension_model(FE, mat, n, 0.005)
+    ref = RefSolver(fe, nthreads=0)
+    marks = {}
+
+    def hook(il):
+        if il == PREROLL + warmup:
+            marks['t0'] = time.perf_counter()
+            marks['s0'] = ref.timers['n_sweeps']
+        if il == PREROLL + warmup + steps:
+            marks['t1'] = time.perf_counter()
+            marks['s1'] = ref.timers['n_sweeps']
+
+    ref.solve(min_step=50, max_load_steps=PREROLL + warmup + steps, step_hook=hook)
+    dt = marks['t1'] - marks['t0']
+    sweeps = marks['s1'] - marks['s0']
+    return {'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'cores': os.cpu_count(),
+            'kind': 'port',
+            'sample': '%dx%d mesh, same material/loading/schedule, load steps %d..%d, %d sweeps in %.1f s '
+                      '(OpenMP sweep on all cores, scipy sparse assembly + SuperLU solve on 1 core)'
+                      % (n, n, PREROLL + warmup, PREROLL + warmup + steps, sweeps, dt),
+            'ms_per_step': 1e3 * dt / steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mesh', type=int, default=1024)
+    ap.add_argument('--cpu-mesh', type=int, default=160)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+
+    import torch
+    import pylabfea_amd as FE
+    from pylabfea_amd import _lib
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    K, W, n = args.steps, args.warmup, args.mesh
+    mat = hill_material(FE)
+    fe = tension_model(FE, mat, n, 0.005, device=local)
+    if world > 1:
+        uid = [None]
+        if rank == 0:
+            uid[0] = _lib.Context(local).comm_unique_id()
+        dist.broadcast_object_list(uid, src=0)
+        fe.distribute(rank, world, uid[0])
+    eng = fe._ensure_engine()
+    devname, cus, hbm = eng.device_info()
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    marks = {}
+
+    def hook(il):
+        if il == PREROLL + W:
+            eng.timing_reset()
+            eng.timing_enable(True)
+            barrier()
+            marks['t0'] = time.perf_counter()
+            marks['sw0'] = fe.n_sweeps
+            marks['so0'] = len(fe.solver_stats)
+        if il == PREROLL + W + K:
+            barrier()
+            marks['t1'] = time.perf_counter()
+            marks['sw1'] = fe.n_sweeps
+            marks['so1'] = len(fe.solver_stats)
+            eng.timing_enable(False)
+
+    fe._step_hook = hook
+    fe._max_load_steps = PREROLL + W + K
+    fe.solve(min_step=50)
+
+    dt = marks['t1'] - marks['t0']
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sweeps = marks['sw1'] - marks['sw0']
+    its = [s[0] for s in fe.solver_stats[marks['so0']:marks['so1']]]
+    updates = fe.Nel * sweeps  # whole-job: all strips together
+    value = updates / dt
+
+    # roofline of the dominant kernel, from HIP events recorded on the library's stream
+    fam = {'sweep': _lib.T_SWEEP, 'spmv': _lib.T_SPMV, 'cg_update': _lib.T_CGUPD, 'assemble': _lib.T_ASSEMBLE}
+    tim = {k: eng.timing_get(v) for k, v in fam.items()}
+    nel_rank = fe._e1 - fe._e0
+    # algorithmic (compulsory) bytes per launch, DESIGN.md "Kernels":
+    #   k_spmv<1>: block-ELL values 288 + column ids 36 + z,p_old,p_new,q 4x16 = 388 B per node
+    #   k_sweep:   conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
+    #              + fyn 8 + tangent 168 + M 48 written (tangent/M written only when it changed) = 616 B
+    bytes_per = {'spmv': 388. * fe.Nnode / world,
+                 'sweep': 616. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.}
+    dominant = max(('spmv', 'sweep', 'cg_update'), key=lambda k: tim[k][0])
+
+    def roof(k):
+        ms, cnt = tim[k]
+        if cnt == 0:
+            return None
+        avg_s = ms * 1e-3 / cnt
+        ach = bytes_per[k] / avg_s / 1e9
+        return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
+                           'sweep': 'k_sweep (strain gather + return mapping + tangent refresh)',
+                           'cg_update': 'k_cg_update'}[k],
+                'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
+
+    out = {
+        'metric': 'integration-point updates/sec (wall-clock per load step in ms_per_step)',
+        'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%dx%d Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
+                               'plane strain, uniaxial tension eps=0.005, min_step=50; timed load steps %d..%d '
+                               'of 50 (after %d untimed elastic pre-roll steps)'
+                               % (n, n, PREROLL + W, PREROLL + W + K, PREROLL),
+                   'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': 'x-strip element shard x%d' % world,
+                   'solver': 'Jacobi-PCG rtol=%g on block-ELL' % fe.cg_rtol, 'device': devname},
+        'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
+        'roofline': roof(dominant),
+        'roofline_sweep': roof('sweep'),
+        'kernel_ms': {k: round(v[0], 3) for k, v in tim.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 2)), 0)
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

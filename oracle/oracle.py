@@ -168,3 +168,25 @@ def strain(lx, ly, planestress, CV, E, nu, ue):
     lib().plfo_strain(C.c_double(lx), C.c_double(ly), int(planestress), _p(_c(CV).reshape(36)),
                       C.c_double(E), C.c_double(nu), _p(_c(ue)), _p(e))
     return e
+
+
+def kel_batch(lxy, mat_id, thick, planestress, CVs, Es, nus, D):
+    lxy = _c(lxy).reshape(-1, 2)
+    nel = len(lxy)
+    mid = _c(mat_id, np.int32)
+    CVs = _c(CVs).reshape(-1, 36)
+    D = _c(D).reshape(nel, 36)
+    K = np.empty((nel, 64))
+    lib().plfo_kel_batch(nel, _p(lxy), _p(mid), C.c_double(thick), int(planestress), _p(CVs),
+                         _p(_c(Es)), _p(_c(nus)), _p(D), _p(K))
+    return K.reshape(nel, 8, 8)
+
+
+def strain_batch(conn, lxy, mat_id, planestress, CVs, Es, nus, u):
+    conn = _c(conn, np.int32).reshape(-1, 4)
+    nel = len(conn)
+    eps = np.empty((nel, 6))
+    lib().plfo_strain_batch(nel, _p(conn), _p(_c(lxy).reshape(nel, 2)), _p(_c(mat_id, np.int32)),
+                            int(planestress), _p(_c(CVs).reshape(-1, 36)), _p(_c(Es)), _p(_c(nus)),
+                            _p(_c(u)), _p(eps))
+    return eps

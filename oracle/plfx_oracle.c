@@ -622,3 +622,30 @@ void plfo_strain(double lx, double ly, int planestress, const double CV[36], dou
         }
     }
 }
+
+void plfo_kel_batch(int nel, const double *lxy, const int *mat_id, double thick, int planestress,
+                    const double *CV, const double *E, const double *nu, const double *D, double *Kel)
+{
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nel; e++) {
+        int m = mat_id[e];
+        plfo_calc_Kel(lxy[2 * e], lxy[2 * e + 1], thick, planestress, CV + 36 * (size_t)m, E[m], nu[m],
+                      D + 36 * (size_t)e, Kel + 64 * (size_t)e);
+    }
+}
+
+void plfo_strain_batch(int nel, const int *conn, const double *lxy, const int *mat_id, int planestress,
+                       const double *CV, const double *E, const double *nu, const double *u, double *eps)
+{
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nel; e++) {
+        int m = mat_id[e];
+        double ue[8];
+        for (int a = 0; a < 4; a++) { /* Element.node_num, model.py:372-385 */
+            ue[2 * a] = u[2 * (size_t)conn[4 * e + a]];
+            ue[2 * a + 1] = u[2 * (size_t)conn[4 * e + a] + 1];
+        }
+        plfo_strain(lxy[2 * e], lxy[2 * e + 1], planestress, CV + 36 * (size_t)m, E[m], nu[m], ue,
+                    eps + 6 * (size_t)e);
+    }
+}

@@ -80,6 +80,15 @@ void plfo_calc_Kel(double lx, double ly, double thick, int planestress, const do
 void plfo_strain(double lx, double ly, int planestress, const double CV[36], double E, double nu,
                  const double ue[8], double eps[6]);
 
+/* batched element routines over a mesh (OpenMP): per element class arrays lxy[nel*2], mat_id[nel];
+ * CV/E/nu per material [nmat*36], [nmat], [nmat]. */
+void plfo_kel_batch(int nel, const double *lxy, const int *mat_id, double thick, int planestress,
+                    const double *CV, const double *E, const double *nu, const double *D /* [nel*36] */,
+                    double *Kel /* [nel*64] */);
+void plfo_strain_batch(int nel, const int *conn /* [nel*4] */, const double *lxy, const int *mat_id,
+                       int planestress, const double *CV, const double *E, const double *nu,
+                       const double *u /* [ndof] */, double *eps /* [nel*6] */);
+
 /* scipy 1.15.3 optimize.brentq (Brent 1973) on a scalar callback */
 typedef double (*plfo_fn)(double x, void *ctx);
 double plfo_brentq(plfo_fn f, void *ctx, double xa, double xb, double xtol, double rtol,

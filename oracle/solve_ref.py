@@ -1,0 +1,250 @@
+"""CPU restatement of ``Model.solve`` for meshes the reference cannot hold.  TEST INFRASTRUCTURE ONLY.
+
+The reference assembles a dense ``Ndof x Ndof`` matrix (model.py:963) and cannot run beyond ~175x175
+elements.  This driver restates the same algorithm (model.py:979-1450) with a sparse matrix and a
+sparse direct solve, using the pinned C oracle for every per-element routine:
+
+    plfo_kel_batch (Element.calc_Kel) -> scipy COO/CSR (Model.setupK) -> calc_BC data ->
+    scipy.sparse.linalg.spsolve (Kred + np.linalg.solve) -> plfo_response_batch (the material sweep)
+
+It is used (a) by tests to check the GPU path at sizes beyond the reference's reach and (b) by
+bench.py as the same-host ``cpu_baseline`` (kind "port").  Mesh arrays and boundary-condition
+*definitions* are taken from a ``pylabfea_amd.Model`` that has been meshed but not solved (its index
+generation is pinned bit-exactly against the reference by tests/test_mesh.py); nothing here touches
+libplfx or a GPU.
+"""
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import oracle as O
+
+YF_TOL = 5.e-3
+
+
+class RefSolver(object):
+    def __init__(self, model, nthreads=0):
+        m = self.m = model
+        self.nthreads = nthreads
+        self.conn = np.ascontiguousarray(m._conn, dtype=np.int32)
+        self.mat_id = np.ascontiguousarray(m._mat_id, dtype=np.int32)
+        self.lxy = np.ascontiguousarray(m._lxy, dtype=float)
+        self.nel = len(self.conn)
+        self.ndof = m.Ndof
+        self.ps = bool(m.planestress)
+        self.thick = m.thick
+        self.mats = []
+        self.CVs = []
+        for mat in m.mat:
+            CV = m._element_CV(mat)
+            self.CVs.append(CV.reshape(36))
+            if mat.sy is None:
+                self.mats.append(O.Material(kind=O.ELASTIC, E=mat.E, nu=mat.nu))
+            elif mat.ML_yf:
+                self.mats.append(O.Material(kind=O.SVC6, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
+                                            hill=mat.hill, sv=mat.svc['sv'], dual=mat.svc['dual'],
+                                            gamma=mat.gam_yf, intercept=mat.svc['intercept'],
+                                            scale_seq=mat.scale_seq, dev_only=mat.dev_only))
+            else:
+                self.mats.append(O.Material(kind=O.HILL6, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
+                                            hill=mat.hill, drucker=mat.drucker))
+        self.CVs = np.array(self.CVs)
+        self.Es = np.array([mat.E for mat in m.mat], dtype=float)
+        self.nus = np.array([mat.nu for mat in m.mat], dtype=float)
+        self.plastic = np.array([mat.sy is not None for mat in m.mat])[self.mat_id]
+        self.vel = self.lxy[:, 0] * self.lxy[:, 1] * self.thick
+        dofs = np.stack((2 * self.conn, 2 * self.conn + 1), axis=2).reshape(self.nel, 8)
+        self.rows = np.repeat(dofs, 8, axis=1).ravel()
+        self.cols = np.tile(dofs, (1, 8)).ravel()
+        self.timers = {'assemble': 0., 'solve': 0., 'sweep': 0., 'n_sweeps': 0, 'n_solves': 0}
+
+    # model.py:954-977
+    def setupK(self):
+        t = time.perf_counter()
+        Kel = O.kel_batch(self.lxy, self.mat_id, self.thick, self.ps, self.CVs, self.Es, self.nus, self.elstiff)
+        K = sp.coo_matrix((Kel.ravel(), (self.rows, self.cols)), shape=(self.ndof, self.ndof)).tocsr()
+        self.timers['assemble'] += time.perf_counter() - t
+        return K
+
+    # model.py:1070-1206 + 1028-1033 + 1291
+    def lin_solve(self, K, bcl0, bcb0, dbcr, dbct, dbcn):
+        presc, first, w, fext = self.m._bc_data(bcl0, bcb0, dbcr, dbct, dbcn)
+        t = time.perf_counter()
+        wv = np.zeros(self.ndof)
+        wv[presc] = w
+        df = -(K @ wv)
+        if fext is not None:
+            df += fext
+        mask = np.ones(self.ndof, dtype=bool)
+        mask[presc] = False
+        ind = np.nonzero(mask)[0]
+        du = np.zeros(self.ndof)
+        du[presc] = first
+        Kred = K[ind][:, ind].tocsc()
+        du[ind] = spla.spsolve(Kred, df[ind])
+        self.timers['solve'] += time.perf_counter() - t
+        self.timers['n_solves'] += 1
+        return du
+
+    def strain(self, u):
+        return O.strain_batch(self.conn, self.lxy, self.mat_id, self.ps, self.CVs, self.Es, self.nus, u)
+
+    def sflow(self, epl, sel=None):
+        sy = np.array([0. if mm.sy is None else mm.sy for mm in self.m.mat])[self.mat_id]
+        kh = np.array([0. if mm.khard is None else mm.khard for mm in self.m.mat])[self.mat_id]
+        if sel is not None:
+            sy, kh = sy[sel], kh[sel]
+        e = epl
+        peeq = np.sqrt(2. * (np.sum(e[:, 0:3] ** 2, axis=1) + 0.5 * np.sum(e[:, 3:6] ** 2, axis=1)) / 3.)
+        return sy + peeq * kh
+
+    # model.py:1036-1067
+    def calc_scf(self, du, sld):
+        deps = self.strain(du)
+        dsig = np.einsum('eij,ej->ei', self.elstiff.reshape(-1, 6, 6), deps)
+        sc = []
+        for k, om in enumerate(self.mats):
+            sel = np.nonzero((self.mat_id == k) & self.plastic)[0]
+            if len(sel) == 0:
+                continue
+            sref = O.calc_seq(om, dsig[sel])
+            act = sref > 0.1
+            sel, sref = sel[act], sref[act]
+            if len(sel) == 0:
+                continue
+            yf0 = O.calc_yf(om, self.sig[sel], self.epl[sel])
+            low = yf0 < -0.15
+            if om.c.kind == O.SVC6 and np.any(low):
+                raise NotImplementedError('oracle calc_scf for SVC materials needs the ld variant of ML_full_yf')
+            hh = np.where(low, np.minimum(1., -yf0 / sref),
+                          np.minimum(1., np.sqrt(1.5) * self.sflow(self.epl[sel], sel) / sref))
+            sc.extend(hh.tolist())
+            sc.extend(hh[low].tolist())  # appended twice (model.py:1054 and :1058)
+        if len(sc) == 0:
+            sc = [1.]
+        hh = np.std(sc)
+        scf = np.amin(sc) if hh < 0.1 else np.maximum(1.e-3, np.mean(sc) - hh)
+        return max(scf, 1.e-3)
+
+    def solve(self, min_step=None, max_load_steps=None, step_hook=None):
+        m = self.m
+        nd = self.ndof
+        self.u = np.zeros(nd)
+        self.f = np.zeros(nd)
+        self.sig = np.zeros((self.nel, 6))
+        self.eps = np.zeros((self.nel, 6))
+        self.epl = np.zeros((self.nel, 6))
+        self.elstiff = np.array(self.CVs[self.mat_id])
+        sgl, egl, epgl = [np.zeros(6)], [np.zeros(6)], [np.zeros(6)]
+        bcr0 = np.zeros(2)
+        bct0 = np.zeros(2)
+        bcn0 = np.zeros(2)
+        K = self.setupK()
+        sld = np.zeros(6)
+        if abs(m.bcr[0]) > 1.e-6:
+            sld[0] = np.sign(m.bcr[0])
+        if abs(m.bct[1]) > 1.e-6:
+            sld[1] = np.sign(m.bct[1])
+        if abs(m.bcr[1]) > 1.e-6:
+            sld[5] = np.sign(m.bcr[1])
+        if abs(m.bct[0]) > 1.e-6:
+            sld[5] = np.sign(m.bct[0])
+        if np.linalg.norm(sld) < 1.e-3:
+            sld[0] = 1.
+        il = nit = nconv = 0
+        niter, co_nconv = [], []
+        bc_inc = True
+        dbcn = None
+        res_sig = res_depl = None
+        while bc_inc:
+            max_dbct = m.bct - bct0
+            max_dbcr = m.bcr - bcr0
+            if min_step is not None:
+                sc = max(1, min_step - il)
+                max_dbct /= sc
+                max_dbcr /= sc
+            dbcr, dbct = max_dbcr, max_dbct
+            if m.noset is not None:
+                max_dbcn = m.bcn - bcn0
+                if min_step is not None:
+                    max_dbcn /= max(1, min_step - il)
+                dbcn = max_dbcn
+            du = self.lin_solve(K, m.bcl, m.bcb, dbcr, dbct, dbcn)
+            if m.nonlin:
+                scale_bc = self.calc_scf(du, sld) if il < 10 else 1.
+                dbcr = max_dbcr * scale_bc
+                dbct = max_dbct * scale_bc
+                nit = 0
+                change, conv = True, False
+                while (change or not conv) and nit <= 15:
+                    if il < 6 and nit > 1:
+                        for k in range(2):
+                            for (mx, tot, cur0, d) in ((max_dbcr, m.bcr, bcr0, dbcr), (max_dbct, m.bct, bct0, dbct)):
+                                if mx[k] >= 0:
+                                    d[k] = max(0.05 * mx[k], min(tot[k] - cur0[k], d[k] * 0.5))
+                                else:
+                                    d[k] = min(0.05 * mx[k], max(tot[k] - cur0[k], d[k] * 0.5))
+                            if m.noset is not None:
+                                if max_dbcn[k] >= 0:
+                                    dbcn[k] = max(0.05 * max_dbcn[k], min(m.bcn[k] - bcn0[k], dbcn[k] * 0.5))
+                                else:
+                                    dbcn[k] = min(0.05 * max_dbcn[k], max(m.bcn[k] - bcn0[k], dbcn[k] * 0.5))
+                    K = self.setupK()
+                    du = self.lin_solve(K, m.bcl, m.bcb, dbcr, dbct, dbcn)
+                    t = time.perf_counter()
+                    deps = self.strain(du)
+                    fy, res_sig, res_depl, ct, ns = O.response(self.mats, self.CVs, self.sig, self.epl, deps,
+                                                               mat_id=self.mat_id, nthreads=self.nthreads)
+                    self.timers['sweep'] += time.perf_counter() - t
+                    self.timers['n_sweeps'] += 1
+                    f = np.where(self.plastic, fy / np.where(self.plastic, self.sflow(self.epl), 1.), 0.)
+                    hh = np.linalg.norm(self.elstiff - ct, axis=1)
+                    upd = self.plastic & (hh > 1.e-3)
+                    if nit < 15:
+                        self.elstiff[upd] = ct[upd]
+                    else:
+                        self.elstiff[upd] = 0.5 * (ct[upd] + self.elstiff[upd])
+                    change = bool(np.any(upd))
+                    conv = bool(np.all(f <= YF_TOL * 1.0001))
+                    if not conv:
+                        nconv += 1
+                    nit += 1
+            self.u += du
+            self.f += K @ du
+            deps = self.strain(du)
+            dsig = np.einsum('eij,ej->ei', self.elstiff.reshape(-1, 6, 6), deps)
+            if m.nonlin:
+                p = self.plastic
+                self.epl[p] += res_depl[p]
+                self.sig[p] = res_sig[p]
+                self.sig[~p] += dsig[~p]
+            else:
+                self.sig += dsig
+            self.eps = self.strain(self.u)
+            il += 1
+            niter.append(nit - 1)
+            co_nconv.append(nconv)
+            bcr0 += dbcr
+            bct0 += dbct
+            hl0 = abs(bcr0[0] - m.bcr[0]) > 1.e-6 and abs(m.bcr[0]) > 1.e-9
+            hl1 = abs(bcr0[1] - m.bcr[1]) > 1.e-6 and abs(m.bcr[1]) > 1.e-9
+            hr0 = abs(bct0[0] - m.bct[0]) > 1.e-6 and abs(m.bct[0]) > 1.e-9
+            hr1 = abs(bct0[1] - m.bct[1]) > 1.e-6 and abs(m.bct[1]) > 1.e-9
+            if m.noset is not None:
+                bcn0 += dbcn
+                hr0 = hr0 or (abs(bcn0[0] - m.bcn[0]) > 1.e-6 and abs(m.bcn[0]) > 1.e-9)
+                hr1 = hr1 or (abs(bcn0[1] - m.bcn[1]) > 1.e-6 and abs(m.bcn[1]) > 1.e-9)
+            bc_inc = bool(hr0 or hr1 or hl0 or hl1)
+            Vm = m.lenx * m.leny * m.thick
+            sgl.append(self.sig.T @ self.vel / Vm)
+            egl.append(self.eps.T @ self.vel / Vm)
+            epgl.append(self.epl.T @ self.vel / Vm)
+            if step_hook is not None:
+                step_hook(il)
+            if max_load_steps is not None and il >= max_load_steps:
+                bc_inc = False
+        self.sgl, self.egl, self.epgl = np.array(sgl), np.array(egl), np.array(epgl)
+        self.nsteps, self.niter, self.co_nconv = il, niter, co_nconv
+        return self

@@ -37,6 +37,7 @@ struct Timing {
     size_t head = 0;
     double ms[8] = {0};
     int64_t n[8] = {0};
+    int64_t noop[8] = {0};  // launches that returned immediately (PCG already converged)
 };
 
 // minimal RCCL surface (dlopen'ed so the library loads on hosts without RCCL in the path)
@@ -1181,6 +1182,10 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
     HIPCHK(c, hipGetLastError());
     if (iters) *iters = done ? hs.iters : it;
+    if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
+        c->tim.noop[1] += it - hs.iters;
+        c->tim.noop[2] += it - hs.iters;
+    }
     if (relres) {
         const double bb = hs.thresh2 / (rtol * rtol);
         *relres = (bb > 0. && hs.rr_final >= 0.) ? std::sqrt(hs.rr_final / bb) : 0.;
@@ -1314,6 +1319,7 @@ int plfx_timing_reset(plfx_ctx *c)
     for (int i = 0; i < 8; i++) {
         c->tim.ms[i] = 0.;
         c->tim.n[i] = 0;
+        c->tim.noop[i] = 0;
     }
     return PLFX_OK;
 }
@@ -1323,7 +1329,7 @@ int plfx_timing_get(plfx_ctx *c, int which, double *ms, int64_t *launches)
     if (!c || which < 0 || which >= 8) return PLFX_ERR_ARG;
     tim_flush(c);
     if (ms) *ms = c->tim.ms[which];
-    if (launches) *launches = c->tim.n[which];
+    if (launches) *launches = c->tim.n[which] - c->tim.noop[which];
     return PLFX_OK;
 }
 

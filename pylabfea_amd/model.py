@@ -174,9 +174,12 @@ class Model(object):
         self.cg_rtol = 1.e-12
         self.cg_maxit = 200000
         self.solver_stats = []
+        self.n_sweeps = 0            # material sweeps (K-iterations) executed so far
         self._engine = None
         self._cache = {}
         self._shard = None  # (rank, nranks, uid)
+        self._max_load_steps = None  # benchmarking aid: stop after this many load steps
+        self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
 
     # ------------------------------------------------------------------ pre-processing
     def geom(self, sect=1, LX=None, LY=1., LZ=1.):
@@ -660,6 +663,7 @@ class Model(object):
                     eng.assemble()  # updated tangent stiffness (model.py:1333)
                     self._solve_lin(eng, self._bc_data(bcl0, bcb0, dbcr, dbct, dbcn), True)
                     change, conv = eng.sweep(nit)  # material response of every element (model.py:1340-1361)
+                    self.n_sweeps += 1
                     if self._shard is not None:
                         change, conv = self._allreduce_flags(change, conv)
                     if verb:
@@ -693,6 +697,10 @@ class Model(object):
             self.sgl = np.append(self.sgl, [self.glob['sig']], axis=0)
             self.egl = np.append(self.egl, [self.glob['eps']], axis=0)
             self.epgl = np.append(self.epgl, [self.glob['epl']], axis=0)
+            if self._step_hook is not None:
+                self._step_hook(il)
+            if self._max_load_steps is not None and il >= self._max_load_steps:
+                bc_inc = False
             if verb:
                 print('Iteration step #', nit)
                 print('Load increment ', il, 'total', self.ubctop, 'top ', bct0, '/', self.bct, '; last step ', dbct)

@@ -1,0 +1,84 @@
+"""The CPU solve driver of the oracle (oracle/solve_ref.py: sparse assembly + sparse direct solve +
+C-oracle sweep) pinned against full traces of the reference's Model.solve (tests/golden/solve.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+import pylabfea_amd as FE
+from oracle.solve_ref import RefSolver
+
+MATS = {
+    'j2': (dict(E=200.e3, nu=0.3), dict(sy=150., khard=500., sdim=6)),
+    'hill6': (dict(E=200.e3, nu=0.3), dict(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)),
+}
+
+
+def make_material(name):
+    el, pl = MATS[name]
+    m = FE.Material(name=name)
+    m.elasticity(**el)
+    m.plasticity(**pl)
+    return m
+
+
+def tension_model(mat, n, eps):
+    fe = FE.Model(dim=2)
+    fe.geom([4.], LY=4.)
+    fe.assign([mat])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    fe.mesh(NX=n, NY=n)
+    return fe
+
+
+def check(r, g, p):
+    assert r.nsteps == int(g[p + '_nsteps'])
+    assert list(r.niter) == list(g[p + '_niter'])
+    assert list(r.co_nconv) == list(g[p + '_co_nconv'])
+    for a, k in ((r.u, '_u'), (r.f, '_f'), (r.sig, '_sig'), (r.eps, '_eps'), (r.sgl, '_sgl'), (r.egl, '_egl')):
+        ref = g[p + k]
+        assert np.max(np.abs(a - ref)) < 1e-8 * np.max(np.abs(ref)), k
+    assert np.max(np.abs(r.epl - g[p + '_epl'])) < 1e-8 * np.max(np.abs(g[p + '_eps']))
+    assert np.max(np.abs(r.elstiff - g[p + '_elstiff'])) < 1e-7 * np.max(np.abs(g[p + '_elstiff']))
+
+
+@pytest.mark.parametrize('name,n,eps,ms', [('j2_8', 8, 0.002, None), ('hill6_8', 8, 0.002, None),
+                                           ('hill6_12', 12, 0.003, 8)])
+def test_tension(golden_dir, name, n, eps, ms):
+    g = np.load(os.path.join(golden_dir, 'solve.npz'))
+    fe = tension_model(make_material(name.split('_')[0]), n, eps)
+    r = RefSolver(fe).solve(min_step=ms)
+    check(r, g, name)
+
+
+@pytest.mark.parametrize('name,n,eps,ms', [('incl_j2_9', 9, 0.002, None), ('incl_hill6_12', 12, 0.0015, 6)])
+def test_inclusion(golden_dir, name, n, eps, ms):
+    g = np.load(os.path.join(golden_dir, 'solve.npz'))
+    mat = make_material(name.split('_')[1])
+    soft = FE.Material(num=2)
+    soft.elasticity(E=1.e3, nu=0.27)
+    fe = FE.Model(dim=2)
+    fe.geom(sect=2, LX=4., LY=4.)
+    fe.assign([mat, soft])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    el = np.ones((n, n))
+    a, b = int(n / 3), 2 * int(n / 3)
+    el[a:b, a:b] = 2
+    fe.mesh(elmts=el, NX=n, NY=n)
+    r = RefSolver(fe).solve(min_step=ms)
+    check(r, g, name)
+
+
+def test_elastic32(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'solve.npz'))
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    fe = tension_model(m, 32, 0.001)
+    r = RefSolver(fe).solve()
+    check(r, g, 'el32')
