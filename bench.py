@@ -163,10 +163,10 @@ def main():
     nel_rank = fe._e1 - fe._e0
     # algorithmic (compulsory) bytes per launch, DESIGN.md "Kernels":
     #   k_spmv<1>: block-ELL values 288 + column ids 36 + z,p_old,p_new,q 4x16 = 388 B per node
-    #   k_sweep:   conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
-    #              + fyn 8 + tangent 168 + M 48 written (tangent/M written only when it changed) = 616 B
+    #   k_sweep_light: conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
+    #              + fyn 8 + max_steps 4 written = 412 B (+216 B when the tangent / M is rewritten; not counted)
     bytes_per = {'spmv': 388. * fe.Nnode / world,
-                 'sweep': 616. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.}
+                 'sweep': 412. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.}
     dominant = max(('spmv', 'sweep', 'cg_update'), key=lambda k: tim[k][0])
 
     def roof(k):
@@ -176,7 +176,7 @@ def main():
         avg_s = ms * 1e-3 / cnt
         ach = bytes_per[k] / avg_s / 1e9
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
-                           'sweep': 'k_sweep (strain gather + return mapping + tangent refresh)',
+                           'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
                            'cg_update': 'k_cg_update'}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': None,

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libplfx.so')
+LIB_PATH = os.environ.get('PLFX_LIB', os.path.join(_HERE, 'libplfx.so'))  # PLFX_LIB: kernel-variant experiments
 
 # yield-function kinds (include/plfx.h)
 ELASTIC, HILL6, PRINC3, SVC6 = 0, 1, 2, 3

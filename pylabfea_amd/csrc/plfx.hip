@@ -93,7 +93,7 @@ struct plfx_ctx {
     std::vector<MatDev> hmat;
     MatDev *dmat = nullptr;
     std::vector<double *> dsv;  // owned device copies of sv/dual
-    bool has_svc = false;
+    bool has_svc = false, has_analytic = false, has_elastic = false;
     int svc_lds_need = 0;
 
     // mesh
@@ -117,7 +117,7 @@ struct plfx_ctx {
     // element state (owned)
     double *sig = nullptr, *epl = nullptr, *eps = nullptr, *res_sig = nullptr, *res_depl = nullptr;
     double *elstiff = nullptr, *Mel = nullptr, *fyn = nullptr, *scf_hh = nullptr;
-    int32_t *max_steps = nullptr, *scf_mult = nullptr;
+    int32_t *max_steps = nullptr, *scf_mult = nullptr, *heavy_list = nullptr;
     // dof vectors
     double *u = nullptr, *f = nullptr, *du = nullptr, *rhs = nullptr, *dinv = nullptr, *diag = nullptr,
            *is_presc = nullptr, *dup = nullptr, *wv = nullptr, *fext = nullptr;
@@ -132,6 +132,7 @@ struct plfx_ctx {
     double *val_tmp = nullptr;
     size_t tmp_cap = 0;
     bool assembled = false, bc_set = false;
+    int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
     int grid_nodes = 0, grid_el = 0;
 
     // multi-GPU
@@ -363,6 +364,7 @@ void free_mesh(plfx_ctx *c)
     dfree(c->scf_hh);
     dfree(c->max_steps);
     dfree(c->scf_mult);
+    dfree(c->heavy_list);
     dfree(c->u);
     dfree(c->f);
     dfree(c->du);
@@ -505,7 +507,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (!c || !c->stream) return PLFX_ERR_STATE;
     if (nmat < 1 || nmat > MAXMAT || !mats) return fail(c, PLFX_ERR_ARG, "nmat must be in 1..%d", MAXMAT);
     free_materials(c);
-    c->has_svc = false;
+    c->has_svc = c->has_analytic = c->has_elastic = false;
     c->svc_lds_need = 0;
     c->nonlin = false;
     c->hmat.resize(nmat);
@@ -545,6 +547,8 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         m.kind = s.kind;
         m.sdim = 6;
         if (s.kind != PLFX_ELASTIC) c->nonlin = true;
+        if (s.kind == PLFX_HILL6) c->has_analytic = true;
+        if (s.kind == PLFX_ELASTIC) c->has_elastic = true;
         if (s.kind == PLFX_SVC6) {
             if (s.nsv < 1 || s.nfeat != 6 || !s.sv || !s.dual)
                 return fail(c, PLFX_ERR_ARG, "material %d: SVC needs nsv>=1, nfeat==6, sv and dual", k);
@@ -573,9 +577,10 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->has_svc) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_point_eval, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_scf_elements, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     return PLFX_OK;
@@ -662,9 +667,14 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
     double *d_fy = d_out, *d_so = d_out + N, *d_dp = d_out + 7 * N, *d_ct = d_out + 13 * N;
     EvPair *ev;
     tim_begin(c, 0, &ev);
-    hipLaunchKernelGGL(k_response_batch, dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
-                       c->dmat, c->nmat, c->svc_lds_need, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N,
-                       d_fy, d_so, d_dp, d_ct, d_ns);
+    if (c->has_analytic || c->has_elastic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<false>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream,
+                           c->dmat, c->nmat, 0, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N,
+                           d_fy, d_so, d_dp, d_ct, d_ns);
+    if (c->has_svc)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<true>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, c->dmat, c->nmat, c->svc_lds_need, n, d_mid, d_in, d_in + 6 * N,
+                           d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fy, d_fy, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -816,6 +826,7 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     ALLOC(c->scf_hh, nown);
     ALLOC(c->max_steps, nown);
     ALLOC(c->scf_mult, nown);
+    ALLOC(c->heavy_list, nown);
     const size_t nd = c->ndof;
     ALLOC(c->u, nd);
     ALLOC(c->f, nd);
@@ -1200,10 +1211,23 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     HIPCHK(c, hipMemsetAsync(c->flags, 0, 16, c->stream));
     EvPair *ev;
     tim_begin(c, 0, &ev);
-    hipLaunchKernelGGL(k_sweep, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream, c->dmat,
-                       c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
-                       (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel, c->res_sig,
-                       c->res_depl, c->fyn, c->max_steps, nit, c->flags);
+#define SWEEP_ARGS(lds) c->dmat, c->nmat, c->dcls, c->ncls, lds, c->nel, c->e0, c->dconn, c->dcls_id,          \
+                        (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel, c->res_sig, c->res_depl, \
+                        c->fyn, c->max_steps, nit, c->flags, c->heavy_list
+    if (c->has_analytic || c->has_elastic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<false>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0));
+    if (c->has_svc)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<true>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+    // phase 2 reads the list length from the device; an empty list costs one empty launch
+    if (c->has_analytic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<false>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0));
+    if (c->has_svc)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<true>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+#undef SWEEP_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     int h[4];
@@ -1211,6 +1235,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (changed) *changed = h[0];
     if (conv) *conv = h[1] ? 0 : 1;
+    c->last_heavy = h[2];
     return PLFX_OK;
 }
 

@@ -324,11 +324,21 @@ struct YfSvc {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Material.response (material.py:207-346) for one point.  In/out: sig (updated to the end of the
-// step).  Out: fy, depl, Ct (21 symmetric entries).  Returns msg['nsteps'] (last loop index).
+// Material.response (material.py:207-346) for one point, in two phases so that the sweep can run
+// the cheap, memory-bound part at high occupancy and compact the expensive part (SURVEY "divergence"):
+//
+// response_light: elastic predictor (:243-256), elastic/plastic split (:259-274) and the trial step
+//   with the full remaining increment (:277-293).  Returns 0 = purely elastic step, 1 = the trial
+//   ended inside the tolerance (the reference then runs its loop exactly once on the same inputs and
+//   reproduces the trial's numbers, so the trial IS the result), 2 = the increment has to be
+//   sub-divided: sig then holds the stress at the start of the plastic part, deps_r the remaining
+//   increment and st_scal the plastic share; fy/depl/Ct are not valid yet.
+// response_heavy: the maxit = 50 sub-steps with radial scale-back (:295-344).
+// In/out: sig (updated to the end of the step).  Out: fy, depl, Ct (21 symmetric entries).
 template <class YF>
-__device__ inline int response_point(const MatDev &m, const YF &yf, double *sig, const double *epl,
-                                     const double *deps, double &fy, double *depl, double *Ct)
+__device__ inline int response_light(const MatDev &m, const YF &yf, double *sig, const double *epl,
+                                     const double *deps, double &fy, double *depl, double *Ct,
+                                     double *deps_r, double &st_scal)
 {
     const double *CV = m.CV;
     double dsig[6], tmp[6];
@@ -348,8 +358,7 @@ __device__ inline int response_point(const MatDev &m, const YF &yf, double *sig,
         fy = fy1;
         return 0;
     }
-    double deps_r[6];
-    double st_scal = 1.;
+    st_scal = 1.;
     double fy0 = yf.plain(sig, epl);  // :259
     if (fy0 < SPLIT_THRESHOLD) {      // :260-270 split into elastic + plastic part
         fy0 = yf.full0(sig, fy0);
@@ -368,14 +377,7 @@ __device__ inline int response_point(const MatDev &m, const YF &yf, double *sig,
 #pragma unroll
         for (int i = 0; i < 6; i++) deps_r[i] = deps[i];
     }
-    // R accumulates sum_it [ (Ca)(Ca)^T/h + corr3 ]; Ct = CV - (st_scal/nsteps) R at the end
-    // (:343 with T = CV - (Ca)(Ca)^T/h - corr3 and the elastic share CV*(1-st_scal) of :269).
-    double R[21];
-#pragma unroll
-    for (int i = 0; i < 21; i++) R[i] = 0.;
-
     double a[6], ca[6], dsr[6], ddepl[6], eplt[6];
-    int nsteps = 1;
     // trial step with the full remaining increment (:277-293)
     {
         symv(CV, deps_r, dsr);
@@ -384,22 +386,55 @@ __device__ inline int response_point(const MatDev &m, const YF &yf, double *sig,
         const double hh = dot6(a, ca) + m.khard;
 #pragma unroll
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
-        const double yfun = yf.plain(tmp, epl);  // epl_dot :1032
+        const double yfun = yf.plain(tmp, epl);  // epl_dot :1032, absolute tolerance :1041
         const double lam = (yfun <= YF_TOL) ? 0. : dot6(a, dsr) / hh;
         const double cd = dot6(ca, deps_r) / hh;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            eplt[i] = epl[i] + lam * a[i];
+            ddepl[i] = lam * a[i];
+            eplt[i] = epl[i] + ddepl[i];
             tmp[i] = sig[i] + (dsr[i] - ca[i] * cd);
         }
         fy1 = yf.full(tmp, eplt);
-        if (fy1 > toler) {
-            nsteps = MAXIT;
+        if (!(fy1 > toler)) {  // nsteps = 1 (:292-293)
+            const double w1 = st_scal / hh;
 #pragma unroll
-            for (int i = 0; i < 6; i++) deps_r[i] /= MAXIT;
-            symv(CV, deps_r, dsr);
+            for (int i = 0; i < 6; i++) {
+                sig[i] = tmp[i];
+                depl[i] = ddepl[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) Ct[sym_idx(i, j)] = fma(-w1 * ca[i], ca[j], CV[sym_idx(i, j)]);
+            fy = fy1;
+            return 1;
         }
     }
+    return 2;
+}
+
+template <class YF>
+__device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig, const double *epl,
+                                      double *deps_r, double st_scal, double &fy, double *depl,
+                                      double *Ct)
+{
+    const double *CV = m.CV;
+    const double toler = YF_TOL * sflow_of(m, epl);  // :243
+    double a[6], ca[6], dsr[6], ddepl[6], eplt[6], tmp[6], fy1;
+    // sub-divided step (:288-291): nsteps = maxit
+    const int nsteps = MAXIT;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        deps_r[i] /= MAXIT;
+        depl[i] = 0.;
+    }
+    symv(CV, deps_r, dsr);
+    // R accumulates sum_it [ (Ca)(Ca)^T/h + corr3 ]; Ct = CV - (st_scal/nsteps) R at the end
+    // (:343 with T = CV - (Ca)(Ca)^T/h - corr3 and the elastic share CV*(1-st_scal) of :269).
+    double R[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) R[i] = 0.;
     for (int it = 0; it < nsteps; it++) {  // :295
         yf.fgrad(sig, a);
         symv(CV, a, ca);
@@ -466,7 +501,18 @@ __device__ inline int response_point(const MatDev &m, const YF &yf, double *sig,
 #pragma unroll
     for (int i = 0; i < 21; i++) Ct[i] = fma(-w, R[i], CV[i]);
     fy = fy1;
-    return nsteps - 1;  // :345
+}
+
+// both phases; returns msg['nsteps'] (last loop index, :345)
+template <class YF>
+__device__ inline int response_point(const MatDev &m, const YF &yf, double *sig, const double *epl,
+                                     const double *deps, double &fy, double *depl, double *Ct)
+{
+    double deps_r[6], st_scal;
+    const int st = response_light(m, yf, sig, epl, deps, fy, depl, Ct, deps_r, st_scal);
+    if (st < 2) return 0;
+    response_heavy(m, yf, sig, epl, deps_r, st_scal, fy, depl, Ct);
+    return MAXIT - 1;
 }
 
 }  // namespace plfx

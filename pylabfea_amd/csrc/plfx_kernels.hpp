@@ -19,6 +19,9 @@ constexpr int BLOCK = 256;
 constexpr int MAXMAT = 16;
 constexpr int MAXCLS = 16;
 constexpr int MAXPART = 1024;  // max blocks of a reducing kernel (partials per scalar)
+#ifndef PLFX_SWEEP_WAVES
+#define PLFX_SWEEP_WAVES 1  // min waves per SIMD the sweep kernel is compiled for (register budget)
+#endif
 
 // Element class = (material, lx, ly): everything the element routines need besides the state.
 // B-matrix structure (model.py:475-501): B[0][2a] = B[5][2a+1] = bx_a, B[1][2a+1] = B[5][2a] = by_a,
@@ -104,23 +107,27 @@ __device__ __forceinline__ void stage_svc(const MatDev *smat, int nmat, double *
     dual = lds + 6 * n;
 }
 
-// dispatch response on the material kind
-__device__ inline int response_any(const MatDev &m, const double *sv, const double *dual,
-                                   double *sig, const double *epl, const double *deps, double &fy,
-                                   double *depl, double *Ct)
+// response for one material kind per kernel instantiation: the analytic kernels do not carry the
+// SVC code (and its registers), the SVC kernels skip analytic elements and vice versa.
+template <bool SVC>
+__device__ __forceinline__ int response_kind(const MatDev &m, const double *sv, const double *dual,
+                                             double *sig, const double *epl, const double *deps,
+                                             double &fy, double *depl, double *Ct)
 {
-    if (m.kind == 3) {
+    if (SVC) {
         YfSvc yf(m, sv ? sv : m.sv, dual ? dual : m.dual);
         return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
+    } else {
+        YfHill yf(m);
+        return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
     }
-    YfHill yf(m);
-    return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
 }
 
 extern __shared__ double dyn_lds[];
 
 // ---------------------------------------------------------------------------------------------
 // Material.response on n points, host-layout (AoS) arrays.
+template <bool SVC>
 __global__ void __launch_bounds__(BLOCK)
 k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
                  const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
@@ -129,13 +136,16 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
     __syncthreads();
-    int svc_mat;
-    const double *sv, *dual;
-    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
-    __syncthreads();
+    int svc_mat = -1;
+    const double *sv = nullptr, *dual = nullptr;
+    if (SVC) {
+        stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+        __syncthreads();
+    }
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const int mid = mat_id ? mat_id[i] : 0;
         const MatDev &m = smat[mid];
+        if ((m.kind == 3) != SVC) continue;  // handled by the other instantiation
         double sig[6], epl[6], deps[6], depl[6], Ct[21], f = 0.;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
@@ -151,8 +161,8 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
             for (int c = 0; c < 21; c++) Ct[c] = m.CV[c];
         } else {
             const bool staged = (mid == svc_mat);
-            ns = response_any(m, staged ? sv : nullptr, staged ? dual : nullptr, sig, epl, deps, f,
-                              depl, Ct);
+            ns = response_kind<SVC>(m, staged ? sv : nullptr, staged ? dual : nullptr, sig, epl, deps, f,
+                                    depl, Ct);
         }
         fy[i] = f;
         nsteps[i] = ns;
@@ -253,82 +263,185 @@ __device__ __forceinline__ void tangent_to_M(const double *D, double kappa, doub
     M[5] = D[sym_idx(5, 5)];                                                                       // SS
 }
 
-// Material sweep over the owned elements (model.py:1340-1359).  SoA state: component c of element
-// e at [c*nel + e].  flags[0] |= changed, flags[1] |= not converged.
-__global__ void __launch_bounds__(BLOCK)
-k_sweep(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int lds_doubles, int nel,
-        int e_off, const int32_t *conn, const int32_t *cls, const double2 *du2,
-        const double *sig, const double *epl, double *elstiff, double *Mel, double *res_sig,
-        double *res_depl, double *fyn, int32_t *max_steps, int nit, int *flags)
+// Tail of the per-element sweep (model.py:1343-1357): store the response, yield-function ratio,
+// tangent test ||elstiff - Ct||_F > 1e-3 and tangent / stiffness-generator refresh.
+__device__ __forceinline__ void sweep_epilogue(const ClassDev &c, const MatDev &m, int e, int nel,
+                                               const double *s, const double *ep, const double *depl,
+                                               double *Ct, double fy, int ns, double *elstiff,
+                                               double *Mel, double *res_sig, double *res_depl,
+                                               double *fyn, int32_t *max_steps, int nit, int &changed,
+                                               int &nconv)
 {
-    __shared__ MatDev smat[MAXMAT];
-    __shared__ ClassDev scls[MAXCLS];
-    stage_materials(smat, gmat, nmat);
-    {
-        const int words = ncls * (int)(sizeof(ClassDev) / 8);
-        const double *src = reinterpret_cast<const double *>(gcls);
-        double *dst = reinterpret_cast<double *>(scls);
-        for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        res_sig[(size_t)k * nel + e] = s[k];
+        res_depl[(size_t)k * nel + e] = depl[k];
     }
+    const double f = fy / sflow_of(m, ep);  // model.py:1345
+    fyn[e] = f;
+    if (!(f <= YF_TOL * 1.0001)) nconv = 1;  // model.py:1361
+    // Frobenius norm of the tangent change over the full 6x6 (model.py:1346)
+    double hh = 0.;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+            const double d = elstiff[(size_t)sym_idx(i, j) * nel + e] - Ct[sym_idx(i, j)];
+            hh += (i == j ? 1. : 2.) * d * d;
+        }
+    hh = sqrt(hh);
+    if (hh > 1.e-3) {  // model.py:1348-1355
+        if (nit >= 15) {
+#pragma unroll
+            for (int k = 0; k < 21; k++) Ct[k] = 0.5 * (Ct[k] + elstiff[(size_t)k * nel + e]);
+        }
+#pragma unroll
+        for (int k = 0; k < 21; k++) elstiff[(size_t)k * nel + e] = Ct[k];
+        double M[6];
+        tangent_to_M(Ct, c.kappa, M);
+#pragma unroll
+        for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+        changed = 1;
+    }
+    if (ns > max_steps[e]) max_steps[e] = ns;  // stat_nlin['max_steps'] (model.py:1356)
+}
+
+struct SweepTables {
+    MatDev smat[MAXMAT];
+    ClassDev scls[MAXCLS];
+};
+
+__device__ __forceinline__ void stage_tables(SweepTables &t, const MatDev *gmat, int nmat,
+                                             const ClassDev *gcls, int ncls)
+{
+    stage_materials(t.smat, gmat, nmat);
+    const int words = ncls * (int)(sizeof(ClassDev) / 8);
+    const double *src = reinterpret_cast<const double *>(gcls);
+    double *dst = reinterpret_cast<double *>(t.scls);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+}
+
+// Material sweep over the owned elements (model.py:1340-1359), phase 1: elastic and one-step plastic
+// elements are finished here (streaming, HBM-bound); elements whose increment must be sub-divided are
+// appended to `list` (one atomic per wave) for k_sweep_heavy.  SoA state: component c of element e at
+// [c*nel + e].  flags[0] |= changed, flags[1] |= not converged, flags[2] = length of `list`.
+// Material / class tables are staged in LDS (wave-uniform addresses -> broadcast reads); holding them
+// in SGPRs instead (scalar loads + waterfall over classes) was measured 35 % slower (SGPR spills).
+template <bool SVC>
+__global__ void __launch_bounds__(BLOCK, PLFX_SWEEP_WAVES)
+k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
+              int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
+              const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
+              const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
+              double *Mel, double *res_sig, double *res_depl, double *fyn, int32_t *max_steps, int nit,
+              int *flags, int32_t *list)
+{
+    __shared__ SweepTables tb;
+    stage_tables(tb, gmat, nmat, gcls, ncls);
     __syncthreads();
-    int svc_mat;
-    const double *sv, *dual;
-    stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
-    __syncthreads();
+    int svc_mat = -1;
+    const double *sv = nullptr, *dual = nullptr;
+    if (SVC) {
+        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+        __syncthreads();
+    }
     int changed = 0, nconv = 0;
     const int nb = gridDim.x;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nel; t += nb) {
         const int e = t * BLOCK + threadIdx.x;
-        if (e >= nel) continue;
-        const ClassDev &c = scls[cls[e]];
-        const MatDev &m = smat[c.mat];
-        if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
-            fyn[e] = 0.;
-            continue;
+        bool heavy = false;
+        if (e < nel) {
+            const ClassDev &c = tb.scls[cls[e]];
+            const MatDev &m = tb.smat[c.mat];
+            if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
+                if (!SVC) fyn[e] = 0.;
+            } else if ((m.kind == 3) == SVC) {
+                const size_t ge = (size_t)e + e_off;
+                double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
+                class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    s[k] = sig[(size_t)k * nel + e];
+                    ep[k] = epl[(size_t)k * nel + e];
+                }
+                int st;
+                if (SVC) {
+                    const bool staged = (c.mat == svc_mat);
+                    YfSvc yf(m, staged ? sv : m.sv, staged ? dual : m.dual);
+                    st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+                } else {
+                    YfHill yf(m);
+                    st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+                }
+                if (st == 2)
+                    heavy = true;
+                else
+                    sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, res_sig, res_depl,
+                                   fyn, max_steps, nit, changed, nconv);
+            }
         }
-        const size_t ge = (size_t)e + e_off;  // global element id (connectivity is global)
-        double deps[6], s[6], ep[6], depl[6], Ct[21], fy;
-        class_strain(c, du2, conn[ge * 4 + 0], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+        // compact the elements that need the 50-sub-step corrector: one atomic per wave
+        const unsigned long long mask = __ballot(heavy);
+        if (mask) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&flags[2], __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (heavy) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+        }
+    }
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+    if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// Phase 2: the sub-divided plastic corrector for the compacted element list.  Every lane runs the
+// same 50 sub-steps (no divergence); FP64-VALU bound.
+template <bool SVC>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
+              int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
+              const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
+              const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
+              double *Mel, double *res_sig, double *res_depl, double *fyn, int32_t *max_steps, int nit,
+              int *flags, const int32_t *__restrict__ list)
+{
+    const int count = flags[2];
+    if (count == 0) return;
+    __shared__ SweepTables tb;
+    stage_tables(tb, gmat, nmat, gcls, ncls);
+    __syncthreads();
+    int svc_mat = -1;
+    const double *sv = nullptr, *dual = nullptr;
+    if (SVC) {
+        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+        __syncthreads();
+    }
+    int changed = 0, nconv = 0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const int e = list[i];
+        const ClassDev &c = tb.scls[cls[e]];
+        const MatDev &m = tb.smat[c.mat];
+        if ((m.kind == 3) != SVC) continue;
+        const size_t ge = (size_t)e + e_off;
+        double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             s[k] = sig[(size_t)k * nel + e];
             ep[k] = epl[(size_t)k * nel + e];
         }
-        const bool staged = (c.mat == svc_mat);
-        const int ns = response_any(m, staged ? sv : nullptr, staged ? dual : nullptr, s, ep, deps,
-                                    fy, depl, Ct);
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            res_sig[(size_t)k * nel + e] = s[k];
-            res_depl[(size_t)k * nel + e] = depl[k];
+        if (SVC) {
+            const bool staged = (c.mat == svc_mat);
+            YfSvc yf(m, staged ? sv : m.sv, staged ? dual : m.dual);
+            response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);  // recompute the prelude
+            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
+        } else {
+            YfHill yf(m);
+            response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
         }
-        const double f = fy / sflow_of(m, ep);  // model.py:1345
-        fyn[e] = f;
-        if (!(f <= YF_TOL * 1.0001)) nconv = 1;  // model.py:1361
-        // Frobenius norm of the tangent change over the full 6x6 (model.py:1346)
-        double hh = 0.;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = i; j < 6; j++) {
-                const double d = elstiff[(size_t)sym_idx(i, j) * nel + e] - Ct[sym_idx(i, j)];
-                hh += (i == j ? 1. : 2.) * d * d;
-            }
-        hh = sqrt(hh);
-        if (hh > 1.e-3) {  // model.py:1348-1355
-            if (nit >= 15) {
-#pragma unroll
-                for (int k = 0; k < 21; k++) Ct[k] = 0.5 * (Ct[k] + elstiff[(size_t)k * nel + e]);
-            }
-#pragma unroll
-            for (int k = 0; k < 21; k++) elstiff[(size_t)k * nel + e] = Ct[k];
-            double M[6];
-            tangent_to_M(Ct, c.kappa, M);
-#pragma unroll
-            for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
-            changed = 1;
-        }
-        if (ns > max_steps[e]) max_steps[e] = ns;  // stat_nlin['max_steps'] (model.py:1356)
+        sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, res_sig, res_depl, fyn,
+                       max_steps, nit, changed, nconv);
     }
     if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
     if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
