@@ -158,16 +158,19 @@ def main():
     value = updates / dt
 
     # roofline of the dominant kernel, from HIP events recorded on the library's stream
-    fam = {'sweep': _lib.T_SWEEP, 'spmv': _lib.T_SPMV, 'cg_update': _lib.T_CGUPD, 'assemble': _lib.T_ASSEMBLE}
+    fam = {'sweep': _lib.T_SWEEP, 'spmv': _lib.T_SPMV, 'cg_update': _lib.T_CGUPD, 'assemble': _lib.T_ASSEMBLE,
+           'vcycle': _lib.T_VCYCLE, 'mg_smooth': _lib.T_SMOOTH}
     tim = {k: eng.timing_get(v) for k, v in fam.items()}
     nel_rank = fe._e1 - fe._e0
     # algorithmic (compulsory) bytes per launch, DESIGN.md "Kernels":
     #   k_spmv<1>: block-ELL values 288 + column ids 36 + z,p_old,p_new,q 4x16 = 388 B per node
+    #   k_mg_smooth (fine level): values 288 + column ids 36 + x_in, dinv, b, x_out 4x16 = 388 B per node
     #   k_sweep_light: conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
     #              + fyn 8 + max_steps 4 written = 412 B (+216 B when the tangent / M is rewritten; not counted)
     bytes_per = {'spmv': 388. * fe.Nnode / world,
-                 'sweep': 412. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.}
-    dominant = max(('spmv', 'sweep', 'cg_update'), key=lambda k: tim[k][0])
+                 'sweep': 412. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.,
+                 'mg_smooth': 388. * fe.Nnode}
+    dominant = max(('spmv', 'sweep', 'cg_update', 'mg_smooth'), key=lambda k: tim[k][0])
 
     def roof(k):
         ms, cnt = tim[k]
@@ -177,7 +180,9 @@ def main():
         ach = bytes_per[k] / avg_s / 1e9
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
                            'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
-                           'cg_update': 'k_cg_update'}[k],
+                           'cg_update': 'k_cg_update',
+                           'mg_smooth': 'k_mg_smooth / k_mg_smooth2_zero (fine-level damped-Jacobi sweep of the '
+                                        'multigrid V-cycle: block-ELL SpMV + update)'}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
                 'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
@@ -192,7 +197,8 @@ def main():
                                'of 50 (after %d untimed elastic pre-roll steps)'
                                % (n, n, PREROLL + W, PREROLL + W + K, PREROLL),
                    'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': 'x-strip element shard x%d' % world,
-                   'solver': 'Jacobi-PCG rtol=%g on block-ELL' % fe.cg_rtol, 'device': devname},
+                   'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
+                              else 'Jacobi-PCG') + ' rtol=%g on block-ELL' % fe.cg_rtol, 'device': devname},
         'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),

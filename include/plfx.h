@@ -100,6 +100,14 @@ int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const doubl
  * pass 0, nel for a single GPU. */
 int plfx_set_mesh(plfx_ctx *ctx, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
                   const double *lxy, double thick, int planestress, int el_begin, int el_end);
+/* Declare that the mesh is the reference's structured NX x NY grid (node j*(NY+1)+k, element j*NY+k,
+ * model.py:893, 935); verified against conn.  Enables the geometric-multigrid preconditioner of
+ * plfx_solve when all elements have one shape and NX, NY halve down to a small grid. */
+int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
+/* preconditioner of plfx_solve: kind 0 = Jacobi, 1 = multigrid V(nu,nu) with damped-Jacobi smoothing
+ * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.7, 2) */
+int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
+int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
 int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);
 /* element stiffness of element e from its current tangent (Element.calc_Kel, model.py:365), [64] */
@@ -154,7 +162,8 @@ int plfx_comm_init(plfx_ctx *ctx, const char id[128], int rank, int nranks);
 
 /* ---------------------------------------------------------------- instrumentation */
 /* accumulated HIP-event time (ms) and launch count of a named kernel family since the last reset:
- * which: 0 sweep, 1 spmv(+dot), 2 cg vector update, 3 assemble */
+ * which: 0 sweep, 1 spmv(+dot), 2 cg vector update, 3 assemble, 4 multigrid V-cycle (whole cycle),
+ *        5 fine-level multigrid smoother launches */
 int plfx_timing_get(plfx_ctx *ctx, int which, double *ms, int64_t *launches);
 int plfx_timing_reset(plfx_ctx *ctx);
 int plfx_timing_enable(plfx_ctx *ctx, int on);

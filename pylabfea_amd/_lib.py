@@ -19,7 +19,7 @@ ELASTIC, HILL6, PRINC3, SVC6 = 0, 1, 2, 3
 ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS = range(11)
 
 # timing families
-T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE = range(4)
+T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE, T_VCYCLE, T_SMOOTH = range(6)
 
 
 class PlfxError(RuntimeError):
@@ -43,7 +43,8 @@ SYMBOLS = [
     'plfx_get_kel', 'plfx_state_get', 'plfx_state_set', 'plfx_state_reset', 'plfx_gather',
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
-    'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable',
+    'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
+    'plfx_precond_info',
 ]
 
 _lib = None
@@ -228,6 +229,18 @@ class Context(object):
         self.nel = nel
         self.nel_owned = el_end - el_begin
         self.ndof = 2 * int(nnode)
+
+    def set_grid(self, nx, ny):
+        self._chk(self.lib.plfx_set_grid(self.h, int(nx), int(ny)))
+
+    def set_precond(self, kind, omega=0., nu=0):
+        self._chk(self.lib.plfx_set_precond(self.h, int(kind), C.c_double(omega), int(nu)))
+
+    def precond_info(self):
+        k = C.c_int()
+        lv = C.c_int()
+        self._chk(self.lib.plfx_precond_info(self.h, C.byref(k), C.byref(lv)))
+        return k.value, lv.value
 
     def get_bmat(self, e):
         B = np.empty((4, 6, 8))

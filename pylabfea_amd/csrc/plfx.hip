@@ -9,6 +9,7 @@
 //     x r z q p0 p1
 #include "../../include/plfx.h"
 #include "plfx_kernels.hpp"
+#include "plfx_mg.hpp"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -134,6 +135,24 @@ struct plfx_ctx {
     bool assembled = false, bc_set = false;
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
     int grid_nodes = 0, grid_el = 0;
+
+    // geometric multigrid preconditioner (structured grids, plfx_set_grid)
+    struct MgLevel {
+        int nx = 0, ny = 0, nnode = 0, nel = 0, nslot = 0, nq = 0, grid = 1;
+        int32_t *col = nullptr, *contrib = nullptr, *cls0 = nullptr;
+        double *val = nullptr, *diag = nullptr, *dinv = nullptr, *Mel = nullptr;
+        double *x = nullptr, *b = nullptr, *t = nullptr, *res = nullptr;
+        double *ainv = nullptr;  // dense inverse (coarsest level, small grids)
+        bool owned = false;  // level 0 aliases the fine-grid arrays of the context
+    };
+    std::vector<MgLevel> mg;
+    ClassDev *mg_cls = nullptr;  // geometry tables shared by all levels
+    MgLevDev *mg_dev = nullptr;  // level descriptors for the single-workgroup tail kernel
+    int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
+    int gx = 0, gy = 0;          // structured grid (elements) if known
+    int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
+    double mg_omega = 0.7;
+    int mg_nu = 2;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -345,6 +364,68 @@ ClassDev make_class(const plfx_ctx *c, int mat, double lx, double ly)
     return k;
 }
 
+// Block-ELL pattern of the elements [e0, e1): per node the sorted neighbour list (slots) and, per
+// (node, slot), the element contributions (e_local*16 + a*4 + b) in ascending element order.
+bool build_pattern(int nnode, const int32_t *conn, int el_begin, int el_end, std::vector<int32_t> &hcol,
+                   std::vector<int32_t> &hcontrib, int &nslot, int &nq, int &nb, int &ne)
+{
+    std::vector<int32_t> deg(nnode + 1, 0);
+    for (int e = el_begin; e < el_end; e++)
+        for (int a = 0; a < 4; a++) deg[conn[4 * e + a] + 1]++;
+    for (int i = 0; i < nnode; i++) deg[i + 1] += deg[i];
+    std::vector<int32_t> adj(deg[nnode]);  // packed (local element, local node), ascending element order
+    {
+        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
+        for (int e = el_begin; e < el_end; e++)
+            for (int a = 0; a < 4; a++) adj[fill[conn[4 * e + a]]++] = (e - el_begin) * 4 + a;
+    }
+    nslot = 0;
+    nq = 0;
+    nb = nnode;
+    ne = 0;
+    std::vector<int32_t> tmp;
+    for (int i = 0; i < nnode; i++) {  // pass 1: sizes
+        const int a0 = deg[i], a1 = deg[i + 1];
+        if (a1 == a0) continue;
+        nb = std::min(nb, i);
+        ne = std::max(ne, i + 1);
+        nq = std::max(nq, a1 - a0);
+        tmp.clear();
+        for (int k = a0; k < a1; k++) {
+            const int e = adj[k] >> 2;
+            for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        nslot = std::max(nslot, (int)tmp.size());
+    }
+    if (nslot == 0) return false;
+    hcol.assign((size_t)nslot * nnode, -1);
+    hcontrib.assign((size_t)nslot * nq * nnode, -1);
+    for (int i = 0; i < nnode; i++) {  // pass 2: fill
+        const int a0 = deg[i], a1 = deg[i + 1];
+        if (a1 == a0) continue;
+        tmp.clear();
+        for (int k = a0; k < a1; k++) {
+            const int e = adj[k] >> 2;
+            for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (size_t s = 0; s < tmp.size(); s++) {
+            hcol[s * nnode + i] = tmp[s];
+            int qn = 0;
+            for (int k = a0; k < a1; k++) {  // ascending element order = reference's addition order
+                const int e = adj[k] >> 2, a = adj[k] & 3;
+                for (int b = 0; b < 4; b++)
+                    if (conn[4 * (e + el_begin) + b] == tmp[s])
+                        hcontrib[((size_t)s * nq + qn++) * nnode + i] = e * 16 + a * 4 + b;
+            }
+        }
+    }
+    return true;
+}
+
 void free_mesh(plfx_ctx *c)
 {
     dfree(c->dcls);
@@ -381,6 +462,28 @@ void free_mesh(plfx_ctx *c)
     dfree(c->q);
     dfree(c->p[0]);
     dfree(c->p[1]);
+    for (auto &L : c->mg) {
+        if (!L.owned) continue;
+        dfree(L.col);
+        dfree(L.contrib);
+        dfree(L.cls0);
+        dfree(L.val);
+        dfree(L.diag);
+        dfree(L.dinv);
+        dfree(L.Mel);
+        dfree(L.x);
+        dfree(L.b);
+    }
+    for (auto &L : c->mg) {
+        dfree(L.t);
+        dfree(L.res);
+        dfree(L.ainv);
+    }
+    c->mg.clear();
+    dfree(c->mg_cls);
+    dfree(c->mg_dev);
+    c->mg_tail = -1;
+    c->gx = c->gy = 0;
     c->assembled = c->bc_set = false;
 }
 
@@ -418,6 +521,115 @@ int plain_spmv(plfx_ctx *c, const double *in, double *out)
         if (g_rccl.AllReduce(out, out, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
             return fail(c, PLFX_ERR_HIP, "ncclAllReduce failed");
     }
+    return 0;
+}
+
+
+bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2 && c->nranks == 1; }
+
+// coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
+int mg_assemble(plfx_ctx *c)
+{
+    for (size_t l = 1; l < c->mg.size(); l++) {
+        auto &F = c->mg[l - 1];
+        auto &L = c->mg[l];
+        hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
+                           F.nel, F.Mel, L.Mel);
+        hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
+                           L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Dirichlet masks / Jacobi scalings of the coarse levels from the fine dinv (called by apply_bc)
+int mg_update_dinv(plfx_ctx *c)
+{
+    for (size_t l = 1; l < c->mg.size(); l++) {
+        auto &F = c->mg[l - 1];
+        auto &L = c->mg[l];
+        hipLaunchKernelGGL(k_mg_coarse_dinv, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1,
+                           L.ny + 1, F.ny + 1, (const double2 *)F.dinv, (const double2 *)L.diag,
+                           (double2 *)L.dinv);
+    }
+    auto &Lc = c->mg.back();
+    if (Lc.ainv) {
+        const int n = 2 * Lc.nnode;
+        hipLaunchKernelGGL(k_mg_coarse_invert, dim3(1), dim3(BLOCK), (size_t)n * n * sizeof(double), c->stream,
+                           Lc.nnode, Lc.nslot, Lc.col, Lc.val, (const double2 *)Lc.dinv, Lc.ainv);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r)
+int mg_vcycle(plfx_ctx *c)
+{
+    const int nl = (int)c->mg.size();
+    const double om = c->mg_omega;
+    auto smooth = [&](plfx_ctx::MgLevel &L, const double *xin, double *xout, int first) {
+        hipLaunchKernelGGL(k_mg_smooth, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col, L.val,
+                           (const double2 *)L.dinv, (const double2 *)L.b, (const double2 *)xin, (double2 *)xout,
+                           om, first, c->sc);
+    };
+    const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;  // levels >= lt run inside one workgroup
+    for (int l = 0; l < lt; l++) {  // down
+        auto &L = c->mg[l];
+        auto &C = c->mg[l + 1];
+        // nu pre-smoothing sweeps from a zero guess, ending in x
+        const int nu = c->mg_nu;
+        EvPair *ev = nullptr;
+        if (nu == 2) {  // both sweeps in one pass over the matrix
+            if (l == 0) tim_begin(c, 5, &ev);
+            hipLaunchKernelGGL(k_mg_smooth2_zero, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col,
+                               L.val, (const double2 *)L.dinv, (const double2 *)L.b, (double2 *)L.x, om, c->sc);
+            if (l == 0) tim_end(c, ev);
+        } else {
+            double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
+            for (int k = 0; k < nu; k++) {
+                smooth(L, src, dst, k == 0);
+                src = dst;
+                dst = (dst == L.x) ? L.t : L.x;
+            }
+        }
+        hipLaunchKernelGGL(k_mg_residual, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col, L.val,
+                           (const double2 *)L.dinv, (const double2 *)L.b, (const double2 *)L.x, (double2 *)L.res,
+                           c->sc);
+        hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
+                           L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
+    }
+    {
+        auto &L = c->mg[nl - 1];
+        const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
+        if (lt < nl - 1)
+            hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(MG_TAIL_BLOCK), lds, c->stream, c->mg_dev, lt, nl, om,
+                               c->mg_nu, c->sc);
+        else if (L.ainv)
+            hipLaunchKernelGGL(k_mg_coarse_dense, dim3(1), dim3(BLOCK), 0, c->stream, L.nnode, L.ainv,
+                               (const double2 *)L.b, (double2 *)L.x, c->sc);
+        else
+            hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(BLOCK), lds, c->stream, L.nnode, L.nslot, L.col,
+                               L.val, (const double2 *)L.dinv, (const double2 *)L.b, (double2 *)L.x,
+                               4 * L.nnode + 20, 1.e-10, c->sc);
+    }
+    for (int l = lt - 1; l >= 0; l--) {  // up
+        auto &L = c->mg[l];
+        auto &C = c->mg[l + 1];
+        hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
+                           C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
+        const int nu = c->mg_nu;
+        double *src = L.x, *dst = L.t;
+        for (int k = 0; k < nu; k++) {
+            EvPair *ev = nullptr;
+            if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
+            smooth(L, src, dst, 0);
+            if (l == 0) tim_end(c, ev);
+            std::swap(src, dst);
+        }
+        if (src != L.x)  // odd nu: result sits in t
+            HIPCHK(c, hipMemcpyAsync(L.x, L.t, (size_t)L.nnode * 16, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 
@@ -743,68 +955,12 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
 
     // node -> owned elements adjacency, neighbour slots, assembly gather lists
     const int nown = c->nel;
-    std::vector<int32_t> deg(nnode + 1, 0);
-    for (int e = el_begin; e < el_end; e++)
-        for (int a = 0; a < 4; a++) deg[conn[4 * e + a] + 1]++;
-    for (int i = 0; i < nnode; i++) deg[i + 1] += deg[i];
-    std::vector<int32_t> adj(deg[nnode]);  // packed (local element, local node) in ascending element order
-    {
-        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
-        for (int e = el_begin; e < el_end; e++)
-            for (int a = 0; a < 4; a++) adj[fill[conn[4 * e + a]]++] = (e - el_begin) * 4 + a;
-    }
-    int nslot = 0, nq = 0, nb = nnode, ne = 0;
-    std::vector<std::vector<int32_t>> nbrs;  // only to size; recomputed below to limit memory
-    // pass 1: sizes
-    {
-        std::vector<int32_t> tmp;
-        for (int i = 0; i < nnode; i++) {
-            const int a0 = deg[i], a1 = deg[i + 1];
-            if (a1 == a0) continue;
-            nb = std::min(nb, i);
-            ne = std::max(ne, i + 1);
-            nq = std::max(nq, a1 - a0);
-            tmp.clear();
-            for (int k = a0; k < a1; k++) {
-                const int e = adj[k] >> 2;
-                for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
-            }
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            nslot = std::max(nslot, (int)tmp.size());
-        }
-    }
-    if (nslot == 0) return fail(c, PLFX_ERR_ARG, "no owned elements");
+    std::vector<int32_t> hcontrib;
+    int nslot = 0, nq = 0;
+    if (!build_pattern(nnode, conn, el_begin, el_end, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
+        return fail(c, PLFX_ERR_ARG, "no owned elements");
     c->nslot = nslot;
     c->nq = nq;
-    c->n_begin = nb;
-    c->n_end = ne;
-    c->hcol.assign((size_t)nslot * nnode, -1);
-    std::vector<int32_t> hcontrib((size_t)nslot * nq * nnode, -1);
-    {
-        std::vector<int32_t> tmp;
-        for (int i = 0; i < nnode; i++) {
-            const int a0 = deg[i], a1 = deg[i + 1];
-            if (a1 == a0) continue;
-            tmp.clear();
-            for (int k = a0; k < a1; k++) {
-                const int e = adj[k] >> 2;
-                for (int b = 0; b < 4; b++) tmp.push_back(conn[4 * (e + el_begin) + b]);
-            }
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            for (size_t s = 0; s < tmp.size(); s++) {
-                c->hcol[s * nnode + i] = tmp[s];
-                int qn = 0;
-                for (int k = a0; k < a1; k++) {  // ascending element order = reference's addition order
-                    const int e = adj[k] >> 2, a = adj[k] & 3;
-                    for (int b = 0; b < 4; b++)
-                        if (conn[4 * (e + el_begin) + b] == tmp[s])
-                            hcontrib[((size_t)s * nq + qn++) * nnode + i] = e * 16 + a * 4 + b;
-                }
-            }
-        }
-    }
     if ((size_t)nown * 16 > 0x7fffffffULL) return fail(c, PLFX_ERR_UNSUPPORTED, "too many elements for int32 gather codes");
 
     int rc;
@@ -896,6 +1052,141 @@ int plfx_get_kel(plfx_ctx *c, int e, double *Kel)
             Kel[(2 * a + 1) * 8 + 2 * b] = M[1] * syx + M[4] * syy + M[2] * sxx + M[5] * sxy;
             Kel[(2 * a + 1) * 8 + 2 * b + 1] = M[3] * syy + M[4] * (syx + sxy) + M[5] * sxx;
         }
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ structured grid / multigrid
+int plfx_set_grid(plfx_ctx *c, int nx, int ny)
+{
+    if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (nx < 1 || ny < 1 || (long long)nx * ny != c->nel_total || (long long)(nx + 1) * (ny + 1) != c->nnode)
+        return fail(c, PLFX_ERR_ARG, "grid %dx%d does not match the mesh", nx, ny);
+    const int nrow = ny + 1;
+    for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
+        const int n1 = (e / ny) * nrow + e % ny;
+        const int32_t *q = &c->hconn[4 * (size_t)e];
+        if (q[0] != n1 || q[1] != n1 + 1 || q[2] != n1 + nrow || q[3] != n1 + nrow + 1)
+            return fail(c, PLFX_ERR_ARG, "connectivity of element %d is not the structured numbering", e);
+    }
+    c->gx = nx;
+    c->gy = ny;
+    for (auto &L : c->mg) {  // drop a previous hierarchy
+        if (L.owned) {
+            dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
+            dfree(L.Mel); dfree(L.x); dfree(L.b);
+        }
+        dfree(L.t); dfree(L.res); dfree(L.ainv);
+    }
+    c->mg.clear();
+    if (c->nranks > 1 || c->nel != c->nel_total) return PLFX_OK;  // sharded runs use Jacobi-PCG
+    for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly needs one element shape
+        if (c->hlxy[2 * (size_t)e] != c->hlxy[0] || c->hlxy[2 * (size_t)e + 1] != c->hlxy[1]) return PLFX_OK;
+    std::vector<std::pair<int, int>> dims;
+    dims.push_back({nx, ny});
+    while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 &&
+           (long long)dims.back().first * dims.back().second > 16)
+        dims.push_back({dims.back().first / 2, dims.back().second / 2});
+    if (dims.size() < 2) return PLFX_OK;
+    if ((long long)(dims.back().first + 1) * (dims.back().second + 1) > MG_COARSE_MAX) return PLFX_OK;
+    int rc;
+    if (!c->mg_cls) {
+        if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->mg_cls, &c->hcls[0], sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
+    }
+    c->mg.resize(dims.size());
+    for (size_t l = 0; l < dims.size(); l++) {
+        auto &L = c->mg[l];
+        L.nx = dims[l].first;
+        L.ny = dims[l].second;
+        L.nnode = (L.nx + 1) * (L.ny + 1);
+        L.nel = L.nx * L.ny;
+        L.grid = grid_xcd(L.nnode);
+        if ((rc = dalloc(c, &L.t, (size_t)2 * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.res, (size_t)2 * L.nnode))) return rc;
+        if (l == 0) {
+            L.owned = false;
+            L.nslot = c->nslot;
+            L.nq = c->nq;
+            L.col = c->dcol;
+            L.val = c->dval;
+            L.diag = c->diag;
+            L.dinv = c->dinv;
+            L.Mel = c->Mel;
+            L.x = c->z;
+            L.b = c->r;
+            continue;
+        }
+        L.owned = true;
+        std::vector<int32_t> conn((size_t)4 * L.nel), hcol, hcontrib;
+        const int nr = L.ny + 1;
+        for (int e = 0; e < L.nel; e++) {
+            const int n1 = (e / L.ny) * nr + e % L.ny;
+            conn[4 * (size_t)e] = n1;
+            conn[4 * (size_t)e + 1] = n1 + 1;
+            conn[4 * (size_t)e + 2] = n1 + nr;
+            conn[4 * (size_t)e + 3] = n1 + nr + 1;
+        }
+        int nb, ne;
+        if (!build_pattern(L.nnode, conn.data(), 0, L.nel, hcol, hcontrib, L.nslot, L.nq, nb, ne))
+            return fail(c, PLFX_ERR_ARG, "empty multigrid level");
+        if ((rc = dalloc(c, &L.col, hcol.size()))) return rc;
+        if ((rc = dalloc(c, &L.contrib, hcontrib.size()))) return rc;
+        if ((rc = dalloc(c, &L.cls0, (size_t)L.nel))) return rc;
+        if ((rc = dalloc(c, &L.val, (size_t)L.nslot * 4 * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.diag, (size_t)2 * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.dinv, (size_t)2 * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.Mel, (size_t)6 * L.nel))) return rc;
+        if ((rc = dalloc(c, &L.x, (size_t)2 * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.b, (size_t)2 * L.nnode))) return rc;
+        HIPCHK(c, hipMemcpyAsync(L.col, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L.contrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    {
+        auto &Lc = c->mg.back();
+        const int n = 2 * Lc.nnode;
+        if (n <= MG_DENSE_MAX) {
+            if ((rc = dalloc(c, &Lc.ainv, (size_t)n * n))) return rc;
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          n * n * (int)sizeof(double)));
+        }
+    }
+    const int lds = c->mg.back().nnode * 4 * (int)sizeof(double2);
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    {   // levels small enough for the single-workgroup tail (never level 0)
+        std::vector<MgLevDev> hd(c->mg.size());
+        c->mg_tail = -1;
+        for (size_t l = 0; l < c->mg.size(); l++) {
+            auto &L = c->mg[l];
+            hd[l] = MgLevDev{L.nx, L.ny, L.nnode, L.nslot, L.ainv, L.col, L.val, (const double2 *)L.dinv,
+                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res};
+            if (c->mg_tail < 0 && l > 0 && L.nnode <= MG_TAIL_NODES) c->mg_tail = (int)l;
+        }
+        dfree(c->mg_dev);
+        if ((rc = dalloc(c, &c->mg_dev, hd.size()))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->mg_dev, hd.data(), hd.size() * sizeof(MgLevDev), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->assembled = false;
+    return PLFX_OK;
+}
+
+int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
+{
+    if (!c) return PLFX_ERR_STATE;
+    if (kind != 0 && kind != 1) return fail(c, PLFX_ERR_ARG, "precond kind must be 0 (Jacobi) or 1 (multigrid)");
+    c->precond = kind;
+    if (omega > 0.) c->mg_omega = omega;
+    if (nu > 0) c->mg_nu = nu;
+    return PLFX_OK;
+}
+
+int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
+{
+    if (!c) return PLFX_ERR_STATE;
+    if (kind) *kind = mg_active(c) ? 1 : 0;
+    if (levels) *levels = (int)c->mg.size();
     return PLFX_OK;
 }
 
@@ -1044,6 +1335,10 @@ int plfx_assemble(plfx_ctx *c)
         if (g_rccl.AllReduce(c->diag, c->diag, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
             return fail(c, PLFX_ERR_HIP, "ncclAllReduce(diag) failed");
     }
+    if (mg_active(c)) {
+        int rc = mg_assemble(c);
+        if (rc) return rc;
+    }
     c->assembled = true;
     return PLFX_OK;
 }
@@ -1116,6 +1411,10 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
                        fext ? c->fext : nullptr, c->q, c->diag, c->is_presc, c->rhs, c->dinv);
     HIPCHK(c, hipGetLastError());
     if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mg_active(c)) {
+        rc = mg_update_dinv(c);
+        if (rc) return rc;
+    }
     c->bc_set = true;
     return PLFX_OK;
 }
@@ -1142,12 +1441,19 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                        warm ? (const double2 *)c->q : nullptr, (const double2 *)c->dinv,
                        (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
     hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
+    const bool mg = mg_active(c);
+    if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init
+        rc = mg_vcycle(c);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
+                           (const double2 *)c->z, P_rz[1]);
+    }
     // beta of the first iteration must be 0: rz_old = +inf, p_old = 0
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(BLOCK), 0, c->stream, P_rz[0], (size_t)gn, (double)INFINITY);
     HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
     HIPCHK(c, hipGetLastError());
 
-    const int chunk = 50;
+    const int chunk = mg ? 1 : 50;  // a V-cycle is ~1 ms: poll the convergence flag every iteration
     int it = 0, done = 0;
     CgScalars hs;
     while (it < maxit && !done) {
@@ -1172,12 +1478,26 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 hipLaunchKernelGGL(k_dot_pq, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
                                    (const double2 *)c->q, P_pq, c->sc);
             }
-            tim_begin(c, 2, &ev);
-            hipLaunchKernelGGL(k_cg_update, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
-                               (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
-                               (double2 *)c->r, (double2 *)c->z, P_pq, gn, P_rz[prev], P_rr[prev], gn,
-                               P_rz[cur], P_rr[cur], c->sc);
-            tim_end(c, ev);
+            if (mg) {
+                tim_begin(c, 2, &ev);
+                hipLaunchKernelGGL(k_cg_update_mg, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
+                                   (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
+                                   (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc);
+                tim_end(c, ev);
+                tim_begin(c, 4, &ev);
+                rc = mg_vcycle(c);
+                tim_end(c, ev);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
+                                   (const double2 *)c->z, P_rz[cur]);
+            } else {
+                tim_begin(c, 2, &ev);
+                hipLaunchKernelGGL(k_cg_update, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
+                                   (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
+                                   (double2 *)c->r, (double2 *)c->z, P_pq, gn, P_rz[prev], P_rr[prev], gn,
+                                   P_rz[cur], P_rr[cur], c->sc);
+                tim_end(c, ev);
+            }
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
@@ -1196,6 +1516,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
         c->tim.noop[1] += it - hs.iters;
         c->tim.noop[2] += it - hs.iters;
+        c->tim.noop[4] += it - hs.iters;
+        c->tim.noop[5] += 3 * (it - hs.iters);
     }
     if (relres) {
         const double bb = hs.thresh2 / (rtol * rtol);

@@ -1,0 +1,559 @@
+// plfx_mg.hpp — geometric multigrid V-cycle used as the PCG preconditioner on structured Q4 grids.
+//
+// The reference solves K du = f with dense LU (model.py:1028-1033, 1291); any solver that returns the
+// same du to round-off is a legal replacement.  Jacobi-PCG needs O(NX) iterations; a V(2,2) cycle on
+// the node grid (node id = j*(NY+1)+k, model.py:893) makes the count mesh-independent.
+//   * transfer: bilinear interpolation P per displacement component, restriction R = P^T
+//   * coarse operators: re-assembly with the arithmetic mean of the four children's stiffness
+//     generators M (Q4 stiffness is invariant under uniform scaling of the element, so the class
+//     tables of the fine grid apply on every level)
+//   * smoother: damped Jacobi, same number of pre- and post-sweeps  -> symmetric, SPD preconditioner
+//   * Dirichlet DOFs: a coarse DOF is prescribed iff its coincident fine DOF is; corrections and
+//     residuals are kept zero on prescribed DOFs on every level
+//   * coarsest grid: Jacobi-PCG inside one workgroup (vectors in LDS)
+#pragma once
+#include "plfx_kernels.hpp"
+
+namespace plfx {
+
+// xout = xin + omega * dinv * (b - K xin)      (first != 0: xin == 0 -> xout = omega * dinv * b)
+__global__ void __launch_bounds__(BLOCK)
+k_mg_smooth(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+            const double2 *__restrict__ dinv, const double2 *__restrict__ b,
+            const double2 *__restrict__ xin, double2 *__restrict__ xout, double omega, int first,
+            const CgScalars *sc)
+{
+    if (sc->done) return;  // PCG already converged: the remaining launches of the chunk are no-ops
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        const double2 di = dinv[i], bi = b[i];
+        if (first) {
+            xout[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+            continue;
+        }
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < nslot; s++) {
+            const int j = col[(size_t)s * nnode + i];
+            if (j < 0) continue;
+            const double2 pj = xin[j];
+            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
+            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
+        }
+        const double2 xi = xin[i];
+        xout[i] = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
+    }
+}
+
+// two damped-Jacobi sweeps from a zero guess in one pass:
+//   x1 = w D^-1 b ;  x2 = x1 + w D^-1 (b - K x1)   with x1 of the neighbours recomputed from (dinv, b)
+__global__ void __launch_bounds__(BLOCK)
+k_mg_smooth2_zero(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+                  const double2 *__restrict__ dinv, const double2 *__restrict__ b,
+                  double2 *__restrict__ xout, double omega, const CgScalars *sc)
+{
+    if (sc->done) return;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < nslot; s++) {
+            const int j = col[(size_t)s * nnode + i];
+            if (j < 0) continue;
+            const double2 dj = dinv[j], bj = b[j];
+            const double px = omega * dj.x * bj.x, py = omega * dj.y * bj.y;
+            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], px, fma(val[((size_t)s * 4 + 1) * nnode + i], py, qx));
+            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], px, fma(val[((size_t)s * 4 + 3) * nnode + i], py, qy));
+        }
+        const double2 di = dinv[i], bi = b[i];
+        const double x1x = omega * di.x * bi.x, x1y = omega * di.y * bi.y;
+        xout[i] = make_double2(fma(omega * di.x, bi.x - qx, x1x), fma(omega * di.y, bi.y - qy, x1y));
+    }
+}
+
+// res = P_free (b - K x)
+__global__ void __launch_bounds__(BLOCK)
+k_mg_residual(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+              const double2 *__restrict__ dinv, const double2 *__restrict__ b,
+              const double2 *__restrict__ x, double2 *__restrict__ res, const CgScalars *sc)
+{
+    if (sc->done) return;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < nslot; s++) {
+            const int j = col[(size_t)s * nnode + i];
+            if (j < 0) continue;
+            const double2 pj = x[j];
+            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
+            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
+        }
+        const double2 di = dinv[i], bi = b[i];
+        res[i] = make_double2(di.x != 0. ? bi.x - qx : 0., di.y != 0. ? bi.y - qy : 0.);
+    }
+}
+
+// full-weighting restriction b_c = P^T res_f (coarse node (J,K) <-> fine node (2J,2K)); nyf/nyc = nodes per column
+__global__ void __launch_bounds__(BLOCK)
+k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__restrict__ res_f,
+              const double2 *__restrict__ dinv_c, double2 *__restrict__ b_c)
+{
+    const int nc = nxc_nodes * nyc;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
+        const int J = i / nyc, K = i - J * nyc;
+        double sx = 0., sy = 0.;
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+            const int jf = 2 * J + dj;
+            if (jf < 0 || jf >= nxf_nodes) continue;
+#pragma unroll
+            for (int dk = -1; dk <= 1; dk++) {
+                const int kf = 2 * K + dk;
+                if (kf < 0 || kf >= nyf) continue;
+                const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
+                const double2 r = res_f[(size_t)jf * nyf + kf];
+                sx = fma(w, r.x, sx);
+                sy = fma(w, r.y, sy);
+            }
+        }
+        const double2 d = dinv_c[i];
+        b_c[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+    }
+}
+
+// x_f += P x_c on free fine DOFs
+__global__ void __launch_bounds__(BLOCK)
+k_mg_prolong_add(int nxf_nodes, int nyf, int nyc, const double2 *__restrict__ x_c,
+                 const double2 *__restrict__ dinv_f, double2 *__restrict__ x_f)
+{
+    const int nf = nxf_nodes * nyf;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nf; i += gridDim.x * BLOCK) {
+        const int j = i / nyf, k = i - j * nyf;
+        const int J0 = j >> 1, K0 = k >> 1;
+        const int oj = j & 1, ok = k & 1;
+        double2 v = x_c[(size_t)J0 * nyc + K0];
+        double cx = v.x, cy = v.y;
+        if (oj) {
+            v = x_c[(size_t)(J0 + 1) * nyc + K0];
+            cx += v.x;
+            cy += v.y;
+        }
+        if (ok) {
+            v = x_c[(size_t)J0 * nyc + K0 + 1];
+            cx += v.x;
+            cy += v.y;
+        }
+        if (oj && ok) {
+            v = x_c[(size_t)(J0 + 1) * nyc + K0 + 1];
+            cx += v.x;
+            cy += v.y;
+        }
+        const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+        const double2 d = dinv_f[i];
+        double2 xf = x_f[i];
+        if (d.x != 0.) xf.x = fma(w, cx, xf.x);
+        if (d.y != 0.) xf.y = fma(w, cy, xf.y);
+        x_f[i] = xf;
+    }
+}
+
+// coarse stiffness generator: mean of the four children (element id = j*NY + k, model.py:935)
+__global__ void __launch_bounds__(BLOCK)
+k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ M_f, double *__restrict__ M_c)
+{
+    const int nel_c = nxc * nyc;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nel_c; i += gridDim.x * BLOCK) {
+        const int J = i / nyc, K = i - J * nyc;
+        const size_t e00 = (size_t)(2 * J) * nyf + 2 * K, e10 = e00 + nyf;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double *m = M_f + (size_t)c * nel_f;
+            M_c[(size_t)c * nel_c + i] = 0.25 * (m[e00] + m[e00 + 1] + m[e10] + m[e10 + 1]);
+        }
+    }
+}
+
+// coarse Dirichlet mask from the coincident fine nodes; dinv_c = free ? 1/|diag_c| : 0
+__global__ void __launch_bounds__(BLOCK)
+k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ dinv_f,
+                 const double2 *__restrict__ diag_c, double2 *__restrict__ dinv_c)
+{
+    const int nc = nxc_nodes * nyc;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
+        const int J = i / nyc, K = i - J * nyc;
+        const double2 df = dinv_f[(size_t)(2 * J) * nyf + 2 * K];
+        const double2 dg = diag_c[i];
+        double2 o;
+        o.x = (df.x != 0.) ? (fabs(dg.x) > 1e-300 ? 1. / fabs(dg.x) : 1.) : 0.;
+        o.y = (df.y != 0.) ? (fabs(dg.y) > 1e-300 ? 1. / fabs(dg.y) : 1.) : 0.;
+        dinv_c[i] = o;
+    }
+}
+
+// Coarsest grid: Jacobi-PCG on (nnode <= MG_COARSE_MAX) nodes inside one workgroup, vectors in LDS.
+constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
+constexpr int MG_TAIL_BLOCK = 512;   // threads of the single-workgroup tail kernel
+constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel
+constexpr int MG_DENSE_MAX = 128;    // coarsest grids up to this many DOFs are solved with a dense inverse
+
+struct MgLevDev {
+    int nx, ny, nnode, nslot;
+    const double *ainv;  // dense inverse of the (masked) operator, coarsest level only (or nullptr)
+    const int32_t *col;
+    const double *val;
+    const double2 *dinv;
+    double2 *x, *b, *t, *res;
+};
+
+__device__ inline void coarse_solve_block(int nnode, int nslot, const int32_t *__restrict__ col,
+                                          const double *__restrict__ val, const double2 *__restrict__ dinv,
+                                          const double2 *__restrict__ b, double2 *__restrict__ x, int maxit,
+                                          double rtol, double2 *sh2)
+{
+    const int nt = blockDim.x, nw = nt >> 6;
+    double2 *xs = sh2, *r = sh2 + nnode, *p = sh2 + 2 * nnode, *q = sh2 + 3 * nnode;
+    __shared__ double red[MG_TAIL_BLOCK / 64];
+    __shared__ double bc;
+    auto bsum = [&](double v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.;
+            for (int i = 0; i < nw; i++) t += red[i];
+            bc = t;
+        }
+        __syncthreads();
+        return bc;
+    };
+    double a_rz = 0., a_bb = 0.;
+    for (int i = threadIdx.x; i < nnode; i += nt) {
+        const double2 bi = b[i], di = dinv[i];
+        xs[i] = make_double2(0., 0.);
+        r[i] = bi;
+        const double2 zi = make_double2(di.x * bi.x, di.y * bi.y);
+        p[i] = zi;
+        a_rz += bi.x * zi.x + bi.y * zi.y;
+        a_bb += bi.x * bi.x + bi.y * bi.y;
+    }
+    double rz = bsum(a_rz);
+    const double bb = bsum(a_bb);
+    const double thresh = rtol * rtol * bb;
+    for (int it = 0; it < maxit && bb > 0.; it++) {
+        double a_pq = 0.;
+        for (int i = threadIdx.x; i < nnode; i += nt) {
+            double qx = 0., qy = 0.;
+            for (int s = 0; s < nslot; s++) {
+                const int j = col[(size_t)s * nnode + i];
+                if (j < 0) continue;
+                const double2 pj = p[j];
+                qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
+                qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
+            }
+            const double2 di = dinv[i];
+            if (di.x == 0.) qx = 0.;
+            if (di.y == 0.) qy = 0.;
+            q[i] = make_double2(qx, qy);
+            a_pq += p[i].x * qx + p[i].y * qy;
+        }
+        const double pq = bsum(a_pq);
+        if (!(pq > 0.)) break;
+        const double alpha = rz / pq;
+        double a_rzn = 0., a_rr = 0.;
+        for (int i = threadIdx.x; i < nnode; i += nt) {
+            double2 xi = xs[i], ri = r[i];
+            const double2 pi = p[i], qi = q[i], di = dinv[i];
+            xi.x += alpha * pi.x;
+            xi.y += alpha * pi.y;
+            ri.x -= alpha * qi.x;
+            ri.y -= alpha * qi.y;
+            xs[i] = xi;
+            r[i] = ri;
+            a_rzn += ri.x * ri.x * di.x + ri.y * ri.y * di.y;
+            a_rr += ri.x * ri.x + ri.y * ri.y;
+        }
+        const double rzn = bsum(a_rzn);
+        const double rr = bsum(a_rr);
+        if (rr <= thresh) break;
+        const double beta = rzn / rz;
+        rz = rzn;
+        for (int i = threadIdx.x; i < nnode; i += nt) {
+            const double2 ri = r[i], di = dinv[i], pi = p[i];
+            p[i] = make_double2(fma(beta, pi.x, di.x * ri.x), fma(beta, pi.y, di.y * ri.y));
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nnode; i += nt) x[i] = xs[i];
+    __syncthreads();
+}
+
+// Dense inverse of the coarsest operator (n = 2*nnode <= MG_DENSE_MAX) by in-place Gauss-Jordan in
+// LDS; prescribed DOFs are replaced by identity rows/columns.  Runs once per apply_bc.
+__global__ void __launch_bounds__(BLOCK)
+k_mg_coarse_invert(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+                   const double2 *__restrict__ dinv, double *__restrict__ ainv)
+{
+    extern __shared__ double A[];
+    const int n = 2 * nnode;
+    const double *dv = reinterpret_cast<const double *>(dinv);
+    for (int i = threadIdx.x; i < n * n; i += BLOCK) A[i] = 0.;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nnode * nslot; idx += BLOCK) {
+        const int i = idx % nnode, s = idx / nnode;
+        const int j = col[(size_t)s * nnode + i];
+        if (j < 0) continue;
+        for (int r = 0; r < 2; r++)
+            for (int cc = 0; cc < 2; cc++) {
+                const int row = 2 * i + r, cl = 2 * j + cc;
+                const bool freedof = dv[row] != 0. && dv[cl] != 0.;
+                A[row * n + cl] = freedof ? val[((size_t)s * 4 + r * 2 + cc) * nnode + i] : (row == cl ? 1. : 0.);
+            }
+    }
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        __shared__ double piv;
+        if (threadIdx.x == 0) {
+            double p = A[k * n + k];
+            if (fabs(p) < 1e-300) p = 1.;
+            piv = 1. / p;
+            A[k * n + k] = 1.;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += BLOCK) A[k * n + j] *= piv;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < n * n; idx += BLOCK) {
+            const int i = idx / n, j = idx - i * n;
+            if (i == k) continue;
+            const double f = A[i * n + k];
+            if (j == k) continue;  // column k is finalised below, after every row has read its factor
+            A[i * n + j] = fma(-f, A[k * n + j], A[i * n + j]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += BLOCK)
+            if (i != k) A[i * n + k] = -A[i * n + k] * A[k * n + k];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n * n; i += BLOCK) ainv[i] = A[i];
+}
+
+// x = Ainv b on the coarsest grid (masked DOFs stay zero because b is zero there)
+__device__ inline void coarse_dense_block(int nnode, const double *__restrict__ ainv,
+                                          const double2 *__restrict__ b, double2 *__restrict__ x)
+{
+    const int n = 2 * nnode;
+    const double *bv = reinterpret_cast<const double *>(b);
+    double *xv = reinterpret_cast<double *>(x);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s = 0.;
+        for (int j = 0; j < n; j++) s = fma(ainv[(size_t)i * n + j], bv[j], s);
+        xv[i] = s;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_mg_coarse_solve(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+                  const double2 *__restrict__ dinv, const double2 *__restrict__ b, double2 *__restrict__ x,
+                  int maxit, double rtol, const CgScalars *sc)
+{
+    if (sc->done) return;
+    extern __shared__ double2 sh2[];
+    coarse_solve_block(nnode, nslot, col, val, dinv, b, x, maxit, rtol, sh2);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_mg_coarse_dense(int nnode, const double *__restrict__ ainv, const double2 *__restrict__ b,
+                  double2 *__restrict__ x, const CgScalars *sc)
+{
+    if (sc->done) return;
+    coarse_dense_block(nnode, ainv, b, x);
+}
+
+// ---- single-workgroup pieces of the V-cycle (levels with few nodes are launch-latency bound:
+//      one workgroup walks them all, separated by workgroup barriers instead of kernel boundaries)
+__device__ inline void blk_smooth(const MgLevDev &L, const double2 *xin, double2 *xout, double omega, int first)
+{
+    for (int i = threadIdx.x; i < L.nnode; i += blockDim.x) {
+        const double2 di = L.dinv[i], bi = L.b[i];
+        if (first) {
+            xout[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+            continue;
+        }
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < L.nslot; s++) {
+            const int j = L.col[(size_t)s * L.nnode + i];
+            if (j < 0) continue;
+            const double2 pj = xin[j];
+            qx = fma(L.val[((size_t)s * 4 + 0) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 1) * L.nnode + i], pj.y, qx));
+            qy = fma(L.val[((size_t)s * 4 + 2) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 3) * L.nnode + i], pj.y, qy));
+        }
+        const double2 xi = xin[i];
+        xout[i] = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
+    }
+    __syncthreads();
+}
+
+__device__ inline void blk_residual(const MgLevDev &L)
+{
+    for (int i = threadIdx.x; i < L.nnode; i += blockDim.x) {
+        double qx = 0., qy = 0.;
+        for (int s = 0; s < L.nslot; s++) {
+            const int j = L.col[(size_t)s * L.nnode + i];
+            if (j < 0) continue;
+            const double2 pj = L.x[j];
+            qx = fma(L.val[((size_t)s * 4 + 0) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 1) * L.nnode + i], pj.y, qx));
+            qy = fma(L.val[((size_t)s * 4 + 2) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 3) * L.nnode + i], pj.y, qy));
+        }
+        const double2 di = L.dinv[i], bi = L.b[i];
+        L.res[i] = make_double2(di.x != 0. ? bi.x - qx : 0., di.y != 0. ? bi.y - qy : 0.);
+    }
+    __syncthreads();
+}
+
+__device__ inline void blk_restrict(const MgLevDev &F, const MgLevDev &Cc)
+{
+    const int nyc = Cc.ny + 1, nyf = F.ny + 1, nxf = F.nx + 1;
+    for (int i = threadIdx.x; i < Cc.nnode; i += blockDim.x) {
+        const int J = i / nyc, K = i - J * nyc;
+        double sx = 0., sy = 0.;
+        for (int dj = -1; dj <= 1; dj++) {
+            const int jf = 2 * J + dj;
+            if (jf < 0 || jf >= nxf) continue;
+            for (int dk = -1; dk <= 1; dk++) {
+                const int kf = 2 * K + dk;
+                if (kf < 0 || kf >= nyf) continue;
+                const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
+                const double2 r = F.res[(size_t)jf * nyf + kf];
+                sx = fma(w, r.x, sx);
+                sy = fma(w, r.y, sy);
+            }
+        }
+        const double2 d = Cc.dinv[i];
+        Cc.b[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+    }
+    __syncthreads();
+}
+
+__device__ inline void blk_prolong_add(const MgLevDev &F, const MgLevDev &Cc)
+{
+    const int nyc = Cc.ny + 1, nyf = F.ny + 1;
+    for (int i = threadIdx.x; i < F.nnode; i += blockDim.x) {
+        const int j = i / nyf, k = i - j * nyf;
+        const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
+        double2 v = Cc.x[(size_t)J0 * nyc + K0];
+        double cx = v.x, cy = v.y;
+        if (oj) {
+            v = Cc.x[(size_t)(J0 + 1) * nyc + K0];
+            cx += v.x;
+            cy += v.y;
+        }
+        if (ok) {
+            v = Cc.x[(size_t)J0 * nyc + K0 + 1];
+            cx += v.x;
+            cy += v.y;
+        }
+        if (oj && ok) {
+            v = Cc.x[(size_t)(J0 + 1) * nyc + K0 + 1];
+            cx += v.x;
+            cy += v.y;
+        }
+        const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+        const double2 d = F.dinv[i];
+        double2 xf = F.x[i];
+        if (d.x != 0.) xf.x = fma(w, cx, xf.x);
+        if (d.y != 0.) xf.y = fma(w, cy, xf.y);
+        F.x[i] = xf;
+    }
+    __syncthreads();
+}
+
+// V-cycle over the levels [l0, nl) in ONE workgroup: b of level l0 in, x of level l0 out.
+__global__ void __launch_bounds__(MG_TAIL_BLOCK)
+k_mg_tail(const MgLevDev *__restrict__ lev, int l0, int nl, double omega, int nu, const CgScalars *sc)
+{
+    if (sc->done) return;
+    extern __shared__ double2 sh2[];
+    for (int l = l0; l < nl - 1; l++) {
+        const MgLevDev L = lev[l];
+        double2 *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
+        for (int k = 0; k < nu; k++) {
+            blk_smooth(L, src, dst, omega, k == 0);
+            src = dst;
+            dst = (dst == L.x) ? L.t : L.x;
+        }
+        blk_residual(L);
+        blk_restrict(L, lev[l + 1]);
+    }
+    {
+        const MgLevDev L = lev[nl - 1];
+        if (L.ainv)
+            coarse_dense_block(L.nnode, L.ainv, L.b, L.x);
+        else
+            coarse_solve_block(L.nnode, L.nslot, L.col, L.val, L.dinv, L.b, L.x, 4 * L.nnode + 20, 1.e-10, sh2);
+    }
+    for (int l = nl - 2; l >= l0; l--) {
+        const MgLevDev L = lev[l];
+        blk_prolong_add(L, lev[l + 1]);
+        double2 *src = L.x, *dst = L.t;
+        for (int k = 0; k < nu; k++) {
+            blk_smooth(L, src, dst, omega, 0);
+            double2 *tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+        if (src != L.x) {
+            for (int i = threadIdx.x; i < L.nnode; i += blockDim.x) L.x[i] = L.t[i];
+            __syncthreads();
+        }
+    }
+}
+
+// PCG update without the Jacobi z (the V-cycle computes z): x += alpha p; r -= alpha q; partial r.r
+__global__ void __launch_bounds__(BLOCK)
+k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q,
+               const double2 *__restrict__ dinv, double2 *x, double2 *r, const double *part_pq,
+               int npart_pq, const double *part_rz, int npart_prev, double *part_rr_out,
+               const CgScalars *sc)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    const double pq = sum_partials(part_pq, npart_pq, sh);
+    const double rz = sum_partials(part_rz, npart_prev, sh);
+    const double alpha = rz / pq;
+    double a_rr = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 pi = p[i], qi = q[i], di = dinv[i];
+        double2 xi = x[i], ri = r[i];
+        xi.x = fma(alpha, pi.x, xi.x);
+        xi.y = fma(alpha, pi.y, xi.y);
+        ri.x = (di.x != 0.) ? fma(-alpha, qi.x, ri.x) : 0.;
+        ri.y = (di.y != 0.) ? fma(-alpha, qi.y, ri.y) : 0.;
+        x[i] = xi;
+        r[i] = ri;
+        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+    }
+    const double t2 = block_sum(a_rr, sh);
+    if (threadIdx.x == 0) part_rr_out[blockIdx.x] = t2;
+}
+
+// partial sums of r.z
+__global__ void __launch_bounds__(BLOCK)
+k_dot_rz(int nnode, const double2 *__restrict__ r, const double2 *__restrict__ z, double *part_rz_out)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 a = r[i], b = z[i];
+        acc = fma(a.x, b.x, fma(a.y, b.y, acc));
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) part_rz_out[blockIdx.x] = t;
+}
+
+}  // namespace plfx

@@ -173,10 +173,12 @@ class Model(object):
                      'eps': np.zeros(6), 'sig': np.zeros(6), 'epl': np.zeros(6)}
         self.cg_rtol = 1.e-12
         self.cg_maxit = 200000
+        self.precond = None          # None: library default (multigrid when available), 0 Jacobi, 1 multigrid
         self.solver_stats = []
         self.n_sweeps = 0            # material sweeps (K-iterations) executed so far
         self._engine = None
         self._cache = {}
+        self._bnd_idx = None
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -356,6 +358,7 @@ class Model(object):
         self._lxy = lxy
         self._NX, self._NY = NX, NY
         self.element = _ElementList(self, self.Nel)
+        self._bnd_idx = None
         self._drop_engine()
 
     # ------------------------------------------------------------------ engine plumbing
@@ -408,6 +411,9 @@ class Model(object):
             eng.comm_init(uid, rank, nranks)
             e0, e1 = self.strip_range(rank, nranks)
         eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+        eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
+        if self.precond is not None:
+            eng.set_precond(self.precond)
         self._e0, self._e1 = e0, e1
         self._engine = eng
         self._mat_versions = vers
@@ -440,62 +446,69 @@ class Model(object):
 
     # ------------------------------------------------------------------ boundary conditions
     def _bc_data(self, bcl0, bcb0, dbcr, dbct, dbcn):
-        """calc_BC (model.py:1070-1206) as data: prescribed DOFs (in order of first application),
-        value written to du, multiplicity-weighted value for the right-hand side, external forces."""
-        nd = self.Ndof
-        first = np.full(nd, np.nan)
-        w = np.zeros(nd)
-        fext = np.zeros(nd)
-        any_force = False
+        """calc_BC (model.py:1070-1206) as data, in O(boundary) work: prescribed DOFs (ascending),
+        value written to du (first application), multiplicity-weighted value for the right-hand side
+        (a DOF shared by two edges enters the rhs twice, :1115-1122, 1163-1170), external forces."""
+        idx_l, val_l = [], []
+        f_idx, f_val = [], []
 
-        def disp(nodes, k, val, who):
-            idx = 2 * np.asarray(nodes, dtype=np.int64) + k
-            new = np.isnan(first[idx])
-            if not np.all(new):
-                old = first[idx[~new]]
-                if np.any(old != val):
-                    warnings.warn('Inconsistent BC at {} nodes ({} vs {}).'.format(who, old[old != val][0], val))
-            first[idx[new]] = val
-            w[idx] += val  # a DOF shared by two edges enters the rhs twice (:1115-1122, 1163-1170)
+        def disp(nodes, k, val):
+            nodes = np.asarray(nodes, dtype=np.int64)
+            idx_l.append(2 * nodes + k)
+            val_l.append(np.full(len(nodes), float(val)))
+
+        def force(nodes, k, val, npart, pos, length):
+            nodes = np.asarray(nodes, dtype=np.int64)
+            hh = np.full(len(nodes), 1. / (npart - 1))   # share of the edge force per node
+            hp = self.npos[2 * nodes + pos]
+            hh[(hp < 1.e-3) | (hp > length - 1.e-3)] *= 0.5  # half on corner nodes
+            if val != 0.:
+                f_idx.append(2 * nodes + k)
+                f_val.append(val * hh)
 
         for k in range(2):
             if self.ubcleft[k]:
-                disp(self.noleft, k, bcl0[k], 'left')
+                disp(self.noleft, k, bcl0[k])
         for k in range(2):
             if self.ubcbot[k]:
-                disp(self.nobot, k, bcb0[k], 'bottom')
+                disp(self.nobot, k, bcb0[k])
         for k in range(2):
             if self.ubcright[k]:
-                disp(self.noright, k, dbcr[k], 'right')
+                disp(self.noright, k, dbcr[k])
             else:
-                nodes = np.asarray(self.noright, dtype=np.int64)
-                hh = np.full(len(nodes), 1. / (self.NnodeY - 1))
-                hy = self.npos[2 * nodes + 1]
-                hh[(hy < 1.e-3) | (hy > self.leny - 1.e-3)] *= 0.5
-                fext[2 * nodes + k] += dbcr[k] * hh
-                any_force = any_force or dbcr[k] != 0.
+                force(self.noright, k, dbcr[k], self.NnodeY, 1, self.leny)
         for k in range(2):
             if self.ubctop[k]:
-                disp(self.notop, k, dbct[k], 'top')
+                disp(self.notop, k, dbct[k])
             else:
-                nodes = np.asarray(self.notop, dtype=np.int64)
-                hh = np.full(len(nodes), 1. / (self.NnodeX - 1))
-                hx = self.npos[2 * nodes]
-                hh[(hx < 1.e-3) | (hx > self.lenx - 1.e-3)] *= 0.5
-                fext[2 * nodes + k] += dbct[k] * hh
-                any_force = any_force or dbct[k] != 0.
+                force(self.notop, k, dbct[k], self.NnodeX, 0, self.lenx)
         if self.noset is not None:
             if dbcn is None:
                 raise ValueError('No BC for selected node set given.')
             for k in range(2):
                 if self.ubcn[k]:
-                    disp(self.noset, k, dbcn[k], 'node set')
-                else:
-                    for j in self.noset:
-                        fext[2 * int(j) + k] += dbcn[k]
-                    any_force = any_force or dbcn[k] != 0.
-        presc = np.nonzero(~np.isnan(first))[0]
-        return presc, first[presc], w[presc], (fext if any_force else None)
+                    disp(self.noset, k, dbcn[k])
+                elif dbcn[k] != 0.:
+                    nodes = np.asarray(self.noset, dtype=np.int64)
+                    f_idx.append(2 * nodes + k)
+                    f_val.append(np.full(len(nodes), float(dbcn[k])))
+        if idx_l:
+            idx = np.concatenate(idx_l)
+            val = np.concatenate(val_l)
+            presc, first_pos, inv = np.unique(idx, return_index=True, return_inverse=True)
+            first = val[first_pos]
+            w = np.bincount(inv, weights=val, minlength=len(presc))
+            bad = val != first[inv]
+            if np.any(bad):
+                warnings.warn('Inconsistent BC at DOF {} ({} vs {}).'.format(idx[bad][0], first[inv][bad][0], val[bad][0]))
+        else:
+            presc = np.zeros(0, dtype=np.int64)
+            first = w = np.zeros(0)
+        fext = None
+        if f_idx:
+            fext = np.zeros(self.Ndof)
+            np.add.at(fext, np.concatenate(f_idx), np.concatenate(f_val))
+        return presc, first, w, fext
 
     def free_dofs(self):
         """The reference's ``ind`` list (ascending free DOFs) for the current BC flags."""
@@ -746,14 +759,22 @@ class Model(object):
 
     def _calc_global_device(self, eng):
         """calc_global during solve: boundary DOFs gathered from HBM, element sums reduced on the GPU."""
+        sets = (self.noleft, self.noright, self.nobot, self.notop)
+        if self._bnd_idx is None:
+            parts = []
+            for nodes in sets:
+                idx = 2 * np.asarray(nodes, dtype=np.int64)
+                parts.extend((idx, idx + 1))
+            self._bnd_idx = np.concatenate(parts)
+        uu = eng.gather(_lib.ST_U, self._bnd_idx)
+        ff = eng.gather(_lib.ST_F, self._bnd_idx)
         bv = []
-        for nodes in (self.noleft, self.noright, self.nobot, self.notop):
-            idx = 2 * np.asarray(nodes, dtype=np.int64)
-            n = len(idx)
-            both = np.concatenate((idx, idx + 1))
-            uu = eng.gather(_lib.ST_U, both)
-            ff = eng.gather(_lib.ST_F, both)
-            bv.append((np.sum(uu[:n]) / n, np.sum(uu[n:]) / n, np.sum(ff[:n]), np.sum(ff[n:])))
+        o = 0
+        for nodes in sets:
+            n = len(nodes)
+            bv.append((np.sum(uu[o:o + n]) / n, np.sum(uu[o + n:o + 2 * n]) / n,
+                       np.sum(ff[o:o + n]), np.sum(ff[o + n:o + 2 * n])))
+            o += 2 * n
         sums = eng.global_sums()
         if self._shard is not None:
             sums = self._allreduce_sum(sums.ravel()).reshape(3, 6)
