@@ -59,11 +59,17 @@ Rccl g_rccl;
 bool load_rccl()
 {
     if (g_rccl.h) return true;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // prefer an RCCL that is already in the process (torch.distributed's), then the system one
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
-        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (g_rccl.h) break;
     }
+    if (!g_rccl.h)
+        for (const char *n : names) {
+            g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.h) break;
+        }
     if (!g_rccl.h) return false;
     g_rccl.GetUniqueId = (fn_ncclGetUniqueId)dlsym(g_rccl.h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (fn_ncclCommInitRank)dlsym(g_rccl.h, "ncclCommInitRank");
@@ -517,7 +523,7 @@ int plain_spmv(plfx_ctx *c, const double *in, double *out)
                        c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)in, nullptr, nullptr,
                        (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
     HIPCHK(c, hipGetLastError());
-    if (c->nranks > 1) {
+    if (c->comm) {
         if (g_rccl.AllReduce(out, out, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
             return fail(c, PLFX_ERR_HIP, "ncclAllReduce failed");
     }
@@ -525,7 +531,7 @@ int plain_spmv(plfx_ctx *c, const double *in, double *out)
 }
 
 
-bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2 && c->nranks == 1; }
+bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2 && !c->comm; }
 
 // coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
 int mg_assemble(plfx_ctx *c)
@@ -1078,7 +1084,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         dfree(L.t); dfree(L.res); dfree(L.ainv);
     }
     c->mg.clear();
-    if (c->nranks > 1 || c->nel != c->nel_total) return PLFX_OK;  // sharded runs use Jacobi-PCG
+    if (c->comm || c->nel != c->nel_total) return PLFX_OK;  // sharded runs use Jacobi-PCG
     for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly needs one element shape
         if (c->hlxy[2 * (size_t)e] != c->hlxy[0] || c->hlxy[2 * (size_t)e + 1] != c->hlxy[1]) return PLFX_OK;
     std::vector<std::pair<int, int>> dims;
@@ -1331,7 +1337,7 @@ int plfx_assemble(plfx_ctx *c)
                        c->Mel, c->dcol, c->dval, c->diag);
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
-    if (c->nranks > 1) {  // Jacobi needs the full diagonal
+    if (c->comm) {  // Jacobi needs the full diagonal
         if (g_rccl.AllReduce(c->diag, c->diag, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
             return fail(c, PLFX_ERR_HIP, "ncclAllReduce(diag) failed");
     }
@@ -1428,7 +1434,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     const int gn = c->grid_nodes;
     double *P_pq = c->part, *P_rz[2] = {c->part + MAXPART, c->part + 2 * MAXPART},
            *P_rr[2] = {c->part + 3 * MAXPART, c->part + 4 * MAXPART}, *P_bb = c->part + 5 * MAXPART;
-    const bool multi = c->nranks > 1;
+    const bool multi = c->comm != nullptr;  // sharded run: all-reduce of the global vector per CG step
     // x0
     hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
     int rc = 0;
