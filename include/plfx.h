@@ -31,8 +31,12 @@ typedef struct plfx_ctx plfx_ctx;
 enum {
     PLFX_ELASTIC = 0, /* Material.sy is None: no response() call (model.py:1341) */
     PLFX_HILL6 = 1,   /* analytic Hill-6p on the full Voigt stress, J2 = all ones (material.py:650-661) */
-    PLFX_PRINC3 = 2,  /* sdim=3: Hill-3p/J2 on principal stresses (material.py:662-670)  [not yet built] */
-    PLFX_SVC6 = 3     /* RBF-SVC yield function on 6 stress features (material.py:398-405, 765-807) */
+    PLFX_PRINC3 = 2,  /* sdim=3: Hill-3p/J2 on principal stresses in sig_princ's axis-tracking order
+                         (material.py:662-670, basic.py:107-179); exact for plane stress states */
+    PLFX_SVC6 = 3,    /* RBF-SVC yield function on 6 stress features (material.py:398-405, 765-807) */
+    PLFX_TRESCA = 4,  /* Tresca equivalent stress (material.py:630-632): calc_seq only, the reference has
+                         no flow rule for it (calc_fgrad raises, material.py:824) */
+    PLFX_BARLAT = 5   /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) */
 };
 
 /* error codes */
@@ -48,7 +52,7 @@ enum {
  * plus the trained SVC parameters (svm_yf.support_vectors_, dual_coef_, intercept_, gam_yf, scale_seq). */
 typedef struct plfx_material {
     int32_t kind;      /* PLFX_* */
-    int32_t sdim;      /* 6 (3 reserved) */
+    int32_t sdim;      /* 6, or 3 for PLFX_PRINC3 */
     double CV[36];     /* ELEMENT elastic matrix, i.e. after the plane-stress/strain choice of
                           Element.__init__ (model.py:272-303); must be symmetric */
     double E, nu;      /* used by the plane-stress B-matrix row (model.py:498-501) */
@@ -62,6 +66,8 @@ typedef struct plfx_material {
     double gamma, intercept, scale_seq;
     const double *sv;   /* [nsv*nfeat] row-major */
     const double *dual; /* [nsv] */
+    double barlat[18];  /* Yld2004-18p coefficients c'_12.. (material.py:2578-2591) */
+    double barlat_exp;  /* exponent a */
 } plfx_material;
 
 /* ---------------------------------------------------------------- context */

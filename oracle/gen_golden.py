@@ -53,6 +53,9 @@ MATERIALS = {
     'workhard': (dict(E=300.e3, nu=0.3), dict(sy=150., khard=2000.)),
     'cubic': (dict(C11=170.e3, C12=124.e3, C44=75.e3), dict(sy=80., khard=300., sdim=6,
                                                              hill=[1.1, 0.9, 1.0, 1.2, 1.0, 0.9])),
+    # sdim=3: flow rule on principal stresses (tests/test_basic.py:106, :120)
+    'hill3': (dict(E=300.e3, nu=0.3), dict(sy=150., hill=[0.7, 1., 1.4], khard=100., sdim=3)),
+    'j2s3': (dict(E=300.e3, nu=0.3), dict(sy=150., khard=500., sdim=3)),
 }
 
 
@@ -69,8 +72,10 @@ def make_material(name):
 def mat_params(m):
     """Flat parameter record consumed by both the oracle and the product tests."""
     d0 = m.lhs if m.lhs is not None else np.ones(3) * m.drucker
+    hill = np.ones(6)
+    hill[:len(m.hill)] = m.hill
     return dict(CV=np.array(m.CV, dtype=float), E=float(m.E), nu=float(m.nu),
-                sy=float(m.sy), khard=float(m.khard), hill=np.array(m.hill, dtype=float),
+                sy=float(m.sy), khard=float(m.khard), hill=hill,
                 dp=np.array(d0, dtype=float), sdim=int(m.sdim),
                 hill_6p=bool(m.hill_6p), hill_3p=bool(m.hill_3p))
 
@@ -177,13 +182,20 @@ def gen_material():
         sig = rng.normal(size=(N, 6)) * np.array([120., 120., 120., 60., 60., 60.])
         sig[:50, 3:] = 0.           # axis-aligned
         sig[50:60] *= 1.e-3          # tiny
+        s3 = (m.sdim == 3)
+        if s3:
+            sig[:, 3:5] = 0.         # plane states: the axis-tracking order of sig_princ is well defined
         epl = rng.normal(size=(N, 6)) * 3.e-3
         epl[:, 0:3] -= epl[:, 0:3].mean(axis=1)[:, None]
         epl[::3] = 0.
         rec['b_sig'] = sig
         rec['b_epl'] = epl
         rec['b_seq'] = m.calc_seq(sig)
-        rec['b_fgrad'] = m.calc_fgrad(sig)
+        if s3:
+            rec['b_sp'] = FE.sig_princ(sig)[0]
+            rec['b_fgrad'] = m.calc_fgrad(rec['b_sp'])      # (N,3): gradient w.r.t. principal stresses
+        else:
+            rec['b_fgrad'] = m.calc_fgrad(sig)
         rec['b_yf'] = np.array([m.calc_yf(sig[i], epl=epl[i]) for i in range(N)])
         rec['b_sflow'] = np.array([m.get_sflow(epl[i]) for i in range(N)])
         rec['b_peeq'] = FE.eps_eq(epl)
@@ -194,6 +206,8 @@ def gen_material():
         ctan = np.zeros((nsub, 36))
         pdot = np.zeros((nsub, 6))
         dd = rng.normal(size=(nsub, 6)) * 1.e-3
+        if s3:
+            dd[:, 3:5] = 0.
         for i in range(nsub):
             ctan[i] = m.C_tan(sig[i], CV, epl=epl[i]).reshape(36)
             pdot[i] = m.epl_dot(sig[i], epl[i], CV, dd[i])
@@ -204,6 +218,8 @@ def gen_material():
         for tag, CVr, twod in (('pe', element_CV(m, False), True),
                                ('ps', element_CV(m, True), True),
                                ('3d', np.array(m.CV), False)):
+            if s3 and tag == '3d':
+                continue
             n = 240
             s, e, d = gen_response_inputs(m, CVr, rng, n, twod)
             fy, so, dp, ct, ns = run_response(m, s, e, d, CVr)
@@ -217,10 +233,28 @@ def gen_material():
             rec['r%s_ct' % tag] = ct
             rec['r%s_nsteps' % tag] = ns
         np.savez_compressed(os.path.join(OUT, 'material_%s.npz' % name), **rec)
-        nb = {t: np.bincount(np.minimum(rec['r%s_nsteps' % t], 49) // 49 +
-                             (rec['r%s_nsteps' % t] < 0).astype(int) * 0)
-              for t in ('pe', 'ps', '3d')}
+        nb = {t: np.bincount(np.minimum(rec['r%s_nsteps' % t], 49) // 49)
+              for t in ('pe', 'ps', '3d') if 'r%s_nsteps' % t in rec}
         print('material', name, 'done', '%.1fs' % (time.time() - t0), nb)
+    # equivalent stresses that have no flow rule in the reference (calc_fgrad raises, material.py:822-825)
+    rng = np.random.default_rng(99)
+    sig = rng.normal(size=(500, 6)) * np.array([120., 120., 120., 60., 60., 60.])
+    sig[:40, 3:] = 0.
+    rec = {'sig': sig}
+    mt = FE.Material(name='tresca')
+    mt.elasticity(E=200.e3, nu=0.3)
+    mt.plasticity(sy=100., tresca=True, sdim=6)
+    rec['tresca_seq'] = mt.calc_seq(sig)
+    bar = [0.81766, -0.36431, 0.86993, 1.07052, 0.85640, 1.22269, 0.47370, 0.49740, 0.52740,
+           0.27328, 0.56924, 0.66140, 0.40440, 1.30700, 0.98900, 0.49500, 1.27500, 0.53400]
+    mb = FE.Material(name='barlat')
+    mb.elasticity(E=151220., nu=0.3)
+    mb.plasticity(sy=46.76, barlat=bar, barlat_exp=8, sdim=6)     # settings of examples/train_goss_barlat.py:36-41
+    rec['barlat_par'] = np.array(bar)
+    rec['barlat_exp'] = np.array(8.)
+    rec['barlat_seq'] = mb.calc_seq(sig)
+    np.savez_compressed(os.path.join(OUT, 'seq_extra.npz'), **rec)
+    print('tresca/barlat done')
     # SURVEY anchor values
     m = make_material('j2')
     f, s, d, c = m.response(np.array([10, 80, 30, 0, 0, 5.]), np.zeros(6),
@@ -538,6 +572,40 @@ def gen_solve():
                 rec[p + '_peeq'] = np.array(mat.propJ2[lc]['peeq'])
             rec['prop_%s_args' % name] = np.array([eps, -1 if ms is None else ms], dtype=float)
             print('calc_properties', name, '%.1fs' % (time.time() - t))
+
+        # tests/test_basic.py:test_model (b): 4x4 laminate elastic + J2 with sdim=3, plane strain
+        mat1 = FE.Material()
+        mat1.elasticity(E=100.e3, nu=0.35)
+        mat2 = FE.Material()
+        mat2.elasticity(E=300.e3, nu=0.3)
+        mat2.plasticity(sy=150., khard=500., sdim=3)
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom([2, 2], LY=4.)
+        fe.assign([mat1, mat2])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.1 * fe.leny, 'disp')
+        fe.mesh(NX=4, NY=4)
+        t = time.time()
+        fe.solve()
+        fe.calc_global()
+        solve_record(fe, 'lam4x4_j2s3', rec, time.time() - t)
+        print('lam4x4_j2s3', fe.glob['epl'][1], fe.nsteps, fe.niter)
+        # tests/test_basic.py:test_plasticity: Hill-3p, sdim=3, calc_properties(eps=0.05)
+        mat = make_material('hill3')
+        mat.calc_properties(eps=0.05, sigeps=True)
+        for lc in ('stx', 'sty', 'et2', 'ect'):
+            p = 'prop_hill3_%s' % lc
+            rec[p + '_sig'] = np.array(mat.sigeps[lc]['sig'])
+            rec[p + '_eps'] = np.array(mat.sigeps[lc]['eps'])
+            rec[p + '_epl'] = np.array(mat.sigeps[lc]['epl'])
+            rec[p + '_ys'] = np.array([mat.prop[lc]['ys'], mat.propJ2[lc]['ys']])
+            rec[p + '_seq'] = np.array(mat.prop[lc]['seq'])
+            rec[p + '_seqJ2'] = np.array(mat.propJ2[lc]['seq'])
+            rec[p + '_peeq'] = np.array(mat.propJ2[lc]['peeq'])
+        rec['prop_hill3_args'] = np.array([0.05, -1.])
+        print('calc_properties hill3', mat.propJ2['stx']['ys'], mat.propJ2['sty']['seq'][-1])
 
         # re-entrant solve (checkpoint/resume semantics): two successive loads
         mat = make_material('j2')

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libplfx_oracle.so')
 
-ELASTIC, HILL6, PRINC3, SVC6 = 0, 1, 2, 3
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT = 0, 1, 2, 3, 4, 5
 
 
 class _Mat(C.Structure):
@@ -22,7 +22,8 @@ class _Mat(C.Structure):
                 ('sy', C.c_double), ('khard', C.c_double), ('hill', C.c_double * 6),
                 ('dp', C.c_double * 3), ('nsv', C.c_int), ('ndof', C.c_int),
                 ('dev_only', C.c_int), ('gamma', C.c_double), ('intercept', C.c_double),
-                ('scale_seq', C.c_double), ('sv', C.c_void_p), ('dual', C.c_void_p)]
+                ('scale_seq', C.c_double), ('sv', C.c_void_p), ('dual', C.c_void_p),
+                ('barlat', C.c_double * 18), ('barlat_exp', C.c_double)]
 
 
 def build():
@@ -54,7 +55,8 @@ class Material(object):
     """Parameter record of one material (analytic Hill-6p/J2, elastic, or SVC)."""
 
     def __init__(self, kind=HILL6, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., sdim=6,
-                 sv=None, dual=None, gamma=0., intercept=0., scale_seq=1., dev_only=False):
+                 sv=None, dual=None, gamma=0., intercept=0., scale_seq=1., dev_only=False,
+                 barlat=None, barlat_exp=0.):
         m = _Mat()
         m.kind = kind
         m.sdim = sdim
@@ -64,6 +66,10 @@ class Material(object):
             m.hill[i] = h[i] if i < len(h) else 1.
         for i in range(3):
             m.dp[i] = drucker
+        if barlat is not None:
+            for i in range(18):
+                m.barlat[i] = barlat[i]
+            m.barlat_exp = barlat_exp
         self._sv = self._dual = None
         if sv is not None:
             self._sv = _c(sv)
@@ -85,7 +91,8 @@ class Material(object):
                        gamma=float(z[prefix + 'gamma']), intercept=float(z[prefix + 'intercept']),
                        scale_seq=float(z[prefix + 'scale_seq']), dev_only=bool(z[prefix + 'dev_only']))
         dp = z[prefix + 'dp']
-        return cls(kind=HILL6, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']),
+        sdim = int(z[prefix + 'sdim'])
+        return cls(kind=HILL6 if sdim == 6 else PRINC3, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']),
                    sy=float(z[prefix + 'sy']), khard=float(z[prefix + 'khard']),
                    hill=z[prefix + 'hill'], drucker=float(dp[0]), sdim=int(z[prefix + 'sdim']))
 
@@ -95,6 +102,14 @@ def _mat_array(mats):
     for i, m in enumerate(mats):
         arr[i] = m.c
     return arr
+
+
+def sig_princ(sig):
+    sig = _c(sig).reshape(-1, 6)
+    out = np.empty((len(sig), 3))
+    for i in range(len(sig)):
+        lib().plfo_sig_princ(_p(sig[i]), _p(out[i]))
+    return out
 
 
 def calc_seq(mat, sig):

@@ -150,9 +150,86 @@ double plfo_eps_eq(const double e[6]) /* basic.py:350-352 */
     return sqrt(2. * (n + 0.5 * s) / 3.);
 }
 
+/* basic.py:107-179 */
+void plfo_sig_princ(const double s[6], double sp[3])
+{
+    if (s[3] == 0. && s[4] == 0.) {
+        /* plane state: the 2x2 block decouples; the eigenvector closer to axis 0 carries the larger
+         * eigenvalue iff s0 >= s1 (argmax of |ev|, first maximum on ties, basic.py:156) */
+        double mean = 0.5 * (s[0] + s[1]);
+        double R = sqrt(0.25 * (s[0] - s[1]) * (s[0] - s[1]) + s[5] * s[5]);
+        if (s[5] == 0.) {
+            sp[0] = s[0];
+            sp[1] = s[1];
+        } else if (s[0] >= s[1]) {
+            sp[0] = mean + R;
+            sp[1] = mean - R;
+        } else {
+            sp[0] = mean - R;
+            sp[1] = mean + R;
+        }
+        sp[2] = s[2];
+        return;
+    }
+    double G[9] = {s[0], s[5], s[4], s[5], s[1], s[3], s[4], s[3], s[2]}, w[3], V[9];
+    jacobi3(G, w, V);
+    for (int i = 0; i < 3; i++) {
+        int k = 0;
+        for (int c = 1; c < 3; c++)
+            if (fabs(V[i * 3 + c]) > fabs(V[i * 3 + k])) k = c;
+        sp[i] = w[k];
+    }
+}
+
+static void eig3_values(const double s[6], double w[3])
+{
+    double G[9] = {s[0], s[5], s[4], s[5], s[1], s[3], s[4], s[3], s[2]}, V[9];
+    jacobi3(G, w, V);
+}
+
+static double calc_seqB(const plfo_material *m, const double sv[6]) /* material.py:678-702 */
+{
+    const double *b = m->barlat;
+    double sd[6], st1[6], st2[6], p1[3], p2[3];
+    plfo_sig_dev(sv, sd);
+    /* Bar_m1 / Bar_m2 (material.py:2578-2591) */
+    st1[0] = -b[0] * sd[1] - b[1] * sd[2];
+    st1[1] = -b[2] * sd[0] - b[3] * sd[2];
+    st1[2] = -b[4] * sd[0] - b[5] * sd[1];
+    st1[3] = b[6] * sd[3];
+    st1[4] = b[7] * sd[4];
+    st1[5] = b[8] * sd[5];
+    st2[0] = -b[9] * sd[1] - b[10] * sd[2];
+    st2[1] = -b[11] * sd[0] - b[12] * sd[2];
+    st2[2] = -b[13] * sd[0] - b[14] * sd[1];
+    st2[3] = b[15] * sd[3];
+    st2[4] = b[16] * sd[4];
+    st2[5] = b[17] * sd[5];
+    eig3_values(st1, p1);
+    eig3_values(st2, p2);
+    double a = m->barlat_exp, acc = 0.;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) acc += pow(fabs(p1[i] - p2[j]), a);
+    return pow(0.25 * acc, 1. / a);
+}
+
 /* ------------------------------------------------------------------ material.py */
 double plfo_calc_seq(const plfo_material *m, const double sig[6]) /* material.py:636-673 */
 {
+    if (m->kind == PLFO_TRESCA) { /* material.py:630-632 */
+        double sp[3];
+        eig3_values(sig, sp);
+        return fmax(fmax(sp[0], sp[1]), sp[2]) - fmin(fmin(sp[0], sp[1]), sp[2]);
+    }
+    if (m->kind == PLFO_BARLAT) return calc_seqB(m, sig); /* material.py:633-637 */
+    if (m->kind == PLFO_PRINC3) {                         /* material.py:662-673, 3-parameter Hill on principal stresses */
+        double sp[3];
+        plfo_sig_princ(sig, sp);
+        double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
+        double I2 = 0.5 * (m->hill[0] * d12 * d12 + m->hill[1] * d23 * d23 + m->hill[2] * d31 * d31);
+        double I1 = (sig[0] * m->dp[0] + sig[1] * m->dp[1] + sig[2] * m->dp[2]) / 3.;
+        return sqrt(I2) + I1;
+    }
     double hp[6] = {1., 1., 1., 1., 1., 1.};
     double d0[3] = {0., 0., 0.};
     if (m->kind != PLFO_ELASTIC) { /* self.sy is not None */
@@ -218,6 +295,23 @@ void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]) /
             for (int i = 0; i < 6; i++) dK[i] += m->dual[k] * (kk * (-2. * m->gamma * hv[i]));
         }
         for (int i = 0; i < 6; i++) a[i] = dK[i] / m->scale_seq; /* material.py:807 */
+        return;
+    }
+    if (m->kind == PLFO_PRINC3) {
+        /* epl_dot / C_tan with sdim == 3 (material.py:1044-1047, 1079-1081): the gradient w.r.t. the
+         * principal stresses is written into the normal Voigt components, shear components stay 0 */
+        double sp[3], sq;
+        plfo_sig_princ(sig, sp);
+        double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
+        sq = sqrt(0.5 * (m->hill[0] * d12 * d12 + m->hill[1] * d23 * d23 + m->hill[2] * d31 * d31)) +
+             (sp[0] * m->dp[0] + sp[1] * m->dp[1] + sp[2] * m->dp[2]) / 3.;
+        double pm = (sp[0] + sp[1] + sp[2]) / 3.;
+        double s0 = sp[0] - pm, s1 = sp[1] - pm, s2 = sp[2] - pm;
+        double g0 = m->hill[0], g1 = m->hill[1], g2 = m->hill[2];
+        a[0] = ((g0 + g2) * s0 - g0 * s1 - g2 * s2) / (2. * sq) + m->dp[0] / 3.;
+        a[1] = ((g1 + g0) * s1 - g0 * s0 - g1 * s2) / (2. * sq) + m->dp[1] / 3.;
+        a[2] = ((g2 + g1) * s2 - g2 * s0 - g1 * s1) / (2. * sq) + m->dp[2] / 3.;
+        a[3] = a[4] = a[5] = 0.;
         return;
     }
     double h0 = m->hill[0], h1 = m->hill[1], h2 = m->hill[2];

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-enum { PLFO_ELASTIC = 0, PLFO_HILL6 = 1, PLFO_PRINC3 = 2, PLFO_SVC6 = 3 };
+enum { PLFO_ELASTIC = 0, PLFO_HILL6 = 1, PLFO_PRINC3 = 2, PLFO_SVC6 = 3, PLFO_TRESCA = 4, PLFO_BARLAT = 5 };
 
 typedef struct plfo_material {
     int kind;            /* PLFO_* */
@@ -33,13 +33,21 @@ typedef struct plfo_material {
     double gamma, intercept, scale_seq;
     const double *sv;    /* [nsv*ndof] row-major support vectors */
     const double *dual;  /* [nsv] dual coefficients */
+    /* Barlat Yld2004-18p (material.py:2575-2591): 18 coefficients and exponent; calc_seq only */
+    double barlat[18];
+    double barlat_exp;
 } plfo_material;
 
 /* basic.py:304 sig_dev, :328 eps_eq */
 void plfo_sig_dev(const double sig[6], double out[6]);
 double plfo_eps_eq(const double eps[6]);
 
-/* material.py:576 calc_seq (sdim=6 branch; J2 for elastic/SVC materials) */
+/* basic.py:107-179 sig_princ: principal stresses in the reference's axis-tracking order.  Exact for
+ * plane states (s23 = s13 = 0); for general 3-d states the reference's order depends on LAPACK's
+ * dgeev output order and only the natural rule (axis i -> eigenvector with the largest |component i|)
+ * is restated. */
+void plfo_sig_princ(const double sig[6], double sp[3]);
+/* material.py:576 calc_seq (Hill-6p/J2 on Voigt, Hill-3p/J2 on principal stresses, Tresca, Barlat) */
 double plfo_calc_seq(const plfo_material *m, const double sig[6]);
 /* material.py:974 get_sflow */
 double plfo_get_sflow(const plfo_material *m, const double epl[6]);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PLFX_LIB', os.path.join(_HERE, 'libplfx.so'))  # PLFX_LIB: kernel-variant experiments
 
 # yield-function kinds (include/plfx.h)
-ELASTIC, HILL6, PRINC3, SVC6 = 0, 1, 2, 3
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT = 0, 1, 2, 3, 4, 5
 
 # state ids of plfx_state_get/_set
 ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS = range(11)
@@ -32,7 +32,8 @@ class CMaterial(C.Structure):
                 ('hill', C.c_double * 6), ('drucker', C.c_double), ('nsv', C.c_int32),
                 ('nfeat', C.c_int32), ('dev_only', C.c_int32), ('_pad', C.c_int32),
                 ('gamma', C.c_double), ('intercept', C.c_double), ('scale_seq', C.c_double),
-                ('sv', C.c_void_p), ('dual', C.c_void_p)]
+                ('sv', C.c_void_p), ('dual', C.c_void_p), ('barlat', C.c_double * 18),
+                ('barlat_exp', C.c_double)]
 
 
 # every symbol include/plfx.h declares (tests/test_abi.py checks the library exports them all)
@@ -79,12 +80,17 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None):
+def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None, barlat=None,
+                  barlat_exp=0.):
     """Build a plfx_material record.  svc = dict(sv, dual, gamma, intercept, scale_seq, dev_only).
     Returns (struct, keepalive) - keepalive holds the arrays the struct points to."""
     m = CMaterial()
     m.kind = int(kind)
-    m.sdim = 6
+    m.sdim = 3 if kind == PRINC3 else 6
+    if barlat is not None:
+        for i in range(18):
+            m.barlat[i] = float(barlat[i])
+        m.barlat_exp = float(barlat_exp)
     cv = _f64(CV).reshape(36)
     for i in range(36):
         m.CV[i] = cv[i]

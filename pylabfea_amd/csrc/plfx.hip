@@ -100,7 +100,7 @@ struct plfx_ctx {
     std::vector<MatDev> hmat;
     MatDev *dmat = nullptr;
     std::vector<double *> dsv;  // owned device copies of sv/dual
-    bool has_svc = false, has_analytic = false, has_elastic = false;
+    bool has_svc = false, has_analytic = false, has_elastic = false, has_princ = false;
     int svc_lds_need = 0;
 
     // mesh
@@ -725,7 +725,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (!c || !c->stream) return PLFX_ERR_STATE;
     if (nmat < 1 || nmat > MAXMAT || !mats) return fail(c, PLFX_ERR_ARG, "nmat must be in 1..%d", MAXMAT);
     free_materials(c);
-    c->has_svc = c->has_analytic = c->has_elastic = false;
+    c->has_svc = c->has_analytic = c->has_elastic = c->has_princ = false;
     c->svc_lds_need = 0;
     c->nonlin = false;
     c->hmat.resize(nmat);
@@ -733,9 +733,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         const plfx_material &s = mats[k];
         MatDev &m = c->hmat[k];
         memset(&m, 0, sizeof(m));
-        if (s.kind == PLFX_PRINC3 || s.sdim == 3)
-            return fail(c, PLFX_ERR_UNSUPPORTED, "material %d: sdim=3 (principal-stress) flow rules are not built yet", k);
-        if (s.kind != PLFX_ELASTIC && s.kind != PLFX_HILL6 && s.kind != PLFX_SVC6)
+        if (s.kind < PLFX_ELASTIC || s.kind > PLFX_BARLAT)
             return fail(c, PLFX_ERR_ARG, "material %d: unknown kind %d", k, s.kind);
         for (int i = 0; i < 6; i++)
             for (int j = i + 1; j < 6; j++)
@@ -763,9 +761,12 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         m.E = s.E;
         m.nu = s.nu;
         m.kind = s.kind;
-        m.sdim = 6;
+        m.sdim = (s.kind == PLFX_PRINC3) ? 3 : 6;
+        for (int i = 0; i < 18; i++) m.barlat[i] = s.barlat[i];
+        m.barlat_exp = s.barlat_exp;
         if (s.kind != PLFX_ELASTIC) c->nonlin = true;
         if (s.kind == PLFX_HILL6) c->has_analytic = true;
+        if (s.kind == PLFX_PRINC3) c->has_princ = true;
         if (s.kind == PLFX_ELASTIC) c->has_elastic = true;
         if (s.kind == PLFX_SVC6) {
             if (s.nsv < 1 || s.nfeat != 6 || !s.sv || !s.dual)
@@ -795,10 +796,10 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->has_svc) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_point_eval, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_scf_elements, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     return PLFX_OK;
@@ -885,14 +886,15 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
     double *d_fy = d_out, *d_so = d_out + N, *d_dp = d_out + 7 * N, *d_ct = d_out + 13 * N;
     EvPair *ev;
     tim_begin(c, 0, &ev);
+#define RB_ARGS(lds) c->dmat, c->nmat, lds, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns
     if (c->has_analytic || c->has_elastic)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<false>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream,
-                           c->dmat, c->nmat, 0, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N,
-                           d_fy, d_so, d_dp, d_ct, d_ns);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<1>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
+    if (c->has_princ)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
     if (c->has_svc)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<true>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, c->dmat, c->nmat, c->svc_lds_need, n, d_mid, d_in, d_in + 6 * N,
-                           d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<3>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, RB_ARGS(c->svc_lds_need));
+#undef RB_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fy, d_fy, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1542,18 +1544,32 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #define SWEEP_ARGS(lds) c->dmat, c->nmat, c->dcls, c->ncls, lds, c->nel, c->e0, c->dconn, c->dcls_id,          \
                         (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel, c->res_sig, c->res_depl, \
                         c->fyn, c->max_steps, nit, c->flags, c->heavy_list
-    if (c->has_analytic || c->has_elastic)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<false>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0));
-    if (c->has_svc)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<true>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+    // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
+    int first = 1;
+    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc)) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0), first);
+        first = 0;
+    }
+    if (c->has_princ) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0), first);
+        first = 0;
+    }
+    if (c->has_svc) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first);
+        first = 0;
+    }
     // phase 2 reads the list length from the device; an empty list costs one empty launch
     if (c->has_analytic)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<false>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0));
+    if (c->has_princ)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0));
     if (c->has_svc)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<true>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need));
 #undef SWEEP_ARGS
     tim_end(c, ev);

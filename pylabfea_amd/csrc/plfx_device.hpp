@@ -39,6 +39,7 @@ struct MatDev {
     double gamma, intercept, scale_seq;
     const double *sv;    // device pointer [nsv*6]
     const double *dual;  // device pointer [nsv]
+    double barlat[18], barlat_exp;  // Yld2004-18p coefficients (calc_seq only)
     int32_t kind, sdim, nsv, dev_only;
 };
 
@@ -100,6 +101,146 @@ __device__ __forceinline__ void hill_fgrad(const MatDev &m, const double *s, dou
     a[3] = 3. * m.hill[3] * s[3] / seq;
     a[4] = 3. * m.hill[4] * s[4] / seq;
     a[5] = 3. * m.hill[5] * s[5] / seq;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (Voigt input), V columns = eigenvectors.
+__device__ inline void jacobi3_dev(const double *s, double *w, double *V)
+{
+    double A[9] = {s[0], s[5], s[4], s[5], s[1], s[3], s[4], s[3], s[2]};
+#pragma unroll
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+        if (off == 0.) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = A[p * 3 + q];
+                if (apq == 0.) continue;
+                const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2. * apq);
+                const double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+                const double c = 1. / sqrt(t * t + 1.), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - sn * akq;
+                    A[k * 3 + q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - sn * aqk;
+                    A[q * 3 + k] = sn * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - sn * vkq;
+                    V[k * 3 + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0];
+    w[1] = A[4];
+    w[2] = A[8];
+}
+
+// basic.py:107-179 sig_princ: principal stresses in the reference's axis-tracking order.  Plane
+// states (s23 = s13 = 0, every stress of the 2-d FE path) have the closed form below; the larger
+// eigenvalue of the in-plane block belongs to axis 0 iff s0 >= s1 (argmax |ev|, first maximum on ties).
+// General 3-d states follow the natural rule "axis i -> eigenvector with the largest |component i|"
+// (the reference's order there depends on LAPACK's dgeev output order).
+__device__ inline void sig_princ_dev(const double *s, double *sp)
+{
+    if (s[3] == 0. && s[4] == 0.) {
+        const double mean = 0.5 * (s[0] + s[1]);
+        const double hd = 0.5 * (s[0] - s[1]);
+        const double R = sqrt(hd * hd + s[5] * s[5]);
+        if (s[5] == 0.) {
+            sp[0] = s[0];
+            sp[1] = s[1];
+        } else if (s[0] >= s[1]) {
+            sp[0] = mean + R;
+            sp[1] = mean - R;
+        } else {
+            sp[0] = mean - R;
+            sp[1] = mean + R;
+        }
+        sp[2] = s[2];
+        return;
+    }
+    double w[3], V[9];
+    jacobi3_dev(s, w, V);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int k = 0;
+#pragma unroll
+        for (int c = 1; c < 3; c++)
+            if (fabs(V[i * 3 + c]) > fabs(V[i * 3 + k])) k = c;
+        sp[i] = w[k];
+    }
+}
+
+// 3-parameter Hill / J2 on principal stresses (material.py:662-673); I1 from the Voigt normal components
+__device__ __forceinline__ double princ_seq_sp(const MatDev &m, const double *sp, double tr)
+{
+    const double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
+    const double I2 = 0.5 * (m.hill[0] * d12 * d12 + m.hill[1] * d23 * d23 + m.hill[2] * d31 * d31);
+    return sqrt(I2) + tr * m.d0 / 3.;
+}
+
+__device__ inline double princ_seq(const MatDev &m, const double *s)
+{
+    double sp[3];
+    sig_princ_dev(s, sp);
+    return princ_seq_sp(m, sp, s[0] + s[1] + s[2]);
+}
+
+// epl_dot / C_tan with sdim == 3 (material.py:1044-1047, 1079-1081): the gradient w.r.t. the principal
+// stresses goes into the normal Voigt components, the shear components stay zero
+__device__ inline void princ_fgrad(const MatDev &m, const double *s, double *a)
+{
+    double sp[3];
+    sig_princ_dev(s, sp);
+    const double tr = sp[0] + sp[1] + sp[2];
+    const double seq = princ_seq_sp(m, sp, tr);
+    const double pm = tr / 3.;
+    const double s0 = sp[0] - pm, s1 = sp[1] - pm, s2 = sp[2] - pm;
+    const double h0 = m.hill[0], h1 = m.hill[1], h2 = m.hill[2], d3 = m.d0 / 3.;
+    a[0] = ((h0 + h2) * s0 - h0 * s1 - h2 * s2) / (2. * seq) + d3;
+    a[1] = ((h1 + h0) * s1 - h0 * s0 - h1 * s2) / (2. * seq) + d3;
+    a[2] = ((h2 + h1) * s2 - h2 * s0 - h1 * s1) / (2. * seq) + d3;
+    a[3] = a[4] = a[5] = 0.;
+}
+
+// Tresca (material.py:630-632) and Barlat Yld2004-18p (material.py:678-702) equivalent stresses
+__device__ inline double tresca_seq(const double *s)
+{
+    double w[3], V[9];
+    jacobi3_dev(s, w, V);
+    return fmax(fmax(w[0], w[1]), w[2]) - fmin(fmin(w[0], w[1]), w[2]);
+}
+
+__device__ inline double barlat_seq(const MatDev &m, const double *s)
+{
+    const double *b = m.barlat;
+    const double p = (s[0] + s[1] + s[2]) / 3.;
+    const double sd[6] = {s[0] - p, s[1] - p, s[2] - p, s[3], s[4], s[5]};
+    const double st1[6] = {-b[0] * sd[1] - b[1] * sd[2], -b[2] * sd[0] - b[3] * sd[2], -b[4] * sd[0] - b[5] * sd[1],
+                           b[6] * sd[3], b[7] * sd[4], b[8] * sd[5]};
+    const double st2[6] = {-b[9] * sd[1] - b[10] * sd[2], -b[11] * sd[0] - b[12] * sd[2],
+                           -b[13] * sd[0] - b[14] * sd[1], b[15] * sd[3], b[16] * sd[4], b[17] * sd[5]};
+    double p1[3], p2[3], V[9];
+    jacobi3_dev(st1, p1, V);
+    jacobi3_dev(st2, p2, V);
+    double acc = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) acc += pow(fabs(p1[i] - p2[j]), m.barlat_exp);
+    return pow(0.25 * acc, 1. / m.barlat_exp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,6 +324,20 @@ struct YfHill {
     __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
     __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { hill_fgrad(m, s, a); }
+};
+
+// Yield-function policy: sdim = 3, Hill-3p / J2 on principal stresses.
+struct YfPrinc3 {
+    const MatDev &m;
+    __device__ YfPrinc3(const MatDev &mm) : m(mm) {}
+    __device__ __forceinline__ double seq(const double *s) const { return princ_seq(m, s); }
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        return princ_seq(m, s) - sflow_of(m, epl);
+    }
+    __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
+    __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const { princ_fgrad(m, s, a); }
 };
 
 // scipy.optimize.brentq (scipy 1.15.3, Brent 1973) specialised to f(x) = decision(x*su)

@@ -107,27 +107,35 @@ __device__ __forceinline__ void stage_svc(const MatDev *smat, int nmat, double *
     dual = lds + 6 * n;
 }
 
-// response for one material kind per kernel instantiation: the analytic kernels do not carry the
-// SVC code (and its registers), the SVC kernels skip analytic elements and vice versa.
-template <bool SVC>
-__device__ __forceinline__ int response_kind(const MatDev &m, const double *sv, const double *dual,
-                                             double *sig, const double *epl, const double *deps,
-                                             double &fy, double *depl, double *Ct)
-{
-    if (SVC) {
-        YfSvc yf(m, sv ? sv : m.sv, dual ? dual : m.dual);
-        return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
-    } else {
-        YfHill yf(m);
-        return response_point(m, yf, sig, epl, deps, fy, depl, Ct);
+// One material kind per kernel instantiation (KIND = 1 Hill-6p/J2 on Voigt, 2 Hill-3p/J2 on principal
+// stresses, 3 RBF-SVC): the analytic kernels do not carry the SVC code (and its registers); every
+// instantiation skips the elements of the other kinds.
+template <int KIND>
+struct YfOf;
+template <>
+struct YfOf<1> {
+    typedef YfHill type;
+    __device__ static YfHill make(const MatDev &m, const double *, const double *) { return YfHill(m); }
+};
+template <>
+struct YfOf<2> {
+    typedef YfPrinc3 type;
+    __device__ static YfPrinc3 make(const MatDev &m, const double *, const double *) { return YfPrinc3(m); }
+};
+template <>
+struct YfOf<3> {
+    typedef YfSvc type;
+    __device__ static YfSvc make(const MatDev &m, const double *sv, const double *dual)
+    {
+        return YfSvc(m, sv ? sv : m.sv, dual ? dual : m.dual);
     }
-}
+};
 
 extern __shared__ double dyn_lds[];
 
 // ---------------------------------------------------------------------------------------------
 // Material.response on n points, host-layout (AoS) arrays.
-template <bool SVC>
+template <int KIND>
 __global__ void __launch_bounds__(BLOCK)
 k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
                  const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
@@ -138,14 +146,14 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (SVC) {
+    if (KIND == 3) {
         stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
         __syncthreads();
     }
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const int mid = mat_id ? mat_id[i] : 0;
         const MatDev &m = smat[mid];
-        if ((m.kind == 3) != SVC) continue;  // handled by the other instantiation
+        if (m.kind != KIND && !(m.kind == 0 && KIND == 1)) continue;  // handled by another instantiation
         double sig[6], epl[6], deps[6], depl[6], Ct[21], f = 0.;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
@@ -161,8 +169,8 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
             for (int c = 0; c < 21; c++) Ct[c] = m.CV[c];
         } else {
             const bool staged = (mid == svc_mat);
-            ns = response_kind<SVC>(m, staged ? sv : nullptr, staged ? dual : nullptr, sig, epl, deps, f,
-                                    depl, Ct);
+            const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+            ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
         }
         fy[i] = f;
         nsteps[i] = ns;
@@ -207,25 +215,29 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
             s[c] = sig_in[6 * (size_t)i + c];
             e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
         }
+        const int kd = m.kind;
         if (what == 0) {
-            out[i] = hill_seq(m, s);
+            out[i] = kd == 2 ? princ_seq(m, s) : kd == 4 ? tresca_seq(s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s);
         } else if (what == 1) {
             double a[6];
             if (svc)
                 svc_fgrad(m, psv, pdu, s, a);
+            else if (kd == 2)
+                princ_fgrad(m, s, a);
             else
                 hill_fgrad(m, s, a);
 #pragma unroll
             for (int c = 0; c < 6; c++) out[6 * (size_t)i + c] = a[c];
         } else if (what == 2) {
-            out[i] = svc ? svc_decision(m, psv, pdu, s) : hill_seq(m, s) - sflow_of(m, e);
+            out[i] = svc ? svc_decision(m, psv, pdu, s)
+                         : (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
         } else {
             int st = 0;
             if (svc) {
                 YfSvc yf(m, psv, pdu);
                 out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
             } else {
-                out[i] = hill_seq(m, s) - sflow_of(m, e);
+                out[i] = (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
             }
             if (status) status[i] = st;
         }
@@ -327,21 +339,21 @@ __device__ __forceinline__ void stage_tables(SweepTables &t, const MatDev *gmat,
 // [c*nel + e].  flags[0] |= changed, flags[1] |= not converged, flags[2] = length of `list`.
 // Material / class tables are staged in LDS (wave-uniform addresses -> broadcast reads); holding them
 // in SGPRs instead (scalar loads + waterfall over classes) was measured 35 % slower (SGPR spills).
-template <bool SVC>
+template <int KIND>
 __global__ void __launch_bounds__(BLOCK, PLFX_SWEEP_WAVES)
 k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
               int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, double *res_sig, double *res_depl, double *fyn, int32_t *max_steps, int nit,
-              int *flags, int32_t *list)
+              int *flags, int32_t *list, int first_kind)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (SVC) {
+    if (KIND == 3) {
         stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
         __syncthreads();
     }
@@ -354,8 +366,8 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             const ClassDev &c = tb.scls[cls[e]];
             const MatDev &m = tb.smat[c.mat];
             if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
-                if (!SVC) fyn[e] = 0.;
-            } else if ((m.kind == 3) == SVC) {
+                if (first_kind) fyn[e] = 0.;
+            } else if (m.kind == KIND) {
                 const size_t ge = (size_t)e + e_off;
                 double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
                 class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -364,15 +376,9 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
                     s[k] = sig[(size_t)k * nel + e];
                     ep[k] = epl[(size_t)k * nel + e];
                 }
-                int st;
-                if (SVC) {
-                    const bool staged = (c.mat == svc_mat);
-                    YfSvc yf(m, staged ? sv : m.sv, staged ? dual : m.dual);
-                    st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
-                } else {
-                    YfHill yf(m);
-                    st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
-                }
+                const bool staged = (c.mat == svc_mat);
+                const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+                const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
                 if (st == 2)
                     heavy = true;
                 else
@@ -396,7 +402,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
 
 // Phase 2: the sub-divided plastic corrector for the compacted element list.  Every lane runs the
 // same 50 sub-steps (no divergence); FP64-VALU bound.
-template <bool SVC>
+template <int KIND>
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
               int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
@@ -412,7 +418,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (SVC) {
+    if (KIND == 3) {
         stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
         __syncthreads();
     }
@@ -421,7 +427,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         const int e = list[i];
         const ClassDev &c = tb.scls[cls[e]];
         const MatDev &m = tb.smat[c.mat];
-        if ((m.kind == 3) != SVC) continue;
+        if (m.kind != KIND) continue;
         const size_t ge = (size_t)e + e_off;
         double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
         class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -430,16 +436,10 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             s[k] = sig[(size_t)k * nel + e];
             ep[k] = epl[(size_t)k * nel + e];
         }
-        if (SVC) {
-            const bool staged = (c.mat == svc_mat);
-            YfSvc yf(m, staged ? sv : m.sv, staged ? dual : m.dual);
-            response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);  // recompute the prelude
-            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
-        } else {
-            YfHill yf(m);
-            response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
-            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
-        }
+        const bool staged = (c.mat == svc_mat);
+        const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+        response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);  // recompute the prelude
+        response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
         sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, res_sig, res_depl, fyn,
                        max_steps, nit, changed, nconv);
     }
@@ -890,7 +890,7 @@ k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int
         int mult = 0;
         double hh = 0.;
         if (m.kind != 0) {
-            const double sref = hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
+            const double sref = (m.kind == 2) ? princ_seq(m, ds) : hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
             if (sref > 0.1) {
                 double s[6], ep[6];
 #pragma unroll
@@ -912,7 +912,7 @@ k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int
                         mult = 1;
                     }
                 } else {
-                    yf0 = hill_seq(m, s) - sflow_of(m, ep);
+                    yf0 = (m.kind == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, ep);
                     if (yf0 < SPLIT_THRESHOLD) {
                         hh = fmin(1., -yf0 / sref);
                         mult = 2;

@@ -9,7 +9,9 @@ Same names, argument meaning and error behaviour; arguments are never mutated.
 
 Out of scope here: SVC *training*, data import, plotting, texture/work-hardening
 features.  A trained SVC enters through :meth:`Material.set_svc` / :meth:`Material.from_sklearn`.
-Not built yet: sdim=3 (principal-stress) flow rules, Tresca and Barlat equivalent stresses.
+sdim=3 flow rules use the reference's axis-tracking principal stresses (exact for plane states);
+Tresca and Barlat Yld2004-18p are equivalent stresses only (the reference has no normal for them).
+Not built: the 2-feature SVC of sdim=3 materials (``setup_yf_SVM_3D``).
 """
 import warnings
 
@@ -121,13 +123,8 @@ class Material(object):
             raise NotImplementedError('lhs (Liu-Huang-Stout asymmetry) is not supported')
         if sdim != 3 and sdim != 6:
             raise ValueError('{} in plasticity: sdim must be either 3 or 6'.format(self.name))
-        if sdim == 3:
-            raise NotImplementedError('sdim=3 (principal-stress flow rule) is not built yet in pylabfea_amd')
-        if tresca:
-            raise NotImplementedError('Tresca equivalent stress is not built yet in pylabfea_amd')
-        if barlat is not None:
-            raise NotImplementedError('Barlat Yld2004-18p is not built yet in pylabfea_amd '
-                                      '(the reference has no flow rule for it either, material.py:822)')
+        if barlat is not None and len(barlat) != 18:
+            raise ValueError('plasticity: barlat must hold the 18 Yld2004-18p coefficients')
         if self.sdim is not None and self.sdim != sdim:
             print('plasticity: Parameter sdim is changed. New value:', sdim)
         self.sdim = sdim
@@ -146,9 +143,10 @@ class Material(object):
             hill[0] = rinv[0] ** 2 + rinv[1] ** 2 - rinv[2] ** 2
             hill[1] = rinv[1] ** 2 + rinv[2] ** 2 - rinv[0] ** 2
             hill[2] = rinv[2] ** 2 + rinv[0] ** 2 - rinv[1] ** 2
-            hill[3] = rinv[3] ** 2
-            hill[4] = rinv[4] ** 2
-            hill[5] = rinv[5] ** 2
+            if sdim == 6:
+                hill[3] = rinv[3] ** 2
+                hill[4] = rinv[4] ** 2
+                hill[5] = rinv[5] ** 2
         elif rv is not None:
             warnings.warn('plasticity: Both, hill and rv, have been provided. Using Hill parameters.')
         hill = list(hill)
@@ -162,19 +160,29 @@ class Material(object):
             raise ValueError('plasticity: When hill_6p is set True, 6 Hill parameters must be provided')
         if hill_3p and lh != 3:
             raise ValueError('plasticity: When hill_3p is set True, only 3 Hill parameters can be provided')
-        if hill_3p:  # sdim == 6 here
+        if hill_6p and sdim == 3:
+            warnings.warn('plasticity: 6 Hill parameters are provided, but sdim=3; ignoring shear parameters')
+            hill_6p = False
+            hill_3p = True
+            hill = hill[0:3]
+        if hill_3p and sdim == 6:
             print('Material', self.name)
             warnings.warn('plasticity: 3 Hill parameters are provided, but sdim=6; shear parameters set to 1')
             hill_3p = False
             hill_6p = True
             hill.extend([1., 1., 1.])
-        if lh == 3 and len(hill) == 3:
+        if sdim == 6 and lh == 3 and len(hill) == 3:
             hill.extend([1., 1., 1.])
         self.hill_6p = bool(hill_6p)
         self.hill_3p = bool(hill_3p)
         self.hill = np.array(hill, dtype=float)
-        self.tresca = False
-        self.barlat = False
+        self.tresca = bool(tresca)
+        if barlat is not None:
+            self.barlat = True
+            self.barlat_par = np.array(barlat, dtype=float)
+            self.barlat_exp = barlat_exp
+        else:
+            self.barlat = False
         self._version += 1
 
     def set_svc(self, support_vectors, dual_coef, intercept, gamma, scale_seq, dev_only=False, C=None):
@@ -183,6 +191,9 @@ class Material(object):
         scikit-learn's public ``dual_coef_[0]`` / ``intercept_[0]``."""
         if self.sy is None:
             raise ValueError('set_svc: call elasticity() and plasticity(sy=..., sdim=6) first')
+        if self.sdim != 6:
+            raise NotImplementedError('set_svc: the 2-feature (seq, polar angle) SVC of sdim=3 materials '
+                                      '(setup_yf_SVM_3D) is not built; use sdim=6')
         sv = np.ascontiguousarray(support_vectors, dtype=float)
         if sv.ndim != 2 or sv.shape[1] != 6:
             raise ValueError('set_svc: support vectors must have shape (nsv, 6) (sdim=6 features)')
@@ -223,8 +234,21 @@ class Material(object):
                        gamma=self.gam_yf, scale_seq=self.scale_seq, dev_only=self.dev_only)
             return _lib.pack_material(_lib.SVC6, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
                                       hill=self.hill, drucker=self.drucker, svc=svc)
-        return _lib.pack_material(_lib.HILL6, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
-                                  hill=self.hill, drucker=self.drucker)
+        kind = _lib.HILL6 if self.sdim == 6 else _lib.PRINC3
+        if self.tresca:
+            kind = _lib.TRESCA
+        elif self.barlat:
+            kind = _lib.BARLAT
+        return _lib.pack_material(kind, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
+                                  hill=self.hill, drucker=self.drucker,
+                                  barlat=self.barlat_par if self.barlat else None,
+                                  barlat_exp=self.barlat_exp if self.barlat else 0.)
+
+    def _no_flow_rule(self):
+        if self.barlat:
+            raise ValueError('calc_fgrad: analytical gradient for Barlat not implemented')
+        if self.tresca:
+            raise ValueError('calc_fgrad: analytical gradient for Tresca not implemented')
 
     def _load(self, CV=None, ana=False):
         """Make this material (with element matrix CV) material 0 of the shared point context."""
@@ -261,7 +285,8 @@ class Material(object):
             seq = sig_eq_j2(s)  # elastic material: J2 (material.py:637-640)
         else:
             seq = self._load(ana=True).seq(0, s)
-            self.msg['equiv'] = '6-parameter Hill, full Voigt stress'
+            self.msg['equiv'] = ('6-parameter Hill, full Voigt stress'
+                                 if self.sdim == 6 and not (self.tresca or self.barlat) else '3-parameter Hill')
         return seq[0] if single else seq
 
     def get_sflow(self, epl):
@@ -318,9 +343,13 @@ class Material(object):
         s0 = np.asarray(sig, dtype=float)
         if epl is not None and np.shape(epl) != s0.shape:
             raise ValueError('Parameter sig and epl must have the same shape.')
-        if s0.shape not in ((6,),) and not (s0.ndim == 2 and s0.shape[1] == 6):
+        nd = self.sdim if self.sdim is not None else 6
+        if s0.shape not in ((3,), (6,)) and not (s0.ndim == 2 and s0.shape[1] == nd):
             raise ValueError('Unknown format of stress in calc_fgrad')
+        if not (self.ML_yf and not ana):
+            self._no_flow_rule()
         s, single = self._voigt(s0, 'calc_fgrad')
+        nout = s0.shape[-1]  # principal stresses in -> gradient w.r.t. principal stresses out
         if self.ML_yf and not ana:
             a = self._load().fgrad(0, s)
             self.khard = 0.  # side effect of the reference (material.py:812-814, no work-hardening data)
@@ -328,8 +357,13 @@ class Material(object):
         else:
             a = self._load(ana=True).fgrad(0, s)
             h = self.hill
-            self.msg['gradient'] = ('analytical, J2 isotropic, full stress' if np.all(h == 1.)
-                                    else 'analytical, 6-parameter Hill, full stress')
+            if self.sdim == 6:
+                self.msg['gradient'] = ('analytical, J2 isotropic, full stress' if np.all(h == 1.)
+                                        else 'analytical, 6-parameter Hill, full stress')
+            else:
+                self.msg['gradient'] = ('analytical, J2 isotropic, princ. stress' if np.all(h == 1.)
+                                        else 'analytical, 3-parameter Hill, princ. stress')
+        a = a[:, :nout]
         return a[0] if single else a
 
     def response(self, sig, epl, deps, CV, maxit=50):
@@ -341,7 +375,8 @@ class Material(object):
             raise ValueError('Only individual stress tensors supported in material.response. '
                              'Shape of argument is {}'.format(sh))
         if sh == (3,):
-            raise NotImplementedError('response: principal-stress (sdim=3) states are not built yet')
+            raise NotImplementedError('response: pass the Voigt stress (6,); (3,) principal input is not supported')
+        self._no_flow_rule()
         if maxit != 50:
             raise NotImplementedError('response: the device kernel is compiled for maxit=50 (reference default)')
         if self.sy is None:

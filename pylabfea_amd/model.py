@@ -403,6 +403,9 @@ class Model(object):
         if self._engine is not None and self.u is not None:
             raise RuntimeError('materials were modified after the model was solved; call mesh() again')
         self._drop_engine()
+        for m in self.mat:
+            if m.sy is not None:
+                m._no_flow_rule()  # Tresca / Barlat have no normal in the reference either (material.py:822-825)
         eng = _lib.Context(self.device)
         eng.set_materials([m._record(self._element_CV(m)) for m in self.mat])
         e0, e1 = 0, self.Nel

@@ -106,3 +106,50 @@ def test_svc(ctx, golden_dir, name):
         assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sy
         assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
         assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
+
+
+@pytest.mark.parametrize('name', ['hill3', 'j2s3'])
+def test_sdim3(ctx, golden_dir, name):
+    """sdim=3 flow rule: principal stresses in the reference's axis-tracking order (plane states)."""
+    from pylabfea_amd import _lib
+    z = np.load(os.path.join(golden_dir, 'material_%s.npz' % name))
+    sy = float(z['par_sy'])
+
+    def load(CV):
+        ctx.set_materials([_lib.pack_material(_lib.PRINC3, CV, E=float(z['par_E']), nu=float(z['par_nu']), sy=sy,
+                                              khard=float(z['par_khard']), hill=z['par_hill'],
+                                              drucker=float(z['par_dp'][0]))])
+    load(z['par_CV'])
+    sig = z['b_sig']
+    assert np.max(np.abs(ctx.seq(0, sig) - z['b_seq'])) < 1e-10
+    a = ctx.fgrad(0, sig)
+    ok = z['b_seq'] > 1e-6
+    assert np.max(np.abs(a[ok, :3] - z['b_fgrad'][ok])) < 1e-10 and np.all(a[:, 3:] == 0.)
+    assert np.max(np.abs(ctx.yf(0, sig, z['b_epl']) - z['b_yf'])) < 1e-10
+    for tag in ('pe', 'ps'):
+        CV = z['r%s_CV' % tag]
+        load(CV)
+        fy, so, dp, ct, ns = ctx.response(z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+        assert np.array_equal(ns, z['r%s_nsteps' % tag])
+        assert np.max(np.abs(fy - z['r%s_fy' % tag])) < 1e-8 * sy
+        assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-9 * sy
+        assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-12
+        assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-7 * CV[0, 0]
+
+
+def test_tresca_barlat_seq(ctx, golden_dir):
+    """Equivalent stresses without a flow rule in the reference (material.py:630-637, 678-702)."""
+    import pylabfea_amd as FE
+    z = np.load(os.path.join(golden_dir, 'seq_extra.npz'))
+    mt = FE.Material(name='tresca')
+    mt.elasticity(E=200.e3, nu=0.3)
+    mt.plasticity(sy=100., tresca=True, sdim=6)
+    assert np.max(np.abs(mt.calc_seq(z['sig']) - z['tresca_seq'])) < 1e-10
+    mb = FE.Material(name='barlat')
+    mb.elasticity(E=151220., nu=0.3)
+    mb.plasticity(sy=46.76, barlat=list(z['barlat_par']), barlat_exp=int(z['barlat_exp']), sdim=6)
+    assert np.max(np.abs(mb.calc_seq(z['sig']) - z['barlat_seq']) / z['barlat_seq']) < 1e-11
+    with pytest.raises(ValueError):          # same error as the reference (material.py:822-825)
+        mb.calc_fgrad(z['sig'][0])
+    with pytest.raises(ValueError):
+        mt.response(z['sig'][0], np.zeros(6), np.zeros(6), mt.CV)

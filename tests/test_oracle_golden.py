@@ -77,3 +77,34 @@ def test_svc(golden_dir, name):
         assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sc
         assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
         assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
+
+
+@pytest.mark.parametrize('name', ['hill3', 'j2s3'])
+def test_sdim3(golden_dir, name):
+    """sdim=3 flow rule (principal stresses in the reference's axis-tracking order) on plane states."""
+    z = np.load(os.path.join(golden_dir, 'material_%s.npz' % name))
+    m = O.Material.from_golden(z)
+    assert m.c.kind == O.PRINC3
+    sig = z['b_sig']
+    assert np.max(np.abs(O.sig_princ(sig) - z['b_sp'])) < 1e-10
+    assert np.max(np.abs(O.calc_seq(m, sig) - z['b_seq'])) < 1e-10
+    a = O.calc_fgrad(m, sig)                       # Voigt-embedded: [d/dsp, 0, 0, 0]
+    ok = z['b_seq'] > 1e-6
+    assert np.max(np.abs(a[ok, :3] - z['b_fgrad'][ok])) < 1e-10 and np.all(a[:, 3:] == 0.)
+    assert np.max(np.abs(O.calc_yf(m, sig, z['b_epl']) - z['b_yf'])) < 1e-10
+    for tag in ('pe', 'ps'):
+        CV = z['r%s_CV' % tag]
+        fy, so, dp, ct, ns = O.response(m, CV, z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+        assert np.array_equal(ns, z['r%s_nsteps' % tag])
+        sc = float(m.c.sy)
+        assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-9 * sc
+        assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-12
+        assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-7 * CV[0, 0]
+
+
+def test_tresca_barlat(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'seq_extra.npz'))
+    mt = O.Material(kind=O.TRESCA, sy=100.)
+    assert np.max(np.abs(O.calc_seq(mt, z['sig']) - z['tresca_seq'])) < 1e-10
+    mb = O.Material(kind=O.BARLAT, sy=46.76, barlat=z['barlat_par'], barlat_exp=float(z['barlat_exp']))
+    assert np.max(np.abs(O.calc_seq(mb, z['sig']) - z['barlat_seq']) / z['barlat_seq']) < 1e-11
