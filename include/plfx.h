@@ -111,7 +111,7 @@ int plfx_set_mesh(plfx_ctx *ctx, int nel, int nnode, const int32_t *conn, const 
  * plfx_solve when all elements have one shape and NX, NY halve down to a small grid. */
 int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
 /* preconditioner of plfx_solve: kind 0 = Jacobi, 1 = multigrid V(nu,nu) with damped-Jacobi smoothing
- * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.7, 2) */
+ * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.65, 2) */
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */

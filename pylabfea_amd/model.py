@@ -172,7 +172,7 @@ class Model(object):
         self.glob = {'ebc1': None, 'ebc2': None, 'sbc1': None, 'sbc2': None,
                      'eps': np.zeros(6), 'sig': np.zeros(6), 'epl': np.zeros(6)}
         self.cg_rtol = 1.e-12
-        self.cg_maxit = 200000
+        self.cg_maxit = 100000
         self.precond = None          # None: library default (multigrid when available), 0 Jacobi, 1 multigrid
         self.solver_stats = []
         self.n_sweeps = 0            # material sweeps (K-iterations) executed so far

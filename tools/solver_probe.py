@@ -20,7 +20,10 @@ for n in [int(a) for a in sys.argv[2:]]:
         fe = bench.tension_model(FE, mat, n, 0.005)
         fe.precond = pc
         fe._max_load_steps = steps
+        fe.cg_maxit = 20000 if pc == 0 else 300
         eng = fe._ensure_engine()
+        if pc == 1 and os.environ.get('MG_NU'):
+            eng.set_precond(1, float(os.environ.get('MG_OMEGA', '0.7')), int(os.environ['MG_NU']))
         eng.sync()
         eng.timing_enable(True)
         t = time.perf_counter()
