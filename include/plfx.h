@@ -36,7 +36,9 @@ enum {
     PLFX_SVC6 = 3,    /* RBF-SVC yield function on 6 stress features (material.py:398-405, 765-807) */
     PLFX_TRESCA = 4,  /* Tresca equivalent stress (material.py:630-632): calc_seq only, the reference has
                          no flow rule for it (calc_fgrad raises, material.py:824) */
-    PLFX_BARLAT = 5   /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) */
+    PLFX_BARLAT = 5,  /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) */
+    PLFX_SVC3 = 6     /* sdim=3 ML material: RBF-SVC on 2 features (seq_J2/scale - 1, polar angle/pi) of the
+                         principal stresses, gradient through the Jacobian (material.py:779-807, 2331-2333) */
 };
 
 /* error codes */
@@ -60,7 +62,7 @@ typedef struct plfx_material {
     double hill[6];    /* material.py:2573 */
     double drucker;    /* material.py:2514 (d0 = ones*drucker) */
     int32_t nsv;       /* SVC: number of support vectors */
-    int32_t nfeat;     /* SVC: features per support vector (6) */
+    int32_t nfeat;     /* SVC: features per support vector (6, or 2 for PLFX_SVC3) */
     int32_t dev_only;  /* SVC: deviatoric features (material.py:2336) */
     int32_t _pad;
     double gamma, intercept, scale_seq;

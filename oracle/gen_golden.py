@@ -632,6 +632,51 @@ def svc_params(mat):
                 hill=np.array(mat.hill), sdim=np.array(mat.sdim), Ndof=np.array(mat.Ndof))
 
 
+def gen_svc3(name, ml, rec):
+    """sdim=3 ML material: features (seq/scale - 1, polar angle/pi); plane stress states only."""
+    rng = np.random.default_rng(11)
+    N = 300
+    sy = ml.sy
+    sig = np.zeros((N, 6))
+    sig[:, [0, 1, 2, 5]] = rng.normal(size=(N, 4))
+    sig[:60, 5] = 0.
+    sig /= np.linalg.norm(sig, axis=1)[:, None]
+    sig *= (sy * rng.uniform(0.2, 1.5, size=N))[:, None]
+    rec['b_sig'] = sig
+    rec['b_yf'] = ml.calc_yf(sig)
+    rec['b_seq'] = ml.calc_seq(sig)
+    sp = FE.sig_princ(sig)[0]
+    rec['b_sp'] = sp
+    rec['b_fgrad'] = ml.calc_fgrad(sp)               # (N,3)
+    nf = 100
+    rec['b_full_yf'] = np.array([ml.ML_full_yf(sig[i], verb=False) for i in range(nf)])
+    for tag, ps in (('pe', False), ('ps', True)):
+        CVr = element_CV(ml, ps)
+        n = 64
+        s, e, d = gen_response_inputs(ml, CVr, rng, n, True)
+        e[:] = 0.
+        fy, so, dp, ct, ns = run_response(ml, s, e, d, CVr)
+        print('svc3', name, tag, np.bincount(ns))
+        rec['r%s_CV' % tag] = CVr
+        rec['r%s_sig' % tag] = s
+        rec['r%s_epl' % tag] = e
+        rec['r%s_deps' % tag] = d
+        rec['r%s_fy' % tag] = fy
+        rec['r%s_sig_out' % tag] = so
+        rec['r%s_depl' % tag] = dp
+        rec['r%s_ct' % tag] = ct
+        rec['r%s_nsteps' % tag] = ns
+    t = time.time()
+    ml.calc_properties(eps=0.01, sigeps=True, min_step=12)
+    for lc in ('stx', 'sty', 'et2', 'ect'):
+        rec['prop_%s_sig' % lc] = np.array(ml.sigeps[lc]['sig'])
+        rec['prop_%s_epl' % lc] = np.array(ml.sigeps[lc]['epl'])
+        rec['prop_%s_ys' % lc] = np.array([ml.prop[lc]['ys'], ml.propJ2[lc]['ys']])
+    print('svc3 calc_properties %.1fs' % (time.time() - t), ml.propJ2['stx']['ys'], ml.propJ2['sty']['seq'][-1],
+          ml.propJ2['ect']['peeq'][-1])
+    np.savez_compressed(os.path.join(OUT, 'svc_%s.npz' % name), **rec)
+
+
 def gen_svc():
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
@@ -656,8 +701,32 @@ def gen_svc():
         print('test_ml_shear SVC: %d SVs' % len(mls.svm_yf.support_vectors_))
         cases['shear'] = (mls, mat_s)
 
+        # tests/test_ml.py:71-92 (test_ml_training): SVC trained on a J2 reference, sdim=6
+        mat_J2 = FE.Material(name='J2-reference')
+        mat_J2.elasticity(E=200000., nu=0.3)
+        mat_J2.plasticity(sy=60., sdim=6)
+        ml2 = FE.Material('ML-J2_C15_G25')
+        ml2.dev_only = False
+        ml2.train_SVC(C=15., gamma=2.5, mat_ref=mat_J2, Nlc=150, Nseq=25, Fe=0.1, Ce=0.99)
+        print('test_ml_training SVC: %d SVs' % len(ml2.svm_yf.support_vectors_))
+        cases['j2train'] = (ml2, mat_J2)
+        # tests/test_ml.py:10-27 (test_ml_plasticity): sdim=3 SVC on (seq, polar angle) features
+        mat_h3 = FE.Material(name='anisotropic Hill')
+        mat_h3.elasticity(E=200.e3, nu=0.3)
+        mat_h3.plasticity(sy=150., hill=[0.7, 1., 1.4], drucker=0., khard=0., sdim=3)
+        ml3 = FE.Material(name='ML flow rule')
+        ml3.elasticity(E=200.e3, nu=0.3)
+        ml3.plasticity(sy=150., sdim=3)
+        x_train, y_train = ml3.create_sig_data(36, mat_ref=mat_h3, extend=True)
+        ml3.setup_yf_SVM_3D(x_train, y_train, C=10, gamma=4., fs=0.3)
+        print('test_ml_plasticity SVC (sdim=3): %d SVs' % len(ml3.svm_yf.support_vectors_))
+        cases['hill3d'] = (ml3, mat_h3)
+
         for name, (ml, ref) in cases.items():
             rec = {('par_' + k): v for k, v in svc_params(ml).items()}
+            if ml.sdim == 3:
+                gen_svc3(name, ml, rec)
+                continue
             rng = np.random.default_rng(7 + len(name))
             N = 400
             sy = ml.sy
@@ -691,6 +760,15 @@ def gen_svc():
                 rec['r%s_depl' % tag] = dp
                 rec['r%s_ct' % tag] = ct
                 rec['r%s_nsteps' % tag] = ns
+            if name == 'j2train':
+                t = time.time()
+                ml.calc_properties(verb=False, eps=0.01, sigeps=True)
+                for lc in ('stx', 'sty', 'et2', 'ect'):
+                    rec['prop_%s_sig' % lc] = np.array(ml.sigeps[lc]['sig'])
+                    rec['prop_%s_epl' % lc] = np.array(ml.sigeps[lc]['epl'])
+                    rec['prop_%s_ys' % lc] = np.array([ml.prop[lc]['ys'], ml.propJ2[lc]['ys']])
+                print('j2train calc_properties %.1fs' % (time.time() - t), ml.propJ2['et2']['ys'],
+                      ml.propJ2['ect']['peeq'][-1])
             np.savez_compressed(os.path.join(OUT, 'svc_%s.npz' % name), **rec)
 
         # tests/test_ml.py:test_ml_shear model (6x3 plane stress simple shear)

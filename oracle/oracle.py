@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libplfx_oracle.so')
 
-ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT = 0, 1, 2, 3, 4, 5
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3 = 0, 1, 2, 3, 4, 5, 6
 
 
 class _Mat(C.Structure):
@@ -85,7 +85,7 @@ class Material(object):
     def from_golden(cls, z, prefix='par_'):
         """Build from the ``par_*`` entries written by oracle/gen_golden.py."""
         if prefix + 'sv' in z:
-            return cls(kind=SVC6, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']),
+            return cls(kind=SVC6 if int(z[prefix + 'sdim']) == 6 else SVC3, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']),
                        sy=float(z[prefix + 'sy']), khard=float(z[prefix + 'khard']),
                        hill=z[prefix + 'hill'], sv=z[prefix + 'sv'], dual=z[prefix + 'dual'],
                        gamma=float(z[prefix + 'gamma']), intercept=float(z[prefix + 'intercept']),

@@ -222,7 +222,7 @@ double plfo_calc_seq(const plfo_material *m, const double sig[6]) /* material.py
         return fmax(fmax(sp[0], sp[1]), sp[2]) - fmin(fmin(sp[0], sp[1]), sp[2]);
     }
     if (m->kind == PLFO_BARLAT) return calc_seqB(m, sig); /* material.py:633-637 */
-    if (m->kind == PLFO_PRINC3) {                         /* material.py:662-673, 3-parameter Hill on principal stresses */
+    if (m->kind == PLFO_PRINC3 || m->kind == PLFO_SVC3) { /* material.py:662-673, 3-parameter Hill on principal stresses */
         double sp[3];
         plfo_sig_princ(sig, sp);
         double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
@@ -251,6 +251,43 @@ double plfo_get_sflow(const plfo_material *m, const double epl[6]) /* material.p
     return m->sy + plfo_eps_eq(epl) * m->khard;
 }
 
+/* basic.py:68-104 sig_polar_ang on principal stresses */
+static const double A_VEC[3] = {0.816496580927726, -0.408248290463863, -0.408248290463863}; /* [1,-.5,-.5]/sqrt(1.5) */
+static const double B_VEC[3] = {0., 0.7071067811865476, -0.7071067811865476};               /* [0,.5,-.5]*sqrt(2) */
+
+static double polar_ang(const double sp[3])
+{
+    double hyd = (sp[0] + sp[1] + sp[2]) / 3.;
+    double dev[3] = {sp[0] - hyd, sp[1] - hyd, sp[2] - hyd};
+    double vn = sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
+    if (vn < 1.e-4) vn = 1.;
+    double dsa = (dev[0] * A_VEC[0] + dev[1] * A_VEC[1] + dev[2] * A_VEC[2]) / vn;
+    double dsb = (dev[0] * B_VEC[0] + dev[1] * B_VEC[1] + dev[2] * B_VEC[2]) / vn;
+    return atan2(dsb, dsa);
+}
+
+/* create_scaled_input, sdim == 3 (material.py:2331-2333) on the principal stresses of sig */
+static void svc3_features(const plfo_material *m, const double sp[3], double x[2])
+{
+    double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
+    double seq = sqrt(0.5 * (d12 * d12 + d23 * d23 + d31 * d31)); /* sig_eq_j2, basic.py:58-62 */
+    x[0] = seq / m->scale_seq - 1.;
+    x[1] = polar_ang(sp) / 3.141592653589793;
+}
+
+static double svc3_decision(const plfo_material *m, const double sig[6])
+{
+    double sp[3], x[2], f = 0.;
+    plfo_sig_princ(sig, sp);
+    svc3_features(m, sp, x);
+    for (int k = 0; k < m->nsv; k++) {
+        const double *v = m->sv + (size_t)k * m->ndof;
+        double hh = (x[0] - v[0]) * (x[0] - v[0]) + (x[1] - v[1]) * (x[1] - v[1]);
+        f += m->dual[k] * exp(-m->gamma * hh);
+    }
+    return f + m->intercept;
+}
+
 static double svc_decision(const plfo_material *m, const double sig[6]) /* material.py:398-405, 2330-2340 */
 {
     double s[6], x[6];
@@ -272,6 +309,7 @@ static double svc_decision(const plfo_material *m, const double sig[6]) /* mater
 double plfo_calc_yf(const plfo_material *m, const double sig[6], const double epl[6]) /* material.py:378-411 */
 {
     if (m->kind == PLFO_SVC6) return svc_decision(m, sig);
+    if (m->kind == PLFO_SVC3) return svc3_decision(m, sig);
     return plfo_calc_seq(m, sig) - plfo_get_sflow(m, epl);
 }
 
@@ -295,6 +333,33 @@ void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]) /
             for (int i = 0; i < 6; i++) dK[i] += m->dual[k] * (kk * (-2. * m->gamma * hv[i]));
         }
         for (int i = 0; i < 6; i++) a[i] = dK[i] / m->scale_seq; /* material.py:807 */
+        return;
+    }
+    if (m->kind == PLFO_SVC3) {
+        /* gradient of the 2-feature SVC through the Jacobian of (seq, theta) (material.py:779-807), written
+         * into the normal Voigt components like every sdim == 3 normal (material.py:1044-1047) */
+        double sp[3], x[2], dK1 = 0.;
+        plfo_sig_princ(sig, sp);
+        svc3_features(m, sp, x);
+        for (int k = 0; k < m->nsv; k++) {
+            const double *v = m->sv + (size_t)k * m->ndof;
+            double h0 = x[0] - v[0], h1 = x[1] - v[1];
+            double kk = exp(-m->gamma * (h0 * h0 + h1 * h1));
+            dK1 += m->dual[k] * (kk * (-2. * m->gamma * h1));
+        }
+        double hyd = (sp[0] + sp[1] + sp[2]) / 3.;
+        double dev[3] = {sp[0] - hyd, sp[1] - hyd, sp[2] - hyd};
+        double vn = sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) * sqrt(1.5);
+        if (vn > 0.1) {
+            double cr = sp[0] * A_VEC[0] + sp[1] * A_VEC[1] + sp[2] * A_VEC[2];
+            double ci = sp[0] * B_VEC[0] + sp[1] * B_VEC[1] + sp[2] * B_VEC[2];
+            double n2 = cr * cr + ci * ci;
+            for (int i = 0; i < 3; i++) /* J[:,0] = 3 dev/vn ; J[:,1] = Re(-i((a+ib)/sc - dseqds/vn)) */
+                a[i] = 3. * dev[i] / vn + (B_VEC[i] * cr - A_VEC[i] * ci) / n2 * dK1;
+        } else {
+            for (int i = 0; i < 3; i++) a[i] = 1. + dK1; /* J = ones */
+        }
+        a[3] = a[4] = a[5] = 0.;
         return;
     }
     if (m->kind == PLFO_PRINC3) {
@@ -478,7 +543,7 @@ void plfo_C_tan(const plfo_material *m, const double sig[6], const double Cel[36
 
 static double resp_yf(const plfo_material *m, const double s[6], const double e[6])
 {
-    if (m->kind == PLFO_SVC6) return plfo_ML_full_yf(m, s, e, NULL); /* material.py:249-252 */
+    if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3) return plfo_ML_full_yf(m, s, e, NULL); /* material.py:249-252 */
     return plfo_calc_yf(m, s, e);
 }
 
@@ -503,7 +568,7 @@ int plfo_response(const plfo_material *m, const double sig_in[6], const double e
         double deps_r[6];
         double fy0 = plfo_calc_yf(m, sig, epl); /* :259 */
         if (fy0 < -0.15) {
-            if (m->kind == PLFO_SVC6) fy0 = plfo_ML_full_yf(m, sig, NULL, NULL); /* :265 */
+            if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3) fy0 = plfo_ML_full_yf(m, sig, NULL, NULL); /* :265 */
             st_scal += fy0 / plfo_calc_seq(m, dsig);                             /* :266 */
             double deps_el[6], ds_el[6];
             for (int i = 0; i < 6; i++) deps_el[i] = deps[i] * (1. - st_scal);

@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-enum { PLFO_ELASTIC = 0, PLFO_HILL6 = 1, PLFO_PRINC3 = 2, PLFO_SVC6 = 3, PLFO_TRESCA = 4, PLFO_BARLAT = 5 };
+enum { PLFO_ELASTIC = 0, PLFO_HILL6 = 1, PLFO_PRINC3 = 2, PLFO_SVC6 = 3, PLFO_TRESCA = 4, PLFO_BARLAT = 5,
+       PLFO_SVC3 = 6 /* sdim=3 ML material: 2 features (seq_J2/scale - 1, polar angle/pi), material.py:2330-2333 */ };
 
 typedef struct plfo_material {
     int kind;            /* PLFO_* */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PLFX_LIB', os.path.join(_HERE, 'libplfx.so'))  # PLFX_LIB: kernel-variant experiments
 
 # yield-function kinds (include/plfx.h)
-ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT = 0, 1, 2, 3, 4, 5
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3 = 0, 1, 2, 3, 4, 5, 6
 
 # state ids of plfx_state_get/_set
 ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS = range(11)
@@ -86,7 +86,7 @@ def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0.,
     Returns (struct, keepalive) - keepalive holds the arrays the struct points to."""
     m = CMaterial()
     m.kind = int(kind)
-    m.sdim = 3 if kind == PRINC3 else 6
+    m.sdim = 3 if kind in (PRINC3, SVC3) else 6
     if barlat is not None:
         for i in range(18):
             m.barlat[i] = float(barlat[i])

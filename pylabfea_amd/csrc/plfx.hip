@@ -100,7 +100,7 @@ struct plfx_ctx {
     std::vector<MatDev> hmat;
     MatDev *dmat = nullptr;
     std::vector<double *> dsv;  // owned device copies of sv/dual
-    bool has_svc = false, has_analytic = false, has_elastic = false, has_princ = false;
+    bool has_svc = false, has_svc3 = false, has_analytic = false, has_elastic = false, has_princ = false;
     int svc_lds_need = 0;
 
     // mesh
@@ -515,7 +515,7 @@ int ensure_tmp(plfx_ctx *c, size_t n)
     return 0;
 }
 
-size_t dyn_lds_bytes(const plfx_ctx *c) { return c->has_svc ? (size_t)c->svc_lds_need * 8 : 0; }
+size_t dyn_lds_bytes(const plfx_ctx *c) { return (c->has_svc || c->has_svc3) ? (size_t)c->svc_lds_need * 8 : 0; }
 
 int plain_spmv(plfx_ctx *c, const double *in, double *out)
 {
@@ -725,7 +725,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (!c || !c->stream) return PLFX_ERR_STATE;
     if (nmat < 1 || nmat > MAXMAT || !mats) return fail(c, PLFX_ERR_ARG, "nmat must be in 1..%d", MAXMAT);
     free_materials(c);
-    c->has_svc = c->has_analytic = c->has_elastic = c->has_princ = false;
+    c->has_svc = c->has_svc3 = c->has_analytic = c->has_elastic = c->has_princ = false;
     c->svc_lds_need = 0;
     c->nonlin = false;
     c->hmat.resize(nmat);
@@ -733,7 +733,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         const plfx_material &s = mats[k];
         MatDev &m = c->hmat[k];
         memset(&m, 0, sizeof(m));
-        if (s.kind < PLFX_ELASTIC || s.kind > PLFX_BARLAT)
+        if (s.kind < PLFX_ELASTIC || s.kind > PLFX_SVC3)
             return fail(c, PLFX_ERR_ARG, "material %d: unknown kind %d", k, s.kind);
         for (int i = 0; i < 6; i++)
             for (int j = i + 1; j < 6; j++)
@@ -761,32 +761,34 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         m.E = s.E;
         m.nu = s.nu;
         m.kind = s.kind;
-        m.sdim = (s.kind == PLFX_PRINC3) ? 3 : 6;
+        m.sdim = (s.kind == PLFX_PRINC3 || s.kind == PLFX_SVC3) ? 3 : 6;
         for (int i = 0; i < 18; i++) m.barlat[i] = s.barlat[i];
         m.barlat_exp = s.barlat_exp;
         if (s.kind != PLFX_ELASTIC) c->nonlin = true;
         if (s.kind == PLFX_HILL6) c->has_analytic = true;
         if (s.kind == PLFX_PRINC3) c->has_princ = true;
         if (s.kind == PLFX_ELASTIC) c->has_elastic = true;
-        if (s.kind == PLFX_SVC6) {
-            if (s.nsv < 1 || s.nfeat != 6 || !s.sv || !s.dual)
-                return fail(c, PLFX_ERR_ARG, "material %d: SVC needs nsv>=1, nfeat==6, sv and dual", k);
+        if (s.kind == PLFX_SVC6 || s.kind == PLFX_SVC3) {
+            const int nf = (s.kind == PLFX_SVC6) ? 6 : 2;
+            if (s.nsv < 1 || s.nfeat != nf || !s.sv || !s.dual)
+                return fail(c, PLFX_ERR_ARG, "material %d: SVC needs nsv>=1, nfeat==%d, sv and dual", k, nf);
             double *dsv = nullptr, *ddu = nullptr;
-            HIPCHK(c, hipMalloc((void **)&dsv, (size_t)s.nsv * 6 * 8));
+            HIPCHK(c, hipMalloc((void **)&dsv, (size_t)s.nsv * nf * 8));
             c->dsv.push_back(dsv);
             HIPCHK(c, hipMalloc((void **)&ddu, (size_t)s.nsv * 8));
             c->dsv.push_back(ddu);
-            HIPCHK(c, hipMemcpy(dsv, s.sv, (size_t)s.nsv * 6 * 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(dsv, s.sv, (size_t)s.nsv * nf * 8, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(ddu, s.dual, (size_t)s.nsv * 8, hipMemcpyHostToDevice));
             m.sv = dsv;
             m.dual = ddu;
             m.nsv = s.nsv;
+            m.nfeat = nf;
             m.dev_only = s.dev_only;
             m.gamma = s.gamma;
             m.intercept = s.intercept;
             m.scale_seq = s.scale_seq;
-            if (!c->has_svc && s.nsv * 7 <= c->lds_doubles) c->svc_lds_need = s.nsv * 7;
-            c->has_svc = true;
+            if (s.nsv * (nf + 1) <= c->lds_doubles) c->svc_lds_need = std::max(c->svc_lds_need, s.nsv * (nf + 1));
+            if (s.kind == PLFX_SVC6) c->has_svc = true; else c->has_svc3 = true;
         }
     }
     c->nmat = nmat;
@@ -794,9 +796,12 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->has_svc) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
+    if (c->has_svc || c->has_svc3) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
         HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_point_eval, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -893,6 +898,9 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
     if (c->has_svc)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<3>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, RB_ARGS(c->svc_lds_need));
+    if (c->has_svc3)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<6>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, RB_ARGS(c->svc_lds_need));
 #undef RB_ARGS
     tim_end(c, ev);
@@ -1546,7 +1554,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                         c->fyn, c->max_steps, nit, c->flags, c->heavy_list
     // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
     int first = 1;
-    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc)) {
+    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), first);
         first = 0;
@@ -1561,6 +1569,11 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            c->stream, SWEEP_ARGS(c->svc_lds_need), first);
         first = 0;
     }
+    if (c->has_svc3) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first);
+        first = 0;
+    }
     // phase 2 reads the list length from the device; an empty list costs one empty launch
     if (c->has_analytic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
@@ -1570,6 +1583,9 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            SWEEP_ARGS(0));
     if (c->has_svc)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+    if (c->has_svc3)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need));
 #undef SWEEP_ARGS
     tim_end(c, ev);

@@ -40,7 +40,7 @@ struct MatDev {
     const double *sv;    // device pointer [nsv*6]
     const double *dual;  // device pointer [nsv]
     double barlat[18], barlat_exp;  // Yld2004-18p coefficients (calc_seq only)
-    int32_t kind, sdim, nsv, dev_only;
+    int32_t kind, sdim, nsv, dev_only, nfeat, _pad;
 };
 
 // y = C x for a symmetric 21-entry matrix
@@ -340,6 +340,67 @@ struct YfPrinc3 {
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { princ_fgrad(m, s, a); }
 };
 
+// ---------------------------------------------------------------------------------------------
+// 2-feature SVC of sdim = 3 ML materials: x = (seq_J2/scale - 1, polar angle/pi) of the principal
+// stresses (create_scaled_input, material.py:2331-2333; sig_polar_ang, basic.py:68-104)
+__device__ __forceinline__ void svc3_features(const MatDev &m, const double *sp, double *x)
+{
+    const double d12 = sp[0] - sp[1], d23 = sp[1] - sp[2], d31 = sp[2] - sp[0];
+    const double seq = sqrt(0.5 * (d12 * d12 + d23 * d23 + d31 * d31));
+    const double hyd = (sp[0] + sp[1] + sp[2]) / 3.;
+    const double e0 = sp[0] - hyd, e1 = sp[1] - hyd, e2 = sp[2] - hyd;
+    double vn = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    if (vn < 1.e-4) vn = 1.;
+    const double dsa = (e0 * 0.816496580927726 - (e1 + e2) * 0.408248290463863) / vn;
+    const double dsb = (e1 - e2) * 0.7071067811865476 / vn;
+    x[0] = seq / m.scale_seq - 1.;
+    x[1] = atan2(dsb, dsa) / 3.141592653589793;
+}
+
+__device__ inline double svc3_decision(const MatDev &m, const double *sv, const double *dual, const double *s)
+{
+    double sp[3], x[2];
+    sig_princ_dev(s, sp);
+    svc3_features(m, sp, x);
+    double f = 0.;
+    const double g = -m.gamma;
+    for (int k = 0; k < m.nsv; k++) {
+        const double h0 = x[0] - sv[2 * k], h1 = x[1] - sv[2 * k + 1];
+        f = fma(dual[k], exp(g * fma(h0, h0, h1 * h1)), f);
+    }
+    return f + m.intercept;
+}
+
+// gradient through the Jacobian of (seq, theta) (material.py:779-807), in the normal Voigt components
+__device__ inline void svc3_fgrad(const MatDev &m, const double *sv, const double *dual, const double *s, double *a)
+{
+    double sp[3], x[2];
+    sig_princ_dev(s, sp);
+    svc3_features(m, sp, x);
+    double dK1 = 0.;
+    const double g = -m.gamma;
+    for (int k = 0; k < m.nsv; k++) {
+        const double h0 = x[0] - sv[2 * k], h1 = x[1] - sv[2 * k + 1];
+        dK1 = fma(dual[k] * exp(g * fma(h0, h0, h1 * h1)), 2. * g * h1, dK1);
+    }
+    const double hyd = (sp[0] + sp[1] + sp[2]) / 3.;
+    const double dev[3] = {sp[0] - hyd, sp[1] - hyd, sp[2] - hyd};
+    const double vn = sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) * sqrt(1.5);
+    const double av[3] = {0.816496580927726, -0.408248290463863, -0.408248290463863};
+    const double bv[3] = {0., 0.7071067811865476, -0.7071067811865476};
+    if (vn > 0.1) {
+        const double cr = sp[0] * av[0] + sp[1] * av[1] + sp[2] * av[2];
+        const double ci = sp[0] * bv[0] + sp[1] * bv[1] + sp[2] * bv[2];
+        const double n2 = cr * cr + ci * ci;
+#pragma unroll
+        for (int i = 0; i < 3; i++) a[i] = 3. * dev[i] / vn + (bv[i] * cr - av[i] * ci) / n2 * dK1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) a[i] = 1. + dK1;
+    }
+    a[3] = a[4] = a[5] = 0.;
+}
+
 // scipy.optimize.brentq (scipy 1.15.3, Brent 1973) specialised to f(x) = decision(x*su)
 template <class F>
 __device__ inline double brentq_dev(F f, double xa, double xb, double fa, double fb, double xtol,
@@ -399,24 +460,30 @@ __device__ inline double brentq_dev(F f, double xa, double xb, double fa, double
     return xcur;
 }
 
-// Yield-function policy: RBF-SVC (ML_yf).  calc_seq of an ML material is J2 (hill = ones).
-struct YfSvc {
+// Yield-function policy: RBF-SVC (ML_yf) on NF = 6 stress features (sdim 6) or NF = 2 (sdim 3).
+// calc_seq of an ML material is J2 (hill = ones), on Voigt or on principal stresses.
+template <int NF>
+struct YfSvcT {
     const MatDev &m;
     const double *sv;
     const double *dual;
-    __device__ YfSvc(const MatDev &mm, const double *s, const double *d) : m(mm), sv(s), dual(d) {}
-    __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
+    __device__ YfSvcT(const MatDev &mm, const double *s, const double *d) : m(mm), sv(s), dual(d) {}
+    __device__ __forceinline__ double seq(const double *s) const { return NF == 6 ? hill_seq(m, s) : princ_seq(m, s); }
+    __device__ __forceinline__ double decision(const double *s) const
+    {
+        return NF == 6 ? svc_decision(m, sv, dual, s) : svc3_decision(m, sv, dual, s);
+    }
     __device__ __forceinline__ double plain(const double *s, const double *epl) const
     {
         (void)epl;
-        return svc_decision(m, sv, dual, s);
+        return decision(s);
     }
     // ML_full_yf (material.py:414-516): distance to the yield locus along the ray through s
     // (ld == nullptr) or along the loading direction ld.
     __device__ inline double full_ld(const double *s, const double *epl, const double *ld,
                                      int *status) const
     {
-        double seqv = hill_seq(m, s);
+        double seqv = seq(s);
         double sflow = sflow_of(m, epl);
         if (status) *status = 0;
         if (seqv < 0.01 && ld == nullptr) return seqv - 0.85 * sflow;
@@ -425,21 +492,25 @@ struct YfSvc {
 #pragma unroll
             for (int i = 0; i < 6; i++) su[i] = s[i] / seqv;
         } else {
-            double hh = sqrt(dot6(ld, ld));  // material.py:455-462
+            // su = ld[0:sdim] * sqrt(1.5) / |ld[0:sdim]|  (material.py:455-462)
+            double hh = 0.;
+#pragma unroll
+            for (int i = 0; i < 6; i++) hh += (i < (NF == 6 ? 6 : 3)) ? ld[i] * ld[i] : 0.;
+            hh = sqrt(hh);
             if (hh < 1.e-3) {
                 su[0] = sqrt(1.5);
 #pragma unroll
                 for (int i = 1; i < 6; i++) su[i] = 0.;
             } else {
 #pragma unroll
-                for (int i = 0; i < 6; i++) su[i] = ld[i] * sqrt(1.5) / hh;
+                for (int i = 0; i < 6; i++) su[i] = (i < (NF == 6 ? 6 : 3)) ? ld[i] * sqrt(1.5) / hh : 0.;
             }
         }
         auto f = [&](double x) {  // find_yloc_scalar (material.py:547-574): calc_yf(x*su)
             double xs[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) xs[i] = x * su[i];
-            return svc_decision(m, sv, dual, xs);
+            return decision(xs);
         };
         double x0 = sflow;
         if (su[0] * su[1] < -1.e-5) x0 *= 0.5;  // material.py:468-473
@@ -460,7 +531,7 @@ struct YfSvc {
         }
         bool conv;
         double xs = brentq_dev(f, x0, x1, f0, f1, 1.e-5, 4. * 2.220446049250313e-16, 100, conv);
-        if (conv && xs < 4. * sflow) return seqv - xs * hill_seq(m, su);  // material.py:507
+        if (conv && xs < 4. * sflow) return seqv - xs * seq(su);  // material.py:507
         if (status) *status = 2;
         return seqv - 0.85 * sflow;  // material.py:510
     }
@@ -475,8 +546,16 @@ struct YfSvc {
         const double z[6] = {0., 0., 0., 0., 0., 0.};
         return full_ld(s, z, nullptr, nullptr);
     }
-    __device__ __forceinline__ void fgrad(const double *s, double *a) const { svc_fgrad(m, sv, dual, s, a); }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const
+    {
+        if (NF == 6)
+            svc_fgrad(m, sv, dual, s, a);
+        else
+            svc3_fgrad(m, sv, dual, s, a);
+    }
 };
+typedef YfSvcT<6> YfSvc;
+typedef YfSvcT<2> YfSvc3;
 
 // ---------------------------------------------------------------------------------------------
 // Material.response (material.py:207-346) for one point, in two phases so that the sweep can run

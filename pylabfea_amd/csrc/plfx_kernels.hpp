@@ -71,6 +71,8 @@ __device__ __forceinline__ double sum_partials(const double *part, int n, double
     return t;
 }
 
+__host__ __device__ constexpr bool kind_is_svc(int k) { return k == 3 || k == 6; }
+
 // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
 // contiguous range of tiles so that the neighbour columns a tile gathers are in the same L2.
 __device__ __forceinline__ int xcd_tile(int b, int nb)
@@ -90,21 +92,22 @@ __device__ __forceinline__ void stage_materials(MatDev *smat, const MatDev *gmat
 
 // stage the support vectors of the first SVC material into dynamic LDS (if they fit)
 __device__ __forceinline__ void stage_svc(const MatDev *smat, int nmat, double *lds, int lds_doubles,
-                                          int &svc_mat, const double *&sv, const double *&dual)
+                                          int &svc_mat, const double *&sv, const double *&dual, int kind = 0)
 {
     svc_mat = -1;
     sv = dual = nullptr;
     for (int k = 0; k < nmat; k++)
-        if (smat[k].kind == 3 && smat[k].nsv * 7 <= lds_doubles) {
+        if ((kind ? smat[k].kind == kind : kind_is_svc(smat[k].kind)) &&
+            smat[k].nsv * (smat[k].nfeat + 1) <= lds_doubles) {
             svc_mat = k;
             break;
         }
     if (svc_mat < 0) return;
-    const int n = smat[svc_mat].nsv;
-    for (int i = threadIdx.x; i < 6 * n; i += blockDim.x) lds[i] = smat[svc_mat].sv[i];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[6 * n + i] = smat[svc_mat].dual[i];
+    const int n = smat[svc_mat].nsv, nf = smat[svc_mat].nfeat;
+    for (int i = threadIdx.x; i < nf * n; i += blockDim.x) lds[i] = smat[svc_mat].sv[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[nf * n + i] = smat[svc_mat].dual[i];
     sv = lds;
-    dual = lds + 6 * n;
+    dual = lds + nf * n;
 }
 
 // One material kind per kernel instantiation (KIND = 1 Hill-6p/J2 on Voigt, 2 Hill-3p/J2 on principal
@@ -130,6 +133,15 @@ struct YfOf<3> {
         return YfSvc(m, sv ? sv : m.sv, dual ? dual : m.dual);
     }
 };
+template <>
+struct YfOf<6> {
+    typedef YfSvc3 type;
+    __device__ static YfSvc3 make(const MatDev &m, const double *sv, const double *dual)
+    {
+        return YfSvc3(m, sv ? sv : m.sv, dual ? dual : m.dual);
+    }
+};
+
 
 extern __shared__ double dyn_lds[];
 
@@ -146,8 +158,8 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (KIND == 3) {
-        stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    if (kind_is_svc(KIND)) {
+        stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual, KIND);
         __syncthreads();
     }
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
@@ -200,7 +212,8 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
     stage_svc(smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
     __syncthreads();
     const MatDev &m = smat[mat];
-    const bool svc = (m.kind == 3);
+    const bool svc = kind_is_svc(m.kind);
+    const bool svc3 = (m.kind == 6);
     const double *psv = (mat == svc_mat) ? sv : m.sv;
     const double *pdu = (mat == svc_mat) ? dual : m.dual;
     double ldv[6];
@@ -217,10 +230,12 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
         }
         const int kd = m.kind;
         if (what == 0) {
-            out[i] = kd == 2 ? princ_seq(m, s) : kd == 4 ? tresca_seq(s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s);
+            out[i] = (kd == 2 || kd == 6) ? princ_seq(m, s) : kd == 4 ? tresca_seq(s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s);
         } else if (what == 1) {
             double a[6];
-            if (svc)
+            if (svc3)
+                svc3_fgrad(m, psv, pdu, s, a);
+            else if (svc)
                 svc_fgrad(m, psv, pdu, s, a);
             else if (kd == 2)
                 princ_fgrad(m, s, a);
@@ -229,11 +244,15 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
 #pragma unroll
             for (int c = 0; c < 6; c++) out[6 * (size_t)i + c] = a[c];
         } else if (what == 2) {
-            out[i] = svc ? svc_decision(m, psv, pdu, s)
-                         : (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
+            out[i] = svc3 ? svc3_decision(m, psv, pdu, s)
+                          : svc ? svc_decision(m, psv, pdu, s)
+                                : (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
         } else {
             int st = 0;
-            if (svc) {
+            if (svc3) {
+                YfSvc3 yf(m, psv, pdu);
+                out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
+            } else if (svc) {
                 YfSvc yf(m, psv, pdu);
                 out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
             } else {
@@ -353,8 +372,8 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (KIND == 3) {
-        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    if (kind_is_svc(KIND)) {
+        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual, KIND);
         __syncthreads();
     }
     int changed = 0, nconv = 0;
@@ -418,8 +437,8 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
     __syncthreads();
     int svc_mat = -1;
     const double *sv = nullptr, *dual = nullptr;
-    if (KIND == 3) {
-        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual);
+    if (kind_is_svc(KIND)) {
+        stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual, KIND);
         __syncthreads();
     }
     int changed = 0, nconv = 0;
@@ -890,7 +909,7 @@ k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int
         int mult = 0;
         double hh = 0.;
         if (m.kind != 0) {
-            const double sref = (m.kind == 2) ? princ_seq(m, ds) : hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
+            const double sref = (m.kind == 2 || m.kind == 6) ? princ_seq(m, ds) : hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
             if (sref > 0.1) {
                 double s[6], ep[6];
 #pragma unroll
@@ -899,12 +918,13 @@ k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int
                     ep[k] = epl[(size_t)k * nel + e];
                 }
                 double yf0;
-                if (m.kind == 3) {
+                if (kind_is_svc(m.kind)) {
                     const bool st = (c.mat == svc_mat);
-                    YfSvc yf(m, st ? sv : m.sv, st ? dual : m.dual);
-                    yf0 = yf.plain(s, ep);  // branch test on the decision function (model.py:1046-1048)
-                    if (yf0 < SPLIT_THRESHOLD) {
-                        yf0 = yf.full_ld(s, ep, ld, nullptr);  // model.py:1049-1052
+                    const double *psv = st ? sv : m.sv, *pdu = st ? dual : m.dual;
+                    yf0 = (m.kind == 3) ? YfSvc(m, psv, pdu).plain(s, ep) : YfSvc3(m, psv, pdu).plain(s, ep);
+                    if (yf0 < SPLIT_THRESHOLD) {  // branch test on the decision function (model.py:1046-1048)
+                        yf0 = (m.kind == 3) ? YfSvc(m, psv, pdu).full_ld(s, ep, ld, nullptr)
+                                            : YfSvc3(m, psv, pdu).full_ld(s, ep, ld, nullptr);  // model.py:1049-1052
                         hh = fmin(1., -yf0 / sref);
                         mult = 2;  // appended twice (model.py:1054 and :1058)
                     } else {

@@ -11,7 +11,7 @@ Out of scope here: SVC *training*, data import, plotting, textur
 features.  A trained SVC enters through :meth:`Material.set_svc` / :meth:`Material.from_sklearn`.
 sdim=3 flow rules use the reference's axis-tracking principal stresses (exact for plane states);
 Tresca and Barlat Yld2004-18p are equivalent stresses only (the reference has no normal for them).
-Not built: the 2-feature SVC of sdim=3 materials (``setup_yf_SVM_3D``).
+ML materials: 6 stress features (sdim=6) or the 2 features (seq, polar angle) of ``setup_yf_SVM_3D`` (sdim=3).
 """
 import warnings
 
@@ -191,12 +191,10 @@ class Material(object):
         scikit-learn's public ``dual_coef_[0]`` / ``intercept_[0]``."""
         if self.sy is None:
             raise ValueError('set_svc: call elasticity() and plasticity(sy=..., sdim=6) first')
-        if self.sdim != 6:
-            raise NotImplementedError('set_svc: the 2-feature (seq, polar angle) SVC of sdim=3 materials '
-                                      '(setup_yf_SVM_3D) is not built; use sdim=6')
+        nfeat = 6 if self.sdim == 6 else 2   # sdim=3: (seq_J2/scale - 1, polar angle/pi), material.py:2331-2333
         sv = np.ascontiguousarray(support_vectors, dtype=float)
-        if sv.ndim != 2 or sv.shape[1] != 6:
-            raise ValueError('set_svc: support vectors must have shape (nsv, 6) (sdim=6 features)')
+        if sv.ndim != 2 or sv.shape[1] != nfeat:
+            raise ValueError('set_svc: support vectors must have shape (nsv, %d) for sdim=%d' % (nfeat, self.sdim))
         dual = np.ascontiguousarray(dual_coef, dtype=float).reshape(-1)
         if len(dual) != len(sv):
             raise ValueError('set_svc: dual_coef and support_vectors differ in length')
@@ -206,7 +204,7 @@ class Material(object):
         self.scale_seq = float(scale_seq)
         self.dev_only = bool(dev_only)
         self.ML_yf = True
-        self.Ndof = 6
+        self.Ndof = nfeat
         if self.khard:
             # calc_fgrad of an ML material resets self.khard to 0 on every call (material.py:812-814)
             warnings.warn('set_svc: khard of an ML material is reset to 0 by the reference flow rule')
@@ -232,7 +230,7 @@ class Material(object):
         if self.ML_yf and not ana:
             svc = dict(sv=self.svc['sv'], dual=self.svc['dual'], intercept=self.svc['intercept'],
                        gamma=self.gam_yf, scale_seq=self.scale_seq, dev_only=self.dev_only)
-            return _lib.pack_material(_lib.SVC6, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
+            return _lib.pack_material(_lib.SVC6 if self.sdim == 6 else _lib.SVC3, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
                                       hill=self.hill, drucker=self.drucker, svc=svc)
         kind = _lib.HILL6 if self.sdim == 6 else _lib.PRINC3
         if self.tresca:

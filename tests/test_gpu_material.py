@@ -81,7 +81,7 @@ def test_response_vs_oracle_large(ctx, golden_dir):
     assert np.max(np.abs(ct[ok] - ct2[ok])) < 1e-6 * CV[0, 0]
 
 
-@pytest.mark.parametrize('name', ['hill', 'shear'])
+@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train'])
 def test_svc(ctx, golden_dir, name):
     from pylabfea_amd import _lib
     z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))
@@ -153,3 +153,30 @@ def test_tresca_barlat_seq(ctx, golden_dir):
         mb.calc_fgrad(z['sig'][0])
     with pytest.raises(ValueError):
         mt.response(z['sig'][0], np.zeros(6), np.zeros(6), mt.CV)
+
+
+def test_svc_sdim3(ctx, golden_dir):
+    """2-feature SVC (seq, polar angle) of sdim=3 ML materials, gradient through the Jacobian."""
+    from pylabfea_amd import _lib
+    z = np.load(os.path.join(golden_dir, 'svc_hill3d.npz'))
+    svc = dict(sv=z['par_sv'], dual=z['par_dual'], gamma=float(z['par_gamma']),
+               intercept=float(z['par_intercept']), scale_seq=float(z['par_scale_seq']), dev_only=False)
+    sy = float(z['par_sy'])
+    for tag in ('pe', 'ps'):
+        CV = z['r%s_CV' % tag]
+        ctx.set_materials([_lib.pack_material(_lib.SVC3, CV, E=float(z['par_E']), nu=float(z['par_nu']), sy=sy,
+                                              khard=float(z['par_khard']), hill=z['par_hill'], svc=svc)])
+        if tag == 'pe':
+            sig = z['b_sig']
+            assert np.max(np.abs(ctx.yf(0, sig) - z['b_yf'])) < 1e-9
+            assert np.max(np.abs(ctx.seq(0, sig) - z['b_seq'])) < 1e-10
+            a = ctx.fgrad(0, sig)
+            assert np.max(np.abs(a[:, :3] - z['b_fgrad'])) < 1e-9 and np.all(a[:, 3:] == 0.)
+            nf = len(z['b_full_yf'])
+            fyf, st = ctx.full_yf(0, sig[:nf])
+            assert np.max(np.abs(fyf - z['b_full_yf'])) < 1e-6 * sy
+        fy, so, dp, ct, ns = ctx.response(z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+        assert np.array_equal(ns, z['r%s_nsteps' % tag])
+        assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sy
+        assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
+        assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]

@@ -57,7 +57,7 @@ def test_element(golden_dir):
         assert rel(K, z['e%d_KelD' % k], 1e-6) < 1e-12
 
 
-@pytest.mark.parametrize('name', ['hill', 'shear'])
+@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train'])
 def test_svc(golden_dir, name):
     z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))
     m = O.Material.from_golden(z)
@@ -108,3 +108,26 @@ def test_tresca_barlat(golden_dir):
     assert np.max(np.abs(O.calc_seq(mt, z['sig']) - z['tresca_seq'])) < 1e-10
     mb = O.Material(kind=O.BARLAT, sy=46.76, barlat=z['barlat_par'], barlat_exp=float(z['barlat_exp']))
     assert np.max(np.abs(O.calc_seq(mb, z['sig']) - z['barlat_seq']) / z['barlat_seq']) < 1e-11
+
+
+def test_svc_sdim3(golden_dir):
+    """2-feature SVC of sdim=3 ML materials (tests/test_ml.py:test_ml_plasticity settings)."""
+    z = np.load(os.path.join(golden_dir, 'svc_hill3d.npz'))
+    m = O.Material.from_golden(z)
+    assert m.c.kind == O.SVC3 and m.c.ndof == 2
+    sig = z['b_sig']
+    assert np.max(np.abs(O.calc_yf(m, sig) - z['b_yf'])) < 1e-10
+    assert np.max(np.abs(O.calc_seq(m, sig) - z['b_seq'])) < 1e-10
+    a = O.calc_fgrad(m, sig)
+    assert np.max(np.abs(a[:, :3] - z['b_fgrad'])) < 1e-10 and np.all(a[:, 3:] == 0.)
+    nf = len(z['b_full_yf'])
+    fyf, st = O.ML_full_yf(m, sig[:nf])
+    assert np.max(np.abs(fyf - z['b_full_yf'])) < 1e-7
+    for tag in ('pe', 'ps'):
+        CV = z['r%s_CV' % tag]
+        fy, so, dp, ct, ns = O.response(m, CV, z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag])
+        assert np.array_equal(ns, z['r%s_nsteps' % tag])
+        sc = float(m.c.sy)
+        assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sc
+        assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
+        assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
