@@ -14,9 +14,9 @@ are run untimed as set-up so that warm-up and timed steps lie in the plastic reg
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: the elements are sharded into N x-strips (one rank per GPU); every rank keeps full-length DOF
-vectors and the global vector is all-reduced over RCCL at each CG step (strong scaling: the mesh is
-fixed).  Rank 0 prints ONE JSON line.
+N>1: the elements are sharded into N x-strips (one rank per GPU): material sweep and the rows of the CG
+SpMV are sharded, the global vector is all-reduced over RCCL at each CG step, the matrix / multigrid
+hierarchy is replicated.  Strong scaling: the mesh is fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -196,7 +196,8 @@ def main():
                                'plane strain, uniaxial tension eps=0.005, min_step=50; timed load steps %d..%d '
                                'of 50 (after %d untimed elastic pre-roll steps)'
                                % (n, n, PREROLL + W, PREROLL + W + K, PREROLL),
-                   'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': 'x-strip element shard x%d' % world,
+                   'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': ('single GPU' if world == 1 else 'x-strip element shard x%d: sweep + CG SpMV rows sharded, '
+                                   'RCCL all-reduce per CG step, replicated multigrid hierarchy' % world),
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
                               else 'Jacobi-PCG') + ' rtol=%g on block-ELL' % fe.cg_rtol, 'device': devname},
         'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),

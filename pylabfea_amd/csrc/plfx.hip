@@ -114,6 +114,9 @@ struct plfx_ctx {
     std::vector<double> hlxy;
     ClassDev *dcls = nullptr;
     int32_t *dconn = nullptr, *dcls_id = nullptr;  // dcls_id: owned elements only
+    int32_t *dcls_all = nullptr;                   // class ids of ALL elements (assembly of the replicated matrix)
+    bool sharded = false;                          // owns a strict subset of the elements
+    int own_n0 = 0, own_n1 = 0;                    // disjoint node ownership for the sharded SpMV rows
     int nslot = 0, nq = 0;
     int32_t *dcol = nullptr, *dcontrib = nullptr;
     std::vector<int32_t> hcol;
@@ -437,6 +440,7 @@ void free_mesh(plfx_ctx *c)
     dfree(c->dcls);
     dfree(c->dconn);
     dfree(c->dcls_id);
+    dfree(c->dcls_all);
     dfree(c->dcol);
     dfree(c->dcontrib);
     dfree(c->dval);
@@ -523,15 +527,24 @@ int plain_spmv(plfx_ctx *c, const double *in, double *out)
                        c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)in, nullptr, nullptr,
                        (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
     HIPCHK(c, hipGetLastError());
-    if (c->comm) {
-        if (g_rccl.AllReduce(out, out, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
-            return fail(c, PLFX_ERR_HIP, "ncclAllReduce failed");
-    }
+    return 0;  // the matrix is replicated on every rank: no collective here
+}
+
+// Sharded runs: make the stiffness generators of the whole mesh consistent on every rank after a sweep
+// changed the owned ones (own part + exact zeros elsewhere, summed by one all-reduce).
+int sync_M(plfx_ctx *c)
+{
+    if (!c->comm || !c->sharded) return 0;
+    hipLaunchKernelGGL(k_zero_foreign_M, dim3(grid_for((size_t)6 * c->nel_total)), dim3(BLOCK), 0, c->stream,
+                       c->nel_total, c->e0, c->e0 + c->nel, c->Mel);
+    HIPCHK(c, hipGetLastError());
+    if (g_rccl.AllReduce(c->Mel, c->Mel, (size_t)6 * c->nel_total, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
+        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(M) failed");
     return 0;
 }
 
 
-bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2 && !c->comm; }
+bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2; }
 
 // coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
 int mg_assemble(plfx_ctx *c)
@@ -973,17 +986,30 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     const int nown = c->nel;
     std::vector<int32_t> hcontrib;
     int nslot = 0, nq = 0;
-    if (!build_pattern(nnode, conn, el_begin, el_end, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
-        return fail(c, PLFX_ERR_ARG, "no owned elements");
+    // The matrix (and its multigrid hierarchy) is assembled for the WHOLE mesh on every rank; a sharded
+    // rank owns the material state of its x-strip only and the rows [own_n0, own_n1) of the CG SpMV.
+    c->sharded = (nown != nel);
+    if (!build_pattern(nnode, conn, 0, nel, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
+        return fail(c, PLFX_ERR_ARG, "empty mesh");
+    {
+        int lo = nnode, nxt = nnode;
+        for (int e = el_begin; e < el_end; e++)
+            for (int a = 0; a < 4; a++) lo = std::min(lo, (int)conn[4 * (size_t)e + a]);
+        for (int e = el_end; e < nel; e++)
+            for (int a = 0; a < 4; a++) nxt = std::min(nxt, (int)conn[4 * (size_t)e + a]);
+        c->own_n0 = (el_begin == 0) ? 0 : lo;   // the node column shared with the left neighbour is ours,
+        c->own_n1 = (el_end == nel) ? nnode : nxt;  // the one shared with the right neighbour is theirs
+    }
     c->nslot = nslot;
     c->nq = nq;
-    if ((size_t)nown * 16 > 0x7fffffffULL) return fail(c, PLFX_ERR_UNSUPPORTED, "too many elements for int32 gather codes");
+    if ((size_t)nel * 16 > 0x7fffffffULL) return fail(c, PLFX_ERR_UNSUPPORTED, "too many elements for int32 gather codes");
 
     int rc;
 #define ALLOC(ptr, n) if ((rc = dalloc(c, &(ptr), (size_t)(n)))) return rc
     ALLOC(c->dcls, c->ncls);
     ALLOC(c->dconn, (size_t)4 * nel);
     ALLOC(c->dcls_id, nown);
+    ALLOC(c->dcls_all, nel);
     ALLOC(c->dcol, (size_t)nslot * nnode);
     ALLOC(c->dcontrib, (size_t)nslot * nq * nnode);
     ALLOC(c->dval, (size_t)nslot * 4 * nnode);
@@ -993,7 +1019,7 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     ALLOC(c->res_sig, (size_t)6 * nown);
     ALLOC(c->res_depl, (size_t)6 * nown);
     ALLOC(c->elstiff, (size_t)21 * nown);
-    ALLOC(c->Mel, (size_t)6 * nown);
+    ALLOC(c->Mel, (size_t)6 * nel);  // whole mesh (global element ids)
     ALLOC(c->fyn, nown);
     ALLOC(c->scf_hh, nown);
     ALLOC(c->max_steps, nown);
@@ -1020,6 +1046,7 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     HIPCHK(c, hipMemcpyAsync(c->dcls, c->hcls.data(), sizeof(ClassDev) * c->ncls, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dconn, conn, (size_t)16 * nel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dcls_id, c->hcls_id.data() + el_begin, (size_t)4 * nown, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dcls_all, c->hcls_id.data(), (size_t)4 * nel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dcol, c->hcol.data(), c->hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dcontrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1056,9 +1083,8 @@ int plfx_get_kel(plfx_ctx *c, int e, double *Kel)
     if (!c || !c->Mel) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (e < c->e0 || e >= c->e0 + c->nel || !Kel) return fail(c, PLFX_ERR_ARG, "element not owned");
     double M[6];
-    const int le = e - c->e0;
     for (int k = 0; k < 6; k++)
-        HIPCHK(c, hipMemcpy(&M[k], c->Mel + (size_t)k * c->nel + le, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&M[k], c->Mel + (size_t)k * c->nel_total + e, 8, hipMemcpyDeviceToHost));
     const ClassDev &k = c->hcls[c->hcls_id[e]];
     for (int a = 0; a < 4; a++)
         for (int b = 0; b < 4; b++) {
@@ -1094,7 +1120,6 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         dfree(L.t); dfree(L.res); dfree(L.ainv);
     }
     c->mg.clear();
-    if (c->comm || c->nel != c->nel_total) return PLFX_OK;  // sharded runs use Jacobi-PCG
     for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly needs one element shape
         if (c->hlxy[2 * (size_t)e] != c->hlxy[0] || c->hlxy[2 * (size_t)e + 1] != c->hlxy[1]) return PLFX_OK;
     std::vector<std::pair<int, int>> dims;
@@ -1128,6 +1153,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             L.diag = c->diag;
             L.dinv = c->dinv;
             L.Mel = c->Mel;
+            L.nel = c->nel_total;
             L.x = c->z;
             L.b = c->r;
             continue;
@@ -1222,7 +1248,10 @@ int plfx_state_reset(plfx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->f, 0, 8 * nd, c->stream));
     HIPCHK(c, hipMemsetAsync(c->du, 0, 8 * nd, c->stream));
     hipLaunchKernelGGL(k_init_tangent, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
-                       c->dmat, c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel);
+                       c->dmat, c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel + c->e0, c->nel_total);
+    if (c->sharded)
+        hipLaunchKernelGGL(k_init_M_all, dim3((c->nel_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
+                           c->dmat, c->dcls, c->nel_total, c->dcls_all, c->Mel);
     HIPCHK(c, hipGetLastError());
     c->assembled = false;
     return PLFX_OK;
@@ -1310,8 +1339,10 @@ int plfx_state_set(plfx_ctx *c, int which, const double *in)
     HIPCHK(c, hipMemcpyAsync(p, t.data(), 8 * comps * n, hipMemcpyHostToDevice, c->stream));
     if (which == 5) {
         hipLaunchKernelGGL(k_refresh_M, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
-                           c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel);
+                           c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel + c->e0, c->nel_total);
         HIPCHK(c, hipGetLastError());
+        int rcm = sync_M(c);
+        if (rcm) return rcm;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PLFX_OK;
@@ -1343,14 +1374,10 @@ int plfx_assemble(plfx_ctx *c)
     EvPair *ev;
     tim_begin(c, 3, &ev);
     hipLaunchKernelGGL(k_assemble, dim3(grid_for(c->nnode), c->nslot), dim3(BLOCK), 0, c->stream,
-                       c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel, c->dcontrib, c->dcls_id,
+                       c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel_total, c->dcontrib, c->dcls_all,
                        c->Mel, c->dcol, c->dval, c->diag);
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
-    if (c->comm) {  // Jacobi needs the full diagonal
-        if (g_rccl.AllReduce(c->diag, c->diag, (size_t)c->ndof, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
-            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(diag) failed");
-    }
     if (mg_active(c)) {
         int rc = mg_assemble(c);
         if (rc) return rc;
@@ -1480,14 +1507,15 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             double *pold = c->p[prev], *pnew = c->p[cur];
             EvPair *ev;
             tim_begin(c, 1, &ev);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<1>), dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->n_begin, c->n_end,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<1>), dim3(gn), dim3(BLOCK), 0, c->stream, nn,
+                               multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
                                c->nslot, c->dcol, c->dval, (const double2 *)pold, (const double2 *)c->z,
                                (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn,
                                P_pq, c->sc, it);
             tim_end(c, ev);
             if (multi) {
-                hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->n_begin,
-                                   c->n_end, (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew,
+                hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->own_n0,
+                                   c->own_n1, (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew,
                                    (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, c->sc);
                 if (g_rccl.AllReduce(c->q, c->q, nd, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
                     return fail(c, PLFX_ERR_HIP, "ncclAllReduce(q) failed");
@@ -1550,8 +1578,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     EvPair *ev;
     tim_begin(c, 0, &ev);
 #define SWEEP_ARGS(lds) c->dmat, c->nmat, c->dcls, c->ncls, lds, c->nel, c->e0, c->dconn, c->dcls_id,          \
-                        (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel, c->res_sig, c->res_depl, \
-                        c->fyn, c->max_steps, nit, c->flags, c->heavy_list
+                        (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total,   \
+                        c->res_sig, c->res_depl, c->fyn, c->max_steps, nit, c->flags, c->heavy_list
     // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
     int first = 1;
     if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3)) {
@@ -1590,6 +1618,10 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #undef SWEEP_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
+    {
+        int rcm = sync_M(c);
+        if (rcm) return rcm;
+    }
     int h[4];
     HIPCHK(c, hipMemcpyAsync(h, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -299,9 +299,9 @@ __device__ __forceinline__ void tangent_to_M(const double *D, double kappa, doub
 __device__ __forceinline__ void sweep_epilogue(const ClassDev &c, const MatDev &m, int e, int nel,
                                                const double *s, const double *ep, const double *depl,
                                                double *Ct, double fy, int ns, double *elstiff,
-                                               double *Mel, double *res_sig, double *res_depl,
-                                               double *fyn, int32_t *max_steps, int nit, int &changed,
-                                               int &nconv)
+                                               double *Mel, int mel_stride, double *res_sig,
+                                               double *res_depl, double *fyn, int32_t *max_steps, int nit,
+                                               int &changed, int &nconv)
 {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -331,7 +331,7 @@ __device__ __forceinline__ void sweep_epilogue(const ClassDev &c, const MatDev &
         double M[6];
         tangent_to_M(Ct, c.kappa, M);
 #pragma unroll
-        for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+        for (int k = 0; k < 6; k++) Mel[(size_t)k * mel_stride + e] = M[k];
         changed = 1;
     }
     if (ns > max_steps[e]) max_steps[e] = ns;  // stat_nlin['max_steps'] (model.py:1356)
@@ -364,8 +364,8 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
-              double *Mel, double *res_sig, double *res_depl, double *fyn, int32_t *max_steps, int nit,
-              int *flags, int32_t *list, int first_kind)
+              double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
+              int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
@@ -401,8 +401,8 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
                 if (st == 2)
                     heavy = true;
                 else
-                    sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, res_sig, res_depl,
-                                   fyn, max_steps, nit, changed, nconv);
+                    sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, mel_stride, res_sig,
+                                   res_depl, fyn, max_steps, nit, changed, nconv);
             }
         }
         // compact the elements that need the 50-sub-step corrector: one atomic per wave
@@ -427,8 +427,8 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
-              double *Mel, double *res_sig, double *res_depl, double *fyn, int32_t *max_steps, int nit,
-              int *flags, const int32_t *__restrict__ list)
+              double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
+              int32_t *max_steps, int nit, int *flags, const int32_t *__restrict__ list)
 {
     const int count = flags[2];
     if (count == 0) return;
@@ -459,8 +459,8 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
         response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);  // recompute the prelude
         response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
-        sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, res_sig, res_depl, fyn,
-                       max_steps, nit, changed, nconv);
+        sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
+                       res_depl, fyn, max_steps, nit, changed, nconv);
     }
     if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
     if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
@@ -469,7 +469,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
 // elstiff = CV, M from CV for all owned elements (model.py:1219-1221)
 __global__ void __launch_bounds__(BLOCK)
 k_init_tangent(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t *cls,
-               double *elstiff, double *Mel)
+               double *elstiff, double *Mel, int mel_stride)
 {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= nel) return;
@@ -484,12 +484,39 @@ k_init_tangent(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t 
     double M[6];
     tangent_to_M(D, c.kappa, M);
 #pragma unroll
+    for (int k = 0; k < 6; k++) Mel[(size_t)k * mel_stride + e] = M[k];
+}
+
+// M from CV for ALL elements of the mesh (sharded runs keep the stiffness generators of the whole
+// mesh on every rank: the matrix hierarchy is replicated, only the sweep is sharded)
+__global__ void __launch_bounds__(BLOCK)
+k_init_M_all(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t *cls, double *Mel)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= nel) return;
+    const ClassDev &c = gcls[cls[e]];
+    double M[6];
+    tangent_to_M(gmat[c.mat].CV, c.kappa, M);
+#pragma unroll
     for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+}
+
+// zero the stiffness generators of the elements this rank does not own (before the all-reduce that
+// makes M consistent on every rank: x + 0 + ... + 0 = x exactly)
+__global__ void __launch_bounds__(BLOCK)
+k_zero_foreign_M(int nel_total, int e0, int e1, double *Mel)
+{
+    const size_t n = (size_t)6 * nel_total;
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const int e = (int)(i % nel_total);
+        if (e < e0 || e >= e1) Mel[i] = 0.;
+    }
 }
 
 // recompute M from elstiff (after plfx_state_set of the tangent)
 __global__ void __launch_bounds__(BLOCK)
-k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *elstiff, double *Mel)
+k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *elstiff, double *Mel,
+            int mel_stride)
 {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= nel) return;
@@ -498,7 +525,7 @@ k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *els
     for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
     tangent_to_M(D, gcls[cls[e]].kappa, M);
 #pragma unroll
-    for (int k = 0; k < 6; k++) Mel[(size_t)k * nel + e] = M[k];
+    for (int k = 0; k < 6; k++) Mel[(size_t)k * mel_stride + e] = M[k];
 }
 
 // ---------------------------------------------------------------------------------------------
