@@ -87,7 +87,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--mesh', type=int, default=1024)
-    ap.add_argument('--cpu-mesh', type=int, default=160)
+    ap.add_argument('--cpu-mesh', type=int, default=224)
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 
@@ -101,8 +101,9 @@ def main():
     import pylabfea_amd as FE
     from pylabfea_amd import _lib
 
+    force_dist = os.environ.get('PLFX_FORCE_DIST') == '1'  # exercise the sharded path with a single rank
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -110,7 +111,7 @@ def main():
     K, W, n = args.steps, args.warmup, args.mesh
     mat = hill_material(FE)
     fe = tension_model(FE, mat, n, 0.005, device=local)
-    if world > 1:
+    if dist is not None:
         uid = [None]
         if rank == 0:
             uid[0] = _lib.Context(local).comm_unique_id()
@@ -206,7 +207,7 @@ def main():
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items()},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 2)), 0)
+        out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 3)), 0)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
