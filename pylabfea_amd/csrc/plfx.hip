@@ -143,6 +143,7 @@ struct plfx_ctx {
     size_t tmp_cap = 0;
     bool assembled = false, bc_set = false;
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
+    int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int grid_nodes = 0, grid_el = 0;
 
     // geometric multigrid preconditioner (structured grids, plfx_set_grid)
@@ -1497,6 +1498,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     HIPCHK(c, hipGetLastError());
 
     const int chunk = mg ? 1 : 50;  // a V-cycle is ~1 ms: poll the convergence flag every iteration
+    const int maxit_all = maxit;
+    if (mg) maxit = std::min(maxit, 300);  // multigrid-PCG converges in tens of iterations or not at all
     int it = 0, done = 0;
     CgScalars hs;
     while (it < maxit && !done) {
@@ -1548,6 +1551,21 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         HIPCHK(c, hipStreamSynchronize(c->stream));
         done = hs.done;
     }
+    if (mg && done != 1) {
+        // breakdown (indefinite tangent, preconditioner not SPD) or stagnation: fall back to Jacobi-PCG,
+        // warm-started from the last iterate
+        hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
+        HIPCHK(c, hipGetLastError());
+        const int saved = c->precond;
+        c->precond = 0;
+        c->mg_fallbacks++;
+        int it2 = 0;
+        const int rc2 = plfx_solve(c, rtol, maxit_all, 1, &it2, relres);
+        c->precond = saved;
+        if (iters) *iters = it + it2;
+        return rc2;
+    }
+    if (done == 2) done = 0;  // Jacobi-PCG breakdown: report as not converged
     if (!done) {
         // the convergence test of iteration `it` has not run yet: evaluate the last residual
         hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[(it - 1) & 1], gn, c->sc);
@@ -1556,7 +1574,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     }
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
     HIPCHK(c, hipGetLastError());
-    if (iters) *iters = done ? hs.iters : it;
+    if (iters) *iters = (done && hs.iters >= 0) ? hs.iters : it;
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
         c->tim.noop[1] += it - hs.iters;
         c->tim.noop[2] += it - hs.iters;

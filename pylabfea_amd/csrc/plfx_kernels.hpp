@@ -599,9 +599,9 @@ k_spmv(int nnode, int n_begin, int n_end, int nslot, const int32_t *col, const d
     if (MODE == 1) {
         if (sc->done) return;
         const double rr = sum_partials(part_rr, npart_prev, sh);
-        if (rr <= sc->thresh2) {  // all blocks take the same decision from the same partials
+        if (rr <= sc->thresh2 || !(rr == rr)) {  // all blocks take the same decision from the same partials
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                sc->done = 1;
+                sc->done = (rr == rr) ? 1 : 2;   // 2 = breakdown (NaN residual)
                 sc->iters = it;
                 sc->rr_final = rr;
             }
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_cg_update(int nnode, const double2 *p, const double2 *q, const double2 *dinv, double2 *x,
             double2 *r, double2 *z, const double *part_pq, int npart_pq, const double *part_rz,
             const double *part_rr_prev, int npart_prev, double *part_rz_out, double *part_rr_out,
-            const CgScalars *sc)
+            CgScalars *sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
@@ -703,6 +703,10 @@ k_cg_update(int nnode, const double2 *p, const double2 *q, const double2 *dinv, 
     const double pq = sum_partials(part_pq, npart_pq, sh);
     const double rz = sum_partials(part_rz, npart_prev, sh);
     (void)part_rr_prev;
+    if (!(pq > 0.)) {  // p^T K p <= 0: operator or preconditioner not positive definite -> stop, keep x
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 2;
+        return;
+    }
     const double alpha = rz / pq;
     double a_rz = 0., a_rr = 0.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {

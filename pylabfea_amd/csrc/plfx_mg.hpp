@@ -519,12 +519,16 @@ __global__ void __launch_bounds__(BLOCK)
 k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q,
                const double2 *__restrict__ dinv, double2 *x, double2 *r, const double *part_pq,
                int npart_pq, const double *part_rz, int npart_prev, double *part_rr_out,
-               const CgScalars *sc)
+               CgScalars *sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
     const double pq = sum_partials(part_pq, npart_pq, sh);
     const double rz = sum_partials(part_rz, npart_prev, sh);
+    if (!(pq > 0.)) {  // breakdown: stop and keep the last iterate (the host falls back to Jacobi-PCG)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 2;
+        return;
+    }
     const double alpha = rz / pq;
     double a_rr = 0.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
