@@ -1,0 +1,130 @@
+"""Edge cases and error behaviour of the C-ABI on the GPU (empty batches, bad arguments, call order,
+degenerate inputs), and of the façade (shapes, un-meshed model, unsupported options)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from pylabfea_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def j2_record(kind=None):
+    from pylabfea_amd import _lib
+    CV = np.zeros((6, 6))
+    CV[:3, :3] = 115384.6153846154
+    CV[[0, 1, 2], [0, 1, 2]] = 269230.7692307692
+    CV[[3, 4, 5], [3, 4, 5]] = 76923.07692307692
+    return _lib.pack_material(_lib.HILL6 if kind is None else kind, CV, E=200.e3, nu=0.3, sy=150., khard=500.), CV
+
+
+def test_call_order_and_bad_arguments(ctx):
+    from pylabfea_amd import _lib
+    with pytest.raises(_lib.PlfxError):           # batch call before set_materials
+        ctx.seq(0, np.zeros((1, 6)))
+    rec, CV = j2_record()
+    ctx.set_materials([rec])
+    with pytest.raises(_lib.PlfxError):           # material index out of range
+        ctx.seq(3, np.zeros((1, 6)))
+    with pytest.raises(_lib.PlfxError):           # mat_id out of range
+        ctx.response(np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 6)), mat_id=[0, 5])
+    with pytest.raises(_lib.PlfxError):           # assemble before set_mesh
+        ctx.assemble()
+    bad = _lib.pack_material(99, CV)
+    with pytest.raises(_lib.PlfxError):           # unknown kind
+        ctx.set_materials([bad])
+    asym = np.array(CV)
+    asym[0, 1] += 1.
+    with pytest.raises(_lib.PlfxError):           # non-symmetric CV
+        ctx.set_materials([_lib.pack_material(_lib.HILL6, asym, E=1., nu=0.3, sy=1.)])
+    ctx.set_materials([rec])
+    conn = np.array([[0, 1, 2, 7]])               # node id out of range
+    with pytest.raises(_lib.PlfxError):
+        ctx.set_mesh(conn, [0], [[1., 1.]], 4, 1., False)
+    conn = np.array([[0, 1, 2, 3]])
+    ctx.set_mesh(conn, [0], [[1., 1.]], 4, 1., False)
+    with pytest.raises(_lib.PlfxError):           # solve before apply_bc
+        ctx.solve()
+    with pytest.raises(_lib.PlfxError):           # grid that does not match the mesh
+        ctx.set_grid(2, 2)
+    ctx.assemble()
+    with pytest.raises(_lib.PlfxError):           # prescribed DOF out of range
+        ctx.apply_bc([99], [0.], [0.])
+
+
+def test_empty_and_degenerate_batches(ctx):
+    rec, CV = j2_record()
+    ctx.set_materials([rec])
+    assert ctx.seq(0, np.zeros((0, 6))).shape == (0,)
+    fy, so, dp, ct, ns = ctx.response(np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)))
+    assert fy.shape == (0,) and ct.shape == (0, 36)
+    # zero stress, zero increment: elastic step, tangent = CV, nothing changes
+    fy, so, dp, ct, ns = ctx.response(np.zeros((3, 6)), np.zeros((3, 6)), np.zeros((3, 6)))
+    assert np.all(so == 0.) and np.all(dp == 0.) and np.all(ns == 0)
+    assert np.allclose(ct[0].reshape(6, 6), CV) and np.allclose(fy, -150.)
+    # huge increments from the stress-free state (5 % strain in one step): finite, and equal to the oracle
+    from oracle import oracle as O
+    deps = np.zeros((4, 6))
+    deps[0, 1] = 0.05
+    deps[1, 5] = 0.08
+    deps[2, :3] = [0.05, -0.02, 0.01]
+    deps[3, [0, 5]] = [1e-9, -1e-9]           # tiny
+    fy, so, dp, ct, ns = ctx.response(np.zeros((4, 6)), np.zeros((4, 6)), deps)
+    om = O.Material(kind=O.HILL6, E=200.e3, nu=0.3, sy=150., khard=500.)
+    fy2, so2, dp2, ct2, ns2 = O.response(om, CV, np.zeros((4, 6)), np.zeros((4, 6)), deps)
+    assert np.array_equal(ns, ns2) and np.all(np.isfinite(so)) and np.all(np.isfinite(ct))
+    assert np.max(np.abs(so - so2)) < 1e-9 * 150. and np.max(np.abs(dp - dp2)) < 1e-12
+    assert np.max(np.abs(ct - ct2)) < 1e-7 * CV[0, 0]
+
+
+def test_single_element_model_and_force_bc():
+    """1x1 mesh (no multigrid hierarchy -> Jacobi-PCG), force-controlled loading on the right edge."""
+    import pylabfea_amd as FE
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    fe = FE.Model(dim=2, planestress=True)
+    fe.geom([2.], LY=2.)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(100., 'force')      # total force 100 on an edge of area 2 -> sig_xx = 50
+    fe.bctop(0., 'force')
+    fe.mesh(NX=1, NY=1)
+    fe.solve()
+    assert fe._engine.precond_info()[0] == 0
+    assert abs(fe.element[0].sig[0] - 50.) < 1e-9 and abs(fe.element[0].sig[1]) < 1e-9
+    assert abs(fe.element[0].eps[0] - 50. / 200.e3) < 1e-14
+    assert abs(fe.glob['sbc1'] - 50.) < 1e-9
+
+
+def test_facade_errors():
+    import pylabfea_amd as FE
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    with pytest.raises(AttributeError):
+        m.response(np.zeros(6), np.zeros(6), np.zeros(6), m.CV)     # elastic material has no flow rule
+    m.plasticity(sy=100., sdim=6)
+    with pytest.raises(ValueError):
+        m.response(np.zeros((2, 6)), np.zeros(6), np.zeros(6), m.CV)
+    with pytest.raises(ValueError):
+        m.calc_fgrad(np.zeros(6), epl=np.zeros(3))
+    with pytest.raises(TypeError):
+        m.calc_seq(np.zeros(5))
+    with pytest.raises(NotImplementedError):
+        m.plasticity(sy=100., lhs=[0.1, 0.1, 0.1])
+    with pytest.raises(AttributeError):
+        m.ML_full_yf(np.ones(6))
+    fe = FE.Model(dim=2)
+    fe.geom([1.], LY=1.)
+    fe.assign([m])
+    with pytest.raises(NotImplementedError):
+        fe.mesh(NX=2, NY=2, SF=2)
+    with pytest.raises(NotImplementedError):
+        FE.Model(dim=1)
