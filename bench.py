@@ -186,7 +186,7 @@ def main():
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
                            'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
                            'cg_update': 'k_cg_update',
-                           'mg_smooth': 'k_mg_smooth / k_mg_smooth2_zero (fine-level damped-Jacobi sweep of the '
+                           'mg_smooth': 'k_mg_smooth<1> / k_mg_smooth2_zero<1> (fine-level damped-Jacobi sweep of the '
                                         'multigrid V-cycle: block-ELL SpMV + update)'}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,

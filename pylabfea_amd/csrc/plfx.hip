@@ -588,9 +588,14 @@ int mg_vcycle(plfx_ctx *c)
     const int nl = (int)c->mg.size();
     const double om = c->mg_omega;
     auto smooth = [&](plfx_ctx::MgLevel &L, const double *xin, double *xout, int first) {
-        hipLaunchKernelGGL(k_mg_smooth, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col, L.val,
-                           (const double2 *)L.dinv, (const double2 *)L.b, (const double2 *)xin, (double2 *)xout,
-                           om, first, c->sc);
+        if (&L == &c->mg[0])
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
+                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                               (const double2 *)xin, (double2 *)xout, om, first, c->sc);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
+                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                               (const double2 *)xin, (double2 *)xout, om, first, c->sc);
     };
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;  // levels >= lt run inside one workgroup
     for (int l = 0; l < lt; l++) {  // down
@@ -601,8 +606,14 @@ int mg_vcycle(plfx_ctx *c)
         EvPair *ev = nullptr;
         if (nu == 2) {  // both sweeps in one pass over the matrix
             if (l == 0) tim_begin(c, 5, &ev);
-            hipLaunchKernelGGL(k_mg_smooth2_zero, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col,
-                               L.val, (const double2 *)L.dinv, (const double2 *)L.b, (double2 *)L.x, om, c->sc);
+            if (l == 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth2_zero<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream,
+                                   L.nnode, L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                                   (double2 *)L.x, om, c->sc);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth2_zero<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream,
+                                   L.nnode, L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                                   (double2 *)L.x, om, c->sc);
             if (l == 0) tim_end(c, ev);
         } else {
             double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
@@ -612,9 +623,14 @@ int mg_vcycle(plfx_ctx *c)
                 dst = (dst == L.x) ? L.t : L.x;
             }
         }
-        hipLaunchKernelGGL(k_mg_residual, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode, L.nslot, L.col, L.val,
-                           (const double2 *)L.dinv, (const double2 *)L.b, (const double2 *)L.x, (double2 *)L.res,
-                           c->sc);
+        if (l == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_residual<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
+                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                               (const double2 *)L.x, (double2 *)L.res, c->sc);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_residual<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
+                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
+                               (const double2 *)L.x, (double2 *)L.res, c->sc);
         hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
                            L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
     }
@@ -1486,7 +1502,15 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                        (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
     hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
     const bool mg = mg_active(c);
-    if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init
+    CgScalars hs;
+    int done = 0;
+    if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
+        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[1], gn, c->sc, 0);
+        HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        done = hs.done;
+    }
+    if (mg && !done) {
         rc = mg_vcycle(c);
         if (rc) return rc;
         hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
@@ -1497,11 +1521,10 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
     HIPCHK(c, hipGetLastError());
 
-    const int chunk = mg ? 1 : 50;  // a V-cycle is ~1 ms: poll the convergence flag every iteration
+    const int chunk = mg ? 1 : 50;  // multigrid: the flag is polled inside the iteration, before the V-cycle
     const int maxit_all = maxit;
     if (mg) maxit = std::min(maxit, 300);  // multigrid-PCG converges in tens of iterations or not at all
-    int it = 0, done = 0;
-    CgScalars hs;
+    int it = 0;
     while (it < maxit && !done) {
         const int stop = std::min(maxit, it + chunk);
         for (; it < stop; it++) {
@@ -1531,6 +1554,14 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                                    (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
                                    (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc);
                 tim_end(c, ev);
+                // stop here if this update converged: the V-cycle below would only prepare the next iteration
+                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[cur], gn, c->sc, it + 1);
+                HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (hs.done) {
+                    it++;
+                    break;
+                }
                 tim_begin(c, 4, &ev);
                 rc = mg_vcycle(c);
                 tim_end(c, ev);
@@ -1547,8 +1578,10 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             }
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!mg) {
+            HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         done = hs.done;
     }
     if (mg && done != 1) {
@@ -1578,8 +1611,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
         c->tim.noop[1] += it - hs.iters;
         c->tim.noop[2] += it - hs.iters;
-        c->tim.noop[4] += it - hs.iters;
-        c->tim.noop[5] += 3 * (it - hs.iters);
+
     }
     if (relres) {
         const double bb = hs.thresh2 / (rtol * rtol);

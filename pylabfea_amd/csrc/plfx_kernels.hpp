@@ -777,6 +777,20 @@ __global__ void k_cg_setup(const double *part_bb, int npart, double rtol, CgScal
     }
 }
 
+// convergence test on the residual partials an update kernel just wrote (one block): lets the host stop
+// BEFORE it launches the next preconditioner application (a V-cycle is the most expensive part of an iteration)
+__global__ void k_cg_check(const double *part_rr, int npart, CgScalars *sc, int it_done)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    const double rr = sum_partials(part_rr, npart, sh);
+    if (threadIdx.x == 0 && (rr <= sc->thresh2 || !(rr == rr))) {
+        sc->done = (rr == rr) ? 1 : 2;
+        sc->iters = it_done;
+        sc->rr_final = rr;
+    }
+}
+
 // final rr for reporting when the iteration limit was hit
 __global__ void k_cg_final(const double *part_rr, int npart, CgScalars *sc)
 {

@@ -26,10 +26,10 @@ def main(d, out):
         dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     lines.append('')
     lines.append('== fine-level / productive launches only (coarse-level and post-convergence no-op launches filtered by duration) ==')
-    for k in ('k_mg_smooth', 'k_mg_smooth2_zero', 'k_mg_residual', 'k_spmv<1>', 'k_cg_update', 'k_cg_update_mg',
+    for k in ('k_mg_smooth<1>', 'k_mg_smooth2_zero<1>', 'k_mg_residual<1>', 'k_spmv<1>', 'k_cg_update', 'k_cg_update_mg',
               'k_sweep_light<1>', 'k_sweep_heavy<1>', 'k_assemble', 'k_spmv<0>', 'k_mg_tail', 'k_mg_restrict',
               'k_mg_prolong_add'):
-        v = [x for x in dur.get(k, []) if x > (60. if k.startswith('k_mg_s') or k == 'k_mg_residual' else 20.)]
+        v = [x for x in dur.get(k, []) if x > 20.]
         if v:
             v.sort()
             lines.append('%-28s n=%6d  avg %9.2f us  median %9.2f us  min %9.2f  max %9.2f' %
@@ -45,9 +45,9 @@ def main(d, out):
             continue
         lines.append('')
         lines.append('== rocprofv3 --pmc %s (raw counter, KiB per dispatch; productive dispatches only) ==' % cname)
-        for k in ('k_mg_smooth', 'k_mg_smooth2_zero', 'k_mg_residual', 'k_spmv<1>', 'k_cg_update_mg', 'k_sweep_light<1>',
+        for k in ('k_mg_smooth<1>', 'k_mg_smooth2_zero<1>', 'k_mg_residual<1>', 'k_spmv<1>', 'k_cg_update_mg', 'k_sweep_light<1>',
                   'k_assemble', 'k_spmv<0>', 'k_axpy_uf', 'k_update_state'):
-            thr = 60000 if (k.startswith('k_mg_s') or k == 'k_mg_residual') else 20000
+            thr = 20000
             v = [x[0] for x in acc.get(k, []) if x[1] > thr]
             if v:
                 lines.append('%-28s n=%6d  avg %14.1f KiB = %10.2f MB' % (k, len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6))
