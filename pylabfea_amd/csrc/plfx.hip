@@ -142,6 +142,12 @@ struct plfx_ctx {
     double *val_tmp = nullptr;
     size_t tmp_cap = 0;
     bool assembled = false, bc_set = false;
+    std::vector<int32_t> bc_idx;  // prescribed DOFs of the last apply_bc (the device mask is reused when unchanged)
+    bool bc_valid = false;
+    double *stage = nullptr;      // pinned host staging buffer
+    size_t stage_cap = 0;
+    int32_t *bc_idx_dev = nullptr;  // device copy of bc_idx (idx_tmp is shared with plfx_gather)
+    size_t bc_idx_cap = 0;
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int grid_nodes = 0, grid_el = 0;
@@ -496,6 +502,8 @@ void free_mesh(plfx_ctx *c)
     c->mg_tail = -1;
     c->gx = c->gy = 0;
     c->assembled = c->bc_set = false;
+    c->bc_valid = false;
+    c->bc_idx.clear();
 }
 
 void free_materials(plfx_ctx *c)
@@ -723,6 +731,8 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->small);
     dfree(c->idx_tmp);
     dfree(c->val_tmp);
+    if (c->stage) hipHostFree(c->stage);
+    dfree(c->bc_idx_dev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1448,21 +1458,39 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     const size_t nd = c->ndof;
     int rc = ensure_tmp(c, std::max(n, 1));
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->is_presc, 0, 8 * nd, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->dup, 0, 8 * nd, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wv, 0, 8 * nd, c->stream));
+    // The set of prescribed DOFs rarely changes between calls (same BC flags, new values): keep the mask
+    // and only overwrite the values then.  Values travel through one pinned staging buffer = one copy.
+    const bool same_set = c->bc_valid && (int)c->bc_idx.size() == n &&
+                          (n == 0 || memcmp(c->bc_idx.data(), idx, (size_t)4 * n) == 0);
+    if (!same_set) {
+        HIPCHK(c, hipMemsetAsync(c->is_presc, 0, 8 * nd, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->dup, 0, 8 * nd, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->wv, 0, 8 * nd, c->stream));
+        c->bc_idx.assign(idx, idx + n);
+        if ((size_t)n > c->bc_idx_cap) {
+            dfree(c->bc_idx_dev);
+            if ((rc = dalloc(c, &c->bc_idx_dev, (size_t)n))) return rc;
+            c->bc_idx_cap = n;
+        }
+        if (n > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->bc_idx_dev, c->bc_idx.data(), (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
+        }
+        c->bc_valid = true;
+    }
     if (n > 0) {
-        std::vector<double> ones(n, 1.);
-        HIPCHK(c, hipMemcpyAsync(c->idx_tmp, idx, (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->val_tmp, du_presc, (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->val_tmp + n, w, (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->val_tmp + 2 * (size_t)n, ones.data(), (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
-        const dim3 g((n + BLOCK - 1) / BLOCK);
-        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp, c->dup);
-        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp + n, c->wv);
-        hipLaunchKernelGGL(k_scatter, g, dim3(BLOCK), 0, c->stream, n, c->idx_tmp, c->val_tmp + 2 * (size_t)n, c->is_presc);
+        if ((size_t)n > c->stage_cap) {
+            if (c->stage) hipHostFree(c->stage);
+            c->stage = nullptr;
+            HIPCHK(c, hipHostMalloc((void **)&c->stage, (size_t)16 * n));
+            c->stage_cap = n;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the previous contents of the staging buffer are consumed
+        memcpy(c->stage, du_presc, (size_t)8 * n);
+        memcpy(c->stage + n, w, (size_t)8 * n);
+        HIPCHK(c, hipMemcpyAsync(c->val_tmp, c->stage, (size_t)16 * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scatter_bc, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->bc_idx_dev,
+                           c->val_tmp, c->val_tmp + n, c->dup, c->wv, c->is_presc, same_set ? 0 : 1);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // `ones` goes out of scope
     }
     if (fext) HIPCHK(c, hipMemcpyAsync(c->fext, fext, 8 * nd, hipMemcpyHostToDevice, c->stream));
     rc = plain_spmv(c, c->wv, c->q);  // K w

@@ -811,6 +811,18 @@ __global__ void __launch_bounds__(BLOCK) k_scatter(int n, const int32_t *idx, co
     if (k < n) y[idx[k]] = v[k];
 }
 
+// y[idx[k]] = a[k], z[idx[k]] = b[k], (flag ? m[idx[k]] = 1)  : prescribed-DOF data of apply_bc in one launch
+__global__ void __launch_bounds__(BLOCK)
+k_scatter_bc(int n, const int32_t *idx, const double *a, const double *b, double *y, double *z, double *m, int flag)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    y[i] = a[k];
+    z[i] = b[k];
+    if (flag) m[i] = 1.;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, const double *y, double *v)
 {
     const int k = blockIdx.x * BLOCK + threadIdx.x;

@@ -179,6 +179,7 @@ class Model(object):
         self._engine = None
         self._cache = {}
         self._bnd_idx = None
+        self._bc_struct = None
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -359,6 +360,7 @@ class Model(object):
         self._NX, self._NY = NX, NY
         self.element = _ElementList(self, self.Nel)
         self._bnd_idx = None
+        self._bc_struct = None
         self._drop_engine()
 
     # ------------------------------------------------------------------ engine plumbing
@@ -496,16 +498,23 @@ class Model(object):
                     f_idx.append(2 * nodes + k)
                     f_val.append(np.full(len(nodes), float(dbcn[k])))
         if idx_l:
-            idx = np.concatenate(idx_l)
             val = np.concatenate(val_l)
-            presc, first_pos, inv = np.unique(idx, return_index=True, return_inverse=True)
+            # the index structure only depends on the BC flags: computed once, reused for every solve
+            key = (tuple(self.ubcleft), tuple(self.ubcbot), tuple(self.ubcright), tuple(self.ubctop),
+                   tuple(self.ubcn), None if self.noset is None else tuple(self.noset), len(val))
+            st = self._bc_struct
+            if st is None or st[0] != key:
+                idx = np.concatenate(idx_l)
+                presc, first_pos, inv = np.unique(idx, return_index=True, return_inverse=True)
+                st = self._bc_struct = (key, idx, presc.astype(np.int32), first_pos, inv)
+            _, idx, presc, first_pos, inv = st
             first = val[first_pos]
             w = np.bincount(inv, weights=val, minlength=len(presc))
             bad = val != first[inv]
             if np.any(bad):
                 warnings.warn('Inconsistent BC at DOF {} ({} vs {}).'.format(idx[bad][0], first[inv][bad][0], val[bad][0]))
         else:
-            presc = np.zeros(0, dtype=np.int64)
+            presc = np.zeros(0, dtype=np.int32)
             first = w = np.zeros(0)
         fext = None
         if f_idx:
