@@ -118,6 +118,8 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         fe.distribute(rank, world, uid[0])
     eng = fe._ensure_engine()
+    if os.environ.get('MG_NU'):  # experiment knob: smoothing sweeps / damping of the multigrid preconditioner
+        eng.set_precond(1, float(os.environ.get('MG_OMEGA', '0.65')), int(os.environ['MG_NU']))
     devname, cus, hbm = eng.device_info()
 
     def barrier():

@@ -165,6 +165,7 @@ struct plfx_ctx {
     ClassDev *mg_cls = nullptr;  // geometry tables shared by all levels
     MgLevDev *mg_dev = nullptr;  // level descriptors for the single-workgroup tail kernel
     int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
+    int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
     int gx = 0, gy = 0;          // structured grid (elements) if known
     int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
     double mg_omega = 0.65;  // damped Jacobi; lambda_max(D^-1 K) ~ 2.3 for Q4 elasticity (0.9 diverges)
@@ -645,7 +646,11 @@ int mg_vcycle(plfx_ctx *c)
     {
         auto &L = c->mg[nl - 1];
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
-        if (lt < nl - 1)
+        if (lt < nl - 1 && c->mg_tail_T > 0 && c->mg_nu == 2)
+            hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(MG_TAIL_BLOCK),
+                               (size_t)c->mg_tail_T * (4 * sizeof(double2) + 9 * sizeof(int)), c->stream, c->mg_dev,
+                               lt, nl, c->mg_tail_T, om, c->sc);
+        else if (lt < nl - 1)
             hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(MG_TAIL_BLOCK), lds, c->stream, c->mg_dev, lt, nl, om,
                                c->mg_nu, c->sc);
         else if (L.ainv)
@@ -1228,9 +1233,27 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         c->mg_tail = -1;
         for (size_t l = 0; l < c->mg.size(); l++) {
             auto &L = c->mg[l];
-            hd[l] = MgLevDev{L.nx, L.ny, L.nnode, L.nslot, L.ainv, L.col, L.val, (const double2 *)L.dinv,
-                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res};
             if (c->mg_tail < 0 && l > 0 && L.nnode <= MG_TAIL_NODES) c->mg_tail = (int)l;
+            int off = 0;
+            if (c->mg_tail >= 0)
+                for (size_t m = c->mg_tail; m < l; m++) off += c->mg[m].nnode;
+            hd[l] = MgLevDev{L.nx, L.ny, L.nnode, L.nslot, L.ainv, off, 0, L.col, L.val, (const double2 *)L.dinv,
+                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res};
+        }
+        c->mg_tail_T = 0;
+        if (c->mg_tail >= 0 && c->mg.back().ainv && c->mg_nu == 2) {
+            int T = 0;
+            bool ok = true;
+            for (size_t m = c->mg_tail; m < c->mg.size(); m++) {
+                T += c->mg[m].nnode;
+                ok = ok && c->mg[m].nslot <= 9;
+            }
+            const size_t bytes = (size_t)T * (4 * sizeof(double2) + 9 * sizeof(int));
+            if (ok && bytes <= 150 * 1024) {
+                c->mg_tail_T = T;
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)bytes));
+            }
         }
         dfree(c->mg_dev);
         if ((rc = dalloc(c, &c->mg_dev, hd.size()))) return rc;

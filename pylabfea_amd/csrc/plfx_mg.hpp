@@ -201,13 +201,14 @@ k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ di
 
 // Coarsest grid: Jacobi-PCG on (nnode <= MG_COARSE_MAX) nodes inside one workgroup, vectors in LDS.
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
-constexpr int MG_TAIL_BLOCK = 512;   // threads of the single-workgroup tail kernel
+constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel
 constexpr int MG_DENSE_MAX = 128;    // coarsest grids up to this many DOFs are solved with a dense inverse
 
 struct MgLevDev {
     int nx, ny, nnode, nslot;
     const double *ainv;  // dense inverse of the (masked) operator, coarsest level only (or nullptr)
+    int tail_off, _pad;  // node offset of this level inside the LDS arena of k_mg_tail_lds
     const int32_t *col;
     const double *val;
     const double2 *dinv;
@@ -516,6 +517,165 @@ k_mg_tail(const MgLevDev *__restrict__ lev, int l0, int nl, double omega, int nu
             for (int i = threadIdx.x; i < L.nnode; i += blockDim.x) L.x[i] = L.t[i];
             __syncthreads();
         }
+    }
+}
+
+// ---- LDS-resident tail: the vectors (x, b, t, res) and the neighbour tables of ALL tail levels live in
+//      LDS (<= ~1500 nodes x 100 B), so a smoothing step is [coalesced matrix loads from L2] + [LDS gathers]
+//      with no dependent global-memory chain; only the level-l0 right-hand side is read from and the
+//      level-l0 correction written to global memory.  Requires the dense coarse inverse.
+struct TailView {
+    double2 *x, *b, *t, *res;
+    const int *col;
+};
+
+__device__ __forceinline__ TailView tail_view(double2 *arena, int *cols, int T, const MgLevDev &L)
+{
+    TailView v;
+    v.x = arena + L.tail_off;
+    v.b = arena + T + L.tail_off;
+    v.t = arena + 2 * T + L.tail_off;
+    v.res = arena + 3 * T + L.tail_off;
+    v.col = cols + 9 * L.tail_off;
+    return v;
+}
+
+// y = K x at node i with x in LDS and the neighbour table in LDS ([node][slot] layout)
+__device__ __forceinline__ double2 tail_apply(const MgLevDev &L, const TailView &v, const double2 *xin, int i)
+{
+    double qx = 0., qy = 0.;
+    for (int s = 0; s < L.nslot; s++) {
+        const int j = v.col[9 * i + s];
+        if (j < 0) continue;
+        const double2 pj = xin[j];
+        qx = fma(L.val[((size_t)s * 4 + 0) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 1) * L.nnode + i], pj.y, qx));
+        qy = fma(L.val[((size_t)s * 4 + 2) * L.nnode + i], pj.x, fma(L.val[((size_t)s * 4 + 3) * L.nnode + i], pj.y, qy));
+    }
+    return make_double2(qx, qy);
+}
+
+__global__ void __launch_bounds__(MG_TAIL_BLOCK)
+k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double omega, const CgScalars *sc)
+{
+    if (sc->done) return;
+    extern __shared__ double2 arena[];  // 4 T double2 + 9 T int
+    int *cols = reinterpret_cast<int *>(arena + 4 * (size_t)T);
+    const int nt = blockDim.x;
+    // stage: neighbour tables of every tail level, right-hand side of level l0
+    for (int l = l0; l < nl; l++) {
+        const MgLevDev L = lev[l];
+        for (int idx = threadIdx.x; idx < L.nnode * 9; idx += nt) {
+            const int i = idx / 9, s = idx - 9 * i;
+            cols[9 * (L.tail_off + i) + s] = (s < L.nslot) ? L.col[(size_t)s * L.nnode + i] : -1;
+        }
+    }
+    {
+        const MgLevDev L = lev[l0];
+        TailView v = tail_view(arena, cols, T, L);
+        for (int i = threadIdx.x; i < L.nnode; i += nt) v.b[i] = L.b[i];
+    }
+    __syncthreads();
+    for (int l = l0; l < nl - 1; l++) {  // down: two Jacobi sweeps from zero (one pass), residual, restriction
+        const MgLevDev L = lev[l];
+        const MgLevDev Cc = lev[l + 1];
+        TailView v = tail_view(arena, cols, T, L), vc = tail_view(arena, cols, T, Cc);
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // t = x1 = w D^-1 b
+            const double2 di = L.dinv[i], bi = v.b[i];
+            v.t[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = x1 + w D^-1 (b - K x1)
+            const double2 q = tail_apply(L, v, v.t, i), di = L.dinv[i], bi = v.b[i], x1 = v.t[i];
+            v.x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // res = P (b - K x)
+            const double2 q = tail_apply(L, v, v.x, i), di = L.dinv[i], bi = v.b[i];
+            v.res[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
+        }
+        __syncthreads();
+        const int nyc = Cc.ny + 1, nyf = L.ny + 1, nxf = L.nx + 1;
+        for (int i = threadIdx.x; i < Cc.nnode; i += nt) {  // b_c = P^T res
+            const int J = i / nyc, K = i - J * nyc;
+            double sx = 0., sy = 0.;
+            for (int dj = -1; dj <= 1; dj++) {
+                const int jf = 2 * J + dj;
+                if (jf < 0 || jf >= nxf) continue;
+                for (int dk = -1; dk <= 1; dk++) {
+                    const int kf = 2 * K + dk;
+                    if (kf < 0 || kf >= nyf) continue;
+                    const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
+                    const double2 r = v.res[jf * nyf + kf];
+                    sx = fma(w, r.x, sx);
+                    sy = fma(w, r.y, sy);
+                }
+            }
+            const double2 d = Cc.dinv[i];
+            vc.b[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+        }
+        __syncthreads();
+    }
+    {   // coarsest grid: x = Ainv b
+        const MgLevDev L = lev[nl - 1];
+        TailView v = tail_view(arena, cols, T, L);
+        const int n = 2 * L.nnode;
+        const double *bv = reinterpret_cast<const double *>(v.b);
+        double *xv = reinterpret_cast<double *>(v.x);
+        for (int i = threadIdx.x; i < n; i += nt) {
+            double acc = 0.;
+            for (int j = 0; j < n; j++) acc = fma(L.ainv[(size_t)i * n + j], bv[j], acc);
+            xv[i] = acc;
+        }
+        __syncthreads();
+    }
+    for (int l = nl - 2; l >= l0; l--) {  // up: prolongation + two post-smoothing sweeps
+        const MgLevDev L = lev[l];
+        const MgLevDev Cc = lev[l + 1];
+        TailView v = tail_view(arena, cols, T, L), vc = tail_view(arena, cols, T, Cc);
+        const int nyc = Cc.ny + 1, nyf = L.ny + 1;
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {
+            const int j = i / nyf, k = i - j * nyf;
+            const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
+            double2 c = vc.x[J0 * nyc + K0];
+            double cx = c.x, cy = c.y;
+            if (oj) {
+                c = vc.x[(J0 + 1) * nyc + K0];
+                cx += c.x;
+                cy += c.y;
+            }
+            if (ok) {
+                c = vc.x[J0 * nyc + K0 + 1];
+                cx += c.x;
+                cy += c.y;
+            }
+            if (oj && ok) {
+                c = vc.x[(J0 + 1) * nyc + K0 + 1];
+                cx += c.x;
+                cy += c.y;
+            }
+            const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+            const double2 d = L.dinv[i];
+            double2 xf = v.x[i];
+            if (d.x != 0.) xf.x = fma(w, cx, xf.x);
+            if (d.y != 0.) xf.y = fma(w, cy, xf.y);
+            v.x[i] = xf;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // t = x + w D^-1 (b - K x)
+            const double2 q = tail_apply(L, v, v.x, i), di = L.dinv[i], bi = v.b[i], xi = v.x[i];
+            v.t[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = t + w D^-1 (b - K t)
+            const double2 q = tail_apply(L, v, v.t, i), di = L.dinv[i], bi = v.b[i], ti = v.t[i];
+            v.x[i] = make_double2(fma(omega * di.x, bi.x - q.x, ti.x), fma(omega * di.y, bi.y - q.y, ti.y));
+        }
+        __syncthreads();
+    }
+    {
+        const MgLevDev L = lev[l0];
+        TailView v = tail_view(arena, cols, T, L);
+        for (int i = threadIdx.x; i < L.nnode; i += nt) L.x[i] = v.x[i];
     }
 }
 
