@@ -575,6 +575,40 @@ k_assemble(const ClassDev *gcls, int ncls, int nnode, int nslot, int nq, int nel
     }
 }
 
+// Row pair i of the block-ELL matrix times a vector given as a functor xf(j) -> double2.
+// Nine slots (every structured Q4 grid): branch-free and fully unrolled, so that the 9 column ids, the 36
+// matrix values and the 9 gathers are all in flight together (empty slots hold exact zeros, their gather
+// is redirected to the node itself).  Other slot counts take the generic loop.
+template <class XF>
+__device__ __forceinline__ double2 bell_apply(int nnode, int nslot, const int32_t *__restrict__ col,
+                                              const double *__restrict__ val, int i, XF xf)
+{
+    double qx = 0., qy = 0.;
+    if (nslot == 9) {
+        int j[9];
+        double v[36];
+#pragma unroll
+        for (int s = 0; s < 9; s++) j[s] = col[(size_t)s * nnode + i];
+#pragma unroll
+        for (int k = 0; k < 36; k++) v[k] = val[(size_t)k * nnode + i];
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            const double2 pj = xf(j[s] < 0 ? i : j[s]);
+            qx = fma(v[4 * s + 0], pj.x, fma(v[4 * s + 1], pj.y, qx));
+            qy = fma(v[4 * s + 2], pj.x, fma(v[4 * s + 3], pj.y, qy));
+        }
+    } else {
+        for (int s = 0; s < nslot; s++) {
+            const int j = col[(size_t)s * nnode + i];
+            if (j < 0) continue;
+            const double2 pj = xf(j);
+            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
+            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
+        }
+    }
+    return make_double2(qx, qy);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Block-ELL SpMV, one thread per node (two rows).
 // MODE 0: q = K p                                   (plain; used for K w, K du, residual)
@@ -617,25 +651,15 @@ k_spmv(int nnode, int n_begin, int n_end, int nslot, const int32_t *col, const d
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < span; t += nb) {
         const int i = n_begin + t * BLOCK + threadIdx.x;
         if (i >= n_end) continue;
-        double qx = 0., qy = 0.;
-        for (int s = 0; s < nslot; s++) {
-            const int j = col[(size_t)s * nnode + i];
-            if (j < 0) continue;
-            double2 pj;
-            if (MODE == 1) {
+        double2 qv;
+        if (MODE == 1)
+            qv = bell_apply(nnode, nslot, col, val, i, [&](int j) {
                 const double2 zj = z[j], po = p[j];
-                pj.x = fma(beta, po.x, zj.x);
-                pj.y = fma(beta, po.y, zj.y);
-            } else {
-                pj = p[j];
-            }
-            const double v00 = val[((size_t)s * 4 + 0) * nnode + i];
-            const double v01 = val[((size_t)s * 4 + 1) * nnode + i];
-            const double v10 = val[((size_t)s * 4 + 2) * nnode + i];
-            const double v11 = val[((size_t)s * 4 + 3) * nnode + i];
-            qx = fma(v00, pj.x, fma(v01, pj.y, qx));
-            qy = fma(v10, pj.x, fma(v11, pj.y, qy));
-        }
+                return make_double2(fma(beta, po.x, zj.x), fma(beta, po.y, zj.y));
+            });
+        else
+            qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return p[j]; });
+        const double qx = qv.x, qy = qv.y;
         q[i] = make_double2(qx, qy);
         if (MODE == 1) {
             const double2 zi = z[i], po = p[i];

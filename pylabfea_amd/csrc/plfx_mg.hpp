@@ -36,14 +36,8 @@ k_mg_smooth(int nnode, int nslot, const int32_t *__restrict__ col, const double 
             xout[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
             continue;
         }
-        double qx = 0., qy = 0.;
-        for (int s = 0; s < nslot; s++) {
-            const int j = col[(size_t)s * nnode + i];
-            if (j < 0) continue;
-            const double2 pj = xin[j];
-            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
-            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
-        }
+        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return xin[j]; });
+        const double qx = qv.x, qy = qv.y;
         const double2 xi = xin[i];
         xout[i] = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
     }
@@ -62,15 +56,11 @@ k_mg_smooth2_zero(int nnode, int nslot, const int32_t *__restrict__ col, const d
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
         if (i >= nnode) continue;
-        double qx = 0., qy = 0.;
-        for (int s = 0; s < nslot; s++) {
-            const int j = col[(size_t)s * nnode + i];
-            if (j < 0) continue;
+        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) {
             const double2 dj = dinv[j], bj = b[j];
-            const double px = omega * dj.x * bj.x, py = omega * dj.y * bj.y;
-            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], px, fma(val[((size_t)s * 4 + 1) * nnode + i], py, qx));
-            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], px, fma(val[((size_t)s * 4 + 3) * nnode + i], py, qy));
-        }
+            return make_double2(omega * dj.x * bj.x, omega * dj.y * bj.y);
+        });
+        const double qx = qv.x, qy = qv.y;
         const double2 di = dinv[i], bi = b[i];
         const double x1x = omega * di.x * bi.x, x1y = omega * di.y * bi.y;
         xout[i] = make_double2(fma(omega * di.x, bi.x - qx, x1x), fma(omega * di.y, bi.y - qy, x1y));
@@ -89,14 +79,8 @@ k_mg_residual(int nnode, int nslot, const int32_t *__restrict__ col, const doubl
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
         if (i >= nnode) continue;
-        double qx = 0., qy = 0.;
-        for (int s = 0; s < nslot; s++) {
-            const int j = col[(size_t)s * nnode + i];
-            if (j < 0) continue;
-            const double2 pj = x[j];
-            qx = fma(val[((size_t)s * 4 + 0) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 1) * nnode + i], pj.y, qx));
-            qy = fma(val[((size_t)s * 4 + 2) * nnode + i], pj.x, fma(val[((size_t)s * 4 + 3) * nnode + i], pj.y, qy));
-        }
+        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return x[j]; });
+        const double qx = qv.x, qy = qv.y;
         const double2 di = dinv[i], bi = b[i];
         res[i] = make_double2(di.x != 0. ? bi.x - qx : 0., di.y != 0. ? bi.y - qy : 0.);
     }
