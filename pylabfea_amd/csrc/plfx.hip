@@ -148,6 +148,9 @@ struct plfx_ctx {
     size_t stage_cap = 0;
     int32_t *bc_idx_dev = nullptr;  // device copy of bc_idx (idx_tmp is shared with plfx_gather)
     size_t bc_idx_cap = 0;
+    int32_t *bc_rows = nullptr;     // nodes whose matrix rows touch a prescribed node (rows of K w that can be non-zero)
+    int bc_nrows = 0;
+    double *kw = nullptr;           // K w, zero outside bc_rows
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int grid_nodes = 0, grid_el = 0;
@@ -505,6 +508,9 @@ void free_mesh(plfx_ctx *c)
     c->assembled = c->bc_set = false;
     c->bc_valid = false;
     c->bc_idx.clear();
+    dfree(c->kw);
+    dfree(c->bc_rows);
+    c->bc_nrows = 0;
 }
 
 void free_materials(plfx_ctx *c)
@@ -738,6 +744,8 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->val_tmp);
     if (c->stage) hipHostFree(c->stage);
     dfree(c->bc_idx_dev);
+    dfree(c->bc_rows);
+    dfree(c->kw);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1498,6 +1506,29 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
         if (n > 0) {
             HIPCHK(c, hipMemcpyAsync(c->bc_idx_dev, c->bc_idx.data(), (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
         }
+        // rows of K that see a prescribed DOF: the neighbours (in the block-ELL pattern) of the prescribed nodes
+        {
+            std::vector<char> mark(c->nnode, 0);
+            const int nn = c->nnode;
+            for (int k = 0; k < n; k++) {
+                const int i = idx[k] >> 1;
+                for (int s2 = 0; s2 < c->nslot; s2++) {
+                    const int j = c->hcol[(size_t)s2 * nn + i];
+                    if (j >= 0) mark[j] = 1;  // the pattern is symmetric: j has i as a neighbour
+                }
+            }
+            std::vector<int32_t> rows;
+            for (int i = 0; i < nn; i++)
+                if (mark[i]) rows.push_back(i);
+            c->bc_nrows = (int)rows.size();
+            dfree(c->bc_rows);
+            if ((rc = dalloc(c, &c->bc_rows, rows.size()))) return rc;
+            if (!rows.empty())
+                HIPCHK(c, hipMemcpyAsync(c->bc_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
+            if (!c->kw && (rc = dalloc(c, &c->kw, nd))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->kw, 0, 8 * nd, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // `rows` goes out of scope
+        }
         c->bc_valid = true;
     }
     if (n > 0) {
@@ -1516,10 +1547,11 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
         HIPCHK(c, hipGetLastError());
     }
     if (fext) HIPCHK(c, hipMemcpyAsync(c->fext, fext, 8 * nd, hipMemcpyHostToDevice, c->stream));
-    rc = plain_spmv(c, c->wv, c->q);  // K w
-    if (rc) return rc;
+    if (c->bc_nrows > 0)  // K w on the few rows where it can be non-zero
+        hipLaunchKernelGGL(k_spmv_rows, dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->bc_nrows,
+                           c->bc_rows, c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)c->wv, (double2 *)c->kw);
     hipLaunchKernelGGL(k_bc_finish, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd,
-                       fext ? c->fext : nullptr, c->q, c->diag, c->is_presc, c->rhs, c->dinv);
+                       fext ? c->fext : nullptr, c->kw, c->diag, c->is_presc, c->rhs, c->dinv);
     HIPCHK(c, hipGetLastError());
     if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mg_active(c)) {

@@ -853,6 +853,18 @@ __global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, con
     if (k < n) v[k] = y[idx[k]];
 }
 
+// q[i] = (K w)[i] for the listed nodes only: w is non-zero on prescribed DOFs, so K w vanishes except on the
+// rows of nodes that touch a prescribed node (O(boundary) work instead of a full matrix pass)
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_rows(int nlist, const int32_t *__restrict__ list, int nnode, int nslot, const int32_t *__restrict__ col,
+            const double *__restrict__ val, const double2 *__restrict__ w, double2 *__restrict__ q)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= nlist) return;
+    const int i = list[k];
+    q[i] = bell_apply(nnode, nslot, col, val, i, [&](int j) { return w[j]; });
+}
+
 // rhs = fext - K w (q holds K w);  dinv = free ? 1/|diag| : 0
 __global__ void __launch_bounds__(BLOCK)
 k_bc_finish(size_t ndof, const double *fext, const double *kw, const double *diag,
