@@ -1,0 +1,130 @@
+"""Randomised (seeded) parity: random orthotropic elastic matrices and Hill coefficients, GPU vs CPU oracle;
+assembled matrix on a plastic state vs the oracle's element matrices; non-uniform laminate (several element
+classes, Jacobi-PCG path) vs the oracle's sparse direct solve."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_material(rng):
+    from oracle import oracle as O
+    from pylabfea_amd import _lib
+    E = rng.uniform(50e3, 400e3)
+    nu = rng.uniform(0.15, 0.4)
+    hh = E / ((1. + nu) * (1. - 2. * nu))
+    CV = np.zeros((6, 6))
+    CV[:3, :3] = nu * hh
+    CV[[0, 1, 2], [0, 1, 2]] = (1. - nu) * hh
+    CV[[3, 4, 5], [3, 4, 5]] = (0.5 - nu) * hh
+    # orthotropic perturbation, kept symmetric positive definite
+    P = rng.uniform(-0.1, 0.1, size=(3, 3)) * hh * 0.2
+    CV[:3, :3] += P + P.T
+    CV[[3, 4, 5], [3, 4, 5]] *= rng.uniform(0.8, 1.2, size=3)
+    sy = rng.uniform(40., 400.)
+    khard = rng.choice([0., rng.uniform(10., 5000.)])
+    hill = rng.uniform(0.6, 1.5, size=6)
+    # perfect plasticity + a Drucker pressure term makes the reference's scale-back iteration unstable for
+    # percent-size strain steps (round-off is amplified through the 50 sub-steps): not a meaningful parity case
+    drucker = rng.choice([0., rng.uniform(0., 0.2)]) if khard > 0. else 0.
+    rec = _lib.pack_material(_lib.HILL6, CV, E=E, nu=nu, sy=sy, khard=khard, hill=hill, drucker=drucker)
+    om = O.Material(kind=O.HILL6, E=E, nu=nu, sy=sy, khard=khard, hill=hill, drucker=drucker)
+    return rec, om, CV, sy
+
+
+def test_random_materials_response():
+    from oracle import oracle as O
+    from pylabfea_amd import _lib
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(2024)
+    nflip = ntot = 0
+    for trial in range(12):
+        rec, om, CV, sy = random_material(rng)
+        ctx.set_materials([rec])
+        n = 3000
+        d = rng.normal(size=(n, 6))
+        seq = O.calc_seq(om, d)
+        sig = d / seq[:, None] * sy * rng.uniform(0.0, 1.03, size=n)[:, None]
+        deps = rng.normal(size=(n, 6)) * 10 ** rng.uniform(-5.5, -2.5, size=n)[:, None]
+        epl = rng.normal(size=(n, 6)) * 2e-3 * (rng.uniform(size=n) < 0.5)[:, None]
+        fy, so, dp, ct, ns = ctx.response(sig, epl, deps)
+        fy2, so2, dp2, ct2, ns2 = O.response(om, CV, sig, epl, deps)
+        ok = ns == ns2
+        nflip += int(np.sum(~ok))
+        ntot += n
+        assert np.max(np.abs(so[ok] - so2[ok])) < 1e-8 * sy
+        assert np.max(np.abs(dp[ok] - dp2[ok])) < 1e-10
+        assert np.max(np.abs(ct[ok] - ct2[ok])) < 1e-6 * CV[0, 0]
+        assert np.max(np.abs(ctx.seq(0, sig) - O.calc_seq(om, sig))) < 1e-9 * sy
+    assert nflip <= 2e-4 * ntot      # inputs within round-off of a branch threshold may flip
+    ctx.close()
+
+
+def test_assembled_matrix_plastic_state():
+    """K on a plastic state (random symmetric tangents) vs sum of the oracle's element matrices."""
+    import scipy.sparse as sp
+    import pylabfea_amd as FE
+    from oracle import oracle as O
+    from pylabfea_amd import _lib
+    mat = FE.Material()
+    mat.elasticity(E=200.e3, nu=0.3)
+    mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+    for ps in (False, True):
+        fe = FE.Model(dim=2, planestress=ps)
+        fe.geom([3.], LY=2.)
+        fe.assign([mat])
+        fe.mesh(NX=24, NY=16)
+        eng = fe._ensure_engine()
+        rng = np.random.default_rng(3)
+        CV = fe._element_CV(mat)
+        A = rng.normal(size=(fe.Nel, 6, 6)) * 5.e3
+        D = CV[None] + A + A.transpose(0, 2, 1)
+        eng.state_set(_lib.ST_ELSTIFF, D.reshape(fe.Nel, 36))
+        eng.assemble()
+        K = eng.get_csr()
+        Kel = O.kel_batch(fe._lxy, fe._mat_id, fe.thick, ps, CV.reshape(1, 36), [mat.E], [mat.nu], D.reshape(-1, 36))
+        dofs = np.stack((2 * fe._conn, 2 * fe._conn + 1), axis=2).reshape(fe.Nel, 8)
+        Kref = sp.coo_matrix((Kel.ravel(), (np.repeat(dofs, 8, axis=1).ravel(), np.tile(dofs, (1, 8)).ravel())),
+                             shape=K.shape).tocsr()
+        diff = (K - Kref)
+        assert abs(diff).max() < 1e-11 * abs(Kref).max()
+        assert abs(K - K.T).max() < 1e-11 * abs(Kref).max()
+
+
+def test_nonuniform_laminate_vs_oracle():
+    """Laminate with non-proportional sections (three element classes, no multigrid hierarchy ->
+    Jacobi-PCG) and two plastic materials against the oracle's sparse direct solve."""
+    import pylabfea_amd as FE
+    from oracle.solve_ref import RefSolver
+
+    def build():
+        ma = FE.Material(num=1)
+        ma.elasticity(E=200.e3, nu=0.3)
+        ma.plasticity(sy=150., khard=500., sdim=6)
+        mb = FE.Material(num=2)
+        mb.elasticity(E=120.e3, nu=0.33)
+        mb.plasticity(sy=90., hill=[0.8, 1.1, 1.3, 1., 0.9, 1.2], khard=300., sdim=6)
+        fe = FE.Model(dim=2, planestress=True)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([ma, mb, ma, mb, ma])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.004 * fe.leny, 'disp')
+        fe.mesh(NX=13, NY=6)
+        return fe
+    fe = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=5)
+    assert fe._engine.precond_info()[0] == 0
+    ref = RefSolver(build()).solve(min_step=5)
+    assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
+    s = np.max(np.abs(ref.sig))
+    assert np.max(np.abs(fe.u - ref.u)) < 1e-6 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
+    assert np.max(np.abs(fe._state('epl') - ref.epl)) < 1e-6 * np.max(np.abs(ref.eps))
+    assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s
