@@ -169,6 +169,7 @@ struct plfx_ctx {
     MgLevDev *mg_dev = nullptr;  // level descriptors for the single-workgroup tail kernel
     int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
     int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
+    bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     int gx = 0, gy = 0;          // structured grid (elements) if known
     int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
     double mg_omega = 0.65;  // damped Jacobi; lambda_max(D^-1 K) ~ 2.3 for Q4 elasticity (0.9 diverges)
@@ -574,11 +575,12 @@ int mg_assemble(plfx_ctx *c)
                            L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
     }
     HIPCHK(c, hipGetLastError());
+    c->mg_inv_valid = false;
     return 0;
 }
 
 // Dirichlet masks / Jacobi scalings of the coarse levels from the fine dinv (called by apply_bc)
-int mg_update_dinv(plfx_ctx *c)
+int mg_update_dinv(plfx_ctx *c, bool same_set)
 {
     for (size_t l = 1; l < c->mg.size(); l++) {
         auto &F = c->mg[l - 1];
@@ -588,10 +590,11 @@ int mg_update_dinv(plfx_ctx *c)
                            (double2 *)L.dinv);
     }
     auto &Lc = c->mg.back();
-    if (Lc.ainv) {
+    if (Lc.ainv && !(c->mg_inv_valid && same_set)) {
         const int n = 2 * Lc.nnode;
         hipLaunchKernelGGL(k_mg_coarse_invert, dim3(1), dim3(BLOCK), (size_t)n * n * sizeof(double), c->stream,
                            Lc.nnode, Lc.nslot, Lc.col, Lc.val, (const double2 *)Lc.dinv, Lc.ainv);
+        c->mg_inv_valid = true;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1555,7 +1558,7 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     HIPCHK(c, hipGetLastError());
     if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mg_active(c)) {
-        rc = mg_update_dinv(c);
+        rc = mg_update_dinv(c, same_set);
         if (rc) return rc;
     }
     c->bc_set = true;

@@ -306,27 +306,36 @@ k_mg_coarse_invert(int nnode, int nslot, const int32_t *__restrict__ col, const 
             }
     }
     __syncthreads();
+    // in-place Gauss-Jordan, two barriers per pivot: every thread first reads what its entries need from the
+    // old matrix (pivot row k, pivot column k), then all write
+    constexpr int PER = (MG_DENSE_MAX * MG_DENSE_MAX + BLOCK - 1) / BLOCK;
     for (int k = 0; k < n; k++) {
-        __shared__ double piv;
-        if (threadIdx.x == 0) {
-            double p = A[k * n + k];
-            if (fabs(p) < 1e-300) p = 1.;
-            piv = 1. / p;
-            A[k * n + k] = 1.;
-        }
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += BLOCK) A[k * n + j] *= piv;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < n * n; idx += BLOCK) {
+        double pk = A[k * n + k];
+        if (fabs(pk) < 1e-300) pk = 1.;
+        const double ip = 1. / pk;
+        double nv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int idx = threadIdx.x + u * BLOCK;
+            if (idx >= n * n) break;
             const int i = idx / n, j = idx - i * n;
-            if (i == k) continue;
-            const double f = A[i * n + k];
-            if (j == k) continue;  // column k is finalised below, after every row has read its factor
-            A[i * n + j] = fma(-f, A[k * n + j], A[i * n + j]);
+            const double aik = A[i * n + k], akj = A[k * n + j], aij = A[idx];
+            double v;
+            if (i == k)
+                v = (j == k) ? ip : akj * ip;
+            else if (j == k)
+                v = -aik * ip;
+            else
+                v = fma(-aik * ip, akj, aij);
+            nv[u] = v;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += BLOCK)
-            if (i != k) A[i * n + k] = -A[i * n + k] * A[k * n + k];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int idx = threadIdx.x + u * BLOCK;
+            if (idx >= n * n) break;
+            A[idx] = nv[u];
+        }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < n * n; i += BLOCK) ainv[i] = A[i];
