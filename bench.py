@@ -183,7 +183,7 @@ def main():
         ach = bytes_per[k] / avg_s / 1e9
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled and
         # WRITE_SIZE as calibrated there, MI355X_MICROARCH.md 'HBM'); measured on this workload (1 GPU, 1024^2)
-        pmc = {'mg_smooth': 411.4e6, 'spmv': 416.3e6, 'sweep': 475.1e6, 'cg_update': 134.7e6}
+        pmc = {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}
         traffic = pmc.get(k) if (world == 1 and n == 1024) else None
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
                            'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
@@ -192,7 +192,7 @@ def main():
                                         'multigrid V-cycle: block-ELL SpMV + update)'}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                'traffic_source': 'profiles/r01b_bench1024_mg_rocprofv3_summary.txt' if traffic else None,
+                'traffic_source': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt' if traffic else None,
                 'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
 
     out = {
