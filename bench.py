@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 
 PREROLL = 6          # untimed elastic increments before warm-up (part of set-up)
 HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
+# calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
+PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
+               'matfree': {}}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': None}
 
 
 def hill_material(FE):
@@ -166,13 +171,17 @@ def main():
     tim = {k: eng.timing_get(v) for k, v in fam.items()}
     nel_rank = fe._e1 - fe._e0
     # algorithmic (compulsory) bytes per launch, DESIGN.md "Kernels":
-    #   k_spmv<1>: block-ELL values 288 + column ids 36 + z,p_old,p_new,q 4x16 = 388 B per node
-    #   k_mg_smooth (fine level): values 288 + column ids 36 + x_in, dinv, b, x_out 4x16 = 388 B per node
+    #   matrix-free operator (default on uniform structured grids): stiffness generators 48 B per element + per node
+    #     k_spmv<1,1>: z, p_old (gathered, compulsory once), p_new, q 4x16 = 64 B
+    #     k_mg_smooth<1,1> (fine level): x_in, dinv, b, x_out 4x16 = 64 B
+    #   assembled operator (PLFX_MATFREE=0): block-ELL values 288 + column ids 36 + the same 64 B = 388 B per node
     #   k_sweep_light: conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
     #              + fyn 8 + max_steps 4 written = 412 B (+216 B when the tangent / M is rewritten; not counted)
-    bytes_per = {'spmv': 388. * fe.Nnode / world,
+    mf = eng.operator_info()[0] == 1
+    op_bytes = (64. * fe.Nnode + 48. * fe.Nel) if mf else 388. * fe.Nnode
+    bytes_per = {'spmv': op_bytes / world,
                  'sweep': 412. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.,
-                 'mg_smooth': 388. * fe.Nnode}
+                 'mg_smooth': op_bytes}
     dominant = max(('spmv', 'sweep', 'cg_update', 'mg_smooth'), key=lambda k: tim[k][0])
 
     def roof(k):
@@ -183,16 +192,17 @@ def main():
         ach = bytes_per[k] / avg_s / 1e9
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled and
         # WRITE_SIZE as calibrated there, MI355X_MICROARCH.md 'HBM'); measured on this workload (1 GPU, 1024^2)
-        pmc = {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}
+        pmc = PMC_TRAFFIC['matfree' if mf else 'assembled']
         traffic = pmc.get(k) if (world == 1 and n == 1024) else None
-        return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + block-ELL SpMV + p.q)',
+        opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
+        return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + %s + p.q)' % opname,
                            'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
                            'cg_update': 'k_cg_update',
                            'mg_smooth': 'k_mg_smooth<1> / k_mg_smooth2_zero<1> (fine-level damped-Jacobi sweep of the '
-                                        'multigrid V-cycle: block-ELL SpMV + update)'}[k],
+                                        'multigrid V-cycle: %s + update)' % opname}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                'traffic_source': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt' if traffic else None,
+                'traffic_source': PMC_SOURCE['matfree' if mf else 'assembled'] if traffic else None,
                 'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
 
     out = {
@@ -207,7 +217,7 @@ def main():
                    'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': ('single GPU' if world == 1 else 'x-strip element shard x%d: sweep + CG SpMV rows sharded, '
                                    'RCCL all-reduce per CG step, replicated multigrid hierarchy' % world),
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
-                              else 'Jacobi-PCG') + ' rtol=%g on block-ELL' % fe.cg_rtol, 'device': devname},
+                              else 'Jacobi-PCG') + ' rtol=%g, %s operator' % (fe.cg_rtol, 'matrix-free' if mf else 'block-ELL'), 'device': devname},
         'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),

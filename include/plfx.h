@@ -116,6 +116,15 @@ int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
  * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.65, 2) */
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
+/* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
+ * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to
+ * the diagonal) wherever plfx_set_grid found a structured grid with one element shape; kind 0 always assembles the
+ * block-ELL matrix (Model.setupK, model.py:954-977).  plfx_get_csr assembles on demand in both cases.
+ * Environment override of the default: PLFX_MATFREE=0|1. */
+int plfx_set_operator(plfx_ctx *ctx, int kind);
+/* y = K x over all DOFs with the current operator (the product of model.py:1384, `K @ du`); host arrays [ndof] */
+int plfx_matvec(plfx_ctx *ctx, const double *x, double *y);
+int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
 int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);
 /* element stiffness of element e from its current tangent (Element.calc_Kel, model.py:365), [64] */

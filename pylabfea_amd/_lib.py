@@ -45,7 +45,7 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec',
 ]
 
 _lib = None
@@ -247,6 +247,23 @@ class Context(object):
         lv = C.c_int()
         self._chk(self.lib.plfx_precond_info(self.h, C.byref(k), C.byref(lv)))
         return k.value, lv.value
+
+    def set_operator(self, kind):
+        self._chk(self.lib.plfx_set_operator(self.h, int(kind)))
+
+    def matvec(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (self.ndof,):
+            raise ValueError('matvec: x must have shape (ndof,)')
+        y = np.empty(self.ndof)
+        self._chk(self.lib.plfx_matvec(self.h, _dp(x), _dp(y)))
+        return y
+
+    def operator_info(self):
+        m = C.c_int()
+        lv = C.c_int()
+        self._chk(self.lib.plfx_operator_info(self.h, C.byref(m), C.byref(lv)))
+        return m.value, lv.value
 
     def get_bmat(self, e):
         B = np.empty((4, 6, 8))

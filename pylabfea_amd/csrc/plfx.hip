@@ -162,6 +162,8 @@ struct plfx_ctx {
         double *val = nullptr, *diag = nullptr, *dinv = nullptr, *Mel = nullptr;
         double *x = nullptr, *b = nullptr, *t = nullptr, *res = nullptr;
         double *ainv = nullptr;  // dense inverse (coarsest level, small grids)
+        KOp op{};                // operator descriptor (block-ELL arrays + grid/generator form)
+        bool matfree = false;    // applied from the generators (no assembled matrix on this level)
         bool owned = false;  // level 0 aliases the fine-grid arrays of the context
     };
     std::vector<MgLevel> mg;
@@ -174,6 +176,13 @@ struct plfx_ctx {
     int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
     double mg_omega = 0.65;  // damped Jacobi; lambda_max(D^-1 K) ~ 2.3 for Q4 elasticity (0.9 diverges)
     int mg_nu = 2;
+    // matrix-free operator on structured grids with one element shape (plfx_set_grid)
+    bool grid_ok = false;        // the structured, uniform grid form is available
+    int want_matfree = 1;        // plfx_set_operator / PLFX_MATFREE
+    double *dtab = nullptr;      // geometry table of grid_apply
+    double *Mop = nullptr;       // generators as of the last plfx_assemble (the matrix-free K is a snapshot like setupK's)
+    KOp op{};                    // fine-level operator
+    bool val_valid = false;      // the fine block-ELL values match the current generators
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -504,6 +513,10 @@ void free_mesh(plfx_ctx *c)
     c->mg.clear();
     dfree(c->mg_cls);
     dfree(c->mg_dev);
+    dfree(c->dtab);
+    dfree(c->Mop);
+    c->grid_ok = false;
+    c->val_valid = false;
     c->mg_tail = -1;
     c->gx = c->gy = 0;
     c->assembled = c->bc_set = false;
@@ -536,13 +549,23 @@ int ensure_tmp(plfx_ctx *c, size_t n)
     return 0;
 }
 
+bool matfree(const plfx_ctx *c) { return c->grid_ok && c->want_matfree; }
+
+// kernels templated on the operator form: <.., 1> matrix-free grid, <.., 0> block-ELL
+#define LAUNCH_OP2(KERN, A, mf, grid, ...)                                                                     \
+    do {                                                                                                       \
+        if (mf)                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 1>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
+        else                                                                                                   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
+    } while (0)
+
 size_t dyn_lds_bytes(const plfx_ctx *c) { return (c->has_svc || c->has_svc3) ? (size_t)c->svc_lds_need * 8 : 0; }
 
 int plain_spmv(plfx_ctx *c, const double *in, double *out)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<0>), dim3(c->grid_nodes), dim3(BLOCK), 0, c->stream, c->nnode, 0,
-                       c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)in, nullptr, nullptr,
-                       (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
+    LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)in, nullptr, nullptr,
+               (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
     HIPCHK(c, hipGetLastError());
     return 0;  // the matrix is replicated on every rank: no collective here
 }
@@ -562,6 +585,32 @@ int sync_M(plfx_ctx *c)
 
 
 bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2; }
+KOp make_op(const plfx_ctx *c, int nnode, int nslot, const int32_t *col, const double *val, int nx, int ny, int nel,
+            const double *M)
+{
+    KOp o;
+    o.nnode = nnode;
+    o.nslot = nslot;
+    o.col = col;
+    o.val = val;
+    o.nxn = nx + 1;
+    o.nyn = ny + 1;
+    o.nel = nel;
+    o.M = M;
+    o.tab = c->dtab;
+    return o;
+}
+
+// fine block-ELL values on demand (matrix-free runs only need them for plfx_get_csr)
+int assemble_fine_val(plfx_ctx *c)
+{
+    hipLaunchKernelGGL(k_assemble, dim3(grid_for(c->nnode), c->nslot), dim3(BLOCK), 0, c->stream,
+                       c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel_total, c->dcontrib, c->dcls_all,
+                       (matfree(c) && c->assembled) ? c->Mop : c->Mel, c->dcol, c->dval, c->diag);
+    HIPCHK(c, hipGetLastError());
+    c->val_valid = true;
+    return 0;
+}
 
 // coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
 int mg_assemble(plfx_ctx *c)
@@ -570,9 +619,13 @@ int mg_assemble(plfx_ctx *c)
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
         hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
-                           F.nel, F.Mel, L.Mel);
-        hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
-                           L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
+                           F.nel, (l == 1 && matfree(c)) ? c->Mop : F.Mel, L.Mel);
+        if (L.matfree && matfree(c))  // only the diagonal (Jacobi smoother) is needed
+            hipLaunchKernelGGL(k_grid_diag, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
+                               (double *)nullptr);
+        else
+            hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
+                               L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
     }
     HIPCHK(c, hipGetLastError());
     c->mg_inv_valid = false;
@@ -606,14 +659,13 @@ int mg_vcycle(plfx_ctx *c)
     const int nl = (int)c->mg.size();
     const double om = c->mg_omega;
     auto smooth = [&](plfx_ctx::MgLevel &L, const double *xin, double *xout, int first) {
+        const bool mf = L.matfree && matfree(c);
         if (&L == &c->mg[0])
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
-                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                               (const double2 *)xin, (double2 *)xout, om, first, c->sc);
+            LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (const double2 *)xin, (double2 *)xout, om, first, c->sc);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
-                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                               (const double2 *)xin, (double2 *)xout, om, first, c->sc);
+            LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (const double2 *)xin, (double2 *)xout, om, first, c->sc);
     };
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;  // levels >= lt run inside one workgroup
     for (int l = 0; l < lt; l++) {  // down
@@ -624,14 +676,13 @@ int mg_vcycle(plfx_ctx *c)
         EvPair *ev = nullptr;
         if (nu == 2) {  // both sweeps in one pass over the matrix
             if (l == 0) tim_begin(c, 5, &ev);
+            const bool mf = L.matfree && matfree(c);
             if (l == 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth2_zero<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream,
-                                   L.nnode, L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                                   (double2 *)L.x, om, c->sc);
+                LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv,
+                           (const double2 *)L.b, (double2 *)L.x, om, c->sc);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_smooth2_zero<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream,
-                                   L.nnode, L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                                   (double2 *)L.x, om, c->sc);
+                LAUNCH_OP2(k_mg_smooth2_zero, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv,
+                           (const double2 *)L.b, (double2 *)L.x, om, c->sc);
             if (l == 0) tim_end(c, ev);
         } else {
             double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
@@ -641,14 +692,15 @@ int mg_vcycle(plfx_ctx *c)
                 dst = (dst == L.x) ? L.t : L.x;
             }
         }
-        if (l == 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_residual<1>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
-                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                               (const double2 *)L.x, (double2 *)L.res, c->sc);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_residual<0>), dim3(L.grid), dim3(BLOCK), 0, c->stream, L.nnode,
-                               L.nslot, L.col, L.val, (const double2 *)L.dinv, (const double2 *)L.b,
-                               (const double2 *)L.x, (double2 *)L.res, c->sc);
+        {
+            const bool mf = L.matfree && matfree(c);
+            if (l == 0)
+                LAUNCH_OP2(k_mg_residual, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                           (const double2 *)L.x, (double2 *)L.res, c->sc);
+            else
+                LAUNCH_OP2(k_mg_residual, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                           (const double2 *)L.x, (double2 *)L.res, c->sc);
+        }
         hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
                            L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
     }
@@ -712,6 +764,7 @@ int plfx_create(int device, plfx_ctx **out)
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipGetDeviceProperties(&c->prop, device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
     // 160 KiB LDS per CU on gfx950; leave room for the static material/class tables
     size_t lds = std::max((size_t)c->prop.sharedMemPerBlock, (size_t)c->prop.maxSharedMemoryPerMultiProcessor);
     lds = std::min(lds, (size_t)160 * 1024);
@@ -1095,6 +1148,9 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->grid_nodes = grid_xcd(nnode);
     c->grid_el = grid_xcd(nown);
+    c->grid_ok = false;
+    c->val_valid = false;
+    c->op = make_op(c, nnode, nslot, c->dcol, c->dval, 0, 0, nel, c->Mel);
     return plfx_state_reset(c);
 }
 
@@ -1163,8 +1219,32 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         dfree(L.t); dfree(L.res); dfree(L.ainv);
     }
     c->mg.clear();
-    for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly needs one element shape
+    c->grid_ok = false;
+    c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, 0, 0, c->nel_total, c->Mel);
+    for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly and the matrix-free operator need one element shape
         if (c->hlxy[2 * (size_t)e] != c->hlxy[0] || c->hlxy[2 * (size_t)e + 1] != c->hlxy[1]) return PLFX_OK;
+    int rc;
+    {   // geometry table of grid_apply: position p = pj*2+pk <-> element (j-1+pj, k-1+pk), in which node (j,k) has the
+        // local number a = (1-pj)*2 + (1-pk) (connectivity order model.py:936-948)
+        double tab[64];
+        const ClassDev &g = c->hcls[0];
+        for (int pj = 0; pj < 2; pj++)
+            for (int pk = 0; pk < 2; pk++) {
+                const int a = (1 - pj) * 2 + (1 - pk), p = pj * 2 + pk;
+                for (int b = 0; b < 4; b++) {
+                    tab[p * 16 + b * 4 + 0] = g.Sxx[a * 4 + b];
+                    tab[p * 16 + b * 4 + 1] = g.Syy[a * 4 + b];
+                    tab[p * 16 + b * 4 + 2] = g.Sxy[a * 4 + b];
+                    tab[p * 16 + b * 4 + 3] = g.Sxy[b * 4 + a];
+                }
+            }
+        if (!c->dtab && (rc = dalloc(c, &c->dtab, 64))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dtab, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = dalloc(c, &c->Mop, (size_t)6 * c->nel_total))) return rc;
+        c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, nx, ny, c->nel_total, c->Mop);
+        c->grid_ok = true;
+    }
     std::vector<std::pair<int, int>> dims;
     dims.push_back({nx, ny});
     while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 &&
@@ -1172,7 +1252,6 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         dims.push_back({dims.back().first / 2, dims.back().second / 2});
     if (dims.size() < 2) return PLFX_OK;
     if ((long long)(dims.back().first + 1) * (dims.back().second + 1) > MG_COARSE_MAX) return PLFX_OK;
-    int rc;
     if (!c->mg_cls) {
         if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->mg_cls, &c->hcls[0], sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
@@ -1266,12 +1345,46 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
                                               (int)bytes));
             }
         }
+        {   // levels above the tail are applied matrix-free; the tail and the coarsest level keep assembled matrices
+            const int nl = (int)c->mg.size();
+            const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
+            for (int l = 0; l < nl; l++) {
+                auto &L = c->mg[l];
+                L.op = make_op(c, L.nnode, L.nslot, L.col, L.val, L.nx, L.ny, L.nel, l == 0 ? c->Mop : L.Mel);
+                L.matfree = l < lt;
+            }
+        }
         dfree(c->mg_dev);
         if ((rc = dalloc(c, &c->mg_dev, hd.size()))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->mg_dev, hd.data(), hd.size() * sizeof(MgLevDev), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->assembled = false;
+    return PLFX_OK;
+}
+
+int plfx_set_operator(plfx_ctx *c, int kind)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (kind != 0 && kind != 1) return fail(c, PLFX_ERR_ARG, "operator kind must be 0 (assembled) or 1 (matrix-free)");
+    if (kind != c->want_matfree) {
+        c->want_matfree = kind;
+        c->assembled = false;  // diagonal / matrix values of the other form have to be rebuilt
+        c->bc_set = false;
+    }
+    return PLFX_OK;
+}
+
+int plfx_operator_info(plfx_ctx *c, int *matrix_free, int *levels_matrix_free)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (matrix_free) *matrix_free = matfree(c) ? 1 : 0;
+    if (levels_matrix_free) {
+        int n = 0;
+        if (matfree(c))
+            for (auto &L : c->mg) n += L.matfree ? 1 : 0;
+        *levels_matrix_free = n;
+    }
     return PLFX_OK;
 }
 
@@ -1434,9 +1547,16 @@ int plfx_assemble(plfx_ctx *c)
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     EvPair *ev;
     tim_begin(c, 3, &ev);
-    hipLaunchKernelGGL(k_assemble, dim3(grid_for(c->nnode), c->nslot), dim3(BLOCK), 0, c->stream,
-                       c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel_total, c->dcontrib, c->dcls_all,
-                       c->Mel, c->dcol, c->dval, c->diag);
+    if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
+        KOp live = c->op;
+        live.M = c->Mel;
+        hipLaunchKernelGGL(k_grid_diag, dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+                           c->Mop);
+        c->val_valid = false;
+    } else {
+        int rc = assemble_fine_val(c);
+        if (rc) return rc;
+    }
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     if (mg_active(c)) {
@@ -1460,6 +1580,10 @@ int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, do
     }
     if (nnz) *nnz = cnt;
     if (!rowptr || !colidx || !val) return PLFX_OK;
+    if (!c->val_valid) {
+        int rc = assemble_fine_val(c);
+        if (rc) return rc;
+    }
     std::vector<double> hv((size_t)ns * 4 * nn);
     HIPCHK(c, hipMemcpyAsync(hv.data(), c->dval, hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1551,8 +1675,14 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     }
     if (fext) HIPCHK(c, hipMemcpyAsync(c->fext, fext, 8 * nd, hipMemcpyHostToDevice, c->stream));
     if (c->bc_nrows > 0)  // K w on the few rows where it can be non-zero
-        hipLaunchKernelGGL(k_spmv_rows, dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->bc_nrows,
-                           c->bc_rows, c->nnode, c->nslot, c->dcol, c->dval, (const double2 *)c->wv, (double2 *)c->kw);
+    {
+        if (matfree(c))
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_rows<1>), dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                               c->stream, c->bc_nrows, c->bc_rows, c->op, (const double2 *)c->wv, (double2 *)c->kw);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_rows<0>), dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                               c->stream, c->bc_nrows, c->bc_rows, c->op, (const double2 *)c->wv, (double2 *)c->kw);
+    }
     hipLaunchKernelGGL(k_bc_finish, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd,
                        fext ? c->fext : nullptr, c->kw, c->diag, c->is_presc, c->rhs, c->dinv);
     HIPCHK(c, hipGetLastError());
@@ -1619,11 +1749,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             double *pold = c->p[prev], *pnew = c->p[cur];
             EvPair *ev;
             tim_begin(c, 1, &ev);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<1>), dim3(gn), dim3(BLOCK), 0, c->stream, nn,
-                               multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
-                               c->nslot, c->dcol, c->dval, (const double2 *)pold, (const double2 *)c->z,
-                               (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn,
-                               P_pq, c->sc, it);
+            LAUNCH_OP2(k_spmv, 1, matfree(c), dim3(gn), c->op, multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
+                       (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev],
+                       P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
             tim_end(c, ev);
             if (multi) {
                 hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->own_n0,
@@ -1815,6 +1943,20 @@ int plfx_update_state(plfx_ctx *c)
                        (const double2 *)c->u, c->sig, c->epl, c->eps, c->elstiff, c->res_sig,
                        c->res_depl, c->nonlin ? 1 : 0);
     HIPCHK(c, hipGetLastError());
+    return PLFX_OK;
+}
+
+int plfx_matvec(plfx_ctx *c, const double *x, double *y)
+{
+    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
+    if (!x || !y) return fail(c, PLFX_ERR_ARG, "null argument");
+    const size_t nd = c->ndof;
+    // p[0] / q are free between solves (plfx_solve re-initialises both)
+    HIPCHK(c, hipMemcpyAsync(c->p[0], x, 8 * nd, hipMemcpyHostToDevice, c->stream));
+    int rc = plain_spmv(c, c->p[0], c->q);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(y, c->q, 8 * nd, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PLFX_OK;
 }
 

@@ -610,7 +610,130 @@ __device__ __forceinline__ double2 bell_apply(int nnode, int nslot, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Block-ELL SpMV, one thread per node (two rows).
+// Operator descriptor.  GRID = 0: assembled block-ELL matrix (any mesh).  GRID = 1: matrix-free on the structured
+// node grid (node id = j*nyn + k, element id = j*(nyn-1) + k, model.py:893/935): the row pair of node i is applied
+// straight from the stiffness generators M of its <= 4 elements (48 B/element instead of 288 + 36 B/node of matrix)
+// and one geometry table shared by all elements (plfx_set_grid requires a uniform element size).
+struct KOp {
+    int nnode, nslot;
+    const int32_t *col;
+    const double *val;
+    int nxn, nyn, nel;   // nodes per row / column, elements
+    const double *M;     // SoA [6][nel]: XX XY XS YY YS SS
+    const double *tab;   // [4 positions][4 b][sxx_ab, syy_ab, sxy_ab, sxy_ba]; position p = pj*2+pk <-> element (j-1+pj, k-1+pk)
+};
+
+// Row pair i of K times a vector given as a functor xf(node) -> double2, from the element generators.
+// With a = local number of node i in the element and u_b the vector at the element's node b:
+//   q_x += Mxx A1 + Mxs (A5+A7+A2) + Mss (A3+A8) + Mxy A6 + Mys A4
+//   q_y += Mxy A7 + Mys (A3+A8+A6) + Mxs A1 + Mss (A5+A2) + Myy A4
+// A1..A8 = sum_b {sxx,sxx,syy,syy,sxy,sxy,syx,syx}_ab * {ux,uy,...}_b   (the 2x2 blocks of k_assemble, regrouped)
+// Elements outside the grid enter with M = 0 (indices clamped, so every load is in range).
+template <class XF>
+__device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
+{
+    const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
+    const int j = i / nyn, k = i - j * nyn;
+    double2 u[3][3];
+#pragma unroll
+    for (int dj = 0; dj < 3; dj++) {
+        const int jj = min(max(j + dj - 1, 0), nxe);
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) {
+            const int kk = min(max(k + dk - 1, 0), nye);
+            u[dj][dk] = xf(jj * nyn + kk);
+        }
+    }
+    double m[4][6];
+#pragma unroll
+    for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            const int ej = j - 1 + pj, ek = k - 1 + pk;
+            const bool ok = ej >= 0 && ej < nxe && ek >= 0 && ek < nye;
+            const int e = min(max(ej, 0), nxe - 1) * nye + min(max(ek, 0), nye - 1);
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double v = g.M[(size_t)c * g.nel + e];
+                m[pj * 2 + pk][c] = ok ? v : 0.;
+            }
+        }
+    double qx = 0., qy = 0.;
+#pragma unroll
+    for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            const int p = pj * 2 + pk;
+            const double *T = g.tab + p * 16;  // wave-uniform -> scalar loads
+            double A1 = 0., A2 = 0., A3 = 0., A4 = 0., A5 = 0., A6 = 0., A7 = 0., A8 = 0.;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const double2 ub = u[pj + (b >> 1)][pk + (b & 1)];
+                const double sxx = T[b * 4 + 0], syy = T[b * 4 + 1], sxy = T[b * 4 + 2], syx = T[b * 4 + 3];
+                A1 = fma(sxx, ub.x, A1);
+                A2 = fma(sxx, ub.y, A2);
+                A3 = fma(syy, ub.x, A3);
+                A4 = fma(syy, ub.y, A4);
+                A5 = fma(sxy, ub.x, A5);
+                A6 = fma(sxy, ub.y, A6);
+                A7 = fma(syx, ub.x, A7);
+                A8 = fma(syx, ub.y, A8);
+            }
+            const double Mxx = m[p][0], Mxy = m[p][1], Mxs = m[p][2], Myy = m[p][3], Mys = m[p][4], Mss = m[p][5];
+            qx = fma(Mxx, A1, fma(Mxs, A5 + A7 + A2, fma(Mss, A3 + A8, fma(Mxy, A6, fma(Mys, A4, qx)))));
+            qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
+        }
+    return make_double2(qx, qy);
+}
+
+template <int GRID, class XF>
+__device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
+{
+    if (GRID) return grid_apply(o, i, xf);
+    return bell_apply(o.nnode, o.nslot, o.col, o.val, i, xf);
+}
+
+// diagonal of K on the structured grid from the generators (what k_assemble writes to diag for the block-ELL matrix).
+// Msnap != nullptr: g.M is the live generator array that the material sweep keeps updating; the operator must stay the
+// one of this moment (the reference's K = setupK() is a snapshot, model.py:1333, used until the next setupK even when
+// the last sweep of a load step changed tangents, :1384), so the generators are copied to Msnap on the way.
+__global__ void __launch_bounds__(BLOCK) k_grid_diag(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap)
+{
+    const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < g.nnode; i += gridDim.x * BLOCK) {
+        const int j = i / nyn, k = i - j * nyn;
+        double dx = 0., dy = 0.;
+#pragma unroll
+        for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+            for (int pk = 0; pk < 2; pk++) {
+                const int ej = j - 1 + pj, ek = k - 1 + pk;
+                if (ej < 0 || ej >= nxe || ek < 0 || ek >= nye) continue;
+                const size_t e = (size_t)ej * nye + ek;
+                const int a = (1 - pj) * 2 + (1 - pk);
+                const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
+                const double sxx = T[0], syy = T[1], sxy = T[2], syx = T[3];
+                const double Mxx = g.M[e], Mxy = g.M[(size_t)g.nel + e], Mxs = g.M[(size_t)2 * g.nel + e],
+                             Myy = g.M[(size_t)3 * g.nel + e], Mys = g.M[(size_t)4 * g.nel + e],
+                             Mss = g.M[(size_t)5 * g.nel + e];
+                dx += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
+                dy += Myy * syy + Mys * (syx + sxy) + Mss * sxx;
+                if (Msnap && pj == 1 && pk == 1) {  // node (j,k) copies "its" element (j,k)
+                    Msnap[e] = Mxx;
+                    Msnap[(size_t)g.nel + e] = Mxy;
+                    Msnap[(size_t)2 * g.nel + e] = Mxs;
+                    Msnap[(size_t)3 * g.nel + e] = Myy;
+                    Msnap[(size_t)4 * g.nel + e] = Mys;
+                    Msnap[(size_t)5 * g.nel + e] = Mss;
+                }
+            }
+        diag[i] = make_double2(dx, dy);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV, one thread per node (two rows); GRID selects the operator form (KOp).
+
 // MODE 0: q = K p                                   (plain; used for K w, K du, residual)
 // MODE 1: PCG step: beta = rz_new/rz_old from the partial sums of the previous update kernel,
 //         p_new = z + beta p_old (written to pnew), q = K p_new, partial sums of p_new . q.
@@ -621,9 +744,9 @@ struct CgScalars {
     double rr_final;
 };
 
-template <int MODE>
+template <int MODE, int GRID>
 __global__ void __launch_bounds__(BLOCK)
-k_spmv(int nnode, int n_begin, int n_end, int nslot, const int32_t *col, const double *val,
+k_spmv(KOp op, int n_begin, int n_end,
        const double2 *p, const double2 *z, double2 *pnew, double2 *q, const double *part_rz_new,
        const double *part_rz_old, const double *part_rr, int npart_prev, double *part_pq,
        CgScalars *sc, int it)
@@ -648,17 +771,18 @@ k_spmv(int nnode, int n_begin, int n_end, int nslot, const int32_t *col, const d
     double acc_pq = 0.;
     const int nb = gridDim.x;
     const int span = n_end - n_begin;
+    (void)op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < span; t += nb) {
         const int i = n_begin + t * BLOCK + threadIdx.x;
         if (i >= n_end) continue;
         double2 qv;
         if (MODE == 1)
-            qv = bell_apply(nnode, nslot, col, val, i, [&](int j) {
+            qv = op_apply<GRID>(op, i, [&](int j) {
                 const double2 zj = z[j], po = p[j];
                 return make_double2(fma(beta, po.x, zj.x), fma(beta, po.y, zj.y));
             });
         else
-            qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return p[j]; });
+            qv = op_apply<GRID>(op, i, [&](int j) { return p[j]; });
         const double qx = qv.x, qy = qv.y;
         q[i] = make_double2(qx, qy);
         if (MODE == 1) {
@@ -855,14 +979,15 @@ __global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, con
 
 // q[i] = (K w)[i] for the listed nodes only: w is non-zero on prescribed DOFs, so K w vanishes except on the
 // rows of nodes that touch a prescribed node (O(boundary) work instead of a full matrix pass)
+template <int GRID>
 __global__ void __launch_bounds__(BLOCK)
-k_spmv_rows(int nlist, const int32_t *__restrict__ list, int nnode, int nslot, const int32_t *__restrict__ col,
-            const double *__restrict__ val, const double2 *__restrict__ w, double2 *__restrict__ q)
+k_spmv_rows(int nlist, const int32_t *__restrict__ list, KOp op, const double2 *__restrict__ w,
+            double2 *__restrict__ q)
 {
     const int k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= nlist) return;
     const int i = list[k];
-    q[i] = bell_apply(nnode, nslot, col, val, i, [&](int j) { return w[j]; });
+    q[i] = op_apply<GRID>(op, i, [&](int j) { return w[j]; });
 }
 
 // rhs = fext - K w (q holds K w);  dinv = free ? 1/|diag| : 0

@@ -19,15 +19,15 @@ namespace plfx {
 // xout = xin + omega * dinv * (b - K xin)      (first != 0: xin == 0 -> xout = omega * dinv * b)
 // FINE = 1 instantiations run the finest grid only, so that profilers list the HBM-bound fine-level
 // launches (the dominant kernels of a load step) separately from the latency-bound coarse ones.
-template <int FINE>
+template <int FINE, int GRID>
 __global__ void __launch_bounds__(BLOCK)
-k_mg_smooth(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+k_mg_smooth(KOp op,
             const double2 *__restrict__ dinv, const double2 *__restrict__ b,
             const double2 *__restrict__ xin, double2 *__restrict__ xout, double omega, int first,
             const CgScalars *sc)
 {
     if (sc->done) return;  // PCG already converged: the remaining launches of the chunk are no-ops
-    const int nb = gridDim.x;
+    const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
         if (i >= nnode) continue;
@@ -36,7 +36,7 @@ k_mg_smooth(int nnode, int nslot, const int32_t *__restrict__ col, const double 
             xout[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
             continue;
         }
-        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return xin[j]; });
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) { return xin[j]; });
         const double qx = qv.x, qy = qv.y;
         const double2 xi = xin[i];
         xout[i] = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
@@ -45,18 +45,18 @@ k_mg_smooth(int nnode, int nslot, const int32_t *__restrict__ col, const double 
 
 // two damped-Jacobi sweeps from a zero guess in one pass:
 //   x1 = w D^-1 b ;  x2 = x1 + w D^-1 (b - K x1)   with x1 of the neighbours recomputed from (dinv, b)
-template <int FINE>
+template <int FINE, int GRID>
 __global__ void __launch_bounds__(BLOCK)
-k_mg_smooth2_zero(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+k_mg_smooth2_zero(KOp op,
                   const double2 *__restrict__ dinv, const double2 *__restrict__ b,
                   double2 *__restrict__ xout, double omega, const CgScalars *sc)
 {
     if (sc->done) return;
-    const int nb = gridDim.x;
+    const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
         if (i >= nnode) continue;
-        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) {
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) {
             const double2 dj = dinv[j], bj = b[j];
             return make_double2(omega * dj.x * bj.x, omega * dj.y * bj.y);
         });
@@ -68,18 +68,18 @@ k_mg_smooth2_zero(int nnode, int nslot, const int32_t *__restrict__ col, const d
 }
 
 // res = P_free (b - K x)
-template <int FINE>
+template <int FINE, int GRID>
 __global__ void __launch_bounds__(BLOCK)
-k_mg_residual(int nnode, int nslot, const int32_t *__restrict__ col, const double *__restrict__ val,
+k_mg_residual(KOp op,
               const double2 *__restrict__ dinv, const double2 *__restrict__ b,
               const double2 *__restrict__ x, double2 *__restrict__ res, const CgScalars *sc)
 {
     if (sc->done) return;
-    const int nb = gridDim.x;
+    const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
         if (i >= nnode) continue;
-        const double2 qv = bell_apply(nnode, nslot, col, val, i, [&](int j) { return x[j]; });
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) { return x[j]; });
         const double qx = qv.x, qy = qv.y;
         const double2 di = dinv[i], bi = b[i];
         res[i] = make_double2(di.x != 0. ? bi.x - qx : 0., di.y != 0. ? bi.y - qy : 0.);

@@ -176,6 +176,7 @@ class Model(object):
         # measured field error vs the reference's dense LU ~ 4 x cg_rtol (4e-10 here, north-star budget 1e-6)
         self.cg_maxit = 100000
         self.precond = None          # None: library default (multigrid when available), 0 Jacobi, 1 multigrid
+        self.operator = None         # None: library default (matrix-free on uniform structured grids), 0 assembled, 1 matrix-free
         self.solver_stats = []
         self.n_sweeps = 0            # material sweeps (K-iterations) executed so far
         self._engine = None
@@ -421,6 +422,8 @@ class Model(object):
         eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
         if self.precond is not None:
             eng.set_precond(self.precond)
+        if self.operator is not None:
+            eng.set_operator(self.operator)
         self._e0, self._e1 = e0, e1
         self._engine = eng
         self._mat_versions = vers
