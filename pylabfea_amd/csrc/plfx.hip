@@ -144,8 +144,11 @@ struct plfx_ctx {
     bool assembled = false, bc_set = false;
     std::vector<int32_t> bc_idx;  // prescribed DOFs of the last apply_bc (the device mask is reused when unchanged)
     bool bc_valid = false;
-    double *stage = nullptr;      // pinned host staging buffer
+    double *stage = nullptr;      // pinned host staging buffer, two halves used alternately
     size_t stage_cap = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};  // H2D copy out of half h has completed
+    bool stage_busy[2] = {false, false};
+    int stage_flip = 0;
     int32_t *bc_idx_dev = nullptr;  // device copy of bc_idx (idx_tmp is shared with plfx_gather)
     size_t bc_idx_cap = 0;
     int32_t *bc_rows = nullptr;     // nodes whose matrix rows touch a prescribed node (rows of K w that can be non-zero)
@@ -799,6 +802,8 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->idx_tmp);
     dfree(c->val_tmp);
     if (c->stage) hipHostFree(c->stage);
+    for (int h = 0; h < 2; h++)
+        if (c->stage_ev[h]) hipEventDestroy(c->stage_ev[h]);
     dfree(c->bc_idx_dev);
     dfree(c->bc_rows);
     dfree(c->kw);
@@ -1660,15 +1665,24 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     }
     if (n > 0) {
         if ((size_t)n > c->stage_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->stage) hipHostFree(c->stage);
             c->stage = nullptr;
-            HIPCHK(c, hipHostMalloc((void **)&c->stage, (size_t)16 * n));
+            HIPCHK(c, hipHostMalloc((void **)&c->stage, (size_t)32 * n));
             c->stage_cap = n;
+            c->stage_busy[0] = c->stage_busy[1] = false;
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // the previous contents of the staging buffer are consumed
-        memcpy(c->stage, du_presc, (size_t)8 * n);
-        memcpy(c->stage + n, w, (size_t)8 * n);
-        HIPCHK(c, hipMemcpyAsync(c->val_tmp, c->stage, (size_t)16 * n, hipMemcpyHostToDevice, c->stream));
+        // no stream-wide sync: only wait until the copy that last read this half has finished
+        const int h = c->stage_flip;
+        c->stage_flip ^= 1;
+        if (!c->stage_ev[h]) HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev[h], hipEventDisableTiming));
+        if (c->stage_busy[h]) HIPCHK(c, hipEventSynchronize(c->stage_ev[h]));
+        double *st = c->stage + (size_t)h * 2 * c->stage_cap;
+        memcpy(st, du_presc, (size_t)8 * n);
+        memcpy(st + n, w, (size_t)8 * n);
+        HIPCHK(c, hipMemcpyAsync(c->val_tmp, st, (size_t)16 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->stage_ev[h], c->stream));
+        c->stage_busy[h] = true;
         hipLaunchKernelGGL(k_scatter_bc, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->bc_idx_dev,
                            c->val_tmp, c->val_tmp + n, c->dup, c->wv, c->is_presc, same_set ? 0 : 1);
         HIPCHK(c, hipGetLastError());

@@ -455,76 +455,89 @@ class Model(object):
         return eng.get_csr()
 
     # ------------------------------------------------------------------ boundary conditions
+    def _bc_plan(self):
+        """Index structure of calc_BC (model.py:1070-1206): depends on the BC flags and node sets only, so it is built
+        once and reused by every solve.  Displacement segments in the reference's order left, bottom, right, top,
+        node set (x before y); force segments with the per-node share of the edge force."""
+        key = (tuple(self.ubcleft), tuple(self.ubcbot), tuple(self.ubcright), tuple(self.ubctop),
+               tuple(self.ubcn) if self.noset is not None else None,
+               None if self.noset is None else tuple(self.noset), self.Nnode)
+        st = self._bc_struct
+        if st is not None and st[0] == key:
+            return st[1]
+        dseg, fseg = [], []   # (source, k, dof indices[, shares])
+
+        def share(nodes, npart, pos, length):
+            hh = np.full(len(nodes), 1. / (npart - 1))   # share of the edge force per node
+            hp = self.npos[2 * nodes + pos]
+            hh[(hp < 1.e-3) | (hp > length - 1.e-3)] *= 0.5  # half on corner nodes
+            return hh
+
+        nl, nb = np.asarray(self.noleft, dtype=np.int64), np.asarray(self.nobot, dtype=np.int64)
+        nr, nt = np.asarray(self.noright, dtype=np.int64), np.asarray(self.notop, dtype=np.int64)
+        for k in range(2):
+            if self.ubcleft[k]:
+                dseg.append(('l', k, 2 * nl + k))
+        for k in range(2):
+            if self.ubcbot[k]:
+                dseg.append(('b', k, 2 * nb + k))
+        for k in range(2):
+            if self.ubcright[k]:
+                dseg.append(('r', k, 2 * nr + k))
+            else:
+                fseg.append(('r', k, 2 * nr + k, share(nr, self.NnodeY, 1, self.leny)))
+        for k in range(2):
+            if self.ubctop[k]:
+                dseg.append(('t', k, 2 * nt + k))
+            else:
+                fseg.append(('t', k, 2 * nt + k, share(nt, self.NnodeX, 0, self.lenx)))
+        if self.noset is not None:
+            ns = np.asarray(self.noset, dtype=np.int64)
+            for k in range(2):
+                if self.ubcn[k]:
+                    dseg.append(('n', k, 2 * ns + k))
+                else:
+                    fseg.append(('n', k, 2 * ns + k, np.ones(len(ns))))
+        plan = {'dseg': [(src, k) for src, k, _ in dseg], 'fseg': fseg}
+        if dseg:
+            idx = np.concatenate([d[2] for d in dseg])
+            plan['seg'] = np.concatenate([np.full(len(d[2]), i, dtype=np.intp) for i, d in enumerate(dseg)])
+            presc, first_pos, inv = np.unique(idx, return_index=True, return_inverse=True)
+            plan.update(idx=idx, presc=presc.astype(np.int32), first_pos=first_pos, inv=inv)
+            # pairs of entries on the same DOF (corner nodes): only these can be inconsistent
+            plan['dup'] = np.nonzero(first_pos[inv] != np.arange(len(idx)))[0]
+        self._bc_struct = (key, plan)
+        return plan
+
     def _bc_data(self, bcl0, bcb0, dbcr, dbct, dbcn):
         """calc_BC (model.py:1070-1206) as data, in O(boundary) work: prescribed DOFs (ascending),
         value written to du (first application), multiplicity-weighted value for the right-hand side
         (a DOF shared by two edges enters the rhs twice, :1115-1122, 1163-1170), external forces."""
-        idx_l, val_l = [], []
-        f_idx, f_val = [], []
-
-        def disp(nodes, k, val):
-            nodes = np.asarray(nodes, dtype=np.int64)
-            idx_l.append(2 * nodes + k)
-            val_l.append(np.full(len(nodes), float(val)))
-
-        def force(nodes, k, val, npart, pos, length):
-            nodes = np.asarray(nodes, dtype=np.int64)
-            hh = np.full(len(nodes), 1. / (npart - 1))   # share of the edge force per node
-            hp = self.npos[2 * nodes + pos]
-            hh[(hp < 1.e-3) | (hp > length - 1.e-3)] *= 0.5  # half on corner nodes
-            if val != 0.:
-                f_idx.append(2 * nodes + k)
-                f_val.append(val * hh)
-
-        for k in range(2):
-            if self.ubcleft[k]:
-                disp(self.noleft, k, bcl0[k])
-        for k in range(2):
-            if self.ubcbot[k]:
-                disp(self.nobot, k, bcb0[k])
-        for k in range(2):
-            if self.ubcright[k]:
-                disp(self.noright, k, dbcr[k])
-            else:
-                force(self.noright, k, dbcr[k], self.NnodeY, 1, self.leny)
-        for k in range(2):
-            if self.ubctop[k]:
-                disp(self.notop, k, dbct[k])
-            else:
-                force(self.notop, k, dbct[k], self.NnodeX, 0, self.lenx)
-        if self.noset is not None:
-            if dbcn is None:
-                raise ValueError('No BC for selected node set given.')
-            for k in range(2):
-                if self.ubcn[k]:
-                    disp(self.noset, k, dbcn[k])
-                elif dbcn[k] != 0.:
-                    nodes = np.asarray(self.noset, dtype=np.int64)
-                    f_idx.append(2 * nodes + k)
-                    f_val.append(np.full(len(nodes), float(dbcn[k])))
-        if idx_l:
-            val = np.concatenate(val_l)
-            # the index structure only depends on the BC flags: computed once, reused for every solve
-            key = (tuple(self.ubcleft), tuple(self.ubcbot), tuple(self.ubcright), tuple(self.ubctop),
-                   tuple(self.ubcn), None if self.noset is None else tuple(self.noset), len(val))
-            st = self._bc_struct
-            if st is None or st[0] != key:
-                idx = np.concatenate(idx_l)
-                presc, first_pos, inv = np.unique(idx, return_index=True, return_inverse=True)
-                st = self._bc_struct = (key, idx, presc.astype(np.int32), first_pos, inv)
-            _, idx, presc, first_pos, inv = st
+        if self.noset is not None and dbcn is None:
+            raise ValueError('No BC for selected node set given.')
+        plan = self._bc_plan()
+        src = {'l': bcl0, 'b': bcb0, 'r': dbcr, 't': dbct, 'n': dbcn}
+        if plan['dseg']:
+            val = np.array([float(src[s][k]) for s, k in plan['dseg']])[plan['seg']]
+            presc, first_pos, inv = plan['presc'], plan['first_pos'], plan['inv']
             first = val[first_pos]
             w = np.bincount(inv, weights=val, minlength=len(presc))
-            bad = val != first[inv]
-            if np.any(bad):
-                warnings.warn('Inconsistent BC at DOF {} ({} vs {}).'.format(idx[bad][0], first[inv][bad][0], val[bad][0]))
+            dup = plan['dup']
+            if len(dup):
+                bad = val[dup] != first[inv[dup]]
+                if np.any(bad):
+                    j = dup[bad][0]
+                    warnings.warn('Inconsistent BC at DOF {} ({} vs {}).'.format(plan['idx'][j], first[inv[j]], val[j]))
         else:
             presc = np.zeros(0, dtype=np.int32)
             first = w = np.zeros(0)
         fext = None
-        if f_idx:
-            fext = np.zeros(self.Ndof)
-            np.add.at(fext, np.concatenate(f_idx), np.concatenate(f_val))
+        for s, k, fidx, hh in plan['fseg']:
+            v = float(src[s][k])
+            if v != 0.:
+                if fext is None:
+                    fext = np.zeros(self.Ndof)
+                np.add.at(fext, fidx, v * hh)
         return presc, first, w, fext
 
     def free_dofs(self):

@@ -8,8 +8,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'plfx::(k_[a-z_0-9]+(<\d>)?)', name)
-    return m.group(1) if m else name[:40]
+    m = re.search(r'plfx::(k_[a-zA-Z_0-9]+(<[0-9, ]+>)?)', name)
+    return m.group(1).replace(' ', '') if m else name[:40]
 
 
 def main(d, out):
@@ -17,7 +17,7 @@ def main(d, out):
     rows = list(csv.DictReader(open('%s/trace/bench_kernel_stats.csv' % d)))
     lines.append('== rocprofv3 --kernel-trace --stats (per-kernel totals over the whole bench.py run) ==')
     lines.append('%-28s %8s %12s %12s %8s' % ('kernel', 'calls', 'avg_us', 'total_ms', 'pct'))
-    for r in rows:
+    for r in rows[:45]:
         lines.append('%-28s %8s %12.2f %12.3f %8.3f' % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3,
                                                         float(r['TotalDurationNs']) / 1e6, float(r['Percentage'])))
     # productive launches only (duration > 20 us filters the post-convergence no-op launches of the PCG kernels)
@@ -26,10 +26,12 @@ def main(d, out):
         dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     lines.append('')
     lines.append('== fine-level / productive launches only (coarse-level and post-convergence no-op launches filtered by duration) ==')
-    for k in ('k_mg_smooth<1>', 'k_mg_smooth2_zero<1>', 'k_mg_residual<1>', 'k_spmv<1>', 'k_cg_update', 'k_cg_update_mg',
-              'k_sweep_light<1>', 'k_sweep_heavy<1>', 'k_assemble', 'k_spmv<0>', 'k_mg_tail', 'k_mg_restrict',
-              'k_mg_prolong_add'):
-        v = [x for x in dur.get(k, []) if x > 20.]
+    FINE = ('k_mg_smooth<1,1>', 'k_mg_smooth2_zero<1,1>', 'k_mg_residual<1,1>', 'k_spmv<1,1>', 'k_spmv<0,1>',
+            'k_mg_smooth<1,0>', 'k_mg_smooth2_zero<1,0>', 'k_mg_residual<1,0>', 'k_spmv<1,0>', 'k_spmv<0,0>',
+            'k_cg_update', 'k_cg_update_mg', 'k_sweep_light<1>', 'k_sweep_heavy<1>', 'k_grid_diag', 'k_assemble',
+            'k_mg_tail_lds', 'k_update_state', 'k_scf_elements', 'k_axpy_uf')
+    for k in FINE:
+        v = [x for x in dur.get(k, []) if x > 15.]
         if v:
             v.sort()
             lines.append('%-28s n=%6d  avg %9.2f us  median %9.2f us  min %9.2f  max %9.2f' %
@@ -45,9 +47,8 @@ def main(d, out):
             continue
         lines.append('')
         lines.append('== rocprofv3 --pmc %s (raw counter, KiB per dispatch; productive dispatches only) ==' % cname)
-        for k in ('k_mg_smooth<1>', 'k_mg_smooth2_zero<1>', 'k_mg_residual<1>', 'k_spmv<1>', 'k_cg_update_mg', 'k_sweep_light<1>',
-                  'k_assemble', 'k_spmv<0>', 'k_axpy_uf', 'k_update_state'):
-            thr = 20000
+        for k in FINE:
+            thr = 15000
             v = [x[0] for x in acc.get(k, []) if x[1] > thr]
             if v:
                 lines.append('%-28s n=%6d  avg %14.1f KiB = %10.2f MB' % (k, len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6))
