@@ -175,6 +175,7 @@ struct plfx_ctx {
     int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
     int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
+    bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
     int gx = 0, gy = 0;          // structured grid (elements) if known
     int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
     double mg_omega = 0.65;  // damped Jacobi; lambda_max(D^-1 K) ~ 2.3 for Q4 elasticity (0.9 diverges)
@@ -618,14 +619,20 @@ int assemble_fine_val(plfx_ctx *c)
 // coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
 int mg_assemble(plfx_ctx *c)
 {
-    for (size_t l = 1; l < c->mg.size(); l++) {
+    const bool mf = matfree(c);
+    const int nl = (int)c->mg.size();
+    c->mg_dinv_current = mf && c->bc_valid;  // the matrix-free levels get their Jacobi scaling with the known Dirichlet mask
+    for (int l = 1; l < nl; l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
-        hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
-                           F.nel, (l == 1 && matfree(c)) ? c->Mop : F.Mel, L.Mel);
-        if (L.matfree && matfree(c))  // only the diagonal (Jacobi smoother) is needed
-            hipLaunchKernelGGL(k_grid_diag, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
-                               (double *)nullptr);
+        if (!(mf && F.matfree))  // otherwise the parent's setup kernel has already produced this level's generators
+            hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
+                               F.nel, F.Mel, L.Mel);
+        if (L.matfree && mf)  // only the diagonal (Jacobi smoother) is needed
+            hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
+                               (double *)nullptr, (l + 1 < nl) ? c->mg[l + 1].Mel : (double *)nullptr,
+                               (const double2 *)c->dinv, c->mg[0].ny + 1, l,
+                               c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr);
         else
             hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
                                L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
@@ -641,6 +648,7 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
     for (size_t l = 1; l < c->mg.size(); l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
+        if (same_set && c->mg_dinv_current && L.matfree && matfree(c)) continue;  // written by mg_assemble already
         hipLaunchKernelGGL(k_mg_coarse_dinv, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1,
                            L.ny + 1, F.ny + 1, (const double2 *)F.dinv, (const double2 *)L.diag,
                            (double2 *)L.dinv);
@@ -1253,7 +1261,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     std::vector<std::pair<int, int>> dims;
     dims.push_back({nx, ny});
     while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 &&
-           (long long)dims.back().first * dims.back().second > 16)
+           (long long)dims.back().first * dims.back().second > 4)
         dims.push_back({dims.back().first / 2, dims.back().second / 2});
     if (dims.size() < 2) return PLFX_OK;
     if ((long long)(dims.back().first + 1) * (dims.back().second + 1) > MG_COARSE_MAX) return PLFX_OK;
@@ -1554,9 +1562,10 @@ int plfx_assemble(plfx_ctx *c)
     tim_begin(c, 3, &ev);
     if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
         KOp live = c->op;
-        live.M = c->Mel;
-        hipLaunchKernelGGL(k_grid_diag, dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
-                           c->Mop);
+        live.M = c->Mel;  // diagonal + snapshot of the generators (+ generators of multigrid level 1) in one pass
+        hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+                           c->Mop, mg_active(c) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
+                           (double2 *)nullptr);
         c->val_valid = false;
     } else {
         int rc = assemble_fine_val(c);

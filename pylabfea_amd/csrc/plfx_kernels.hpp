@@ -693,16 +693,26 @@ __device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
     return bell_apply(o.nnode, o.nslot, o.col, o.val, i, xf);
 }
 
-// diagonal of K on the structured grid from the generators (what k_assemble writes to diag for the block-ELL matrix).
-// Msnap != nullptr: g.M is the live generator array that the material sweep keeps updating; the operator must stay the
-// one of this moment (the reference's K = setupK() is a snapshot, model.py:1333, used until the next setupK even when
-// the last sweep of a load step changed tangents, :1384), so the generators are copied to Msnap on the way.
-__global__ void __launch_bounds__(BLOCK) k_grid_diag(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap)
+// Everything the matrix-free operator of one grid level needs after the generators changed, in ONE pass over them
+// (node (j,k) reads its <= 4 elements):
+//   diag   diagonal of K (what k_assemble writes for the block-ELL matrix) -> Jacobi smoother / preconditioner
+//   Msnap  (finest level) copy of the generators: g.M is the live array that the material sweep keeps updating, but the
+//          operator must stay the one of this moment (the reference's K = setupK() is a snapshot, model.py:1333, used
+//          until the next setupK even when the last sweep of a load step changed tangents, :1384)
+//   Mc     generators of the next coarser level = mean of the four children (node (2J,2K) owns coarse element (J,K))
+//   dinv   (coarse levels, Dirichlet set known) free ? 1/|diag| : 0 with the mask of the coincident finest-grid node
+//          (node (j << shift, k << shift) of the grid with mask_nyn nodes per column)
+__global__ void __launch_bounds__(BLOCK)
+k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, double *__restrict__ Mc,
+             const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv)
 {
     const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
+    const int nyc = nye >> 1;
+    const size_t nel_c = (size_t)(nxe >> 1) * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < g.nnode; i += gridDim.x * BLOCK) {
         const int j = i / nyn, k = i - j * nyn;
         double dx = 0., dy = 0.;
+        double own[6] = {0., 0., 0., 0., 0., 0.};
 #pragma unroll
         for (int pj = 0; pj < 2; pj++)
 #pragma unroll
@@ -718,16 +728,31 @@ __global__ void __launch_bounds__(BLOCK) k_grid_diag(KOp g, double2 *__restrict_
                              Mss = g.M[(size_t)5 * g.nel + e];
                 dx += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
                 dy += Myy * syy + Mys * (syx + sxy) + Mss * sxx;
-                if (Msnap && pj == 1 && pk == 1) {  // node (j,k) copies "its" element (j,k)
-                    Msnap[e] = Mxx;
-                    Msnap[(size_t)g.nel + e] = Mxy;
-                    Msnap[(size_t)2 * g.nel + e] = Mxs;
-                    Msnap[(size_t)3 * g.nel + e] = Myy;
-                    Msnap[(size_t)4 * g.nel + e] = Mys;
-                    Msnap[(size_t)5 * g.nel + e] = Mss;
+                if (pj == 1 && pk == 1) {  // node (j,k) "owns" element (j,k)
+                    own[0] = Mxx; own[1] = Mxy; own[2] = Mxs; own[3] = Myy; own[4] = Mys; own[5] = Mss;
+                    if (Msnap) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) Msnap[(size_t)c * g.nel + e] = own[c];
+                    }
                 }
             }
         diag[i] = make_double2(dx, dy);
+        if (dinv) {
+            const double2 df = mask_dinv[(size_t)(j << shift) * mask_nyn + (k << shift)];
+            double2 o;
+            o.x = (df.x != 0.) ? (fabs(dx) > 1e-300 ? 1. / fabs(dx) : 1.) : 0.;
+            o.y = (df.y != 0.) ? (fabs(dy) > 1e-300 ? 1. / fabs(dy) : 1.) : 0.;
+            dinv[i] = o;
+        }
+        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {  // nxe, nye are even on levels that are coarsened
+            const size_t e00 = (size_t)j * nye + k, e10 = e00 + nye;
+            const size_t ec = (size_t)(j >> 1) * nyc + (k >> 1);
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double *m = g.M + (size_t)c * g.nel;
+                Mc[(size_t)c * nel_c + ec] = 0.25 * (own[c] + m[e00 + 1] + m[e10] + m[e10 + 1]);
+            }
+        }
     }
 }
 
