@@ -102,6 +102,10 @@ struct plfx_ctx {
     std::vector<double *> dsv;  // owned device copies of sv/dual
     bool has_svc = false, has_svc3 = false, has_analytic = false, has_elastic = false, has_princ = false;
     int svc_lds_need = 0;
+    int svc_wave_mat = -1;       // 6-feature SVC material run by the wave-per-element sweep kernels (-1: none)
+    int svc_wave_lds = 0;        // bytes of its SoA tables (7 x nsv padded to 64)
+    int n_svc6 = 0;              // number of 6-feature SVC materials
+    int want_svc_wave = 1;       // PLFX_SVC_WAVE
 
     // mesh
     int nel_total = 0, nnode = 0, ndof = 0, e0 = 0, nel = 0;  // nel = owned
@@ -776,6 +780,7 @@ int plfx_create(int device, plfx_ctx **out)
     HIPCHK(c, hipGetDeviceProperties(&c->prop, device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
+    if (const char *e3 = getenv("PLFX_SVC_WAVE")) c->want_svc_wave = atoi(e3) ? 1 : 0;
     // 160 KiB LDS per CU on gfx950; leave room for the static material/class tables
     size_t lds = std::max((size_t)c->prop.sharedMemPerBlock, (size_t)c->prop.maxSharedMemoryPerMultiProcessor);
     lds = std::min(lds, (size_t)160 * 1024);
@@ -849,6 +854,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     free_materials(c);
     c->has_svc = c->has_svc3 = c->has_analytic = c->has_elastic = c->has_princ = false;
     c->svc_lds_need = 0;
+    c->svc_wave_mat = -1;
+    c->svc_wave_lds = 0;
+    c->n_svc6 = 0;
     c->nonlin = false;
     c->hmat.resize(nmat);
     for (int k = 0; k < nmat; k++) {
@@ -911,6 +919,14 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             m.scale_seq = s.scale_seq;
             if (s.nsv * (nf + 1) <= c->lds_doubles) c->svc_lds_need = std::max(c->svc_lds_need, s.nsv * (nf + 1));
             if (s.kind == PLFX_SVC6) c->has_svc = true; else c->has_svc3 = true;
+            if (s.kind == PLFX_SVC6) {
+                c->n_svc6++;
+                const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
+                if (c->svc_wave_mat < 0 && c->want_svc_wave && 7 * npad <= c->lds_doubles) {
+                    c->svc_wave_mat = k;
+                    c->svc_wave_lds = 7 * npad * 8;
+                }
+            }
         }
     }
     c->nmat = nmat;
@@ -918,6 +934,10 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->svc_wave_mat >= 0) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_svc_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->svc_wave_lds));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_svc_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->svc_wave_lds));
+    }
     if (c->has_svc || c->has_svc3) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
         HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1869,40 +1889,56 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                         c->res_sig, c->res_depl, c->fyn, c->max_steps, nit, c->flags, c->heavy_list
     // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
     int first = 1;
+    const int wm = c->svc_wave_mat;  // this SVC material runs wave-per-element, the thread-per-element kernels skip it
+    const bool svc_thread = c->has_svc && (wm < 0 || c->n_svc6 > 1);
+    // one wave per element, one block per CU and round (the tables fill most of the LDS): 4 waves x 1024 blocks
+    const int grid_w = std::max(1, std::min((c->nel + 3) / 4, 1024));
+#define WAVE_ARGS c->dmat, c->nmat, c->dcls, c->ncls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,  \
+                  c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl, c->fyn,         \
+                  c->max_steps, nit, c->flags, c->heavy_list
     if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), first);
+                           SWEEP_ARGS(0), first, -1);
         first = 0;
     }
     if (c->has_princ) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), first);
+                           SWEEP_ARGS(0), first, -1);
         first = 0;
     }
-    if (c->has_svc) {
+    if (svc_thread) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, wm);
+        first = 0;
+    }
+    if (c->has_svc && wm >= 0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
+                           c->stream, WAVE_ARGS, first, wm);
         first = 0;
     }
     if (c->has_svc3) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1);
         first = 0;
     }
     // phase 2 reads the list length from the device; an empty list costs one empty launch
     if (c->has_analytic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0));
+                           SWEEP_ARGS(0), -1);
     if (c->has_princ)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0));
-    if (c->has_svc)
+                           SWEEP_ARGS(0), -1);
+    if (svc_thread)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), wm);
+    if (c->has_svc && wm >= 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1>), dim3(grid_w), dim3(256), (size_t)c->svc_wave_lds,
+                           c->stream, WAVE_ARGS, 0, wm);
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need));
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1);
 #undef SWEEP_ARGS
+#undef WAVE_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     {

@@ -19,6 +19,62 @@
 
 namespace plfx {
 
+extern __shared__ double dyn_lds[];
+
+// 2^y for the RBF kernel sums, y <= 0 (tiny positive round-off allowed); the callers fold log2(e) into -gamma.
+// n = rint(y), r = y - n exactly (|r| <= 0.5), 2^r by the degree-11 interpolating polynomial on Chebyshev nodes
+// (max relative error 2.2e-16 = 1 ulp, checked against 50-digit arithmetic), 2^n added to the exponent field.
+// Arguments below -1020 are clamped (2^-1020 ~ 1e-307: zero for any kernel sum); no overflow / NaN paths.
+// 17 instructions instead of the ~35 of the library exp().
+__device__ __forceinline__ double exp2_neg(double y)
+{
+    y = fmax(y, -1020.);
+    // n = rint(y) by the 1.5 * 2^52 trick: the low word of (y + magic) is n as a two's-complement integer, so neither
+    // v_rndne_f64 nor v_cvt_i32_f64 is needed
+    const double t = y + 6755399441055744.0;
+    const double n = t - 6755399441055744.0;
+    const double r = y - n;
+    const int ni = __double2loint(t);
+    double p = 4.4558179083360645e-10;
+    p = fma(p, r, 7.074194297288521e-09);
+    p = fma(p, r, 1.0178057087733941e-07);
+    p = fma(p, r, 1.3215432535912375e-06);
+    p = fma(p, r, 1.5252733841556773e-05);
+    p = fma(p, r, 0.00015403530463724353);
+    p = fma(p, r, 0.001333355814640647);
+    p = fma(p, r, 0.009618129107587256);
+    p = fma(p, r, 0.055504108664821625);
+    p = fma(p, r, 0.24022650695910158);
+    p = fma(p, r, 0.6931471805599453);
+    p = fma(p, r, 1.0);
+    return __hiloint2double(__double2hiint(p) + (ni << 20), __double2loint(p));
+}
+constexpr double LOG2E = 1.4426950408889634;
+
+// sum over the 64 lanes of a wave, result in every lane (and wave-uniform for the compiler: scalar branches).
+// Four DPP butterfly steps inside each row of 16 lanes (quad xor 1, xor 2, half-row mirror, row mirror: no LDS
+// crossbar), then the four row sums are read into scalar registers and added.  Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_allsum(double v)
+{
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 constexpr double YF_TOL = 5.e-3;       // basic.py:26
 constexpr double SPLIT_THRESHOLD = -0.15;  // material.py:260
 constexpr int MAXIT = 50;              // material.py:207
@@ -264,7 +320,7 @@ __device__ inline double svc_decision_x(const MatDev &m, const double *sv, const
 {
     double f = 0.;
     const int n = m.nsv;
-    const double g = -m.gamma;
+    const double g = -m.gamma * LOG2E;
     for (int k = 0; k < n; k++) {
         const double *v = sv + 6 * k;
         double hh = 0.;
@@ -273,7 +329,7 @@ __device__ inline double svc_decision_x(const MatDev &m, const double *sv, const
             double d = x[i] - v[i];
             hh = fma(d, d, hh);
         }
-        f = fma(dual[k], exp(g * hh), f);
+        f = fma(dual[k], exp2_neg(g * hh), f);
     }
     return f + m.intercept;
 }
@@ -292,7 +348,7 @@ __device__ inline void svc_fgrad(const MatDev &m, const double *sv, const double
     double x[6], acc[6] = {0., 0., 0., 0., 0., 0.};
     svc_features(m, s, x);
     const int n = m.nsv;
-    const double g = -m.gamma;
+    const double g = -m.gamma * LOG2E;
     for (int k = 0; k < n; k++) {
         const double *v = sv + 6 * k;
         double hv[6], hh = 0.;
@@ -301,7 +357,7 @@ __device__ inline void svc_fgrad(const MatDev &m, const double *sv, const double
             hv[i] = x[i] - v[i];
             hh = fma(hv[i], hv[i], hh);
         }
-        double w = dual[k] * exp(g * hh);
+        double w = dual[k] * exp2_neg(g * hh);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[i] = fma(w, hv[i], acc[i]);
     }
@@ -363,10 +419,10 @@ __device__ inline double svc3_decision(const MatDev &m, const double *sv, const 
     sig_princ_dev(s, sp);
     svc3_features(m, sp, x);
     double f = 0.;
-    const double g = -m.gamma;
+    const double g = -m.gamma * LOG2E;
     for (int k = 0; k < m.nsv; k++) {
         const double h0 = x[0] - sv[2 * k], h1 = x[1] - sv[2 * k + 1];
-        f = fma(dual[k], exp(g * fma(h0, h0, h1 * h1)), f);
+        f = fma(dual[k], exp2_neg(g * fma(h0, h0, h1 * h1)), f);
     }
     return f + m.intercept;
 }
@@ -378,10 +434,10 @@ __device__ inline void svc3_fgrad(const MatDev &m, const double *sv, const doubl
     sig_princ_dev(s, sp);
     svc3_features(m, sp, x);
     double dK1 = 0.;
-    const double g = -m.gamma;
+    const double g = -m.gamma * LOG2E;
     for (int k = 0; k < m.nsv; k++) {
         const double h0 = x[0] - sv[2 * k], h1 = x[1] - sv[2 * k + 1];
-        dK1 = fma(dual[k] * exp(g * fma(h0, h0, h1 * h1)), 2. * g * h1, dK1);
+        dK1 = fma(dual[k] * exp2_neg(g * fma(h0, h0, h1 * h1)), -2. * m.gamma * h1, dK1);
     }
     const double hyd = (sp[0] + sp[1] + sp[2]) / 3.;
     const double dev[3] = {sp[0] - hyd, sp[1] - hyd, sp[2] - hyd};
@@ -462,15 +518,131 @@ __device__ inline double brentq_dev(F f, double xa, double xb, double fa, double
 
 // Yield-function policy: RBF-SVC (ML_yf) on NF = 6 stress features (sdim 6) or NF = 2 (sdim 3).
 // calc_seq of an ML material is J2 (hill = ones), on Voigt or on principal stresses.
-template <int NF>
+// WAVE = NC > 0 (NF = 6): one wave works on ONE material point; every lane carries the same point (the scalar part of the
+// algorithm runs redundantly in lock-step, as cheap as running it once) and the support-vector sums are split over the
+// lanes: lane L takes the vectors L, L+64, ... from the SoA tables in dynamic LDS (stride-1 across lanes: conflict-free
+// ds_read_b64, no dependent flat loads), followed by one wave reduction.  npad = vectors padded to a multiple of 64 NC
+// with dual = 0.  Tables: v[6][npad] at dyn_lds[0], dual[npad] at dyn_lds[6*npad].
+template <int NF, int WAVE = 0>
 struct YfSvcT {
     const MatDev &m;
     const double *sv;
     const double *dual;
-    __device__ YfSvcT(const MatDev &mm, const double *s, const double *d) : m(mm), sv(s), dual(d) {}
+    int npad;
+    __device__ YfSvcT(const MatDev &mm, const double *s, const double *d, int np = 0) : m(mm), sv(s), dual(d), npad(np) {}
     __device__ __forceinline__ double seq(const double *s) const { return NF == 6 ? hill_seq(m, s) : princ_seq(m, s); }
+    // NC = WAVE support vectors per lane and trip (k, k + 64, ...): all 7 NC LDS reads are issued before the first use
+    // (the empty asm pins them: otherwise the scheduler re-uses one register pair and waits after every read), and the
+    // NC independent distance / exp chains give the one or two resident waves of a SIMD instruction-level parallelism.
+    // npad is a multiple of 64 NC.
+    static constexpr int NC = WAVE > 0 ? WAVE : 1;
+    // LDS reads of one trip: issued as a batch (the sched_barrier keeps the scheduler from sinking them to their uses) ...
+    __device__ __forceinline__ static void issue(int npad, int k, double (*v)[7])
+    {
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + 64 * c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ... and awaited together, one trip later (software pipeline: the reads of trip t+1 fly during the arithmetic of t)
+    __device__ __forceinline__ static void pin(double (*v)[7])
+    {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
+                         "+v"(v[c][6]));
+    }
+    // ping-pong over two register sets A, B; body(v) consumes one trip
+    template <class BODY>
+    __device__ __forceinline__ void for_trips(BODY body) const
+    {
+        const int S = 64 * NC;
+        int k = threadIdx.x & 63;
+        if (NC < 4) {  // two resident waves per SIMD already overlap each other's LDS latency: no second register set
+            for (; k < npad; k += S) {
+                double A[NC][7];
+                issue(npad, k, A);
+                pin(A);
+                body(A);
+            }
+            return;
+        }
+        double A[NC][7], B[NC][7];
+        issue(npad, k, A);
+        for (;;) {
+            const int kb = k + S;
+            const bool hasB = kb < npad;
+            if (hasB) issue(npad, kb, B);
+            pin(A);
+            body(A);
+            if (!hasB) break;
+            const int ka = kb + S;
+            const bool hasA = ka < npad;
+            if (hasA) issue(npad, ka, A);
+            pin(B);
+            body(B);
+            if (!hasA) break;
+            k = ka;
+        }
+    }
+    __device__ __forceinline__ double decision_wave(const double *s) const
+    {
+        double x[6];
+        svc_features(m, s, x);
+        const double g = -m.gamma * LOG2E;
+        double f[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) f[c] = 0.;
+        for_trips([&](double (*v)[7]) {
+            double h[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) h[c] = 0.;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const double d = x[i] - v[c][i];
+                    h[c] = fma(d, d, h[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < NC; c++) f[c] = fma(v[c][6], exp2_neg(g * h[c]), f[c]);
+        });
+        double t = f[0];
+#pragma unroll
+        for (int c = 1; c < NC; c++) t += f[c];
+        return wave_allsum(t) + m.intercept;
+    }
+    __device__ __forceinline__ void fgrad_wave(const double *s, double *a) const
+    {
+        double x[6], acc[6] = {0., 0., 0., 0., 0., 0.};
+        svc_features(m, s, x);
+        const double g = -m.gamma * LOG2E;
+        for_trips([&](double (*v)[7]) {
+            double h[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) h[c] = 0.;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    v[c][i] = x[i] - v[c][i];
+                    h[c] = fma(v[c][i], v[c][i], h[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const double w = v[c][6] * exp2_neg(g * h[c]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc[i] = fma(w, v[c][i], acc[i]);
+            }
+        });
+        const double sc = -2. * m.gamma / m.scale_seq;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = wave_allsum(acc[i]) * sc;
+    }
     __device__ __forceinline__ double decision(const double *s) const
     {
+        if (WAVE) return decision_wave(s);
         return NF == 6 ? svc_decision(m, sv, dual, s) : svc3_decision(m, sv, dual, s);
     }
     __device__ __forceinline__ double plain(const double *s, const double *epl) const
@@ -548,7 +720,9 @@ struct YfSvcT {
     }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const
     {
-        if (NF == 6)
+        if (WAVE)
+            fgrad_wave(s, a);
+        else if (NF == 6)
             svc_fgrad(m, sv, dual, s, a);
         else
             svc3_fgrad(m, sv, dual, s, a);
@@ -556,6 +730,8 @@ struct YfSvcT {
 };
 typedef YfSvcT<6> YfSvc;
 typedef YfSvcT<2> YfSvc3;
+template <int NC>
+using YfSvcWave = YfSvcT<6, NC>;
 
 // ---------------------------------------------------------------------------------------------
 // Material.response (material.py:207-346) for one point, in two phases so that the sweep can run

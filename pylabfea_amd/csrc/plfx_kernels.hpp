@@ -143,7 +143,6 @@ struct YfOf<6> {
 };
 
 
-extern __shared__ double dyn_lds[];
 
 // ---------------------------------------------------------------------------------------------
 // Material.response on n points, host-layout (AoS) arrays.
@@ -365,7 +364,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind)
+              int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind, int skip_mat)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
@@ -386,7 +385,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             const MatDev &m = tb.smat[c.mat];
             if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
                 if (first_kind) fyn[e] = 0.;
-            } else if (m.kind == KIND) {
+            } else if (m.kind == KIND && c.mat != skip_mat) {  // skip_mat: handled by the wave-per-element kernels
                 const size_t ge = (size_t)e + e_off;
                 double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
                 class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -428,7 +427,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, const int32_t *__restrict__ list)
+              int32_t *max_steps, int nit, int *flags, const int32_t *__restrict__ list, int skip_mat)
 {
     const int count = flags[2];
     if (count == 0) return;
@@ -446,7 +445,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         const int e = list[i];
         const ClassDev &c = tb.scls[cls[e]];
         const MatDev &m = tb.smat[c.mat];
-        if (m.kind != KIND) continue;
+        if (m.kind != KIND || c.mat == skip_mat) continue;
         const size_t ge = (size_t)e + e_off;
         double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
         class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -464,6 +463,77 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
     }
     if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
     if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-element variants of the two sweep phases for the 6-feature SVC material `wave_mat` (YfSvcWave): the
+// support-vector sums dominate an SVC update (1585 vectors x tens of yield-function evaluations), so one wave
+// works on one element and splits every sum over its lanes.  Lane 0 stores.  The 50-sub-step list is shared with
+// the thread-per-element kernels (flags[2]).
+__device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, int nc)
+{
+    const MatDev &m = smat[wave_mat];
+    const int n = m.nsv, npad = (n + 64 * nc - 1) / (64 * nc) * (64 * nc);
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) dyn_lds[c * npad + i] = (i < n) ? m.sv[6 * (size_t)i + c] : 0.;
+        dyn_lds[6 * npad + i] = (i < n) ? m.dual[i] : 0.;
+    }
+    return npad;
+}
+
+// HEAVY = 0: 512-thread blocks (8 waves share the LDS tables: 2 waves per SIMD, <= 256 VGPRs) with 2 vectors per lane
+// and trip; HEAVY = 1: 256-thread blocks (the sub-stepping loop needs > 256 VGPRs: 1 wave per SIMD) with 4.
+template <int HEAVY>
+__global__ void __launch_bounds__(HEAVY ? 256 : 512)
+k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
+                 int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
+                 const double2 *__restrict__ du2, const double *__restrict__ sig, const double *__restrict__ epl,
+                 double *elstiff, double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
+                 int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind, int wave_mat)
+{
+    const int count = HEAVY ? flags[2] : nel;
+    if (count == 0) return;
+    __shared__ SweepTables tb;
+    stage_tables(tb, gmat, nmat, gcls, ncls);
+    __syncthreads();
+    constexpr int NC = HEAVY ? 4 : 2;
+    const int npad = stage_svc_wave(tb.smat, wave_mat, NC);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int w = blockIdx.x * wpb + (threadIdx.x >> 6), nw = gridDim.x * wpb;
+    int changed = 0, nconv = 0;
+    for (int i = w; i < count; i += nw) {  // wave-uniform
+        const int e = HEAVY ? list[i] : i;
+        const ClassDev &c = tb.scls[cls[e]];
+        const MatDev &m = tb.smat[c.mat];
+        if (!HEAVY && m.kind == 0 && first_kind && lane == 0) fyn[e] = 0.;  // elastic: skipped by the reference
+        if (c.mat != wave_mat) continue;
+        const size_t ge = (size_t)e + e_off;
+        double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            s[k] = sig[(size_t)k * nel + e];
+            ep[k] = epl[(size_t)k * nel + e];
+        }
+        const YfSvcWave<NC> yf(m, nullptr, nullptr, npad);
+        const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+        if (HEAVY) {
+            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
+            if (lane == 0)
+                sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
+                               res_depl, fyn, max_steps, nit, changed, nconv);
+        } else if (st == 2) {
+            if (lane == 0) list[atomicAdd(&flags[2], 1)] = e;
+        } else if (lane == 0) {
+            sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, mel_stride, res_sig, res_depl, fyn,
+                           max_steps, nit, changed, nconv);
+        }
+    }
+    if (lane == 0 && changed) atomicOr(&flags[0], 1);
+    if (lane == 0 && nconv) atomicOr(&flags[1], 1);
 }
 
 // elstiff = CV, M from CV for all owned elements (model.py:1219-1221)
