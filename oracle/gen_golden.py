@@ -793,9 +793,39 @@ def gen_svc():
     print('svc done')
 
 
+# ----------------------------------------------------------------------------
+# 6. SVC parameter files in the reference's wire format (Material.export_MLparam, material.py:2130-2271)
+# ----------------------------------------------------------------------------
+def gen_mlparam():
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = os.path.join(OUT, 'mlparam')
+        os.makedirs(out, exist_ok=True)
+        rec = {}
+        for tag, dev_only in (('J2', False), ('J2dev', True)):
+            mat_J2 = FE.Material(name='J2-reference')
+            mat_J2.elasticity(E=200000., nu=0.3)
+            mat_J2.plasticity(sy=60., sdim=6)
+            ml = FE.Material('ML-%s_C15_G25' % tag)
+            ml.dev_only = dev_only
+            ml.train_SVC(C=15., gamma=2.5, mat_ref=mat_J2, Nlc=100, Nseq=12, Fe=0.1, Ce=0.99)
+            ml.export_MLparam('oracle/gen_golden.py', file='abq_' + ml.name, path=out)
+            rng = np.random.default_rng(3)
+            sig = rand_unit6(rng, 200) * (ml.sy * rng.uniform(0.3, 1.5, size=200))[:, None]
+            rec[tag + '_sig'] = sig
+            rec[tag + '_yf'] = ml.calc_yf(sig)
+            rec[tag + '_fgrad'] = ml.calc_fgrad(sig)
+            for k, v in svc_params(ml).items():
+                rec[tag + '_par_' + k] = v
+            rec[tag + '_C'] = np.array(float(ml.C_yf))
+            print('mlparam', tag, len(ml.svm_yf.support_vectors_), 'SVs')
+        np.savez_compressed(os.path.join(OUT, 'mlparam.npz'), **rec)
+    print('mlparam done')
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -809,6 +839,8 @@ def main():
         gen_solve()
     if 'svc' in todo:
         gen_svc()
+    if 'mlparam' in todo:
+        gen_mlparam()
 
 
 if __name__ == '__main__':

@@ -222,6 +222,129 @@ class Material(object):
                   dev_only=dev_only, C=getattr(svm, 'C', None))
         return m
 
+    # ------------------------------------------------------------------ SVC parameter files (reference wire format)
+    def export_MLparam(self, sname, source=None, file=None, path='../../models/', descr=None, param=None):
+        """Write the trained SVC in the reference's Abaqus-UMAT layout (material.py:2130-2271): ``file-svm.csv``
+        with 8 numbers per line -- header slots 0..28 (nsv, Ndof, C11, C12, C44, intercept, gamma, epc, scale_seq,
+        scale_wh, C22, C33, C13, C23, C55, C66, dev_only flag, Nset, scale_text), dual coefficients from slot 29,
+        then the support vectors row by row -- and ``file-svm_meta.json``."""
+        import getpass
+        import json
+        import platform
+        from datetime import date
+        if not self.ML_yf:
+            raise AttributeError('export_MLparam: No ML flow rule defined.')
+        if (descr is not None and param is not None) and len(descr) != len(param):
+            raise ValueError('Lists for descr and param must have the same lengths.')
+        if file is None:
+            file = 'abq_' + self.name
+        if path[-1] != '/':
+            path += '/'
+        file = path + file
+        dc = self.svc['dual']
+        sv = self.svc['sv']
+        nsv = len(dc)
+        ndof = sv.shape[1]
+        nlin = int((nsv * (ndof + 1) + 30) / 8) + 1
+        ndata = nlin * 8
+        props = np.zeros(ndata)
+        props[0] = nsv
+        props[1] = ndof
+        props[2] = self.C11
+        props[3] = self.C12
+        props[4] = self.C44
+        props[5] = self.svc['intercept']
+        props[6] = self.gam_yf
+        props[7] = 0.          # epc
+        props[8] = self.scale_seq
+        props[9] = 1.          # scale_wh
+        if self.CV is None:
+            props[10:16] = -1
+        else:
+            props[10] = self.CV[1, 1]
+            props[11] = self.CV[2, 2]
+            props[12] = self.CV[0, 2]
+            props[13] = self.CV[1, 2]
+            props[14] = self.CV[4, 4]
+            props[15] = self.CV[5, 5]
+        props[16] = -1. if self.dev_only else 0.
+        props[17] = 1          # Nset
+        props[18] = 1.         # scale_text
+        props[29:29 + nsv] = dc
+        nl = (ndof + 1) * nsv + 29
+        props[29 + nsv:nl] = sv.flatten()
+        np.savetxt(file + '-svm.csv', props.reshape((nlin, 8)), delimiter=', ', newline='\n')
+        descr = [] if descr is None else list(descr)
+        param = [] if param is None else list(param)
+        descr.extend(['Ndata', 'gamma', 'C'])
+        param.extend([ndata, self.gam_yf, self.C_yf])
+        sys_info = platform.uname()
+        from . import __version__ as vers
+        meta = {
+            'Info': {'Owner': getpass.getuser(), 'Institution': None, 'Date': str(date.today()),
+                     'Description': 'SVC-parameters for plasticity model', 'Method': 'Support Vector Classification',
+                     'System': {'sysname': sys_info[0], 'nodename': sys_info[1], 'release': sys_info[2],
+                                'version': sys_info[3], 'machine': sys_info[4]}},
+            'Model': {'Creator': 'pylabfea_amd', 'Version': vers, 'Repository': None, 'Input': source, 'Script': sname,
+                      'Names': descr, 'Parameters': param},
+            'Data': {'Class': 'SVC_parameters', 'Type': 'CSV', 'File': file + '-svm.csv', 'Separator': ',',
+                     'Header': None, 'Format': (nlin, 8),
+                     'Names': ['nsv', 'nsd', 'C11', 'C12', 'C44', 'rho', 'gamma', 'epc', 'scale_seq', 'scale_wh',
+                               'C22', 'C33', 'C13', 'C23', 'C55', 'C66', 'Nset', 'scale_text[0:Nset]',
+                               'dual_coef[0:nsv]', 'sup_vec[0:nsv,0:nsd]'],
+                     'Units': {'Stress': 'MPa', 'Strain': 'None', 'Disp': 'mm', 'Force': 'N'}}}
+        with open(file + '-svm_meta.json', 'w') as fp:
+            json.dump(meta, fp, indent=2)
+
+    def from_MLparam(self, name, path='../../models/'):
+        """Define the material from a parameter file written by ``export_MLparam`` (of stock pyLabFEA or of this
+        package): elastic constants, yield strength (= the stress scaling factor, ``scale_seq = sy`` at training,
+        material.py:1161) and the SVC yield function.  The reference declares this method but raises
+        ``ModuleNotFoundError`` (material.py:2688-2703); the layout read here is the one its ``export_MLparam``
+        writes and its Abaqus UMAT reads (examples/UMAT/ml_umat.f:129-151), including the rule
+        ``dev_only = props[16] < 0``.  Files with work-hardening or texture features (Ndof > 6) are refused."""
+        import json
+        if path and path[-1] != '/':
+            path += '/'
+        trunk = path + name
+        for suffix in ('-svm.csv', '.csv', ''):
+            if trunk.endswith(suffix) and suffix:
+                trunk = trunk[:-len(suffix)]
+                break
+        props = np.loadtxt(trunk + '-svm.csv', delimiter=',').ravel()
+        nsv, ndof = int(round(props[0])), int(round(props[1]))
+        if nsv < 1 or 29 + nsv * (ndof + 1) > len(props):
+            raise ValueError('from_MLparam: inconsistent header (nsv={}, Ndof={}, {} numbers)'.format(nsv, ndof, len(props)))
+        if ndof not in (2, 6):
+            raise NotImplementedError('from_MLparam: {} features (work-hardening / texture descriptors) are not '
+                                      'supported; only the 6 stress features or the 2 features of sdim=3'.format(ndof))
+        C11, C12, C44 = props[2], props[3], props[4]
+        if np.all(props[10:16] == -1.):
+            self.elasticity(C11=C11, C12=C12, C44=C44)
+        else:
+            CV = np.zeros((6, 6))
+            CV[0, 0], CV[1, 1], CV[2, 2] = C11, props[10], props[11]
+            CV[0, 1] = CV[1, 0] = C12
+            CV[0, 2] = CV[2, 0] = props[12]
+            CV[1, 2] = CV[2, 1] = props[13]
+            CV[3, 3], CV[4, 4], CV[5, 5] = C44, props[14], props[15]
+            self.elasticity(CV=CV)
+        scale_seq = float(props[8])
+        self.plasticity(sy=scale_seq, sdim=6 if ndof == 6 else 3)
+        C = None
+        try:
+            with open(trunk + '-svm_meta.json') as fp:
+                meta = json.load(fp)
+            names, par = meta['Model']['Names'], meta['Model']['Parameters']
+            if 'C' in names:
+                C = par[names.index('C')]
+        except (IOError, OSError, KeyError, ValueError):
+            pass
+        dual = props[29:29 + nsv]
+        sv = props[29 + nsv:29 + nsv * (ndof + 1)].reshape(nsv, ndof)
+        self.set_svc(sv, dual, props[5], props[6], scale_seq, dev_only=bool(props[16] < 0.), C=C)
+        return self
+
     # ------------------------------------------------------------------ records for libplfx
     def _record(self, CV, ana=False):
         """plfx_material record of this material with the element matrix CV."""

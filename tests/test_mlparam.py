@@ -1,0 +1,81 @@
+"""SVC parameter files in the reference's wire format (Material.export_MLparam, material.py:2130-2271; read by the
+Abaqus UMAT examples/UMAT/ml_umat.f:129-151).  Fixtures tests/golden/mlparam/* were written by the reference's own
+export_MLparam (oracle/gen_golden.py:gen_mlparam); tests/golden/mlparam.npz holds the trained parameters and
+calc_yf / calc_fgrad of the same materials."""
+import filecmp
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mlparam.npz'))
+
+
+@pytest.mark.parametrize('tag', ['J2', 'J2dev'])
+def test_from_mlparam_reads_reference_file(gold, golden_dir, tag):
+    import pylabfea_amd as FE
+    m = FE.Material(name='loaded')
+    m.from_MLparam('abq_ML-%s_C15_G25' % tag, path=os.path.join(golden_dir, 'mlparam'))
+    assert m.ML_yf and m.sdim == 6 and m.Ndof == 6
+    assert np.array_equal(m.svc['sv'], gold[tag + '_par_sv'])
+    assert np.array_equal(m.svc['dual'], gold[tag + '_par_dual'])
+    assert m.svc['intercept'] == float(gold[tag + '_par_intercept'])
+    assert m.gam_yf == float(gold[tag + '_par_gamma'])
+    assert m.scale_seq == float(gold[tag + '_par_scale_seq']) == m.sy == float(gold[tag + '_par_sy'])
+    assert m.dev_only == bool(gold[tag + '_par_dev_only'])
+    assert m.C_yf == float(gold[tag + '_C'])
+    assert np.allclose(m.CV, gold[tag + '_par_CV'], rtol=1e-15, atol=0.)
+    assert abs(m.E - float(gold[tag + '_par_E'])) < 1e-9 * m.E and abs(m.nu - float(gold[tag + '_par_nu'])) < 1e-12
+
+
+@pytest.mark.parametrize('tag', ['J2', 'J2dev'])
+def test_export_mlparam_is_byte_identical(gold, golden_dir, tmp_path, tag):
+    """read the reference's file, write it again: same bytes in the CSV, same data description in the JSON"""
+    import pylabfea_amd as FE
+    src = os.path.join(golden_dir, 'mlparam')
+    m = FE.Material(name='ML-%s_C15_G25' % tag)
+    m.from_MLparam('abq_ML-%s_C15_G25' % tag, path=src)
+    m.export_MLparam('tests/test_mlparam.py', path=str(tmp_path))
+    f = 'abq_ML-%s_C15_G25-svm.csv' % tag
+    assert filecmp.cmp(os.path.join(src, f), str(tmp_path / f), shallow=False)
+    a = json.load(open(os.path.join(src, f.replace('.csv', '_meta.json'))))
+    b = json.load(open(str(tmp_path / f.replace('.csv', '_meta.json'))))
+    assert a['Data']['Format'] == b['Data']['Format'] and a['Data']['Names'] == b['Data']['Names']
+    assert a['Model']['Names'] == b['Model']['Names'] and a['Model']['Parameters'] == b['Model']['Parameters']
+
+
+def test_mlparam_errors(tmp_path):
+    import pylabfea_amd as FE
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    m.plasticity(sy=60., sdim=6)
+    with pytest.raises(AttributeError):
+        m.export_MLparam('x', path=str(tmp_path))   # no ML flow rule (material.py:2166-2167)
+    props = np.zeros(128)
+    props[0], props[1] = 3, 15                       # 15 features = work-hardening descriptors
+    np.savetxt(str(tmp_path / 'wh-svm.csv'), props.reshape(16, 8), delimiter=', ')
+    with pytest.raises(NotImplementedError):
+        FE.Material().from_MLparam('wh', path=str(tmp_path))
+    props[0] = 500                                   # more vectors than the file holds
+    props[1] = 6
+    np.savetxt(str(tmp_path / 'bad-svm.csv'), props.reshape(16, 8), delimiter=', ')
+    with pytest.raises(ValueError):
+        FE.Material().from_MLparam('bad', path=str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['J2', 'J2dev'])
+def test_loaded_material_on_gpu(gold, golden_dir, tag):
+    """yield function and gradient of the loaded material against the reference's values"""
+    import pylabfea_amd as FE
+    m = FE.Material(name='loaded')
+    m.from_MLparam('abq_ML-%s_C15_G25' % tag, path=os.path.join(golden_dir, 'mlparam'))
+    sig = gold[tag + '_sig']
+    yf = m.calc_yf(sig)
+    assert np.max(np.abs(yf - gold[tag + '_yf'])) < 1e-10 * np.max(np.abs(gold[tag + '_yf']))
+    a = m.calc_fgrad(sig)
+    assert np.max(np.abs(a - gold[tag + '_fgrad'])) < 1e-10 * np.max(np.abs(gold[tag + '_fgrad']))
