@@ -1747,7 +1747,12 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     const int gn = c->grid_nodes;
     double *P_pq = c->part, *P_rz[2] = {c->part + MAXPART, c->part + 2 * MAXPART},
            *P_rr[2] = {c->part + 3 * MAXPART, c->part + 4 * MAXPART}, *P_bb = c->part + 5 * MAXPART;
-    const bool multi = c->comm != nullptr;  // sharded run: all-reduce of the global vector per CG step
+    // Sharded run with the assembled operator: every rank applies its own rows, one all-reduce of the global vector per
+    // CG step.  With the matrix-free operator every rank holds all generators and a full K p costs ~50 us at 1024^2 --
+    // several times less than all-reducing 16.8 MB over xGMI -- so the product is computed redundantly and the solve has
+    // no collective at all (PLFX_SHARD_SPMV=1 restores the sharded rows + all-reduce).
+    static const bool force_shard_spmv = getenv("PLFX_SHARD_SPMV") && atoi(getenv("PLFX_SHARD_SPMV")) != 0;
+    const bool multi = c->comm != nullptr && (!matfree(c) || force_shard_spmv);
     // x0
     hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
     int rc = 0;
