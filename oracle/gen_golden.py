@@ -823,9 +823,27 @@ def gen_mlparam():
     print('mlparam done')
 
 
+# ----------------------------------------------------------------------------
+# 7. basic.py helpers of SURVEY row 16 (sig_princ axis tracking, polar angle, Stress / Strain)
+# ----------------------------------------------------------------------------
+def gen_basic():
+    rng = np.random.default_rng(0)
+    s = rng.normal(size=(500, 6)) * 100
+    s[:100, 3:5] = 0
+    s[100:150, 3:] = 0
+    sp, ev = FE.sig_princ(s)
+    e = rng.normal(size=6) * 1e-3
+    e[4] = 0
+    a = FE.Stress(s[7])
+    np.savez_compressed(os.path.join(OUT, 'basic.npz'), sig=s, princ=sp, evec=ev, polar=FE.sig_polar_ang(s),
+                        polar_p=FE.sig_polar_ang(sp), eps=e, eeq=FE.Strain(e).eeq(), einv=FE.Strain(e).inv(),
+                        seq7=a.seq(), h7=a.h, d7=a.d, theta7=a.theta())
+    print('basic done')
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -841,6 +859,8 @@ def main():
         gen_svc()
     if 'mlparam' in todo:
         gen_mlparam()
+    if 'basic' in todo:
+        gen_basic()
 
 
 if __name__ == '__main__':

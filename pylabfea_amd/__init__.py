@@ -5,9 +5,10 @@ the per-element return mapping, the B^T D B assembly and the linear solve run as
 HIP kernels (gfx950) in ``libplfx.so`` behind the reference's own ``Model`` / ``Material`` API.
 See DESIGN.md for the scope table and INTEGRATION.md for the C-ABI.
 """
-from .basic import eps_eq, sig_dev, sig_eq_j2, yf_tolerance
+from .basic import Strain, Stress, eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, sig_princ, yf_tolerance
 from .material import Material
 from .model import Model
 
 __version__ = '0.1.0'
-__all__ = ['Material', 'Model', 'eps_eq', 'sig_dev', 'sig_eq_j2', 'yf_tolerance']
+__all__ = ['Material', 'Model', 'Stress', 'Strain', 'eps_eq', 'sig_dev', 'sig_eq_j2', 'sig_polar_ang', 'sig_princ',
+           'yf_tolerance']
