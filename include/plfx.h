@@ -153,6 +153,14 @@ int plfx_get_csr(plfx_ctx *ctx, int64_t *nnz, int32_t *rowptr, int32_t *colidx, 
  * fext[ndof] consistent nodal forces (or NULL).  Builds rhs = P (fext - K w) and the free mask. */
 int plfx_apply_bc(plfx_ctx *ctx, int n, const int32_t *presc_idx, const double *du_presc,
                   const double *w, const double *fext);
+/* calc_BC's index structure registered once (it only depends on the BC flags, model.py:1070-1206): nseg segments of
+ * prescribed DOFs in the reference's order (left, bottom, right, top, node set; x before y), seg_len[nseg] entries each,
+ * idx = their DOF numbers concatenated.  plfx_apply_bc_plan then takes ONE value per segment and forms, exactly like
+ * plfx_apply_bc fed by the host: the ascending unique DOF set, the value written to du (first occurrence) and the
+ * multiplicity-weighted right-hand-side value (a DOF shared by two edges is applied twice, :1115-1122).
+ * inconsistent_entry: first entry whose value differs from the first one on its DOF (the reference's warning), -1 if none. */
+int plfx_set_bc_plan(plfx_ctx *ctx, int nseg, const int32_t *seg_len, const int32_t *idx);
+int plfx_apply_bc_plan(plfx_ctx *ctx, const double *seg_val, const double *fext, int *inconsistent_entry);
 /* Kred + np.linalg.solve (model.py:1028-1033, 1291, 1335) as Jacobi-PCG on the free DOFs.
  * warm != 0 starts from the previous du on the free DOFs.  Result in du (state 8). */
 int plfx_solve(plfx_ctx *ctx, double rtol, int maxit, int warm, int *iters, double *relres);
@@ -166,8 +174,14 @@ int plfx_sweep(plfx_ctx *ctx, int nit, int *changed, int *conv);
  * sld[6] loading direction for SVC materials. */
 int plfx_scf_stats(plfx_ctx *ctx, const double *sld, double *sum, double *sumsq_c, double *minv,
                    int64_t *count, double mean_in, int pass);
+/* both passes of calc_scf's statistics in one call (single GPU: the mean of pass 0 stays on the device) */
+int plfx_scf_all(plfx_ctx *ctx, const double *sld, int64_t *count, double *minv, double *sum, double *sumsq_c);
 /* end-of-load-step update (model.py:1383-1392): u += du, f += K du, sig/epl/eps update */
 int plfx_update_state(plfx_ctx *ctx);
+/* End of a load step in one call and one host synchronisation: plfx_update_state, then u and f at the registered DOFs
+ * (the boundary nodes calc_global averages, model.py:1452-1471) and the 18 element sums of plfx_global_sums. */
+int plfx_set_finish_set(plfx_ctx *ctx, int n, const int32_t *idx);
+int plfx_finish_step(plfx_ctx *ctx, double *u_at /* [n] */, double *f_at /* [n] */, double *sums18);
 /* calc_global element sums (model.py:1500-1511): out[18] = sum(sig*Vel), sum(eps*Vel), sum(epl*Vel) */
 int plfx_global_sums(plfx_ctx *ctx, double *out18);
 

@@ -45,7 +45,8 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
+    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all',
 ]
 
 _lib = None
@@ -322,6 +323,31 @@ class Context(object):
         fx = None if fext is None else _f64(fext)
         self._chk(self.lib.plfx_apply_bc(self.h, len(idx), _dp(idx), _dp(du_presc), _dp(w), _dp(fx)))
 
+    def set_bc_plan(self, seg_len, idx):
+        seg_len = _i32(seg_len)
+        idx = _i32(idx)
+        self._chk(self.lib.plfx_set_bc_plan(self.h, len(seg_len), _dp(seg_len), _dp(idx)))
+        self._plan_nseg = len(seg_len)
+
+    def apply_bc_plan(self, seg_val, fext=None):
+        seg_val = _f64(seg_val)
+        if len(seg_val) != self._plan_nseg:
+            raise ValueError('apply_bc_plan: one value per registered segment expected')
+        fx = None if fext is None else _f64(fext)
+        bad = C.c_int(-1)
+        self._chk(self.lib.plfx_apply_bc_plan(self.h, _dp(seg_val), _dp(fx), C.byref(bad)))
+        return bad.value
+
+    def set_finish_set(self, idx):
+        idx = _i32(idx)
+        self._chk(self.lib.plfx_set_finish_set(self.h, len(idx), _dp(idx)))
+        self._fin = (np.empty(len(idx)), np.empty(len(idx)), np.empty(18))
+
+    def finish_step(self):
+        uu, ff, sums = self._fin
+        self._chk(self.lib.plfx_finish_step(self.h, _dp(uu), _dp(ff), _dp(sums)))
+        return uu, ff, sums.reshape(3, 6)
+
     def solve(self, rtol=1e-12, maxit=100000, warm=False):
         it = C.c_int()
         rr = C.c_double()
@@ -344,6 +370,16 @@ class Context(object):
         self._chk(self.lib.plfx_scf_stats(self.h, _dp(sld), C.byref(s), None, C.byref(mn), C.byref(cnt),
                                           C.c_double(0.), 0))
         return cnt.value, mn.value, s.value
+
+    def scf_all(self, sld):
+        """(count, min, sum, centred sum of squares) of the calc_scf list in one call"""
+        sld = _f64(sld).reshape(6)
+        s = C.c_double()
+        s2 = C.c_double()
+        mn = C.c_double()
+        cnt = C.c_int64()
+        self._chk(self.lib.plfx_scf_all(self.h, _dp(sld), C.byref(cnt), C.byref(mn), C.byref(s), C.byref(s2)))
+        return cnt.value, mn.value, s.value, s2.value
 
     def scf_sumsq(self, mean):
         s2 = C.c_double()

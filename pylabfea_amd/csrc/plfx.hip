@@ -159,6 +159,21 @@ struct plfx_ctx {
     int bc_nrows = 0;
     double *kw = nullptr;           // K w, zero outside bc_rows
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
+    // registered boundary-condition plan (plfx_set_bc_plan): calc_BC's index structure, fixed for a load history
+    struct BcPlan {
+        int nseg = 0;
+        std::vector<int32_t> seg_of;    // segment of every entry (reference order)
+        std::vector<int32_t> presc;     // ascending unique prescribed DOFs
+        std::vector<int32_t> first_pos; // entry that writes du for presc[k] (first occurrence)
+        std::vector<int32_t> inv;       // entry -> position in presc
+        std::vector<double> first, w;   // scratch
+        bool valid = false;
+    } plan;
+    // registered DOF set of plfx_finish_step (boundary nodes of calc_global)
+    int32_t *fin_idx = nullptr;
+    int fin_n = 0;
+    double *fin_dev = nullptr;      // [2 n + 18] gathered u, f and the 18 element sums
+    double *fin_host = nullptr;     // pinned mirror
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int grid_nodes = 0, grid_el = 0;
 
@@ -530,6 +545,10 @@ void free_mesh(plfx_ctx *c)
     c->assembled = c->bc_set = false;
     c->bc_valid = false;
     c->bc_idx.clear();
+    c->plan.valid = false;
+    dfree(c->fin_idx);
+    dfree(c->fin_dev);
+    c->fin_n = 0;
     dfree(c->kw);
     dfree(c->bc_rows);
     c->bc_nrows = 0;
@@ -820,6 +839,9 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->bc_idx_dev);
     dfree(c->bc_rows);
     dfree(c->kw);
+    dfree(c->fin_idx);
+    dfree(c->fin_dev);
+    if (c->fin_host) hipHostFree(c->fin_host);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1738,6 +1760,109 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     return PLFX_OK;
 }
 
+int plfx_set_bc_plan(plfx_ctx *c, int nseg, const int32_t *seg_len, const int32_t *idx)
+{
+    if (!c || !c->u) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (nseg < 0 || (nseg > 0 && (!seg_len || !idx))) return fail(c, PLFX_ERR_ARG, "bad argument");
+    auto &P = c->plan;
+    P.valid = false;
+    P.nseg = nseg;
+    P.seg_of.clear();
+    std::vector<int32_t> all;
+    for (int s2 = 0, o = 0; s2 < nseg; s2++) {
+        if (seg_len[s2] < 0) return fail(c, PLFX_ERR_ARG, "negative segment length");
+        for (int k = 0; k < seg_len[s2]; k++, o++) {
+            if (idx[o] < 0 || idx[o] >= c->ndof) return fail(c, PLFX_ERR_ARG, "plan index %d out of range", o);
+            all.push_back(idx[o]);
+            P.seg_of.push_back(s2);
+        }
+    }
+    // ascending unique DOFs, first occurrence and inverse map (what numpy.unique(return_index, return_inverse) gives)
+    const int n = (int)all.size();
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return all[a2] < all[b2]; });
+    P.presc.clear();
+    P.first_pos.clear();
+    P.inv.assign(n, 0);
+    for (int q2 = 0; q2 < n; q2++) {
+        const int i = order[q2];
+        if (q2 == 0 || all[i] != all[order[q2 - 1]]) {
+            P.presc.push_back(all[i]);
+            P.first_pos.push_back(i);  // stable sort: the first entry of a run is the first occurrence
+        }
+        P.inv[i] = (int32_t)P.presc.size() - 1;
+    }
+    P.first.assign(P.presc.size(), 0.);
+    P.w.assign(P.presc.size(), 0.);
+    P.valid = true;
+    return PLFX_OK;
+}
+
+int plfx_apply_bc_plan(plfx_ctx *c, const double *seg_val, const double *fext, int *inconsistent_entry)
+{
+    if (!c || !c->plan.valid) return c ? fail(c, PLFX_ERR_STATE, "set_bc_plan first") : PLFX_ERR_STATE;
+    auto &P = c->plan;
+    if (P.nseg > 0 && !seg_val) return fail(c, PLFX_ERR_ARG, "segment values required");
+    const int n = (int)P.seg_of.size(), np = (int)P.presc.size();
+    for (int k = 0; k < np; k++) {
+        P.first[k] = seg_val[P.seg_of[P.first_pos[k]]];
+        P.w[k] = 0.;
+    }
+    int bad = -1;
+    for (int i = 0; i < n; i++) {  // multiplicity-weighted value (a DOF on two edges enters the rhs twice, model.py:1115-1122)
+        const double v = seg_val[P.seg_of[i]];
+        P.w[P.inv[i]] += v;
+        if (bad < 0 && v != P.first[P.inv[i]]) bad = i;
+    }
+    if (inconsistent_entry) *inconsistent_entry = bad;
+    return plfx_apply_bc(c, np, P.presc.data(), P.first.data(), P.w.data(), fext);
+}
+
+int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)
+{
+    if (!c || !c->u) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (n < 0 || (n > 0 && !idx)) return fail(c, PLFX_ERR_ARG, "bad argument");
+    for (int k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "idx[%d] out of range", k);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c->fin_idx);
+    dfree(c->fin_dev);
+    if (c->fin_host) hipHostFree(c->fin_host);
+    c->fin_host = nullptr;
+    int rc;
+    if ((rc = dalloc(c, &c->fin_idx, (size_t)std::max(n, 1)))) return rc;
+    if ((rc = dalloc(c, &c->fin_dev, (size_t)2 * n + 18))) return rc;
+    HIPCHK(c, hipHostMalloc((void **)&c->fin_host, ((size_t)2 * n + 18) * 8));
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->fin_idx, idx, (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fin_n = n;
+    return PLFX_OK;
+}
+
+int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
+{
+    if (!c || !c->fin_dev) return c ? fail(c, PLFX_ERR_STATE, "set_finish_set first") : PLFX_ERR_STATE;
+    int rc = plfx_update_state(c);
+    if (rc) return rc;
+    const int n = c->fin_n;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, c->fin_dev);
+        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, c->fin_dev + n);
+    }
+    const int g = grid_for(c->nel, 256);
+    hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
+                       c->sig, c->eps, c->epl, c->part_g);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->fin_host, c->fin_dev, ((size_t)2 * n + 18) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (u_at && n > 0) memcpy(u_at, c->fin_host, (size_t)8 * n);
+    if (f_at && n > 0) memcpy(f_at, c->fin_host + n, (size_t)8 * n);
+    if (sums18) memcpy(sums18, c->fin_host + 2 * (size_t)n, 18 * 8);
+    return PLFX_OK;
+}
+
 int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
 {
     if (!c || !c->bc_set) return c ? fail(c, PLFX_ERR_STATE, "apply_bc first") : PLFX_ERR_STATE;
@@ -1992,6 +2117,34 @@ int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c,
     } else if (sumsq_c) {
         *sumsq_c = s;
     }
+    return PLFX_OK;
+}
+
+int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, double *sum, double *sumsq_c)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (!sld) return fail(c, PLFX_ERR_ARG, "sld required");
+    const int g = grid_for(c->nel, 256);
+    HIPCHK(c, hipMemcpyAsync(c->small + 32, sld, 48, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                       c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
+                       c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
+                       c->small + 32, c->scf_hh, c->scf_mult);
+    hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
+                       c->part_g, (const double *)nullptr);
+    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 0, c->small + 40);
+    // second pass with the mean taken from device memory: no host round trip between the passes
+    hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 1,
+                       c->part_g, (const double *)(c->small + 43));
+    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 1, c->small + 40);
+    HIPCHK(c, hipGetLastError());
+    double h[5];
+    HIPCHK(c, hipMemcpyAsync(h, c->small + 40, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sum) *sum = h[0];
+    if (count) *count = (int64_t)(h[1] + 0.5);
+    if (minv) *minv = h[2];
+    if (sumsq_c) *sumsq_c = h[4];
     return PLFX_OK;
 }
 

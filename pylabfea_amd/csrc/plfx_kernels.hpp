@@ -1264,10 +1264,11 @@ k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int
 // pass 0: sum(mult*hh), min(hh | mult>0), count ; pass 1: sum(mult*(hh-mean)^2)
 __global__ void __launch_bounds__(BLOCK)
 k_scf_reduce(int nel, const double *hh, const int32_t *mult, double mean, int pass,
-             double *part /* [3][gridDim.x] */)
+             double *part /* [3][gridDim.x] */, const double *mean_dev = nullptr)
 {
     __shared__ double sh[BLOCK / 64];
     __shared__ double shmin[BLOCK / 64];
+    if (mean_dev) mean = *mean_dev;
     double s = 0., cnt = 0., mn = 1.e300;
     for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
         const int m = mult[e];
@@ -1294,6 +1295,27 @@ k_scf_reduce(int nel, const double *hh, const int32_t *mult, double mean, int pa
         part[blockIdx.x] = ts;
         part[gridDim.x + blockIdx.x] = tc;
         part[2 * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// final sums of the k_scf_reduce partials in block order by one thread (the order the host loop uses):
+// pass 0 -> out[0..3] = sum, count, min, mean;  pass 1 -> out[4] = centred sum of squares
+__global__ void k_scf_finish(const double *part, int g, int pass, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0., cnt = 0., mn = 1.e300;
+    for (int b = 0; b < g; b++) {
+        s += part[b];
+        cnt += part[g + b];
+        mn = fmin(mn, part[2 * g + b]);
+    }
+    if (pass == 0) {
+        out[0] = s;
+        out[1] = cnt;
+        out[2] = mn;
+        out[3] = cnt > 0. ? s / (double)(long long)(cnt + 0.5) : 0.;
+    } else {
+        out[4] = s;
     }
 }
 

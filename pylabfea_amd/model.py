@@ -183,6 +183,7 @@ class Model(object):
         self._cache = {}
         self._bnd_idx = None
         self._bc_struct = None
+        self._bc_registered = None
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -364,6 +365,7 @@ class Model(object):
         self.element = _ElementList(self, self.Nel)
         self._bnd_idx = None
         self._bc_struct = None
+        self._bc_registered = None
         self._drop_engine()
 
     # ------------------------------------------------------------------ engine plumbing
@@ -548,8 +550,40 @@ class Model(object):
         mask[presc] = False
         return np.nonzero(mask)[0]
 
+    def _bc_register(self, eng):
+        """hand calc_BC's index structure to the library once per solve(); later calls pass one value per segment"""
+        plan = self._bc_plan()
+        if self._bc_registered is not plan:
+            if plan['dseg']:
+                segs = np.bincount(plan['seg'], minlength=len(plan['dseg']))
+                eng.set_bc_plan(segs, plan['idx'])
+            else:
+                eng.set_bc_plan(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))
+            self._bc_registered = plan
+        return plan
+
+    def _bc_apply(self, eng, bcl0, bcb0, dbcr, dbct, dbcn):
+        """calc_BC (model.py:1070-1206) through the registered plan: segment values and (rarely) external forces"""
+        if self.noset is not None and dbcn is None:
+            raise ValueError('No BC for selected node set given.')
+        plan = self._bc_register(eng)
+        src = {'l': bcl0, 'b': bcb0, 'r': dbcr, 't': dbct, 'n': dbcn}
+        vals = [float(src[s][k]) for s, k in plan['dseg']]
+        fext = None
+        for s, k, fidx, hh in plan['fseg']:
+            v = float(src[s][k])
+            if v != 0.:
+                if fext is None:
+                    fext = np.zeros(self.Ndof)
+                np.add.at(fext, fidx, v * hh)
+        bad = eng.apply_bc_plan(vals, fext)
+        if bad >= 0:
+            j = bad
+            first = vals[plan['seg'][plan['first_pos'][plan['inv'][j]]]]
+            warnings.warn('Inconsistent BC at DOF {} ({} vs {}).'.format(plan['idx'][j], first, vals[plan['seg'][j]]))
+
     def _solve_lin(self, eng, bc, warm):
-        eng.apply_bc(*bc)
+        self._bc_apply(eng, *bc)
         it, rr, ok = eng.solve(self.cg_rtol, self.cg_maxit, warm)
         self.solver_stats.append((it, rr))
         if not ok:
@@ -557,15 +591,18 @@ class Model(object):
 
     def _calc_scf(self, eng, sld):
         """Load-step scaling factor (model.py:1036-1067) from per-element values reduced on the GPU."""
-        cnt, mn, s = eng.scf_stats(sld)
-        if self._shard is not None:
+        if self._shard is None:
+            cnt, mn, s, s2 = eng.scf_all(sld)
+            if cnt == 0:
+                return 1.
+            mean = s / cnt
+        else:  # the mean is global: one collective between the two passes
+            cnt, mn, s = eng.scf_stats(sld)
             cnt, mn, s = self._allreduce_scf(cnt, mn, s)
-        if cnt == 0:
-            return 1.
-        mean = s / cnt
-        s2 = eng.scf_sumsq(mean)
-        if self._shard is not None:
-            s2 = self._allreduce_sum(s2)
+            if cnt == 0:
+                return 1.
+            mean = s / cnt
+            s2 = self._allreduce_sum(eng.scf_sumsq(mean))
         std = np.sqrt(s2 / cnt)
         if std < 0.1:
             scf = mn
@@ -634,6 +671,9 @@ class Model(object):
             first_call = False
         bcl0 = self.bcl
         bcb0 = self.bcb
+        sgl, egl, epgl = list(self.sgl), list(self.egl), list(self.epgl)
+        self._bc_registered = None
+        self._finish_register(eng)
         eng.assemble()
         # loading direction for the ML yield-point search (model.py:1245-1258)
         sld = np.zeros(6)
@@ -671,7 +711,7 @@ class Model(object):
                     max_dbcn /= np.maximum(1, min_step - il)
                 dbcn = max_dbcn  # alias, exactly as in the reference (model.py:1285)
             # elastic predictor with the stiffness of the previous step (model.py:1290-1291)
-            self._solve_lin(eng, self._bc_data(bcl0, bcb0, dbcr, dbct, dbcn), warm)
+            self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), warm)
             warm = True
             if self.nonlin:
                 scale_bc = self._calc_scf(eng, sld) if il < 10 else 1.
@@ -704,7 +744,7 @@ class Model(object):
                                     hh = np.maximum(self.bcn[k] - bcn0[k], dbcn[k] * hs)
                                     dbcn[k] = np.minimum(0.05 * max_dbcn[k], hh)
                     eng.assemble()  # updated tangent stiffness (model.py:1333)
-                    self._solve_lin(eng, self._bc_data(bcl0, bcb0, dbcr, dbct, dbcn), True)
+                    self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), True)
                     change, conv = eng.sweep(nit)  # material response of every element (model.py:1340-1361)
                     self.n_sweeps += 1
                     if self._shard is not None:
@@ -721,7 +761,7 @@ class Model(object):
                         nconv += 1
                     nit += 1
             # update internal variables with the results of the load step (model.py:1383-1392)
-            eng.update_state()
+            fin = eng.finish_step()  # update_state + boundary u, f + element sums: one call, one synchronisation
             il += 1
             niter.append(nit - 1)
             co_nconv.append(nconv)
@@ -736,10 +776,11 @@ class Model(object):
                 hr0 = hr0 or (np.abs(bcn0[0] - self.bcn[0]) > 1.e-6 and np.abs(self.bcn[0]) > 1.e-9)
                 hr1 = hr1 or (np.abs(bcn0[1] - self.bcn[1]) > 1.e-6 and np.abs(self.bcn[1]) > 1.e-9)
             bc_inc = bool(hr0 or hr1 or hl0 or hl1)
-            self._calc_global_device(eng)
-            self.sgl = np.append(self.sgl, [self.glob['sig']], axis=0)
-            self.egl = np.append(self.egl, [self.glob['eps']], axis=0)
-            self.epgl = np.append(self.epgl, [self.glob['epl']], axis=0)
+            self._calc_global_device(eng, fin)
+            sgl.append(self.glob['sig'])
+            egl.append(self.glob['eps'])
+            epgl.append(self.glob['epl'])
+            self.sgl, self.egl, self.epgl = np.array(sgl), np.array(egl), np.array(epgl)
             if self._step_hook is not None:
                 self._step_hook(il)
             if self._max_load_steps is not None and il >= self._max_load_steps:
@@ -787,8 +828,7 @@ class Model(object):
         g['eps'] = sums[1] / Vm
         g['epl'] = sums[2] / Vm
 
-    def _calc_global_device(self, eng):
-        """calc_global during solve: boundary DOFs gathered from HBM, element sums reduced on the GPU."""
+    def _finish_register(self, eng):
         sets = (self.noleft, self.noright, self.nobot, self.notop)
         if self._bnd_idx is None:
             parts = []
@@ -796,8 +836,18 @@ class Model(object):
                 idx = 2 * np.asarray(nodes, dtype=np.int64)
                 parts.extend((idx, idx + 1))
             self._bnd_idx = np.concatenate(parts)
-        uu = eng.gather(_lib.ST_U, self._bnd_idx)
-        ff = eng.gather(_lib.ST_F, self._bnd_idx)
+        eng.set_finish_set(self._bnd_idx)
+
+    def _calc_global_device(self, eng, fin=None):
+        """calc_global during solve: boundary DOFs gathered from HBM, element sums reduced on the GPU."""
+        sets = (self.noleft, self.noright, self.nobot, self.notop)
+        if fin is None:
+            self._finish_register(eng)
+            uu = eng.gather(_lib.ST_U, self._bnd_idx)
+            ff = eng.gather(_lib.ST_F, self._bnd_idx)
+            sums = eng.global_sums()
+        else:
+            uu, ff, sums = fin
         bv = []
         o = 0
         for nodes in sets:
@@ -805,7 +855,6 @@ class Model(object):
             bv.append((np.sum(uu[o:o + n]) / n, np.sum(uu[o + n:o + 2 * n]) / n,
                        np.sum(ff[o:o + n]), np.sum(ff[o + n:o + 2 * n])))
             o += 2 * n
-        sums = eng.global_sums()
         if self._shard is not None:
             sums = self._allreduce_sum(sums.ravel()).reshape(3, 6)
         self._glob_from(bv, sums)

@@ -29,7 +29,8 @@ def wrap(name):
     setattr(_lib.Context, name, g)
 
 
-for name in ('assemble', 'apply_bc', 'solve', 'sweep', 'scf_stats', 'scf_sumsq', 'update_state', 'gather', 'global_sums'):
+for name in ('assemble', 'apply_bc', 'apply_bc_plan', 'solve', 'sweep', 'scf_all', 'scf_stats', 'scf_sumsq', 'update_state',
+             'finish_step', 'gather', 'global_sums', 'state_get'):
     wrap(name)
 fe = bench.tension_model(FE, bench.hill_material(FE), n, 0.005, device=0)
 eng = fe._ensure_engine()
