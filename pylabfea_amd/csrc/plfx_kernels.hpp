@@ -898,7 +898,7 @@ k_spmv(KOp op, int n_begin, int n_end,
 // partial sums of p.q over all nodes (multi-GPU: after the all-reduce of q), and the p update for
 // nodes outside the rank's own SpMV range
 __global__ void __launch_bounds__(BLOCK)
-k_dot_pq(int nnode, const double2 *p, const double2 *q, double *part_pq, const CgScalars *sc)
+k_dot_pq(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q, double *__restrict__ part_pq, const CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
@@ -913,9 +913,9 @@ k_dot_pq(int nnode, const double2 *p, const double2 *q, double *part_pq, const C
 
 // p_new = z + beta p_old for nodes outside [n_begin, n_end) (multi-GPU only)
 __global__ void __launch_bounds__(BLOCK)
-k_p_update_outside(int nnode, int n_begin, int n_end, const double2 *p, const double2 *z,
-                   double2 *pnew, double2 *q, const double *part_rz_new, const double *part_rz_old,
-                   const double *part_rr, int npart_prev, const CgScalars *sc)
+k_p_update_outside(int nnode, int n_begin, int n_end, const double2 *__restrict__ p, const double2 *__restrict__ z,
+                   double2 *__restrict__ pnew, double2 *__restrict__ q, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
+                   const double *__restrict__ part_rr, int npart_prev, const CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
@@ -934,10 +934,10 @@ k_p_update_outside(int nnode, int n_begin, int n_end, const double2 *p, const do
 
 // alpha = rz/pq;  x += alpha p;  r -= alpha q (free DOFs only);  z = dinv r;  partials r.z, r.r
 __global__ void __launch_bounds__(BLOCK)
-k_cg_update(int nnode, const double2 *p, const double2 *q, const double2 *dinv, double2 *x,
-            double2 *r, double2 *z, const double *part_pq, int npart_pq, const double *part_rz,
-            const double *part_rr_prev, int npart_prev, double *part_rz_out, double *part_rr_out,
-            CgScalars *sc)
+k_cg_update(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q, const double2 *__restrict__ dinv, double2 *__restrict__ x,
+            double2 *__restrict__ r, double2 *__restrict__ z, const double *__restrict__ part_pq, int npart_pq, const double *__restrict__ part_rz,
+            const double *__restrict__ part_rr_prev, int npart_prev, double *__restrict__ part_rz_out, double *__restrict__ part_rr_out,
+            CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
@@ -977,8 +977,8 @@ k_cg_update(int nnode, const double2 *p, const double2 *q, const double2 *dinv, 
 
 // r = mask (b - q), z = dinv r, partial r.z, r.r   (initial residual; q = K x0)
 __global__ void __launch_bounds__(BLOCK)
-k_cg_init(int nnode, const double2 *b, const double2 *q, const double2 *dinv, double2 *r, double2 *z,
-          double *part_rz_out, double *part_rr_out, double *part_bb_out)
+k_cg_init(int nnode, const double2 *__restrict__ b, const double2 *__restrict__ q, const double2 *__restrict__ dinv, double2 *__restrict__ r, double2 *__restrict__ z,
+          double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, double *__restrict__ part_bb_out)
 {
     __shared__ double sh[BLOCK / 64];
     double a_rz = 0., a_rr = 0., a_bb = 0.;
@@ -1087,8 +1087,8 @@ k_spmv_rows(int nlist, const int32_t *__restrict__ list, KOp op, const double2 *
 
 // rhs = fext - K w (q holds K w);  dinv = free ? 1/|diag| : 0
 __global__ void __launch_bounds__(BLOCK)
-k_bc_finish(size_t ndof, const double *fext, const double *kw, const double *diag,
-            const double *is_presc, double *rhs, double *dinv)
+k_bc_finish(size_t ndof, const double *__restrict__ fext, const double *__restrict__ kw, const double *__restrict__ diag,
+            const double *__restrict__ is_presc, double *__restrict__ rhs, double *__restrict__ dinv)
 {
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
         const bool free_dof = (is_presc[i] == 0.);
@@ -1100,7 +1100,7 @@ k_bc_finish(size_t ndof, const double *fext, const double *kw, const double *dia
 
 // du = x (free) + du_presc (prescribed)
 __global__ void __launch_bounds__(BLOCK)
-k_compose_du(size_t ndof, const double *x, const double *dup, const double *is_presc, double *du)
+k_compose_du(size_t ndof, const double *__restrict__ x, const double *__restrict__ dup, const double *__restrict__ is_presc, double *__restrict__ du)
 {
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
         du[i] = (is_presc[i] != 0.) ? dup[i] : x[i];
@@ -1108,7 +1108,7 @@ k_compose_du(size_t ndof, const double *x, const double *dup, const double *is_p
 
 // x0 = warm ? du on free DOFs : 0
 __global__ void __launch_bounds__(BLOCK)
-k_x0(size_t ndof, const double *du, const double *is_presc, int warm, double scale, double *x)
+k_x0(size_t ndof, const double *__restrict__ du, const double *__restrict__ is_presc, int warm, double scale, double *__restrict__ x)
 {
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
         x[i] = (warm && is_presc[i] == 0.) ? scale * du[i] : 0.;
@@ -1116,7 +1116,7 @@ k_x0(size_t ndof, const double *du, const double *is_presc, int warm, double sca
 
 // u += du ; f += q  (q = K du)     (model.py:1383-1384)
 __global__ void __launch_bounds__(BLOCK)
-k_axpy_uf(size_t ndof, const double *du, const double *q, double *u, double *f)
+k_axpy_uf(size_t ndof, const double *__restrict__ du, const double *__restrict__ q, double *__restrict__ u, double *__restrict__ f)
 {
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
         u[i] += du[i];
@@ -1126,9 +1126,9 @@ k_axpy_uf(size_t ndof, const double *du, const double *q, double *u, double *f)
 
 // element state update at the end of a load step (model.py:1385-1392); u already updated
 __global__ void __launch_bounds__(BLOCK)
-k_update_state(const MatDev *gmat, const ClassDev *gcls, int nel, int e_off, const int32_t *conn,
-               const int32_t *cls, const double2 *du2, const double2 *u2, double *sig, double *epl,
-               double *eps, const double *elstiff, const double *res_sig, const double *res_depl,
+k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcls, int nel, int e_off, const int32_t *__restrict__ conn,
+               const int32_t *__restrict__ cls, const double2 *__restrict__ du2, const double2 *__restrict__ u2, double *__restrict__ sig, double *__restrict__ epl,
+               double *__restrict__ eps, const double *__restrict__ elstiff, const double *__restrict__ res_sig, const double *__restrict__ res_depl,
                int nonlin)
 {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
@@ -1160,8 +1160,8 @@ k_update_state(const MatDev *gmat, const ClassDev *gcls, int nel, int e_off, con
 
 // calc_global sums (model.py:1500-1507): partials of sum(x*Vel) for the 18 components
 __global__ void __launch_bounds__(BLOCK)
-k_global_partials(const ClassDev *gcls, int nel, const int32_t *cls, const double *sig,
-                  const double *eps, const double *epl, double *part /* [18][gridDim.x] */)
+k_global_partials(const ClassDev *__restrict__ gcls, int nel, const int32_t *__restrict__ cls, const double *__restrict__ sig,
+                  const double *__restrict__ eps, const double *__restrict__ epl, double *__restrict__ part /* [18][gridDim.x] */)
 {
     __shared__ double sh[BLOCK / 64];
     double acc[18];
@@ -1194,10 +1194,10 @@ __global__ void k_reduce_rows(const double *part, int nrows, int npart, double *
 
 // calc_scf per element (model.py:1036-1054): hh value and multiplicity (0, 1 or 2 appends)
 __global__ void __launch_bounds__(BLOCK)
-k_scf_elements(const MatDev *gmat, int nmat, const ClassDev *gcls, int ncls, int lds_doubles, int nel,
-               int e_off, const int32_t *conn, const int32_t *cls, const double2 *du2,
-               const double *sig, const double *epl, const double *elstiff, const double *sld,
-               double *hh_out, int32_t *mult_out)
+k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls, int lds_doubles, int nel,
+               int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
+               const double *__restrict__ sig, const double *__restrict__ epl, const double *__restrict__ elstiff, const double *__restrict__ sld,
+               double *__restrict__ hh_out, int32_t *__restrict__ mult_out)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);

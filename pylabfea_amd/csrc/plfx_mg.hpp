@@ -675,9 +675,9 @@ k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double om
 // PCG update without the Jacobi z (the V-cycle computes z): x += alpha p; r -= alpha q; partial r.r
 __global__ void __launch_bounds__(BLOCK)
 k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q,
-               const double2 *__restrict__ dinv, double2 *x, double2 *r, const double *part_pq,
-               int npart_pq, const double *part_rz, int npart_prev, double *part_rr_out,
-               CgScalars *sc)
+               const double2 *__restrict__ dinv, double2 *__restrict__ x, double2 *__restrict__ r, const double *__restrict__ part_pq,
+               int npart_pq, const double *__restrict__ part_rz, int npart_prev, double *__restrict__ part_rr_out,
+               CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;

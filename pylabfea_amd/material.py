@@ -438,6 +438,18 @@ class Material(object):
             self.msg['yield_fct'] = 'analytical'
         return f[0] if single else f
 
+    def find_yloc(self, x, su, epl=None, **kw):
+        """Yield function at ``sig = x[:, None] * su`` for N unit stresses at once (material.py:518-545): the objective
+        that the reference's training / plotting scripts hand to ``scipy.optimize.fsolve`` to trace yield loci
+        (``plot_yield_locus`` :3017, ``calc_yf`` on (N, sdim) grids); one batched GPU evaluation per call."""
+        x = np.asarray(x, dtype=float)
+        su = np.asarray(su, dtype=float)
+        return self.calc_yf(x[:, None] * su, epl=epl)
+
+    def find_yloc_scalar(self, x, su, epl=None, **kw):
+        """scalar form of `find_yloc` (material.py:547-574): ``calc_yf(x * su)``"""
+        return self.calc_yf(float(x) * np.asarray(su, dtype=float), epl=epl)
+
     def ML_full_yf(self, sig, epl=None, ld=None, verb=True, **kw):
         """Distance of a stress to the ML yield locus along its ray / the loading direction
         (material.py:414-516).  Accepts a single stress like the reference, or (N,6)."""
