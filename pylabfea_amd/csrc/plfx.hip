@@ -195,6 +195,9 @@ struct plfx_ctx {
     int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
+    hipGraph_t mg_graph = nullptr;         // captured launches of the V-cycle's coarse levels
+    hipGraphExec_t mg_graph_exec = nullptr;
+    int want_mg_graph = 1;                 // PLFX_MG_GRAPH
     int gx = 0, gy = 0;          // structured grid (elements) if known
     int precond = 1;             // 0 = Jacobi, 1 = multigrid when available
     double mg_omega = 0.65;  // damped Jacobi; lambda_max(D^-1 K) ~ 2.3 for Q4 elasticity (0.9 diverges)
@@ -479,8 +482,11 @@ bool build_pattern(int nnode, const int32_t *conn, int el_begin, int el_end, std
     return true;
 }
 
+void mg_graph_drop(plfx_ctx *c);
+
 void free_mesh(plfx_ctx *c)
 {
+    mg_graph_drop(c);
     dfree(c->dcls);
     dfree(c->dconn);
     dfree(c->dcls_id);
@@ -688,56 +694,85 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
 }
 
 // z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r)
-int mg_vcycle(plfx_ctx *c)
+// one level of the down leg: nu pre-smoothing sweeps from a zero guess, residual, restriction to level l+1
+int mg_down_level(plfx_ctx *c, int l)
+{
+    const double om = c->mg_omega;
+    auto &L = c->mg[l];
+    auto &C = c->mg[l + 1];
+    const bool mf = L.matfree && matfree(c);
+    const int nu = c->mg_nu;
+    EvPair *ev = nullptr;
+    if (nu == 2) {  // both sweeps in one pass over the operator
+        if (l == 0) tim_begin(c, 5, &ev);
+        if (l == 0)
+            LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (double2 *)L.x, om, c->sc);
+        else
+            LAUNCH_OP2(k_mg_smooth2_zero, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (double2 *)L.x, om, c->sc);
+        if (l == 0) tim_end(c, ev);
+    } else {
+        double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
+        for (int k = 0; k < nu; k++) {
+            if (l == 0)
+                LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                           (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
+            else
+                LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                           (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
+            src = dst;
+            dst = (dst == L.x) ? L.t : L.x;
+        }
+    }
+    if (l == 0)
+        LAUNCH_OP2(k_mg_residual, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                   (const double2 *)L.x, (double2 *)L.res, c->sc);
+    else
+        LAUNCH_OP2(k_mg_residual, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                   (const double2 *)L.x, (double2 *)L.res, c->sc);
+    hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
+                       L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
+    return 0;
+}
+
+// one level of the up leg: prolongation from level l+1, nu post-smoothing sweeps
+int mg_up_level(plfx_ctx *c, int l)
+{
+    const double om = c->mg_omega;
+    auto &L = c->mg[l];
+    auto &C = c->mg[l + 1];
+    const bool mf = L.matfree && matfree(c);
+    hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
+                       C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
+    const int nu = c->mg_nu;
+    double *src = L.x, *dst = L.t;
+    for (int k = 0; k < nu; k++) {
+        EvPair *ev = nullptr;
+        if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
+        if (l == 0)
+            LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (const double2 *)src, (double2 *)dst, om, 0, c->sc);
+        else
+            LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (const double2 *)src, (double2 *)dst, om, 0, c->sc);
+        if (l == 0) tim_end(c, ev);
+        std::swap(src, dst);
+    }
+    if (src != L.x)  // odd nu: result sits in t
+        HIPCHK(c, hipMemcpyAsync(L.x, L.t, (size_t)L.nnode * 16, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// levels 1 .. coarsest: every kernel here is launch-latency bound (<= 513^2 nodes)
+int mg_coarse_part(plfx_ctx *c)
 {
     const int nl = (int)c->mg.size();
     const double om = c->mg_omega;
-    auto smooth = [&](plfx_ctx::MgLevel &L, const double *xin, double *xout, int first) {
-        const bool mf = L.matfree && matfree(c);
-        if (&L == &c->mg[0])
-            LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                       (const double2 *)xin, (double2 *)xout, om, first, c->sc);
-        else
-            LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                       (const double2 *)xin, (double2 *)xout, om, first, c->sc);
-    };
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;  // levels >= lt run inside one workgroup
-    for (int l = 0; l < lt; l++) {  // down
-        auto &L = c->mg[l];
-        auto &C = c->mg[l + 1];
-        // nu pre-smoothing sweeps from a zero guess, ending in x
-        const int nu = c->mg_nu;
-        EvPair *ev = nullptr;
-        if (nu == 2) {  // both sweeps in one pass over the matrix
-            if (l == 0) tim_begin(c, 5, &ev);
-            const bool mf = L.matfree && matfree(c);
-            if (l == 0)
-                LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv,
-                           (const double2 *)L.b, (double2 *)L.x, om, c->sc);
-            else
-                LAUNCH_OP2(k_mg_smooth2_zero, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv,
-                           (const double2 *)L.b, (double2 *)L.x, om, c->sc);
-            if (l == 0) tim_end(c, ev);
-        } else {
-            double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
-            for (int k = 0; k < nu; k++) {
-                smooth(L, src, dst, k == 0);
-                src = dst;
-                dst = (dst == L.x) ? L.t : L.x;
-            }
-        }
-        {
-            const bool mf = L.matfree && matfree(c);
-            if (l == 0)
-                LAUNCH_OP2(k_mg_residual, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                           (const double2 *)L.x, (double2 *)L.res, c->sc);
-            else
-                LAUNCH_OP2(k_mg_residual, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                           (const double2 *)L.x, (double2 *)L.res, c->sc);
-        }
-        hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
-                           L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
-    }
+    int rc;
+    for (int l = 1; l < lt; l++)
+        if ((rc = mg_down_level(c, l))) return rc;
     {
         auto &L = c->mg[nl - 1];
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
@@ -756,22 +791,49 @@ int mg_vcycle(plfx_ctx *c)
                                L.val, (const double2 *)L.dinv, (const double2 *)L.b, (double2 *)L.x,
                                4 * L.nnode + 20, 1.e-10, c->sc);
     }
-    for (int l = lt - 1; l >= 0; l--) {  // up
-        auto &L = c->mg[l];
-        auto &C = c->mg[l + 1];
-        hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
-                           C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
-        const int nu = c->mg_nu;
-        double *src = L.x, *dst = L.t;
-        for (int k = 0; k < nu; k++) {
-            EvPair *ev = nullptr;
-            if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
-            smooth(L, src, dst, 0);
-            if (l == 0) tim_end(c, ev);
-            std::swap(src, dst);
+    for (int l = lt - 1; l >= 1; l--)
+        if ((rc = mg_up_level(c, l))) return rc;
+    return 0;
+}
+
+void mg_graph_drop(plfx_ctx *c)
+{
+    if (c->mg_graph_exec) hipGraphExecDestroy(c->mg_graph_exec);
+    if (c->mg_graph) hipGraphDestroy(c->mg_graph);
+    c->mg_graph_exec = nullptr;
+    c->mg_graph = nullptr;
+}
+
+// z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r).  The fine level is launched kernel by kernel
+// (its launches are timed for the roofline); the ~35 small launches of all coarser levels are captured once into a
+// hipGraph and replayed (arguments are constant for a hierarchy: pointers, omega, nu).
+int mg_vcycle(plfx_ctx *c)
+{
+    const int nl = (int)c->mg.size();
+    const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
+    int rc;
+    if (lt >= 1) {
+        if ((rc = mg_down_level(c, 0))) return rc;
+    }
+    if (lt < 1) {  // two-level hierarchy without a separate fine leg
+        if ((rc = mg_coarse_part(c))) return rc;
+    } else if (c->want_mg_graph && lt >= 2) {
+        if (!c->mg_graph_exec) {
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            rc = mg_coarse_part(c);
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (rc) return rc;
+            if (e != hipSuccess || !g) return fail(c, PLFX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            c->mg_graph = g;
+            HIPCHK(c, hipGraphInstantiate(&c->mg_graph_exec, g, nullptr, nullptr, 0));
         }
-        if (src != L.x)  // odd nu: result sits in t
-            HIPCHK(c, hipMemcpyAsync(L.x, L.t, (size_t)L.nnode * 16, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipGraphLaunch(c->mg_graph_exec, c->stream));
+    } else {
+        if ((rc = mg_coarse_part(c))) return rc;
+    }
+    if (lt >= 1) {
+        if ((rc = mg_up_level(c, 0))) return rc;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -800,6 +862,7 @@ int plfx_create(int device, plfx_ctx **out)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
     if (const char *e3 = getenv("PLFX_SVC_WAVE")) c->want_svc_wave = atoi(e3) ? 1 : 0;
+    if (const char *e4 = getenv("PLFX_MG_GRAPH")) c->want_mg_graph = atoi(e4) ? 1 : 0;
     // 160 KiB LDS per CU on gfx950; leave room for the static material/class tables
     size_t lds = std::max((size_t)c->prop.sharedMemPerBlock, (size_t)c->prop.maxSharedMemoryPerMultiProcessor);
     lds = std::min(lds, (size_t)160 * 1024);
@@ -1266,6 +1329,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     }
     c->gx = nx;
     c->gy = ny;
+    mg_graph_drop(c);
     for (auto &L : c->mg) {  // drop a previous hierarchy
         if (L.owned) {
             dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
@@ -1423,6 +1487,7 @@ int plfx_set_operator(plfx_ctx *c, int kind)
     if (!c) return PLFX_ERR_ARG;
     if (kind != 0 && kind != 1) return fail(c, PLFX_ERR_ARG, "operator kind must be 0 (assembled) or 1 (matrix-free)");
     if (kind != c->want_matfree) {
+        mg_graph_drop(c);
         c->want_matfree = kind;
         c->assembled = false;  // diagonal / matrix values of the other form have to be rebuilt
         c->bc_set = false;
@@ -1450,6 +1515,7 @@ int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
     c->precond = kind;
     if (omega > 0.) c->mg_omega = omega;
     if (nu > 0) c->mg_nu = nu;
+    mg_graph_drop(c);  // the captured launches carry omega / nu
     return PLFX_OK;
 }
 
