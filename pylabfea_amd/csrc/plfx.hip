@@ -193,6 +193,7 @@ struct plfx_ctx {
     MgLevDev *mg_dev = nullptr;  // level descriptors for the single-workgroup tail kernel
     int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
     int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
+    int mg_tail_E = 0;           // elements of the tail levels without the coarsest; > 0: the matrix-free tail is usable
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
     hipGraph_t mg_graph = nullptr;         // captured launches of the V-cycle's coarse levels
@@ -583,6 +584,11 @@ int ensure_tmp(plfx_ctx *c, size_t n)
 }
 
 bool matfree(const plfx_ctx *c) { return c->grid_ok && c->want_matfree; }
+// the single-workgroup tail of the V-cycle applies its levels from the generators too (needs the dense coarse inverse)
+bool tail_mf(const plfx_ctx *c)
+{
+    return matfree(c) && c->mg_tail_T > 0 && c->mg_tail_E > 0 && c->mg_nu == 2 && !c->mg.empty() && c->mg.back().ainv;
+}
 
 // kernels templated on the operator form: <.., 1> matrix-free grid, <.., 0> block-ELL
 #define LAUNCH_OP2(KERN, A, mf, grid, ...)                                                                     \
@@ -654,10 +660,11 @@ int mg_assemble(plfx_ctx *c)
     for (int l = 1; l < nl; l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
-        if (!(mf && F.matfree))  // otherwise the parent's setup kernel has already produced this level's generators
+        if (!(mf && (F.matfree || tail_mf(c))))  // otherwise the parent's setup kernel has already produced this level's generators
             hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
                                F.nel, F.Mel, L.Mel);
-        if (L.matfree && mf)  // only the diagonal (Jacobi smoother) is needed
+        const bool setup_mf = mf && (L.matfree || (tail_mf(c) && l < nl - 1));  // coarsest: assembled for the dense inverse
+        if (setup_mf)  // only the diagonal (Jacobi smoother) is needed
             hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
                                (double *)nullptr, (l + 1 < nl) ? c->mg[l + 1].Mel : (double *)nullptr,
                                (const double2 *)c->dinv, c->mg[0].ny + 1, l,
@@ -677,7 +684,8 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
     for (size_t l = 1; l < c->mg.size(); l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
-        if (same_set && c->mg_dinv_current && L.matfree && matfree(c)) continue;  // written by mg_assemble already
+        if (same_set && c->mg_dinv_current && matfree(c) && (L.matfree || (tail_mf(c) && l + 1 < c->mg.size())))
+            continue;  // written by mg_assemble already
         hipLaunchKernelGGL(k_mg_coarse_dinv, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1,
                            L.ny + 1, F.ny + 1, (const double2 *)F.dinv, (const double2 *)L.diag,
                            (double2 *)L.dinv);
@@ -776,7 +784,11 @@ int mg_coarse_part(plfx_ctx *c)
     {
         auto &L = c->mg[nl - 1];
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
-        if (lt < nl - 1 && c->mg_tail_T > 0 && c->mg_nu == 2)
+        if (lt < nl - 1 && tail_mf(c))
+            hipLaunchKernelGGL(k_mg_tail_mf, dim3(1), dim3(MG_TAIL_BLOCK),
+                               (size_t)c->mg_tail_T * 3 * sizeof(double2) + (size_t)c->mg_tail_E * 6 * sizeof(double),
+                               c->stream, c->mg_dev, lt, nl, c->mg_tail_T, c->mg_tail_E, c->dtab, om, c->sc);
+        else if (lt < nl - 1 && c->mg_tail_T > 0 && c->mg_nu == 2)
             hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(MG_TAIL_BLOCK),
                                (size_t)c->mg_tail_T * (4 * sizeof(double2) + 9 * sizeof(int)), c->stream, c->mg_dev,
                                lt, nl, c->mg_tail_T, om, c->sc);
@@ -1446,8 +1458,11 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             int off = 0;
             if (c->mg_tail >= 0)
                 for (size_t m = c->mg_tail; m < l; m++) off += c->mg[m].nnode;
+            int eoff = 0;
+            if (c->mg_tail >= 0)
+                for (size_t m = c->mg_tail; m < l; m++) eoff += c->mg[m].nel;
             hd[l] = MgLevDev{L.nx, L.ny, L.nnode, L.nslot, L.ainv, off, 0, L.col, L.val, (const double2 *)L.dinv,
-                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res};
+                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res, L.Mel, L.nel, eoff};
         }
         c->mg_tail_T = 0;
         if (c->mg_tail >= 0 && c->mg.back().ainv && c->mg_nu == 2) {
@@ -1462,6 +1477,16 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
                 c->mg_tail_T = T;
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)bytes));
+            }
+            // matrix-free tail: generators of the tail levels (coarsest excluded) in LDS instead of neighbour tables
+            int E = 0;
+            for (size_t m = c->mg_tail; m + 1 < c->mg.size(); m++) E += c->mg[m].nel;
+            const size_t bytes_mf = (size_t)T * 3 * sizeof(double2) + (size_t)E * 6 * sizeof(double);
+            c->mg_tail_E = 0;
+            if (c->grid_ok && bytes_mf <= 156 * 1024 && E > 0) {
+                c->mg_tail_E = E;
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_mf, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)bytes_mf));
             }
         }
         {   // levels above the tail are applied matrix-free; the tail and the coarsest level keep assembled matrices

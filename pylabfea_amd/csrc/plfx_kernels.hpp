@@ -699,10 +699,11 @@ struct KOp {
 //   q_y += Mxy A7 + Mys (A3+A8+A6) + Mxs A1 + Mss (A5+A2) + Myy A4
 // A1..A8 = sum_b {sxx,sxx,syy,syy,sxy,sxy,syx,syx}_ab * {ux,uy,...}_b   (the 2x2 blocks of k_assemble, regrouped)
 // Elements outside the grid enter with M = 0 (indices clamped, so every load is in range).
-template <class XF>
-__device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
+// mf(q): generator number q = c * nel + e (global memory for the big levels, LDS in the single-workgroup tail)
+template <class MF, class XF>
+__device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const double *tab, int i, MF mf, XF xf)
 {
-    const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
+    const int nye = nyn - 1, nxe = nxn - 1;
     const int j = i / nyn, k = i - j * nyn;
     double2 u[3][3];
 #pragma unroll
@@ -724,7 +725,7 @@ __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
             const int e = min(max(ej, 0), nxe - 1) * nye + min(max(ek, 0), nye - 1);
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const double v = g.M[(size_t)c * g.nel + e];
+                const double v = mf(c * nel + e);
                 m[pj * 2 + pk][c] = ok ? v : 0.;
             }
         }
@@ -734,7 +735,7 @@ __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
 #pragma unroll
         for (int pk = 0; pk < 2; pk++) {
             const int p = pj * 2 + pk;
-            const double *T = g.tab + p * 16;  // wave-uniform -> scalar loads
+            const double *T = tab + p * 16;  // wave-uniform -> scalar loads
             double A1 = 0., A2 = 0., A3 = 0., A4 = 0., A5 = 0., A6 = 0., A7 = 0., A8 = 0.;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
@@ -754,6 +755,13 @@ __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
             qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
         }
     return make_double2(qx, qy);
+}
+
+template <class XF>
+__device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
+{
+    const double *M = g.M;
+    return grid_apply_g(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M[q]; }, xf);
 }
 
 template <int GRID, class XF>

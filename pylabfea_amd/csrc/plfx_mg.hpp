@@ -197,6 +197,8 @@ struct MgLevDev {
     const double *val;
     const double2 *dinv;
     double2 *x, *b, *t, *res;
+    const double *Mel;   // stiffness generators of the level, SoA [6][nel] (matrix-free tail)
+    int nel, elem_off;   // elements of the level, element offset inside the LDS arena of k_mg_tail_mf
 };
 
 __device__ inline void coarse_solve_block(int nnode, int nslot, const int32_t *__restrict__ col,
@@ -537,6 +539,23 @@ __device__ __forceinline__ TailView tail_view(double2 *arena, int *cols, int T, 
 __device__ __forceinline__ double2 tail_apply(const MgLevDev &L, const TailView &v, const double2 *xin, int i)
 {
     double qx = 0., qy = 0.;
+    if (L.nslot == 9) {
+        // branch-free and unrolled like bell_apply: the 36 matrix values (L2) are all in flight together instead of
+        // one dependent global-memory latency per slot; empty slots hold exact zeros and gather the node itself
+        int j[9];
+        double a[36];
+#pragma unroll
+        for (int s = 0; s < 9; s++) j[s] = v.col[9 * i + s];
+#pragma unroll
+        for (int k = 0; k < 36; k++) a[k] = L.val[(size_t)k * L.nnode + i];
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            const double2 pj = xin[j[s] < 0 ? i : j[s]];
+            qx = fma(a[4 * s + 0], pj.x, fma(a[4 * s + 1], pj.y, qx));
+            qy = fma(a[4 * s + 2], pj.x, fma(a[4 * s + 3], pj.y, qy));
+        }
+        return make_double2(qx, qy);
+    }
     for (int s = 0; s < L.nslot; s++) {
         const int j = v.col[9 * i + s];
         if (j < 0) continue;
@@ -669,6 +688,148 @@ k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double om
         const MgLevDev L = lev[l0];
         TailView v = tail_view(arena, cols, T, L);
         for (int i = threadIdx.x; i < L.nnode; i += nt) L.x[i] = v.x[i];
+    }
+}
+
+// ---- matrix-free LDS-resident tail: like k_mg_tail_lds, but the operator is applied from the stiffness generators,
+//      which are staged into LDS together with the vectors (x, b, w: 48 B/node; M: 48 B/element; <= 1502 nodes and
+//      1364 elements = 137.6 KB).  A smoothing step then touches no global memory except the node's own dinv (the
+//      block-ELL tail reads 288 B of matrix per node and application through ONE compute unit: 5-7 us per application
+//      on the 33 x 33 level, measured with in-kernel timestamps).  The residual is written over w.
+__global__ void __launch_bounds__(MG_TAIL_BLOCK)
+k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, const double *__restrict__ tab,
+             double omega, const CgScalars *sc)
+{
+    if (sc->done) return;
+    extern __shared__ double2 arena[];  // 3 T double2 + 6 E double
+    double2 *X = arena, *Bv = arena + T, *W = arena + 2 * (size_t)T;
+    double *Ms = reinterpret_cast<double *>(arena + 3 * (size_t)T);
+    const int nt = blockDim.x;
+    for (int l = l0; l < nl - 1; l++) {  // the coarsest level is solved with the dense inverse: no generators needed
+        const MgLevDev L = lev[l];
+        double *dst = Ms + 6 * (size_t)L.elem_off;
+        for (int q = threadIdx.x; q < 6 * L.nel; q += nt) dst[q] = L.Mel[q];
+    }
+    {
+        const MgLevDev L = lev[l0];
+        for (int i = threadIdx.x; i < L.nnode; i += nt) Bv[L.tail_off + i] = L.b[i];
+    }
+    __syncthreads();
+    for (int l = l0; l < nl - 1; l++) {  // down
+        const MgLevDev L = lev[l];
+        const MgLevDev Cc = lev[l + 1];
+        double2 *x = X + L.tail_off, *b = Bv + L.tail_off, *w = W + L.tail_off, *bc = Bv + Cc.tail_off;
+        const double *Ml = Ms + 6 * (size_t)L.elem_off;
+        const int nxn = L.nx + 1, nyn = L.ny + 1;
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = x1 = omega D^-1 b
+            const double2 di = L.dinv[i], bi = b[i];
+            w[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = x1 + omega D^-1 (b - K x1)
+            const double2 di = L.dinv[i];
+            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
+                                           [&](int j) { return w[j]; });
+            const double2 bi = b[i], x1 = w[i];
+            x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = res = P (b - K x)
+            const double2 di = L.dinv[i];
+            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
+                                           [&](int j) { return x[j]; });
+            const double2 bi = b[i];
+            w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
+        }
+        __syncthreads();
+        const int nyc = Cc.ny + 1;
+        for (int i = threadIdx.x; i < Cc.nnode; i += nt) {  // b_c = P^T res
+            const double2 d = Cc.dinv[i];
+            const int J = i / nyc, K = i - J * nyc;
+            double sx = 0., sy = 0.;
+            for (int dj = -1; dj <= 1; dj++) {
+                const int jf = 2 * J + dj;
+                if (jf < 0 || jf >= nxn) continue;
+                for (int dk = -1; dk <= 1; dk++) {
+                    const int kf = 2 * K + dk;
+                    if (kf < 0 || kf >= nyn) continue;
+                    const double wt = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
+                    const double2 r = w[jf * nyn + kf];
+                    sx = fma(wt, r.x, sx);
+                    sy = fma(wt, r.y, sy);
+                }
+            }
+            bc[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+        }
+        __syncthreads();
+    }
+    {   // coarsest grid: x = Ainv b
+        const MgLevDev L = lev[nl - 1];
+        const int n = 2 * L.nnode;
+        const double *bv = reinterpret_cast<const double *>(Bv + L.tail_off);
+        double *xv = reinterpret_cast<double *>(X + L.tail_off);
+        for (int i = threadIdx.x; i < n; i += nt) {
+            double acc = 0.;
+            for (int j = 0; j < n; j++) acc = fma(L.ainv[(size_t)i * n + j], bv[j], acc);
+            xv[i] = acc;
+        }
+        __syncthreads();
+    }
+    for (int l = nl - 2; l >= l0; l--) {  // up: prolongation + two post-smoothing sweeps
+        const MgLevDev L = lev[l];
+        const MgLevDev Cc = lev[l + 1];
+        double2 *x = X + L.tail_off, *b = Bv + L.tail_off, *w = W + L.tail_off;
+        const double2 *xc = X + Cc.tail_off;
+        const double *Ml = Ms + 6 * (size_t)L.elem_off;
+        const int nxn = L.nx + 1, nyn = L.ny + 1, nyc = Cc.ny + 1;
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {
+            const double2 d = L.dinv[i];
+            const int j = i / nyn, k = i - j * nyn;
+            const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
+            double2 c = xc[J0 * nyc + K0];
+            double cx = c.x, cy = c.y;
+            if (oj) {
+                c = xc[(J0 + 1) * nyc + K0];
+                cx += c.x;
+                cy += c.y;
+            }
+            if (ok) {
+                c = xc[J0 * nyc + K0 + 1];
+                cx += c.x;
+                cy += c.y;
+            }
+            if (oj && ok) {
+                c = xc[(J0 + 1) * nyc + K0 + 1];
+                cx += c.x;
+                cy += c.y;
+            }
+            const double wt = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+            double2 xf = x[i];
+            if (d.x != 0.) xf.x = fma(wt, cx, xf.x);
+            if (d.y != 0.) xf.y = fma(wt, cy, xf.y);
+            x[i] = xf;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = x + omega D^-1 (b - K x)
+            const double2 di = L.dinv[i];
+            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
+                                           [&](int j) { return x[j]; });
+            const double2 bi = b[i], xi = x[i];
+            w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = w + omega D^-1 (b - K w)
+            const double2 di = L.dinv[i];
+            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
+                                           [&](int j) { return w[j]; });
+            const double2 bi = b[i], wi = w[i];
+            x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));
+        }
+        __syncthreads();
+    }
+    {
+        const MgLevDev L = lev[l0];
+        for (int i = threadIdx.x; i < L.nnode; i += nt) L.x[i] = X[L.tail_off + i];
     }
 }
 

@@ -613,29 +613,38 @@ class Model(object):
         return float(scf)
 
     # collectives of the host-side scalars (only in sharded runs; torch.distributed is the plumbing)
-    def _allreduce_sum(self, x):
+    def _allgather(self, x):
+        """(nranks, len(x)) array of every rank's vector: ONE collective per host-side reduction; the reduction itself
+        (sum / min over the rank axis, in rank order) is then done locally and is identical on every rank"""
         import torch
         import torch.distributed as dist
-        t = torch.tensor(np.atleast_1d(np.asarray(x, dtype=np.float64)))
-        if dist.get_backend() == 'nccl':
-            t = t.cuda(self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        r = t.cpu().numpy()
+        v = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        dev = torch.device('cuda', self.device) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        key = (len(v), str(dev))
+        buf = self._gather_buf.get(key) if hasattr(self, '_gather_buf') else None
+        if buf is None:
+            if not hasattr(self, '_gather_buf'):
+                self._gather_buf = {}
+            n = dist.get_world_size()
+            buf = (torch.empty(len(v), dtype=torch.float64, device=dev),
+                   [torch.empty(len(v), dtype=torch.float64, device=dev) for _ in range(n)])
+            self._gather_buf[key] = buf
+        t, outs = buf
+        t.copy_(torch.from_numpy(v))
+        dist.all_gather(outs, t)
+        return torch.stack(outs).cpu().numpy()
+
+    def _allreduce_sum(self, x):
+        r = self._allgather(x).sum(axis=0)
         return r if np.ndim(x) else float(r[0])
 
     def _allreduce_scf(self, cnt, mn, s):
-        import torch
-        import torch.distributed as dist
-        r = self._allreduce_sum(np.array([cnt, s], dtype=np.float64))
-        t = torch.tensor([mn], dtype=torch.float64)
-        if dist.get_backend() == 'nccl':
-            t = t.cuda(self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return int(round(r[0])), float(t.cpu()[0]), float(r[1])
+        g = self._allgather(np.array([cnt, s, mn], dtype=np.float64))
+        return int(round(g[:, 0].sum())), float(g[:, 2].min()), float(g[:, 1].sum())
 
     def _allreduce_flags(self, change, conv):
-        r = self._allreduce_sum(np.array([float(change), float(not conv)]))
-        return r[0] > 0., not (r[1] > 0.)
+        g = self._allgather(np.array([float(change), float(not conv)]))
+        return bool(g[:, 0].sum() > 0.), not bool(g[:, 1].sum() > 0.)
 
     # ------------------------------------------------------------------ solution
     def solve(self, min_step=None, verb=False):
