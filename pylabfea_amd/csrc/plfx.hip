@@ -1019,9 +1019,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             if (s.kind == PLFX_SVC6) {
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
-                if (c->svc_wave_mat < 0 && c->want_svc_wave && 7 * npad <= c->lds_doubles) {
+                if (c->svc_wave_mat < 0 && c->want_svc_wave && 8 * npad <= c->lds_doubles && npad <= 2048) {
                     c->svc_wave_mat = k;
-                    c->svc_wave_lds = 7 * npad * 8;
+                    c->svc_wave_lds = 8 * npad * 8;  // v[6], dual, |v|^2
                 }
             }
         }

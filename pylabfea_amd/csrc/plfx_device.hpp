@@ -516,6 +516,72 @@ __device__ inline double brentq_dev(F f, double xa, double xb, double fa, double
     return xcur;
 }
 
+// The same iteration as brentq_dev, cut at its single function evaluation: next() runs the step logic up to the point
+// where f(xcur) is needed (returns true) or the search has ended (returns false, `root` / `converged` set); the caller
+// evaluates and stores fcur.  Lets ML_full_yf evaluate the yield function from ONE call site.
+struct BrentState {
+    double xpre, xcur, xblk, fpre, fcur, fblk, spre, scur, root;
+    int it;
+    bool converged;
+    __device__ __forceinline__ bool start(double xa, double xb, double fa, double fb)
+    {
+        xpre = xa; xcur = xb; xblk = 0.; fpre = fa; fcur = fb; fblk = 0.; spre = scur = 0.; it = 0;
+        converged = true;
+        if (fpre == 0.) { root = xpre; return false; }
+        if (fcur == 0.) { root = xcur; return false; }
+        return true;
+    }
+    __device__ __forceinline__ bool next(double xtol, double rtol, int maxiter)
+    {
+        if (it >= maxiter) { converged = false; root = xcur; return false; }
+        double sbis, delta, stry, dpre, dblk;
+        if (fpre != 0. && fcur != 0. && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2.;
+        sbis = (xblk - xcur) / 2.;
+        if (fcur == 0. || fabs(sbis) < delta) { root = xcur; return false; }
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            const double lim = fmin(fabs(spre), 3. * fabs(sbis) - delta);
+            if (2. * fabs(stry) < lim) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0. ? delta : -delta);
+        it++;
+        return true;  // caller: fcur = f(xcur)
+    }
+};
+
 // Yield-function policy: RBF-SVC (ML_yf) on NF = 6 stress features (sdim 6) or NF = 2 (sdim 3).
 // calc_seq of an ML material is J2 (hill = ones), on Voigt or on principal stresses.
 // WAVE = NC > 0 (NF = 6): one wave works on ONE material point; every lane carries the same point (the scalar part of the
@@ -553,38 +619,87 @@ struct YfSvcT {
             asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
                          "+v"(v[c][6]));
     }
-    // ping-pong over two register sets A, B; body(v) consumes one trip
+    // body(v) consumes one trip of NC vectors per lane.  (Ping-pong prefetching of the next trip's reads was measured:
+    // no gain, the loop is bound by FP64 issue, not by LDS latency.)
     template <class BODY>
     __device__ __forceinline__ void for_trips(BODY body) const
     {
-        const int S = 64 * NC;
-        int k = threadIdx.x & 63;
-        if (NC < 4) {  // two resident waves per SIMD already overlap each other's LDS latency: no second register set
-            for (; k < npad; k += S) {
-                double A[NC][7];
-                issue(npad, k, A);
-                pin(A);
-                body(A);
-            }
-            return;
-        }
-        double A[NC][7], B[NC][7];
-        issue(npad, k, A);
-        for (;;) {
-            const int kb = k + S;
-            const bool hasB = kb < npad;
-            if (hasB) issue(npad, kb, B);
+        for (int k = threadIdx.x & 63; k < npad; k += 64 * NC) {
+            double A[NC][7];
+            issue(npad, k, A);
             pin(A);
             body(A);
-            if (!hasB) break;
-            const int ka = kb + S;
-            const bool hasA = ka < npad;
-            if (hasA) issue(npad, ka, A);
-            pin(B);
-            body(B);
-            if (!hasA) break;
-            k = ka;
         }
+    }
+    // ---- evaluations along a ray x = t su (ML_full_yf evaluates ~12 points on the same ray): the feature vector is
+    // linear in t, X(t) = t D with D = features(su), so |X - v_k|^2 = t^2 |D|^2 - 2 t (D.v_k) + |v_k|^2.  D.v_k is
+    // computed once per ray and kept in registers (one value per vector of this lane), |v_k|^2 is the 8th LDS table:
+    // 2 fused multiply-adds and 2 LDS reads per vector and evaluation instead of 12 operations and 7 reads.
+    static constexpr int MAXTRIP = 2048 / (64 * NC);   // 64 NC MAXTRIP >= npad: up to 2048 support vectors
+    struct RaySetup {
+        double DD;
+        double ck[WAVE > 0 ? MAXTRIP : 1][NC];
+    };
+    __device__ __forceinline__ void ray_setup(const double *su, RaySetup &r) const
+    {
+        if (WAVE == 0 || NF != 6) return;
+        double D[6];
+        svc_features(m, su, D);
+        r.DD = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++) r.DD = fma(D[i], D[i], r.DD);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int t = 0; t < MAXTRIP; t++) {
+            if (t * 64 * NC < npad) {  // wave-uniform
+                double v[NC][7];
+                issue(npad, lane + t * 64 * NC, v);
+                pin(v);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    double a = 0.;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) a = fma(D[i], v[c][i], a);
+                    r.ck[t][c] = a;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ double ray_eval(const double *su, const RaySetup &r, double x) const
+    {
+        if (WAVE == 0 || NF != 6) {
+            double xs[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) xs[i] = x * su[i];
+            return decision(xs);
+        }
+        const double g = -m.gamma * LOG2E;
+        const int lane = threadIdx.x & 63;
+        const double tt = x * x * r.DD, m2t = -2. * x;
+        double f[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) f[c] = 0.;
+#pragma unroll
+        for (int t = 0; t < MAXTRIP; t++) {
+            if (t * 64 * NC < npad) {
+                const int k = lane + t * 64 * NC;
+                double du[NC], vv[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    du[c] = dyn_lds[6 * npad + k + 64 * c];
+                    vv[c] = dyn_lds[7 * npad + k + 64 * c];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const double h = fma(m2t, r.ck[t][c], tt) + vv[c];
+                    f[c] = fma(du[c], exp2_neg(g * h), f[c]);
+                }
+            }
+        }
+        double tsum = f[0];
+#pragma unroll
+        for (int c = 1; c < NC; c++) tsum += f[c];
+        return wave_allsum(tsum) + m.intercept;
     }
     __device__ __forceinline__ double decision_wave(const double *s) const
     {
@@ -678,31 +793,56 @@ struct YfSvcT {
                 for (int i = 0; i < 6; i++) su[i] = (i < (NF == 6 ? 6 : 3)) ? ld[i] * sqrt(1.5) / hh : 0.;
             }
         }
-        auto f = [&](double x) {  // find_yloc_scalar (material.py:547-574): calc_yf(x*su)
-            double xs[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) xs[i] = x * su[i];
-            return decision(xs);
-        };
+        // find_yloc_scalar (material.py:547-574): f(x) = calc_yf(x*su).  The marching bracket (:468-486) and the
+        // brentq search (:501-503) are driven as one state machine so that f has a single call site (the wave-mode
+        // evaluation is a long unrolled loop).  Evaluation order and arithmetic are those of the straight-line form.
+        RaySetup ray;
+        ray_setup(su, ray);
         double x0 = sflow;
         if (su[0] * su[1] < -1.e-5) x0 *= 0.5;  // material.py:468-473
-        double x1 = x0;
-        double f0 = f(x0);
-        double f1 = f0;
-        while (f0 >= 0. && x0 > 0.01) {  // material.py:475-480
-            x0 *= 0.98;
-            f0 = f(x0);
+        double x1 = x0, f0 = 0., f1 = 0., xs = 0.;
+        bool conv = true;
+        BrentState br;
+        int phase = 0;  // 0 first point, 1 marching down (:475-480), 2 marching up (:481-486), 3 brentq
+        double xq = x0;
+        for (;;) {
+            const double fq = ray_eval(su, ray, xq);
+            if (phase == 0) {
+                f0 = f1 = fq;
+                phase = 1;
+            } else if (phase == 1) {
+                f0 = fq;
+            } else if (phase == 2) {
+                f1 = fq;
+            } else {
+                br.fcur = fq;
+            }
+            if (phase == 1) {
+                if (f0 >= 0. && x0 > 0.01) {
+                    x0 *= 0.98;
+                    xq = x0;
+                    continue;
+                }
+                phase = 2;
+            }
+            if (phase == 2) {
+                if (f1 < 0. && x1 < 5. * sflow) {
+                    x1 *= 1.02;
+                    xq = x1;
+                    continue;
+                }
+                if (f0 * f1 > 0.) {  // material.py:495-499
+                    if (status) *status = 1;
+                    return seqv - 0.85 * sflow;
+                }
+                phase = 3;
+                if (!br.start(x0, x1, f0, f1)) break;
+            }
+            if (!br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) break;
+            xq = br.xcur;
         }
-        while (f1 < 0. && x1 < 5. * sflow) {  // material.py:481-486
-            x1 *= 1.02;
-            f1 = f(x1);
-        }
-        if (f0 * f1 > 0.) {  // material.py:495-499
-            if (status) *status = 1;
-            return seqv - 0.85 * sflow;
-        }
-        bool conv;
-        double xs = brentq_dev(f, x0, x1, f0, f1, 1.e-5, 4. * 2.220446049250313e-16, 100, conv);
+        xs = br.root;
+        conv = br.converged;
         if (conv && xs < 4. * sflow) return seqv - xs * seq(su);  // material.py:507
         if (status) *status = 2;
         return seqv - 0.85 * sflow;  // material.py:510

@@ -478,6 +478,12 @@ __device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, 
 #pragma unroll
         for (int c = 0; c < 6; c++) dyn_lds[c * npad + i] = (i < n) ? m.sv[6 * (size_t)i + c] : 0.;
         dyn_lds[6 * npad + i] = (i < n) ? m.dual[i] : 0.;
+        double vv = 0.;
+        if (i < n) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) vv = fma(m.sv[6 * (size_t)i + c], m.sv[6 * (size_t)i + c], vv);
+        }
+        dyn_lds[7 * npad + i] = vv;  // |v_k|^2 for the evaluations along a ray (YfSvcT::ray_eval)
     }
     return npad;
 }
