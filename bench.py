@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achieva
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
 # calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
 PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
-               'matfree': {'mg_smooth': 120.5e6, 'spmv': 123.4e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r01e_bench1024_matfree_rocprofv3_summary.txt'}
+               'matfree': {'mg_smooth': 120.6e6, 'spmv': 121.7e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r01g_bench1024_rocprofv3_summary.txt'}
 
 
 def hill_material(FE):
@@ -167,7 +167,7 @@ def main():
 
     # roofline of the dominant kernel, from HIP events recorded on the library's stream
     fam = {'sweep': _lib.T_SWEEP, 'spmv': _lib.T_SPMV, 'cg_update': _lib.T_CGUPD, 'assemble': _lib.T_ASSEMBLE,
-           'vcycle': _lib.T_VCYCLE, 'mg_smooth': _lib.T_SMOOTH}
+           'vcycle': _lib.T_VCYCLE, 'mg_smooth': _lib.T_SMOOTH, 'sweep_heavy': _lib.T_SWEEP_HEAVY}
     tim = {k: eng.timing_get(v) for k, v in fam.items()}
     nel_rank = fe._e1 - fe._e0
     # algorithmic (compulsory) bytes per launch, DESIGN.md "Kernels":
@@ -196,7 +196,8 @@ def main():
         traffic = pmc.get(k) if (world == 1 and n == 1024) else None
         opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + %s + p.q)' % opname,
-                           'sweep': 'k_sweep_light + k_sweep_heavy (strain gather + return mapping + tangent refresh)',
+                           'sweep': 'k_sweep_light<1> (strain gather + return mapping + tangent test / refresh; the compacted 50-sub-step '
+                                    'list of k_sweep_heavy is empty on this workload and timed separately)',
                            'cg_update': 'k_cg_update',
                            'mg_smooth': 'k_mg_smooth<1> / k_mg_smooth2_zero<1> (fine-level damped-Jacobi sweep of the '
                                         'multigrid V-cycle: %s + update)' % opname}[k],

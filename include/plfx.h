@@ -193,8 +193,9 @@ int plfx_comm_init(plfx_ctx *ctx, const char id[128], int rank, int nranks);
 
 /* ---------------------------------------------------------------- instrumentation */
 /* accumulated HIP-event time (ms) and launch count of a named kernel family since the last reset:
- * which: 0 sweep, 1 spmv(+dot), 2 cg vector update, 3 assemble, 4 multigrid V-cycle (whole cycle),
- *        5 fine-level multigrid smoother launches */
+ * which: 0 streaming phase of the material sweep (k_sweep_light / k_sweep_svc_wave<0>), 1 spmv(+dot), 2 cg vector
+ *        update, 3 assemble, 4 multigrid V-cycle (whole cycle), 5 fine-level multigrid smoother launches,
+ *        6 sub-stepping phase of the material sweep (k_sweep_heavy / k_sweep_svc_wave<1>) */
 int plfx_timing_get(plfx_ctx *ctx, int which, double *ms, int64_t *launches);
 int plfx_timing_reset(plfx_ctx *ctx);
 int plfx_timing_enable(plfx_ctx *ctx, int on);

@@ -2142,6 +2142,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1);
         first = 0;
     }
+    tim_end(c, ev);  // family 0: the streaming phase (one launch per material kind present)
+    tim_begin(c, 6, &ev);  // family 6: the compacted 50-sub-step corrector
     // phase 2 reads the list length from the device; an empty list costs one empty launch
     if (c->has_analytic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
