@@ -841,9 +841,36 @@ def gen_basic():
     print('basic done')
 
 
+# ----------------------------------------------------------------------------
+# 8. ML_full_yf with a loading direction (material.py:454-462), the form calc_scf uses (model.py:1049-1053)
+# ----------------------------------------------------------------------------
+def gen_fullyf_ld():
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        mat_h = FE.Material(name='Hill-reference', num=1)
+        mat_h.elasticity(E=200.e3, nu=0.3)
+        mat_h.plasticity(sy=50., rv=[1.2, 1.0, 0.8, 1.0, 1.0, 1.0], sdim=6)
+        ml = FE.Material('ML-Hill-p1', num=2)
+        ml.train_SVC(C=2.0, gamma=1.0, mat_ref=mat_h, Nseq=25, Nlc=300, Fe=0.1, Ce=0.99, gridsearch=False)
+        z = np.load(os.path.join(OUT, 'svc_hill.npz'))
+        assert np.array_equal(ml.svm_yf.support_vectors_, z['par_sv']), 'training is not reproducible'
+        rng = np.random.default_rng(21)
+        N = 90
+        sig = rand_unit6(rng, N) * (ml.sy * rng.uniform(0.05, 0.8, size=N))[:, None]
+        sig[:20, 3:5] = 0.
+        lds = np.array([[0., 1., 0., 0., 0., 0.], [1., 0., 0., 0., 0., 0.], [0., 1., 0., 0., 0., 1.],
+                        [1., -1., 0., 0., 0., 0.], [0., 0., 0., 0., 0., 0.]])
+        out = np.zeros((len(lds), N))
+        for a, ld in enumerate(lds):
+            for i in range(N):
+                out[a, i] = ml.ML_full_yf(sig[i], np.zeros(6), ld=np.array(ld), verb=False)
+        np.savez_compressed(os.path.join(OUT, 'svc_fullyf_ld.npz'), sig=sig, ld=lds, full_yf=out)
+    print('fullyf_ld done')
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -861,6 +888,8 @@ def main():
         gen_mlparam()
     if 'basic' in todo:
         gen_basic()
+    if 'fullyf_ld' in todo:
+        gen_fullyf_ld()
 
 
 if __name__ == '__main__':

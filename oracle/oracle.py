@@ -143,6 +143,16 @@ def ML_full_yf(mat, sig, epl=None):
     return out, st
 
 
+def ML_full_yf_ld(mat, sig, epl, ld):
+    """ML_full_yf with a loading direction (material.py:454-462), as calc_scf calls it (model.py:1049-1053)."""
+    sig = _c(sig).reshape(-1, 6)
+    epl = np.zeros_like(sig) if epl is None else _c(epl).reshape(-1, 6)
+    ld = _c(ld).reshape(6)
+    out = np.empty(len(sig))
+    lib().plfo_full_yf_ld_batch(C.byref(mat.c), len(sig), _p(sig), _p(epl), _p(ld), _p(out))
+    return out
+
+
 def response(mats, CVs, sig, epl, deps, mat_id=None, nthreads=0):
     """Batched Material.response.  mats: list of Material, CVs: (nmat,36) element CV."""
     if isinstance(mats, Material):

@@ -472,8 +472,8 @@ static double yloc_scalar(double x, void *vctx) /* material.py:547-574 find_yloc
     return plfo_calc_yf(c->m, s, c->epl);
 }
 
-double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double epl_in[6],
-                       int *status) /* material.py:414-516, ld=None */
+double plfo_ML_full_yf_ld(const plfo_material *m, const double sig[6], const double epl_in[6],
+                          const double *ld, int *status) /* material.py:414-516; ld == NULL: ray through sig */
 {
     static const double zero6[6] = {0., 0., 0., 0., 0., 0.};
     const double *epl = epl_in ? epl_in : zero6;
@@ -481,11 +481,24 @@ double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double
     double seq = plfo_calc_seq(m, sig);
     double sflow = plfo_get_sflow(m, epl);
     double yf;
-    if (seq < 0.01) {
+    if (seq < 0.01 && !ld) {
         yf = seq - 0.85 * sflow; /* :445-448 */
     } else {
         double su[6];
-        for (int i = 0; i < 6; i++) su[i] = sig[i] / seq; /* :452 */
+        if (!ld) {
+            for (int i = 0; i < 6; i++) su[i] = sig[i] / seq; /* :452 */
+        } else { /* :454-462 loading direction -> unit stress (sdim = 6; for sdim = 3 only ld[0:3] counts) */
+            const int sd = (m->kind == PLFO_SVC3) ? 3 : 6;
+            double hh = 0.;
+            for (int i = 0; i < sd; i++) hh += ld[i] * ld[i];
+            hh = sqrt(hh);
+            if (hh < 1.e-3) { /* :456-461 inconsistent ld: x direction */
+                for (int i = 0; i < 6; i++) su[i] = 0.;
+                su[0] = sqrt(1.5);
+            } else {
+                for (int i = 0; i < 6; i++) su[i] = (i < sd) ? ld[i] * sqrt(1.5) / hh : 0.;
+            }
+        }
         double x0 = sflow;
         if (su[0] * su[1] < -1.e-5) x0 *= 0.5; /* :468-473 (tresca off) */
         double x1 = x0;
@@ -508,6 +521,19 @@ double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double
     }
     if (status) *status = st;
     return yf;
+}
+
+double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double epl_in[6], int *status)
+{
+    return plfo_ML_full_yf_ld(m, sig, epl_in, NULL, status); /* material.py:414-516, ld=None */
+}
+
+/* batched ld variant (calc_scf, model.py:1049-1053) */
+void plfo_full_yf_ld_batch(const plfo_material *m, int n, const double *sig, const double *epl, const double *ld,
+                           double *out)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n; i++) out[i] = plfo_ML_full_yf_ld(m, sig + 6 * i, epl ? epl + 6 * i : NULL, ld, NULL);
 }
 
 void plfo_epl_dot(const plfo_material *m, const double sig[6], const double epl[6],

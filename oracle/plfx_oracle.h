@@ -58,6 +58,10 @@ double plfo_calc_yf(const plfo_material *m, const double sig[6], const double ep
 void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]);
 /* material.py:414 ML_full_yf (ld=None path); *status: 0 ok, 1 bracket failure, 2 no convergence */
 double plfo_ML_full_yf(const plfo_material *m, const double sig[6], const double epl[6], int *status);
+/* material.py:414 ML_full_yf with a loading direction ld (:454-462), as calc_scf calls it (model.py:1049-1053) */
+double plfo_ML_full_yf_ld(const plfo_material *m, const double sig[6], const double epl[6], const double *ld, int *status);
+void plfo_full_yf_ld_batch(const plfo_material *m, int n, const double *sig, const double *epl, const double *ld,
+                           double *out);
 /* material.py:1009 epl_dot, :1057 C_tan */
 void plfo_epl_dot(const plfo_material *m, const double sig[6], const double epl[6],
                   const double Cel[36], const double deps[6], double pdot[6]);

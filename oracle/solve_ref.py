@@ -116,8 +116,9 @@ class RefSolver(object):
                 continue
             yf0 = O.calc_yf(om, self.sig[sel], self.epl[sel])
             low = yf0 < -0.15
-            if om.c.kind == O.SVC6 and np.any(low):
-                raise NotImplementedError('oracle calc_scf for SVC materials needs the ld variant of ML_full_yf')
+            if om.c.kind == O.SVC6 and np.any(low):  # model.py:1049-1053: full yield function along the loading direction
+                yf0 = np.array(yf0)
+                yf0[low] = O.ML_full_yf_ld(om, self.sig[sel][low], self.epl[sel][low], sld)
             hh = np.where(low, np.minimum(1., -yf0 / sref),
                           np.minimum(1., np.sqrt(1.5) * self.sflow(self.epl[sel], sel) / sref))
             sc.extend(hh.tolist())

@@ -108,6 +108,23 @@ def test_svc(ctx, golden_dir, name):
         assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
 
 
+def test_svc_full_yf_with_loading_direction(ctx, golden_dir):
+    """plfx_full_yf_batch with ld (the calc_scf form, model.py:1049-1053) against the reference's values"""
+    from pylabfea_amd import _lib
+    z = np.load(os.path.join(golden_dir, 'svc_hill.npz'))
+    g = np.load(os.path.join(golden_dir, 'svc_fullyf_ld.npz'))
+    svc = dict(sv=z['par_sv'], dual=z['par_dual'], gamma=float(z['par_gamma']),
+               intercept=float(z['par_intercept']), scale_seq=float(z['par_scale_seq']),
+               dev_only=bool(z['par_dev_only']))
+    sy = float(z['par_sy'])
+    rec = _lib.pack_material(_lib.SVC6, z['rpe_CV'], E=float(z['par_E']), nu=float(z['par_nu']), sy=sy,
+                             khard=float(z['par_khard']), hill=z['par_hill'], svc=svc)
+    ctx.set_materials([rec])
+    for a, ld in enumerate(g['ld']):
+        fyf, st = ctx.full_yf(0, g['sig'], None, ld)
+        assert np.max(np.abs(fyf - g['full_yf'][a])) < 1e-6 * sy, a
+
+
 @pytest.mark.parametrize('name', ['hill3', 'j2s3'])
 def test_sdim3(ctx, golden_dir, name):
     """sdim=3 flow rule: principal stresses in the reference's axis-tracking order (plane states)."""

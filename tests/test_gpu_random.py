@@ -128,3 +128,48 @@ def test_nonuniform_laminate_vs_oracle():
     assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
     assert np.max(np.abs(fe._state('epl') - ref.epl)) < 1e-6 * np.max(np.abs(ref.eps))
     assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s
+
+
+def test_composite_j2_svc_laminate_vs_oracle(golden_dir):
+    """BASELINE config 5 in small: laminate [2,1,2,1,2] of a J2 phase and an SVC phase (the 1585-vector SVC of config 4)
+    on a uniform grid -> multigrid + matrix-free operator, analytic thread-per-element kernels and wave-per-element SVC
+    kernels in one sweep, material jumps across the coarse levels; against the oracle's sparse direct solve."""
+    import pylabfea_amd as FE
+    from oracle.solve_ref import RefSolver
+    z = np.load(os.path.join(golden_dir, 'svc_hill.npz'))
+
+    def build():
+        ma = FE.Material(num=1)
+        ma.elasticity(E=200.e3, nu=0.3)
+        ma.plasticity(sy=150., khard=500., sdim=6)
+        mb = FE.Material(name='ML-Hill', num=2)
+        mb.elasticity(CV=z['par_CV'])
+        mb.plasticity(sy=float(z['par_sy']), sdim=6)
+        mb.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']),
+                   float(z['par_scale_seq']))
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([ma, mb, ma, mb, ma])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.0012 * fe.leny, 'disp')
+        fe.mesh(NX=16, NY=8)
+        return fe
+    fe = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=4)
+    eng = fe._engine
+    assert eng.precond_info()[0] == 1 and eng.operator_info()[0] == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = RefSolver(build()).solve(min_step=4)
+    assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
+    assert np.max(fe._state('epl')[fe._mat_id == 1]) > 0.   # the SVC phase yields
+    assert np.max(fe._state('max_steps')) == 49             # and runs the 50-sub-step corrector
+    s = np.max(np.abs(ref.sig))
+    assert np.max(np.abs(fe.u - ref.u)) < 1e-6 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
+    assert np.max(np.abs(fe._state('epl') - ref.epl)) < 1e-6 * np.max(np.abs(ref.eps))
+    assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s

@@ -79,6 +79,19 @@ def test_svc(golden_dir, name):
         assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
 
 
+def test_svc_full_yf_with_loading_direction(golden_dir):
+    """ML_full_yf(sig, epl, ld=...) (material.py:454-462) as calc_scf calls it (model.py:1049-1053), five directions
+    incl. the inconsistent all-zero one (:456-461)"""
+    z = np.load(os.path.join(golden_dir, 'svc_hill.npz'))
+    g = np.load(os.path.join(golden_dir, 'svc_fullyf_ld.npz'))
+    m = O.Material.from_golden(z)
+    for a, ld in enumerate(g['ld']):
+        out = O.ML_full_yf_ld(m, g['sig'], None, ld)
+        assert np.max(np.abs(out - g['full_yf'][a])) < 1e-7, a
+    # ld = None path through the same routine
+    assert np.max(np.abs(O.ML_full_yf(m, z['b_sig'][:20])[0] - z['b_full_yf'][:20])) < 1e-7
+
+
 @pytest.mark.parametrize('name', ['hill3', 'j2s3'])
 def test_sdim3(golden_dir, name):
     """sdim=3 flow rule (principal stresses in the reference's axis-tracking order) on plane states."""
