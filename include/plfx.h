@@ -185,6 +185,10 @@ int plfx_finish_step(plfx_ctx *ctx, double *u_at /* [n] */, double *f_at /* [n] 
 /* calc_global element sums (model.py:1500-1511): out[18] = sum(sig*Vel), sum(eps*Vel), sum(epl*Vel) */
 int plfx_global_sums(plfx_ctx *ctx, double *out18);
 
+/* device_collectives = 1: this context shards the elements over an RCCL communicator; plfx_sweep (flags),
+ * plfx_scf_all (statistics) and plfx_finish_step (element sums) then return values of the WHOLE mesh (all-reduced on
+ * the device, on the library's stream) and the caller needs no collective of its own. */
+int plfx_comm_info(plfx_ctx *ctx, int *rank, int *nranks, int *device_collectives);
 /* ---------------------------------------------------------------- multi-GPU
  * RCCL communicator for the per-CG-step all-reduce of the global vector.  id is the 128-byte
  * ncclUniqueId created on rank 0 by plfx_comm_unique_id and broadcast by the caller. */

@@ -46,7 +46,7 @@ SYMBOLS = [
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
     'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
-    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all',
+    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info',
 ]
 
 _lib = None
@@ -395,6 +395,11 @@ class Context(object):
         return out.reshape(3, 6)
 
     # -- multi-GPU
+    def comm_info(self):
+        r, n, d = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.plfx_comm_info(self.h, C.byref(r), C.byref(n), C.byref(d)))
+        return r.value, n.value, bool(d.value)
+
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
         self._chk(self.lib.plfx_comm_unique_id(buf))

@@ -78,7 +78,9 @@ bool load_rccl()
     return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
 }
 constexpr int NCCL_FLOAT64 = 8;  // ncclDouble
+constexpr int NCCL_INT32 = 2;    // ncclInt32
 constexpr int NCCL_SUM = 0;
+constexpr int NCCL_MIN = 3;
 
 template <class T>
 struct DBuf {  // device buffer
@@ -1946,6 +1948,10 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
                        c->sig, c->eps, c->epl, c->part_g);
     hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
+    if (c->comm &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
+        g_rccl.AllReduce(c->fin_dev + 2 * (size_t)n, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, c->comm,
+                         c->stream) != 0)
+        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(sums) failed");
     HIPCHK(c, hipMemcpyAsync(c->fin_host, c->fin_dev, ((size_t)2 * n + 18) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (u_at && n > 0) memcpy(u_at, c->fin_host, (size_t)8 * n);
@@ -2168,6 +2174,10 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
         int rcm = sync_M(c);
         if (rcm) return rcm;
     }
+    if (c->comm) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
+        if (g_rccl.AllReduce(c->flags, c->flags, 3, NCCL_INT32, NCCL_SUM, c->comm, c->stream) != 0)
+            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(flags) failed");
+    }
     int h[4];
     HIPCHK(c, hipMemcpyAsync(h, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2226,10 +2236,19 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr);
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 0, c->small + 40);
+    if (c->comm) {  // statistics of the whole mesh: sum, count (SUM) and minimum (MIN), then the global mean
+        if (g_rccl.AllReduce(c->small + 40, c->small + 40, 2, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0 ||
+            g_rccl.AllReduce(c->small + 42, c->small + 42, 1, NCCL_FLOAT64, NCCL_MIN, c->comm, c->stream) != 0)
+            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
+        hipLaunchKernelGGL(k_scf_mean, dim3(1), dim3(64), 0, c->stream, c->small + 40);
+    }
     // second pass with the mean taken from device memory: no host round trip between the passes
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 1,
                        c->part_g, (const double *)(c->small + 43));
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 1, c->small + 40);
+    if (c->comm &&
+        g_rccl.AllReduce(c->small + 44, c->small + 44, 1, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
+        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
     HIPCHK(c, hipGetLastError());
     double h[5];
     HIPCHK(c, hipMemcpyAsync(h, c->small + 40, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -2285,6 +2304,15 @@ int plfx_global_sums(plfx_ctx *c, double *out18)
 }
 
 // ------------------------------------------------------------------------------ multi-GPU
+int plfx_comm_info(plfx_ctx *c, int *rank, int *nranks, int *device_collectives)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    if (device_collectives) *device_collectives = c->comm ? 1 : 0;
+    return PLFX_OK;
+}
+
 int plfx_comm_unique_id(char id[128])
 {
     if (!id) return PLFX_ERR_ARG;

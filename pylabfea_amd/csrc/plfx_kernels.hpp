@@ -1333,4 +1333,10 @@ __global__ void k_scf_finish(const double *part, int g, int pass, double *out)
     }
 }
 
+// mean of the (all-reduced) calc_scf statistics: out[3] = out[0] / out[1]
+__global__ void k_scf_mean(double *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[3] = out[1] > 0. ? out[0] / (double)(long long)(out[1] + 0.5) : 0.;
+}
+
 }  // namespace plfx

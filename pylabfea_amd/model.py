@@ -185,6 +185,7 @@ class Model(object):
         self._bnd_offs = None
         self._bc_struct = None
         self._bc_registered = None
+        self._dev_coll = False
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -429,6 +430,7 @@ class Model(object):
         if self.operator is not None:
             eng.set_operator(self.operator)
         self._e0, self._e1 = e0, e1
+        self._dev_coll = eng.comm_info()[2]  # RCCL communicator: scalars are all-reduced inside the library
         self._engine = eng
         self._mat_versions = vers
         plastic = any(m.sy is not None for m in self.mat)
@@ -593,7 +595,7 @@ class Model(object):
 
     def _calc_scf(self, eng, sld):
         """Load-step scaling factor (model.py:1036-1067) from per-element values reduced on the GPU."""
-        if self._shard is None:
+        if self._shard is None or self._dev_coll:  # sharded with RCCL: the library all-reduces the statistics itself
             cnt, mn, s, s2 = eng.scf_all(sld)
             if cnt == 0:
                 return 1.
@@ -758,7 +760,7 @@ class Model(object):
                     self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), True)
                     change, conv = eng.sweep(nit)  # material response of every element (model.py:1340-1361)
                     self.n_sweeps += 1
-                    if self._shard is not None:
+                    if self._shard is not None and not self._dev_coll:
                         change, conv = self._allreduce_flags(change, conv)
                     if verb:
                         if not conv:
@@ -866,7 +868,7 @@ class Model(object):
         su = np.add.reduceat(uu, offs)
         sf = np.add.reduceat(ff, offs)
         bv = [(su[2 * q] / cnt[q], su[2 * q + 1] / cnt[q], sf[2 * q], sf[2 * q + 1]) for q in range(4)]
-        if self._shard is not None:
+        if self._shard is not None and not (self._dev_coll and fin is not None):
             sums = self._allreduce_sum(sums.ravel()).reshape(3, 6)
         self._glob_from(bv, sums)
 
