@@ -185,6 +185,37 @@ int plfx_finish_step(plfx_ctx *ctx, double *u_at /* [n] */, double *f_at /* [n] 
 /* calc_global element sums (model.py:1500-1511): out[18] = sum(sig*Vel), sum(eps*Vel), sum(epl*Vel) */
 int plfx_global_sums(plfx_ctx *ctx, double *out18);
 
+/* ---------------------------------------------------------------- one load step of Model.solve (model.py:1262-1392)
+ * The whole body of the reference's load-step loop as ONE call: elastic predictor with the stiffness of the previous
+ * step (:1290-1291), load-step scaling calc_scf while il < 10 (:1296), the stiffness iterations
+ * [halving of the increment while il < 6 (:1308-1330) -> setupK -> calc_BC -> solve -> material sweep] until no tangent
+ * changed and the yield function converged or 16 iterations (:1306-1381), state update (:1383-1392) and the data of
+ * calc_global (= plfx_finish_step).  The host keeps the loop over load steps and its bookkeeping.
+ * Needs plfx_set_bc_plan (with the segment sources below) and plfx_set_finish_set.
+ * Segment source codes: 0 left (value bcl0[k]), 1 bottom (bcb0[k]), 2 right (dbcr[k]), 3 top (dbct[k]), 4 node set (dbcn[k]). */
+typedef struct plfx_step {
+    /* in */
+    int32_t il, nonlin, has_nodeset, warm, maxit, _pad;
+    double rtol;
+    double bcl0[2], bcb0[2];
+    double max_dbcr[2], max_dbct[2], max_dbcn[2]; /* increments planned for this step (max_dbcn is updated like the reference's alias, :1285) */
+    double bcr[2], bct[2], bcn[2];                /* target totals */
+    double bcr0[2], bct0[2], bcn0[2];             /* reached before this step */
+    double sld[6];                                /* loading direction for calc_scf (:1245-1258) */
+    /* out */
+    double dbcr[2], dbct[2], dbcn[2];             /* increments applied in the end */
+    double scale_bc;
+    int32_t nit, nconv, nsweeps, nsolves, soft_fail, inconsistent_entry;
+    int32_t its[40];
+    double relres[40];
+} plfx_step;
+/* which segments of the registered BC plan take which value, and the force-controlled segments (edge force split
+ * over the nodes, model.py:1145-1151): src/k per segment; nf force segments with flen[nf] DOFs each, fidx / fshare
+ * concatenated */
+int plfx_set_bc_sources(plfx_ctx *ctx, int nseg, const int32_t *src, const int32_t *k, int nf, const int32_t *fsrc,
+                        const int32_t *fk, const int32_t *flen, const int32_t *fidx, const double *fshare);
+int plfx_load_step(plfx_ctx *ctx, plfx_step *step, double *u_at, double *f_at, double *sums18);
+
 /* device_collectives = 1: this context shards the elements over an RCCL communicator; plfx_sweep (flags),
  * plfx_scf_all (statistics) and plfx_finish_step (element sums) then return values of the WHOLE mesh (all-reduced on
  * the device, on the library's stream) and the caller needs no collective of its own. */

@@ -46,7 +46,8 @@ SYMBOLS = [
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
     'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
-    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info',
+    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_set_bc_sources',
+    'plfx_load_step',
 ]
 
 _lib = None
@@ -67,6 +68,22 @@ def load():
     lib.plfx_destroy.restype = None
     _lib = lib
     return lib
+
+
+class CStep(C.Structure):
+    """plfx_step of include/plfx.h: one load step of Model.solve"""
+    _fields_ = [('il', C.c_int32), ('nonlin', C.c_int32), ('has_nodeset', C.c_int32), ('warm', C.c_int32),
+                ('maxit', C.c_int32), ('_pad', C.c_int32), ('rtol', C.c_double),
+                ('bcl0', C.c_double * 2), ('bcb0', C.c_double * 2),
+                ('max_dbcr', C.c_double * 2), ('max_dbct', C.c_double * 2), ('max_dbcn', C.c_double * 2),
+                ('bcr', C.c_double * 2), ('bct', C.c_double * 2), ('bcn', C.c_double * 2),
+                ('bcr0', C.c_double * 2), ('bct0', C.c_double * 2), ('bcn0', C.c_double * 2),
+                ('sld', C.c_double * 6),
+                ('dbcr', C.c_double * 2), ('dbct', C.c_double * 2), ('dbcn', C.c_double * 2),
+                ('scale_bc', C.c_double),
+                ('nit', C.c_int32), ('nconv', C.c_int32), ('nsweeps', C.c_int32), ('nsolves', C.c_int32),
+                ('soft_fail', C.c_int32), ('inconsistent_entry', C.c_int32),
+                ('its', C.c_int32 * 40), ('relres', C.c_double * 40)]
 
 
 def _dp(a):
@@ -337,6 +354,18 @@ class Context(object):
         bad = C.c_int(-1)
         self._chk(self.lib.plfx_apply_bc_plan(self.h, _dp(seg_val), _dp(fx), C.byref(bad)))
         return bad.value
+
+    def set_bc_sources(self, src, k, fsrc, fk, flen, fidx, fshare):
+        src, k, fsrc, fk, flen, fidx = (_i32(a) for a in (src, k, fsrc, fk, flen, fidx))
+        fshare = _f64(fshare)
+        self._chk(self.lib.plfx_set_bc_sources(self.h, len(src), _dp(src), _dp(k), len(fsrc), _dp(fsrc), _dp(fk),
+                                               _dp(flen), _dp(fidx), _dp(fshare)))
+
+    def load_step(self, step):
+        """one load step (plfx_load_step); returns the data of finish_step"""
+        uu, ff, sums = self._fin
+        self._chk(self.lib.plfx_load_step(self.h, C.byref(step), _dp(uu), _dp(ff), _dp(sums)))
+        return uu, ff, sums.reshape(3, 6)
 
     def set_finish_set(self, idx):
         idx = _i32(idx)

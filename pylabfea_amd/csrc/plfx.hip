@@ -170,6 +170,10 @@ struct plfx_ctx {
         std::vector<int32_t> inv;       // entry -> position in presc
         std::vector<double> first, w;   // scratch
         bool valid = false;
+        // plfx_set_bc_sources: where each segment's value comes from, and the force-controlled segments
+        std::vector<int32_t> src, k, fsrc, fk, flen, fidx;
+        std::vector<double> fshare, fext;
+        bool sources = false;
     } plan;
     // registered DOF set of plfx_finish_step (boundary nodes of calc_global)
     int32_t *fin_idx = nullptr;
@@ -1910,6 +1914,146 @@ int plfx_apply_bc_plan(plfx_ctx *c, const double *seg_val, const double *fext, i
     }
     if (inconsistent_entry) *inconsistent_entry = bad;
     return plfx_apply_bc(c, np, P.presc.data(), P.first.data(), P.w.data(), fext);
+}
+
+int plfx_set_bc_sources(plfx_ctx *c, int nseg, const int32_t *src, const int32_t *k, int nf, const int32_t *fsrc,
+                        const int32_t *fk, const int32_t *flen, const int32_t *fidx, const double *fshare)
+{
+    if (!c || !c->plan.valid) return c ? fail(c, PLFX_ERR_STATE, "set_bc_plan first") : PLFX_ERR_STATE;
+    auto &P = c->plan;
+    P.sources = false;
+    if (nseg != P.nseg || nf < 0) return fail(c, PLFX_ERR_ARG, "segment count differs from the registered plan");
+    for (int i = 0; i < nseg; i++)
+        if (src[i] < 0 || src[i] > 4 || k[i] < 0 || k[i] > 1) return fail(c, PLFX_ERR_ARG, "bad segment source");
+    P.src.assign(src, src + nseg);
+    P.k.assign(k, k + nseg);
+    P.fsrc.assign(fsrc, fsrc + nf);
+    P.fk.assign(fk, fk + nf);
+    P.flen.assign(flen, flen + nf);
+    size_t tot = 0;
+    for (int i = 0; i < nf; i++) {
+        if (fsrc[i] < 2 || fsrc[i] > 4 || fk[i] < 0 || fk[i] > 1 || flen[i] < 0)
+            return fail(c, PLFX_ERR_ARG, "bad force segment");
+        tot += flen[i];
+    }
+    for (size_t q = 0; q < tot; q++)
+        if (fidx[q] < 0 || fidx[q] >= c->ndof) return fail(c, PLFX_ERR_ARG, "force DOF out of range");
+    P.fidx.assign(fidx, fidx + tot);
+    P.fshare.assign(fshare, fshare + tot);
+    P.sources = true;
+    return PLFX_OK;
+}
+
+namespace {
+
+// calc_BC through the registered plan for the current increments; returns the first inconsistent entry or -1
+int step_apply_bc(plfx_ctx *c, const plfx_step *st, const double *dbcr, const double *dbct, const double *dbcn, int *bad)
+{
+    auto &P = c->plan;
+    const double *val[5] = {st->bcl0, st->bcb0, dbcr, dbct, dbcn};
+    std::vector<double> seg(P.nseg);
+    for (int i = 0; i < P.nseg; i++) seg[i] = val[P.src[i]][P.k[i]];
+    const double *fext = nullptr;
+    bool any = false;
+    size_t o = 0;
+    for (size_t f = 0; f < P.fsrc.size(); f++) {  // edge / node-set forces (model.py:1145-1151, 1173-1179, 1203-1205)
+        const double v = val[P.fsrc[f]][P.fk[f]];
+        if (v != 0.) {
+            if (!any) P.fext.assign(c->ndof, 0.);
+            any = true;
+            for (int q = 0; q < P.flen[f]; q++) P.fext[P.fidx[o + q]] += v * P.fshare[o + q];
+        }
+        o += P.flen[f];
+    }
+    if (any) fext = P.fext.data();
+    int b = -1;
+    int rc = plfx_apply_bc_plan(c, seg.data(), fext, &b);
+    if (bad && *bad < 0) *bad = b;
+    return rc;
+}
+
+int step_solve(plfx_ctx *c, plfx_step *st, int warm)
+{
+    int it = 0;
+    double rr = 0.;
+    const int rc = plfx_solve(c, st->rtol, st->maxit, warm, &it, &rr);
+    if (rc < 0) return rc;
+    if (st->nsolves < 40) {
+        st->its[st->nsolves] = it;
+        st->relres[st->nsolves] = rr;
+    }
+    st->nsolves++;
+    if (rc == 1) st->soft_fail++;
+    return 0;
+}
+
+}  // namespace
+
+int plfx_load_step(plfx_ctx *c, plfx_step *st, double *u_at, double *f_at, double *sums18)
+{
+    if (!c || !st) return PLFX_ERR_ARG;
+    if (!c->plan.valid || !c->plan.sources) return fail(c, PLFX_ERR_STATE, "set_bc_plan / set_bc_sources first");
+    if (!c->fin_dev) return fail(c, PLFX_ERR_STATE, "set_finish_set first");
+    st->nit = st->nconv = st->nsweeps = st->nsolves = st->soft_fail = 0;
+    st->inconsistent_entry = -1;
+    st->scale_bc = 1.;
+    int rc;
+    double dbcr[2] = {st->max_dbcr[0], st->max_dbcr[1]}, dbct[2] = {st->max_dbct[0], st->max_dbct[1]};
+    double *dbcn = st->max_dbcn;  // the reference's dbcn IS max_dbcn (alias, model.py:1285)
+    // elastic predictor with the stiffness of the previous step (model.py:1290-1291)
+    if ((rc = step_apply_bc(c, st, dbcr, dbct, dbcn, &st->inconsistent_entry))) return rc;
+    if ((rc = step_solve(c, st, st->warm))) return rc;
+    if (st->nonlin) {
+        if (st->il < 10) {  // calc_scf (model.py:1036-1067, 1296)
+            int64_t cnt = 0;
+            double mn = 0., sm = 0., s2 = 0.;
+            if ((rc = plfx_scf_all(c, st->sld, &cnt, &mn, &sm, &s2))) return rc;
+            if (cnt > 0) {
+                const double mean = sm / (double)cnt, sd = std::sqrt(s2 / (double)cnt);
+                double scf = (sd < 0.1) ? mn : std::max(1.e-3, mean - sd);
+                if (scf < 1.e-3) scf = 1.e-3;
+                st->scale_bc = scf;
+            }
+        }
+        for (int k = 0; k < 2; k++) {
+            dbcr[k] = st->max_dbcr[k] * st->scale_bc;
+            dbct[k] = st->max_dbct[k] * st->scale_bc;
+        }
+        int nit = 0, change = 1, conv = 0;
+        while ((change || !conv) && nit <= 15) {  // model.py:1306
+            if (st->il < 6 && nit > 1) {          // reduce the load increment to reach convergence (:1308-1330)
+                const double hs = 0.5;
+                auto halve = [&](double mx, double tot, double cur0, double &d) {
+                    if (mx >= 0.)
+                        d = std::max(0.05 * mx, std::min(tot - cur0, d * hs));
+                    else
+                        d = std::min(0.05 * mx, std::max(tot - cur0, d * hs));
+                };
+                for (int k = 0; k < 2; k++) {
+                    halve(st->max_dbcr[k], st->bcr[k], st->bcr0[k], dbcr[k]);
+                    halve(st->max_dbct[k], st->bct[k], st->bct0[k], dbct[k]);
+                    if (st->has_nodeset) {  // d and mx are the same variable here
+                        const double mx = dbcn[k];
+                        halve(mx, st->bcn[k], st->bcn0[k], dbcn[k]);
+                    }
+                }
+            }
+            if ((rc = plfx_assemble(c))) return rc;  // updated tangent stiffness (model.py:1333)
+            if ((rc = step_apply_bc(c, st, dbcr, dbct, dbcn, &st->inconsistent_entry))) return rc;
+            if ((rc = step_solve(c, st, 1))) return rc;
+            if ((rc = plfx_sweep(c, nit, &change, &conv))) return rc;  // model.py:1340-1361
+            st->nsweeps++;
+            if (!conv) st->nconv++;
+            nit++;
+        }
+        st->nit = nit;
+    }
+    for (int k = 0; k < 2; k++) {
+        st->dbcr[k] = dbcr[k];
+        st->dbct[k] = dbct[k];
+        st->dbcn[k] = dbcn[k];
+    }
+    return plfx_finish_step(c, u_at, f_at, sums18);
 }
 
 int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)

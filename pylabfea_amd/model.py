@@ -186,6 +186,8 @@ class Model(object):
         self._bc_struct = None
         self._bc_registered = None
         self._dev_coll = False
+        self._native_step = os.environ.get('PLFX_NATIVE_STEP', '1') != '0'
+        self._step_io = _lib.CStep()
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -563,6 +565,12 @@ class Model(object):
                 eng.set_bc_plan(segs, plan['idx'])
             else:
                 eng.set_bc_plan(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))
+            code = {'l': 0, 'b': 1, 'r': 2, 't': 3, 'n': 4}
+            fseg = plan['fseg']
+            eng.set_bc_sources([code[s] for s, _ in plan['dseg']], [k for _, k in plan['dseg']],
+                               [code[f[0]] for f in fseg], [f[1] for f in fseg], [len(f[2]) for f in fseg],
+                               np.concatenate([f[2] for f in fseg]) if fseg else np.zeros(0, dtype=np.int32),
+                               np.concatenate([f[3] for f in fseg]) if fseg else np.zeros(0))
             self._bc_registered = plan
         return plan
 
@@ -723,10 +731,42 @@ class Model(object):
                 if min_step is not None:
                     max_dbcn /= np.maximum(1, min_step - il)
                 dbcn = max_dbcn  # alias, exactly as in the reference (model.py:1285)
+            native = self._native_step and not verb and (self._shard is None or self._dev_coll)
+            if native:
+                # the body of the load step runs inside the library (plfx_load_step): predictor, calc_scf, stiffness
+                # iterations, state update; verb=True keeps the Python transcription below for its trace output
+                st = self._step_io
+                st.il, st.nonlin, st.warm = il, int(bool(self.nonlin)), int(bool(warm))
+                st.has_nodeset = int(self.noset is not None)
+                st.maxit, st.rtol = int(self.cg_maxit), float(self.cg_rtol)
+                st.bcl0[:], st.bcb0[:] = [float(v) for v in bcl0], [float(v) for v in bcb0]
+                st.max_dbcr[:], st.max_dbct[:] = [float(v) for v in max_dbcr], [float(v) for v in max_dbct]
+                st.bcr[:], st.bct[:] = [float(v) for v in self.bcr], [float(v) for v in self.bct]
+                st.bcr0[:], st.bct0[:] = [float(v) for v in bcr0], [float(v) for v in bct0]
+                if self.noset is not None:
+                    st.max_dbcn[:], st.bcn[:], st.bcn0[:] = ([float(v) for v in max_dbcn], [float(v) for v in self.bcn],
+                                                              [float(v) for v in bcn0])
+                st.sld[:] = [float(v) for v in sld]
+                self._bc_register(eng)
+                fin = eng.load_step(st)
+                warm = True
+                dbcr, dbct = np.array(st.dbcr[:]), np.array(st.dbct[:])
+                if self.noset is not None:
+                    dbcn = np.array(st.dbcn[:])
+                nit = st.nit
+                nconv += st.nconv
+                self.n_sweeps += st.nsweeps
+                for q in range(min(st.nsolves, 40)):
+                    self.solver_stats.append((st.its[q], st.relres[q]))
+                if st.soft_fail:
+                    warnings.warn('PCG reached the iteration limit in {} solve(s) of load step {}'.format(st.soft_fail, il))
+                if st.inconsistent_entry >= 0:
+                    warnings.warn('Inconsistent BC at DOF {}.'.format(self._bc_plan()['idx'][st.inconsistent_entry]))
             # elastic predictor with the stiffness of the previous step (model.py:1290-1291)
-            self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), warm)
-            warm = True
-            if self.nonlin:
+            if not native:
+                self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), warm)
+                warm = True
+            if self.nonlin and not native:
                 scale_bc = self._calc_scf(eng, sld) if il < 10 else 1.
                 dbcr = max_dbcr * scale_bc
                 dbct = max_dbct * scale_bc
@@ -774,7 +814,8 @@ class Model(object):
                         nconv += 1
                     nit += 1
             # update internal variables with the results of the load step (model.py:1383-1392)
-            fin = eng.finish_step()  # update_state + boundary u, f + element sums: one call, one synchronisation
+            if not native:
+                fin = eng.finish_step()  # update_state + boundary u, f + element sums: one call, one synchronisation
             il += 1
             niter.append(nit - 1)
             co_nconv.append(nconv)
