@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -202,6 +203,10 @@ struct plfx_ctx {
     int mg_tail_E = 0;           // elements of the tail levels without the coarsest; > 0: the matrix-free tail is usable
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
+    CgMbox *mbox = nullptr;                // pinned host mailbox of the PCG convergence flag (PLFX_MAILBOX)
+    unsigned long long mbox_seq = 0;
+    double *mb_buf = nullptr;              // pinned result buffer of fetch_results
+    int mb_cap = 0;
     hipGraph_t mg_graph = nullptr;         // captured launches of the V-cycle's coarse levels
     hipGraphExec_t mg_graph_exec = nullptr;
     int want_mg_graph = 1;                 // PLFX_MG_GRAPH
@@ -328,6 +333,42 @@ void tim_flush(plfx_ctx *c)
             t.n[e.which]++;
             e.pending = false;
         }
+}
+
+// wait until a kernel has posted `seq` to the pinned mailbox (a failed launch or a hung queue must not spin forever)
+int mbox_wait(plfx_ctx *c, unsigned long long seq)
+{
+    unsigned spins = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(&c->mbox->seq, __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipSuccess && e != hipErrorNotReady)
+                return fail(c, PLFX_ERR_HIP, "stream error while waiting for device results: %s", hipGetErrorString(e));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(c, PLFX_ERR_HIP, "timeout while waiting for device results");
+        }
+    }
+    return 0;
+}
+
+// n doubles of device results to the host: through the pinned mailbox buffer (kernel writes host memory, host spins on
+// the sequence number) or by a device->host copy + stream synchronisation
+int fetch_results(plfx_ctx *c, const double *src_dev, int n, double *dst_host)
+{
+    if (!c->mbox || n > c->mb_cap) {
+        HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const unsigned long long seq = ++c->mbox_seq;
+    hipLaunchKernelGGL(k_mbox_post, dim3(1), dim3(BLOCK), 0, c->stream, src_dev, n, c->mb_buf, c->mbox, seq);
+    HIPCHK(c, hipGetLastError());
+    int rc = mbox_wait(c, seq);
+    if (rc) return rc;
+    memcpy(dst_host, c->mb_buf, (size_t)8 * n);
+    return 0;
 }
 
 // 6x6 symmetric (row-major 36) -> 21
@@ -881,6 +922,21 @@ int plfx_create(int device, plfx_ctx **out)
     if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
     if (const char *e3 = getenv("PLFX_SVC_WAVE")) c->want_svc_wave = atoi(e3) ? 1 : 0;
     if (const char *e4 = getenv("PLFX_MG_GRAPH")) c->want_mg_graph = atoi(e4) ? 1 : 0;
+    {
+        const char *e5 = getenv("PLFX_MAILBOX");
+        if (!e5 || atoi(e5)) {
+            if (hipHostMalloc((void **)&c->mbox, sizeof(CgMbox), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
+                memset(c->mbox, 0, sizeof(CgMbox));
+            else
+                c->mbox = nullptr;
+            c->mb_cap = 1 << 16;  // 512 KB of results per call (boundary gathers of meshes up to ~8000 x 8000)
+            if (c->mbox && hipHostMalloc((void **)&c->mb_buf, (size_t)8 * c->mb_cap,
+                                         hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                c->mb_buf = nullptr;
+                c->mb_cap = 0;
+            }
+        }
+    }
     // 160 KiB LDS per CU on gfx950; leave room for the static material/class tables
     size_t lds = std::max((size_t)c->prop.sharedMemPerBlock, (size_t)c->prop.maxSharedMemoryPerMultiProcessor);
     lds = std::min(lds, (size_t)160 * 1024);
@@ -923,6 +979,8 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->fin_idx);
     dfree(c->fin_dev);
     if (c->fin_host) hipHostFree(c->fin_host);
+    if (c->mbox) hipHostFree(c->mbox);
+    if (c->mb_buf) hipHostFree(c->mb_buf);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2096,13 +2154,38 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
         g_rccl.AllReduce(c->fin_dev + 2 * (size_t)n, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, c->comm,
                          c->stream) != 0)
         return fail(c, PLFX_ERR_HIP, "ncclAllReduce(sums) failed");
-    HIPCHK(c, hipMemcpyAsync(c->fin_host, c->fin_dev, ((size_t)2 * n + 18) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = fetch_results(c, c->fin_dev, 2 * n + 18, c->fin_host))) return rc;
     if (u_at && n > 0) memcpy(u_at, c->fin_host, (size_t)8 * n);
     if (f_at && n > 0) memcpy(f_at, c->fin_host + n, (size_t)8 * n);
     if (sums18) memcpy(sums18, c->fin_host + 2 * (size_t)n, 18 * 8);
     return PLFX_OK;
 }
+
+namespace {
+
+// launch k_cg_check and fetch the scalars: through the pinned mailbox (host spins on the sequence number) or, without
+// it, by a device->host copy + stream synchronisation
+int cg_check_fetch(plfx_ctx *c, const double *part_rr, int gn, int it_done, CgScalars *hs)
+{
+    if (!c->mbox) {
+        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, part_rr, gn, c->sc, it_done,
+                           (CgMbox *)nullptr, 0ull);
+        HIPCHK(c, hipMemcpyAsync(hs, c->sc, sizeof(*hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const unsigned long long seq = ++c->mbox_seq;
+    hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, part_rr, gn, c->sc, it_done, c->mbox, seq);
+    HIPCHK(c, hipGetLastError());
+    {
+        const int rcw = mbox_wait(c, seq);
+        if (rcw) return rcw;
+    }
+    *hs = c->mbox->sc;
+    return 0;
+}
+
+}  // namespace
 
 int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
 {
@@ -2135,9 +2218,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     CgScalars hs;
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
-        hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[1], gn, c->sc, 0);
-        HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = cg_check_fetch(c, P_rr[1], gn, 0, &hs))) return rc;
         done = hs.done;
     }
     if (mg && !done) {
@@ -2183,9 +2264,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                                    (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc);
                 tim_end(c, ev);
                 // stop here if this update converged: the V-cycle below would only prepare the next iteration
-                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[cur], gn, c->sc, it + 1);
-                HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if ((rc = cg_check_fetch(c, P_rr[cur], gn, it + 1, &hs))) return rc;
                 if (hs.done) {
                     it++;
                     break;
@@ -2323,8 +2402,10 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
             return fail(c, PLFX_ERR_HIP, "ncclAllReduce(flags) failed");
     }
     int h[4];
-    HIPCHK(c, hipMemcpyAsync(h, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        const int rcf = fetch_results(c, reinterpret_cast<const double *>(c->flags), 2, reinterpret_cast<double *>(h));
+        if (rcf) return rcf;
+    }
     if (changed) *changed = h[0];
     if (conv) *conv = h[1] ? 0 : 1;
     c->last_heavy = h[2];
@@ -2395,8 +2476,10 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
         return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
     HIPCHK(c, hipGetLastError());
     double h[5];
-    HIPCHK(c, hipMemcpyAsync(h, c->small + 40, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        const int rcf = fetch_results(c, c->small + 40, 5, h);
+        if (rcf) return rcf;
+    }
     if (sum) *sum = h[0];
     if (count) *count = (int64_t)(h[1] + 0.5);
     if (minv) *minv = h[2];
