@@ -2138,16 +2138,21 @@ int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)
 int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
 {
     if (!c || !c->fin_dev) return c ? fail(c, PLFX_ERR_STATE, "set_finish_set first") : PLFX_ERR_STATE;
-    int rc = plfx_update_state(c);
+    if (!c->assembled) return fail(c, PLFX_ERR_STATE, "assemble first");
+    // plfx_update_state with calc_global's element sums fused into the state-update kernel (one pass over the state)
+    const size_t nd = c->ndof;
+    int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
     if (rc) return rc;
+    hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    const int g = grid_for(c->nel, MAXPART);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<1>), dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, c->nel,
+                       c->e0, c->dconn, c->dcls_id, (const double2 *)c->du, (const double2 *)c->u, c->sig, c->epl,
+                       c->eps, c->elstiff, c->res_sig, c->res_depl, c->nonlin ? 1 : 0, c->part_g);
     const int n = c->fin_n;
     if (n > 0) {
         hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, c->fin_dev);
         hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, c->fin_dev + n);
     }
-    const int g = grid_for(c->nel, 256);
-    hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
-                       c->sig, c->eps, c->epl, c->part_g);
     hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
     if (c->comm &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
@@ -2494,10 +2499,10 @@ int plfx_update_state(plfx_ctx *c)
     int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
     if (rc) return rc;
     hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
-    hipLaunchKernelGGL(k_update_state, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<0>), dim3(grid_for(c->nel, MAXPART)), dim3(BLOCK), 0, c->stream,
                        c->dmat, c->dcls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
                        (const double2 *)c->u, c->sig, c->epl, c->eps, c->elstiff, c->res_sig,
-                       c->res_depl, c->nonlin ? 1 : 0);
+                       c->res_depl, c->nonlin ? 1 : 0, (double *)nullptr);
     HIPCHK(c, hipGetLastError());
     return PLFX_OK;
 }
@@ -2520,7 +2525,7 @@ int plfx_global_sums(plfx_ctx *c, double *out18)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (!out18) return fail(c, PLFX_ERR_ARG, "null output");
-    const int g = grid_for(c->nel, 256);
+    const int g = grid_for(c->nel, MAXPART);  // same grid as the fused sums of plfx_finish_step: identical numbers
     hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
                        c->sig, c->eps, c->epl, c->part_g);
     hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);

@@ -1164,37 +1164,66 @@ k_axpy_uf(size_t ndof, const double *__restrict__ du, const double *__restrict__
 }
 
 // element state update at the end of a load step (model.py:1385-1392); u already updated
+template <int SUMS>
 __global__ void __launch_bounds__(BLOCK)
 k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcls, int nel, int e_off, const int32_t *__restrict__ conn,
                const int32_t *__restrict__ cls, const double2 *__restrict__ du2, const double2 *__restrict__ u2, double *__restrict__ sig, double *__restrict__ epl,
                double *__restrict__ eps, const double *__restrict__ elstiff, const double *__restrict__ res_sig, const double *__restrict__ res_depl,
-               int nonlin)
+               int nonlin, double *__restrict__ part /* SUMS: [18][gridDim.x] volume-weighted sums of the new sig, eps, epl */)
 {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= nel) return;
-    const ClassDev &c = gcls[cls[e]];
-    const MatDev &m = gmat[c.mat];
-    const size_t ge = (size_t)e + e_off;
-    const int n0 = conn[ge * 4], n1 = conn[ge * 4 + 1], n2 = conn[ge * 4 + 2], n3 = conn[ge * 4 + 3];
-    if (m.kind != 0 && nonlin) {  // el.res_sig is set (model.py:1390-1391)
+    // SUMS = 1 fuses calc_global's element sums (k_global_partials: same grid, same order -> identical numbers)
+    __shared__ double sh[BLOCK / 64];
+    double acc[18];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            epl[(size_t)k * nel + e] += res_depl[(size_t)k * nel + e];
-            sig[(size_t)k * nel + e] = res_sig[(size_t)k * nel + e];
+    for (int k = 0; k < 18; k++) acc[k] = 0.;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
+        const ClassDev &c = gcls[cls[e]];
+        const MatDev &m = gmat[c.mat];
+        const size_t ge = (size_t)e + e_off;
+        const int n0 = conn[ge * 4], n1 = conn[ge * 4 + 1], n2 = conn[ge * 4 + 2], n3 = conn[ge * 4 + 3];
+        double sn[6], pn[6];
+        if (m.kind != 0 && nonlin) {  // el.res_sig is set (model.py:1390-1391)
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                pn[k] = epl[(size_t)k * nel + e] + res_depl[(size_t)k * nel + e];
+                sn[k] = res_sig[(size_t)k * nel + e];
+                epl[(size_t)k * nel + e] = pn[k];
+                sig[(size_t)k * nel + e] = sn[k];
+            }
+        } else {  // el.sig += elstiff @ deps ; depl = 0 for elastic materials (model.py:1387-1388)
+            double de[6], D[21], ds[6];
+            class_strain(c, du2, n0, n1, n2, n3, de);
+#pragma unroll
+            for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
+            symv(D, de, ds);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                sn[k] = sig[(size_t)k * nel + e] + ds[k];
+                sig[(size_t)k * nel + e] = sn[k];
+                if (SUMS) pn[k] = epl[(size_t)k * nel + e];
+            }
         }
-    } else {  // el.sig += elstiff @ deps ; depl = 0 for elastic materials (model.py:1387-1388)
-        double de[6], D[21], ds[6];
-        class_strain(c, du2, n0, n1, n2, n3, de);
+        double et[6];
+        class_strain(c, u2, n0, n1, n2, n3, et);  // el.eps = el.eps_t() (model.py:1392)
 #pragma unroll
-        for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
-        symv(D, de, ds);
+        for (int k = 0; k < 6; k++) eps[(size_t)k * nel + e] = et[k];
+        if (SUMS) {
+            const double v = c.vel;
 #pragma unroll
-        for (int k = 0; k < 6; k++) sig[(size_t)k * nel + e] += ds[k];
+            for (int k = 0; k < 6; k++) {
+                acc[k] = fma(sn[k], v, acc[k]);
+                acc[6 + k] = fma(et[k], v, acc[6 + k]);
+                acc[12 + k] = fma(pn[k], v, acc[12 + k]);
+            }
+        }
     }
-    double et[6];
-    class_strain(c, u2, n0, n1, n2, n3, et);  // el.eps = el.eps_t() (model.py:1392)
+    if (SUMS) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) eps[(size_t)k * nel + e] = et[k];
+        for (int k = 0; k < 18; k++) {
+            const double t = block_sum(acc[k], sh);
+            if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = t;
+        }
+    }
 }
 
 // calc_global sums (model.py:1500-1507): partials of sum(x*Vel) for the 18 components
