@@ -162,6 +162,7 @@ struct plfx_ctx {
     int bc_nrows = 0;
     double *kw = nullptr;           // K w, zero outside bc_rows
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
+    bool x_is_du = false;  // c->x still holds the last solution on the free DOFs (0 on the prescribed ones) = the warm start
     // registered boundary-condition plan (plfx_set_bc_plan): calc_BC's index structure, fixed for a load history
     struct BcPlan {
         int nseg = 0;
@@ -597,6 +598,7 @@ void free_mesh(plfx_ctx *c)
     c->mg_tail = -1;
     c->gx = c->gy = 0;
     c->assembled = c->bc_set = false;
+    c->x_is_du = false;
     c->bc_valid = false;
     c->bc_idx.clear();
     c->plan.valid = false;
@@ -638,6 +640,13 @@ bool tail_mf(const plfx_ctx *c)
 }
 
 // kernels templated on the operator form: <.., 1> matrix-free grid, <.., 0> block-ELL
+#define LAUNCH_OP1(KERN, mf, grid, ...)                                                                        \
+    do {                                                                                                       \
+        if (mf)                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<1>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
+        else                                                                                                   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
+    } while (0)
 #define LAUNCH_OP2(KERN, A, mf, grid, ...)                                                                     \
     do {                                                                                                       \
         if (mf)                                                                                                \
@@ -1638,6 +1647,7 @@ int plfx_state_reset(plfx_ctx *c)
                            c->dmat, c->dcls, c->nel_total, c->dcls_all, c->Mel);
     HIPCHK(c, hipGetLastError());
     c->assembled = false;
+    c->x_is_du = false;
     return PLFX_OK;
 }
 
@@ -1707,6 +1717,7 @@ int plfx_state_set(plfx_ctx *c, int which, const double *in)
     int rc = state_ptr(c, which, &p, &comps, &n, &soa);
     if (rc) return rc;
     if (!soa) {
+        c->x_is_du = false;  // u / f / du written from outside
         HIPCHK(c, hipMemcpyAsync(p, in, 8 * n, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return PLFX_OK;
@@ -1832,6 +1843,7 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     const bool same_set = c->bc_valid && (int)c->bc_idx.size() == n &&
                           (n == 0 || memcmp(c->bc_idx.data(), idx, (size_t)4 * n) == 0);
     if (!same_set) {
+        c->x_is_du = false;  // another Dirichlet mask: x0 has to be rebuilt from du
         HIPCHK(c, hipMemsetAsync(c->is_presc, 0, 8 * nd, c->stream));
         HIPCHK(c, hipMemsetAsync(c->dup, 0, 8 * nd, c->stream));
         HIPCHK(c, hipMemsetAsync(c->wv, 0, 8 * nd, c->stream));
@@ -2208,16 +2220,14 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     static const bool force_shard_spmv = getenv("PLFX_SHARD_SPMV") && atoi(getenv("PLFX_SHARD_SPMV")) != 0;
     const bool multi = c->comm != nullptr && (!matfree(c) || force_shard_spmv);
     // x0
-    hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
+    // x0: the previous solution restricted to the free DOFs is still in c->x when neither du nor the Dirichlet set changed
+    if (!(warm && c->x_is_du))
+        hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
+    c->x_is_du = false;
     int rc = 0;
-    if (warm) {
-        rc = plain_spmv(c, c->x, c->q);
-        if (rc) return rc;
-    }
-    // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1")
-    hipLaunchKernelGGL(k_cg_init, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->rhs,
-                       warm ? (const double2 *)c->q : nullptr, (const double2 *)c->dinv,
-                       (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
+    // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1"); one pass (no q round trip)
+    LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, warm ? 1 : 0, (const double2 *)c->x, (const double2 *)c->rhs,
+               (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
     hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
     const bool mg = mg_active(c);
     CgScalars hs;
@@ -2319,6 +2329,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     }
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
     HIPCHK(c, hipGetLastError());
+    c->x_is_du = true;  // x = du on the free DOFs, 0 on the prescribed ones: the next warm start
     if (iters) *iters = (done && hs.iters >= 0) ? hs.iters : it;
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
         c->tim.noop[1] += it - hs.iters;

@@ -989,6 +989,45 @@ k_cg_update(int nnode, const double2 *__restrict__ p, const double2 *__restrict_
     }
 }
 
+// Start of a PCG solve in one pass: q = K x0 (warm start), r = mask (b - q), z = dinv r and the partial sums of r.z,
+// r.r, b.b -- k_spmv<0> + k_cg_init without the round trip of q through memory.
+template <int GRID>
+__global__ void __launch_bounds__(BLOCK)
+k_cg_start(KOp op, int nnode, int warm, const double2 *__restrict__ x, const double2 *__restrict__ b,
+           const double2 *__restrict__ dinv, double2 *__restrict__ r, double2 *__restrict__ z,
+           double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, double *__restrict__ part_bb_out)
+{
+    __shared__ double sh[BLOCK / 64];
+    double a_rz = 0., a_rr = 0., a_bb = 0.;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        double2 qi = make_double2(0., 0.);
+        if (warm) qi = op_apply<GRID>(op, i, [&](int j) { return x[j]; });
+        const double2 bi = b[i], di = dinv[i];
+        double2 ri, zi;
+        ri.x = (di.x != 0.) ? bi.x - qi.x : 0.;
+        ri.y = (di.y != 0.) ? bi.y - qi.y : 0.;
+        zi.x = di.x * ri.x;
+        zi.y = di.y * ri.y;
+        r[i] = ri;
+        z[i] = zi;
+        a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
+        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+        const double bx = (di.x != 0.) ? bi.x : 0., by = (di.y != 0.) ? bi.y : 0.;
+        a_bb = fma(bx, bx, fma(by, by, a_bb));
+    }
+    const double t1 = block_sum(a_rz, sh);
+    const double t2 = block_sum(a_rr, sh);
+    const double t3 = block_sum(a_bb, sh);
+    if (threadIdx.x == 0) {
+        part_rz_out[blockIdx.x] = t1;
+        part_rr_out[blockIdx.x] = t2;
+        part_bb_out[blockIdx.x] = t3;
+    }
+}
+
 // r = mask (b - q), z = dinv r, partial r.z, r.r   (initial residual; q = K x0)
 __global__ void __launch_bounds__(BLOCK)
 k_cg_init(int nnode, const double2 *__restrict__ b, const double2 *__restrict__ q, const double2 *__restrict__ dinv, double2 *__restrict__ r, double2 *__restrict__ z,
