@@ -2242,9 +2242,12 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
                            (const double2 *)c->z, P_rz[1]);
     }
-    // beta of the first iteration must be 0: rz_old = +inf, p_old = 0
-    hipLaunchKernelGGL(k_fill, dim3(1), dim3(BLOCK), 0, c->stream, P_rz[0], (size_t)gn, (double)INFINITY);
-    HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
+    // beta of the first iteration is 0 (k_spmv<1> takes p = z for it == 0 without touching p_old); only the sharded
+    // k_p_update_outside path still derives it from the partials: rz_old = +inf, p_old = 0
+    if (multi) {
+        hipLaunchKernelGGL(k_fill, dim3(1), dim3(BLOCK), 0, c->stream, P_rz[0], (size_t)gn, (double)INFINITY);
+        HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
+    }
     HIPCHK(c, hipGetLastError());
 
     const int chunk = mg ? 1 : 50;  // multigrid: the flag is polled inside the iteration, before the V-cycle

@@ -873,10 +873,13 @@ k_spmv(KOp op, int n_begin, int n_end,
             }
             return;
         }
-        const double rzn = sum_partials(part_rz_new, npart_prev, sh);
-        const double rzo = sum_partials(part_rz_old, npart_prev, sh);
-        beta = rzn / rzo;
+        if (it > 0) {  // first iteration: p = z (beta = 0, p_old is not initialised and never used)
+            const double rzn = sum_partials(part_rz_new, npart_prev, sh);
+            const double rzo = sum_partials(part_rz_old, npart_prev, sh);
+            beta = rzn / rzo;
+        }
     }
+    const bool first = (MODE == 1 && it == 0);
     double acc_pq = 0.;
     const int nb = gridDim.x;
     const int span = n_end - n_begin;
@@ -888,7 +891,7 @@ k_spmv(KOp op, int n_begin, int n_end,
         if (MODE == 1)
             qv = op_apply<GRID>(op, i, [&](int j) {
                 const double2 zj = z[j], po = p[j];
-                return make_double2(fma(beta, po.x, zj.x), fma(beta, po.y, zj.y));
+                return make_double2(first ? zj.x : fma(beta, po.x, zj.x), first ? zj.y : fma(beta, po.y, zj.y));
             });
         else
             qv = op_apply<GRID>(op, i, [&](int j) { return p[j]; });
@@ -897,8 +900,8 @@ k_spmv(KOp op, int n_begin, int n_end,
         if (MODE == 1) {
             const double2 zi = z[i], po = p[i];
             double2 pn;
-            pn.x = fma(beta, po.x, zi.x);
-            pn.y = fma(beta, po.y, zi.y);
+            pn.x = first ? zi.x : fma(beta, po.x, zi.x);
+            pn.y = first ? zi.y : fma(beta, po.y, zi.y);
             pnew[i] = pn;
             acc_pq = fma(pn.x, qx, fma(pn.y, qy, acc_pq));
         }
