@@ -2165,7 +2165,7 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
         hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, c->fin_dev);
         hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, c->fin_dev + n);
     }
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
     if (c->comm &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
         g_rccl.AllReduce(c->fin_dev + 2 * (size_t)n, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, c->comm,
@@ -2479,7 +2479,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
                        c->small + 32, c->scf_hh, c->scf_mult);
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr);
-    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 0, c->small + 40);
+    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 0, c->small + 40);
     if (c->comm) {  // statistics of the whole mesh: sum, count (SUM) and minimum (MIN), then the global mean
         if (g_rccl.AllReduce(c->small + 40, c->small + 40, 2, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0 ||
             g_rccl.AllReduce(c->small + 42, c->small + 42, 1, NCCL_FLOAT64, NCCL_MIN, c->comm, c->stream) != 0)
@@ -2489,7 +2489,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     // second pass with the mean taken from device memory: no host round trip between the passes
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 1,
                        c->part_g, (const double *)(c->small + 43));
-    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(64), 0, c->stream, c->part_g, g, 1, c->small + 40);
+    hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 1, c->small + 40);
     if (c->comm &&
         g_rccl.AllReduce(c->small + 44, c->small + 44, 1, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
         return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
@@ -2542,7 +2542,7 @@ int plfx_global_sums(plfx_ctx *c, double *out18)
     const int g = grid_for(c->nel, MAXPART);  // same grid as the fused sums of plfx_finish_step: identical numbers
     hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
                        c->sig, c->eps, c->epl, c->part_g);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out18, c->small, 18 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

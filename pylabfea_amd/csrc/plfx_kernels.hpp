@@ -1293,13 +1293,16 @@ k_global_partials(const ClassDev *__restrict__ gcls, int nel, const int32_t *__r
     }
 }
 
-__global__ void k_reduce_rows(const double *part, int nrows, int npart, double *out)
+// out[k] = sum of row k of part[nrows][npart]; one block per row (launch with nrows blocks), fixed order
+__global__ void __launch_bounds__(BLOCK) k_reduce_rows(const double *part, int nrows, int npart, double *out)
 {
     __shared__ double sh[BLOCK / 64];
-    for (int k = 0; k < nrows; k++) {
-        const double t = sum_partials(part + (size_t)k * npart, npart, sh);
-        if (threadIdx.x == 0) out[k] = t;
-    }
+    const int k = blockIdx.x;
+    if (k >= nrows) return;
+    double v = 0.;
+    for (int i = threadIdx.x; i < npart; i += BLOCK) v += part[(size_t)k * npart + i];
+    const double t = block_sum(v, sh);
+    if (threadIdx.x == 0) out[k] = t;
 }
 
 // calc_scf per element (model.py:1036-1054): hh value and multiplicity (0, 1 or 2 appends)
@@ -1408,24 +1411,36 @@ k_scf_reduce(int nel, const double *hh, const int32_t *mult, double mean, int pa
     }
 }
 
-// final sums of the k_scf_reduce partials in block order by one thread (the order the host loop uses):
+// final sums of the k_scf_reduce partials (one block, fixed order):
 // pass 0 -> out[0..3] = sum, count, min, mean;  pass 1 -> out[4] = centred sum of squares
-__global__ void k_scf_finish(const double *part, int g, int pass, double *out)
+__global__ void __launch_bounds__(BLOCK) k_scf_finish(const double *part, int g, int pass, double *out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sh[BLOCK / 64];
+    __shared__ double shmin[BLOCK / 64];
     double s = 0., cnt = 0., mn = 1.e300;
-    for (int b = 0; b < g; b++) {
+    for (int b = threadIdx.x; b < g; b += BLOCK) {
         s += part[b];
         cnt += part[g + b];
         mn = fmin(mn, part[2 * g + b]);
     }
-    if (pass == 0) {
-        out[0] = s;
-        out[1] = cnt;
-        out[2] = mn;
-        out[3] = cnt > 0. ? s / (double)(long long)(cnt + 0.5) : 0.;
-    } else {
-        out[4] = s;
+    const double ts = block_sum(s, sh);
+    const double tc = block_sum(cnt, sh);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shmin[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = shmin[0];
+        for (int i = 1; i < BLOCK / 64; i++) t = fmin(t, shmin[i]);
+        if (pass == 0) {
+            out[0] = ts;
+            out[1] = tc;
+            out[2] = t;
+            out[3] = tc > 0. ? ts / (double)(long long)(tc + 0.5) : 0.;
+        } else {
+            out[4] = ts;
+        }
     }
 }
 
