@@ -201,6 +201,8 @@ struct plfx_ctx {
     MgLevDev *mg_dev = nullptr;  // level descriptors for the single-workgroup tail kernel
     int mg_tail = -1;            // first level handled by the tail kernel (-1: none)
     int mg_tail_T = 0;           // nodes of all tail levels; > 0: the LDS-resident tail kernel is usable
+    int mg_cheby = 0;            // > 0: Chebyshev steps that solve the coarsest level (no dense inverse: odd coarse sizes)
+    double mg_cheby_kappa = 1.;  // assumed condition number of D^-1 K on the coarsest level
     int mg_tail_E = 0;           // elements of the tail levels without the coarsest; > 0: the matrix-free tail is usable
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
@@ -854,6 +856,26 @@ int mg_coarse_part(plfx_ctx *c)
         else if (L.ainv)
             hipLaunchKernelGGL(k_mg_coarse_dense, dim3(1), dim3(BLOCK), 0, c->stream, L.nnode, L.ainv,
                                (const double2 *)L.b, (double2 *)L.x, c->sc);
+        else if (c->mg_cheby > 0) {
+            // eigenvalues of D^-1 K assumed in [bmax / kappa, bmax]; bmax = 3 bounds the Q4 elasticity operator with
+            // room (damped Jacobi with omega = 0.9 diverges, 0.65 does not: 2.2 < lambda_max < 3.1)
+            const bool mf = L.matfree && matfree(c);
+            const int m = c->mg_cheby;
+            const double bmax = 3.0, amin = bmax / c->mg_cheby_kappa;
+            const double theta = 0.5 * (bmax + amin), delta = 0.5 * (bmax - amin), sigma = theta / delta;
+            double rho = 1. / sigma;
+            double *cur = (m & 1) ? L.x : L.t, *oth = (m & 1) ? L.t : L.x;  // the m-th result lands in L.x
+            LAUNCH_OP1(k_mg_cheby, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                       (const double2 *)nullptr, (double2 *)cur, (double2 *)L.res, 0., 1. / theta, 1, c->sc);
+            for (int k = 1; k < m; k++) {
+                const double rho_new = 1. / (2. * sigma - rho);
+                LAUNCH_OP1(k_mg_cheby, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                           (const double2 *)cur, (double2 *)oth, (double2 *)L.res, rho_new * rho, 2. * rho_new / delta, 0,
+                           c->sc);
+                std::swap(cur, oth);
+                rho = rho_new;
+            }
+        }
         else
             hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(BLOCK), lds, c->stream, L.nnode, L.nslot, L.col,
                                L.val, (const double2 *)L.dinv, (const double2 *)L.b, (double2 *)L.x,
@@ -1455,7 +1477,6 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
            (long long)dims.back().first * dims.back().second > 4)
         dims.push_back({dims.back().first / 2, dims.back().second / 2});
     if (dims.size() < 2) return PLFX_OK;
-    if ((long long)(dims.back().first + 1) * (dims.back().second + 1) > MG_COARSE_MAX) return PLFX_OK;
     if (!c->mg_cls) {
         if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->mg_cls, &c->hcls[0], sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
@@ -1519,9 +1540,13 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
                                           n * n * (int)sizeof(double)));
         }
     }
-    const int lds = c->mg.back().nnode * 4 * (int)sizeof(double2);
-    HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    c->mg_cheby = 0;
+    const bool small_coarsest = c->mg.back().nnode <= MG_COARSE_MAX;
+    if (small_coarsest) {
+        const int lds = c->mg.back().nnode * 4 * (int)sizeof(double2);
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     {   // levels small enough for the single-workgroup tail (never level 0)
         std::vector<MgLevDev> hd(c->mg.size());
         c->mg_tail = -1;
@@ -1565,10 +1590,20 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         {   // levels above the tail are applied matrix-free; the tail and the coarsest level keep assembled matrices
             const int nl = (int)c->mg.size();
             const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
+            // coarsest level without a dense inverse (odd coarse sizes such as 25 x 25 or 125 x 125 elements) and not
+            // inside a multi-level tail: solved by a fixed number of Jacobi-preconditioned Chebyshev steps
+            c->mg_cheby = 0;
+            if (!c->mg.back().ainv && lt == nl - 1) {
+                const int n = std::max(c->mg.back().nx, c->mg.back().ny);
+                c->mg_cheby = std::min(std::max(n, 16), 160);
+                c->mg_cheby_kappa = std::max(4., 0.5 * (double)n * n);
+                if (const char *e6 = getenv("PLFX_MG_CHEBY")) c->mg_cheby = std::max(0, atoi(e6));
+                if (const char *e7 = getenv("PLFX_MG_CHEBY_KAPPA")) c->mg_cheby_kappa = std::max(1.5, atof(e7));
+            }
             for (int l = 0; l < nl; l++) {
                 auto &L = c->mg[l];
                 L.op = make_op(c, L.nnode, L.nslot, L.col, L.val, L.nx, L.ny, L.nel, l == 0 ? c->Mop : L.Mel);
-                L.matfree = l < lt;
+                L.matfree = l < lt || (c->mg_cheby > 0 && l == nl - 1);
             }
         }
         dfree(c->mg_dev);

@@ -86,6 +86,35 @@ k_mg_residual(KOp op,
     }
 }
 
+// One step of the Jacobi-preconditioned Chebyshev iteration for K x = b (coarsest level too large for a dense inverse):
+//   d <- c1 d + c2 D^-1 (b - K x),  x <- x + d        (first != 0: x = 0, d = c2 D^-1 b)
+// A fixed number of steps with fixed coefficients is a fixed polynomial in D^-1 K: a symmetric positive definite
+// coarse solver, so the V-cycle stays a valid PCG preconditioner.
+template <int GRID>
+__global__ void __launch_bounds__(BLOCK)
+k_mg_cheby(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__ b, const double2 *__restrict__ xin,
+           double2 *__restrict__ xout, double2 *__restrict__ d, double c1, double c2, int first, const CgScalars *sc)
+{
+    if (sc->done) return;
+    const int nb = gridDim.x, nnode = op.nnode;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        const double2 di = dinv[i], bi = b[i];
+        if (first) {
+            const double2 dn = make_double2(c2 * di.x * bi.x, c2 * di.y * bi.y);
+            d[i] = dn;
+            xout[i] = dn;
+            continue;
+        }
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) { return xin[j]; });
+        const double2 xi = xin[i], dold = d[i];
+        const double2 dn = make_double2(fma(c1, dold.x, c2 * di.x * (bi.x - qv.x)), fma(c1, dold.y, c2 * di.y * (bi.y - qv.y)));
+        d[i] = dn;
+        xout[i] = make_double2(xi.x + dn.x, xi.y + dn.y);
+    }
+}
+
 // full-weighting restriction b_c = P^T res_f (coarse node (J,K) <-> fine node (2J,2K)); nyf/nyc = nodes per column
 __global__ void __launch_bounds__(BLOCK)
 k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__restrict__ res_f,

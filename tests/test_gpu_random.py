@@ -173,3 +173,42 @@ def test_composite_j2_svc_laminate_vs_oracle(golden_dir):
     assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
     assert np.max(np.abs(fe._state('epl') - ref.epl)) < 1e-6 * np.max(np.abs(ref.eps))
     assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s
+
+
+def test_odd_coarse_grid_chebyshev_vs_oracle():
+    """50 x 30 elements halve once to 25 x 15 (odd): the coarsest level has 832 DOFs, no dense inverse -> fixed-degree
+    Jacobi-Chebyshev coarse solver inside the V-cycle; plastic tension against the oracle's sparse direct solve"""
+    import pylabfea_amd as FE
+    from oracle.solve_ref import RefSolver
+
+    def build():
+        mat = FE.Material()
+        mat.elasticity(E=200.e3, nu=0.3)
+        mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+        soft = FE.Material(num=2)
+        soft.elasticity(E=1.e3, nu=0.27)
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom(sect=2, LX=5., LY=3.)
+        fe.assign([mat, soft])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.002 * fe.leny, 'disp')
+        el = np.ones((50, 30))
+        el[20:30, 10:20] = 2
+        fe.mesh(elmts=el, NX=50, NY=30)
+        return fe
+    fe = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=5)
+    kind, levels = fe._engine.precond_info()
+    assert kind == 1 and levels == 2
+    assert max(s[0] for s in fe.solver_stats) < 60      # multigrid-type iteration counts, not Jacobi's hundreds
+    ref = RefSolver(build()).solve(min_step=5)
+    assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
+    s = np.max(np.abs(ref.sig))
+    assert np.max(fe._state('epl')) > 0.
+    assert np.max(np.abs(fe.u - ref.u)) < 1e-6 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
+    assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s
