@@ -1605,6 +1605,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
                 L.op = make_op(c, L.nnode, L.nslot, L.col, L.val, L.nx, L.ny, L.nel, l == 0 ? c->Mop : L.Mel);
                 L.matfree = l < lt || (c->mg_cheby > 0 && l == nl - 1);
             }
+            if (c->mg_cheby == 0 && c->mg.back().nnode > MG_COARSE_MAX) c->precond = 0;  // no usable coarse solver
         }
         dfree(c->mg_dev);
         if ((rc = dalloc(c, &c->mg_dev, hd.size()))) return rc;
