@@ -2298,9 +2298,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             double *pold = c->p[prev], *pnew = c->p[cur];
             EvPair *ev;
             tim_begin(c, 1, &ev);
-            LAUNCH_OP2(k_spmv, 1, matfree(c), dim3(gn), c->op, multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
-                       (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev],
-                       P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
+            if (it == 0 && !multi)  // first iteration: p = z, p_old untouched
+                LAUNCH_OP2(k_spmv, 2, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)pold, (const double2 *)c->z,
+                           (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
+            else
+                LAUNCH_OP2(k_spmv, 1, matfree(c), dim3(gn), c->op, multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
+                           (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev],
+                           P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
             tim_end(c, ev);
             if (multi) {
                 hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->own_n0,

@@ -846,6 +846,7 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
 // MODE 0: q = K p                                   (plain; used for K w, K du, residual)
 // MODE 1: PCG step: beta = rz_new/rz_old from the partial sums of the previous update kernel,
 //         p_new = z + beta p_old (written to pnew), q = K p_new, partial sums of p_new . q.
+// MODE 2: first PCG step: p_new = z, q = K z, partial sums of z . q (p_old is neither initialised nor read)
 struct CgScalars {
     double thresh2;  // (rtol * |b|)^2
     int32_t done;    // sticky convergence flag
@@ -862,7 +863,7 @@ k_spmv(KOp op, int n_begin, int n_end,
 {
     __shared__ double sh[BLOCK / 64];
     double beta = 0.;
-    if (MODE == 1) {
+    if (MODE >= 1) {
         if (sc->done) return;
         const double rr = sum_partials(part_rr, npart_prev, sh);
         if (rr <= sc->thresh2 || !(rr == rr)) {  // all blocks take the same decision from the same partials
@@ -873,13 +874,12 @@ k_spmv(KOp op, int n_begin, int n_end,
             }
             return;
         }
-        if (it > 0) {  // first iteration: p = z (beta = 0, p_old is not initialised and never used)
+        if (MODE == 1) {  // MODE 2 = first iteration: p = z (beta = 0, p_old is not initialised and never read)
             const double rzn = sum_partials(part_rz_new, npart_prev, sh);
             const double rzo = sum_partials(part_rz_old, npart_prev, sh);
             beta = rzn / rzo;
         }
     }
-    const bool first = (MODE == 1 && it == 0);
     double acc_pq = 0.;
     const int nb = gridDim.x;
     const int span = n_end - n_begin;
@@ -891,8 +891,10 @@ k_spmv(KOp op, int n_begin, int n_end,
         if (MODE == 1)
             qv = op_apply<GRID>(op, i, [&](int j) {
                 const double2 zj = z[j], po = p[j];
-                return make_double2(first ? zj.x : fma(beta, po.x, zj.x), first ? zj.y : fma(beta, po.y, zj.y));
+                return make_double2(fma(beta, po.x, zj.x), fma(beta, po.y, zj.y));
             });
+        else if (MODE == 2)
+            qv = op_apply<GRID>(op, i, [&](int j) { return z[j]; });
         else
             qv = op_apply<GRID>(op, i, [&](int j) { return p[j]; });
         const double qx = qv.x, qy = qv.y;
@@ -900,13 +902,17 @@ k_spmv(KOp op, int n_begin, int n_end,
         if (MODE == 1) {
             const double2 zi = z[i], po = p[i];
             double2 pn;
-            pn.x = first ? zi.x : fma(beta, po.x, zi.x);
-            pn.y = first ? zi.y : fma(beta, po.y, zi.y);
+            pn.x = fma(beta, po.x, zi.x);
+            pn.y = fma(beta, po.y, zi.y);
             pnew[i] = pn;
             acc_pq = fma(pn.x, qx, fma(pn.y, qy, acc_pq));
+        } else if (MODE == 2) {
+            const double2 zi = z[i];
+            pnew[i] = zi;
+            acc_pq = fma(zi.x, qx, fma(zi.y, qy, acc_pq));
         }
     }
-    if (MODE == 1) {
+    if (MODE >= 1) {
         const double t = block_sum(acc_pq, sh);
         if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
     }
