@@ -769,15 +769,15 @@ int mg_down_level(plfx_ctx *c, int l)
     const bool mf = L.matfree && matfree(c);
     const int nu = c->mg_nu;
     EvPair *ev = nullptr;
+    (void)ev;  // the head of the cycle is enqueued speculatively (may return at once): family 5 times the post-smoothing
+               // launches of k_mg_smooth<1, .> only
     if (nu == 2) {  // both sweeps in one pass over the operator
-        if (l == 0) tim_begin(c, 5, &ev);
         if (l == 0)
             LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (double2 *)L.x, om, c->sc);
         else
             LAUNCH_OP2(k_mg_smooth2_zero, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (double2 *)L.x, om, c->sc);
-        if (l == 0) tim_end(c, ev);
     } else {
         double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
         for (int k = 0; k < nu; k++) {
@@ -897,14 +897,22 @@ void mg_graph_drop(plfx_ctx *c)
 // z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r).  The fine level is launched kernel by kernel
 // (its launches are timed for the roofline); the ~35 small launches of all coarser levels are captured once into a
 // hipGraph and replayed (arguments are constant for a hierarchy: pointers, omega, nu).
-int mg_vcycle(plfx_ctx *c)
+// The cycle in two parts so that plfx_solve can enqueue the head (fine-level pre-smoothing, residual, restriction: 60 us
+// of work whose kernels return at once if the PCG flag says "converged") BEFORE it waits for that flag: the round trip
+// to the host is hidden behind the head instead of idling the GPU.
+int mg_vcycle_head(plfx_ctx *c)
+{
+    const int nl = (int)c->mg.size();
+    const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
+    if (lt >= 1) return mg_down_level(c, 0);
+    return 0;
+}
+
+int mg_vcycle_rest(plfx_ctx *c)
 {
     const int nl = (int)c->mg.size();
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
     int rc;
-    if (lt >= 1) {
-        if ((rc = mg_down_level(c, 0))) return rc;
-    }
     if (lt < 1) {  // two-level hierarchy without a separate fine leg
         if ((rc = mg_coarse_part(c))) return rc;
     } else if (c->want_mg_graph && lt >= 2) {
@@ -927,6 +935,13 @@ int mg_vcycle(plfx_ctx *c)
     }
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+
+int mg_vcycle(plfx_ctx *c)
+{
+    int rc = mg_vcycle_head(c);
+    if (rc) return rc;
+    return mg_vcycle_rest(c);
 }
 
 }  // namespace
@@ -2218,17 +2233,27 @@ namespace {
 
 // launch k_cg_check and fetch the scalars: through the pinned mailbox (host spins on the sequence number) or, without
 // it, by a device->host copy + stream synchronisation
-int cg_check_fetch(plfx_ctx *c, const double *part_rr, int gn, int it_done, CgScalars *hs)
+// post: launch k_cg_check (with the mailbox: it also publishes the scalars); wait: fetch them.  Work enqueued between the
+// two overlaps the round trip.
+unsigned long long cg_check_post(plfx_ctx *c, const double *part_rr, int gn, int it_done)
 {
     if (!c->mbox) {
         hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, part_rr, gn, c->sc, it_done,
                            (CgMbox *)nullptr, 0ull);
-        HIPCHK(c, hipMemcpyAsync(hs, c->sc, sizeof(*hs), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
     const unsigned long long seq = ++c->mbox_seq;
     hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, part_rr, gn, c->sc, it_done, c->mbox, seq);
+    return seq;
+}
+
+int cg_check_wait(plfx_ctx *c, unsigned long long seq, CgScalars *hs)
+{
+    if (!c->mbox) {  // note: waits for everything enqueued so far
+        HIPCHK(c, hipMemcpyAsync(hs, c->sc, sizeof(*hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
     HIPCHK(c, hipGetLastError());
     {
         const int rcw = mbox_wait(c, seq);
@@ -2269,11 +2294,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     CgScalars hs;
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
-        if ((rc = cg_check_fetch(c, P_rr[1], gn, 0, &hs))) return rc;
+        const unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
+        if ((rc = mg_vcycle_head(c))) return rc;  // speculative: its kernels return at once if the flag says converged
+        if ((rc = cg_check_wait(c, seq, &hs))) return rc;
         done = hs.done;
     }
     if (mg && !done) {
-        rc = mg_vcycle(c);
+        rc = mg_vcycle_rest(c);
         if (rc) return rc;
         hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
                            (const double2 *)c->z, P_rz[1]);
@@ -2322,14 +2349,19 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                                    (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc);
                 tim_end(c, ev);
                 // stop here if this update converged: the V-cycle below would only prepare the next iteration
-                if ((rc = cg_check_fetch(c, P_rr[cur], gn, it + 1, &hs))) return rc;
+                const unsigned long long seq = cg_check_post(c, P_rr[cur], gn, it + 1);
+                EvPair *evv;
+                tim_begin(c, 4, &evv);
+                if ((rc = mg_vcycle_head(c))) return rc;  // overlaps the round trip of the flag
+                if ((rc = cg_check_wait(c, seq, &hs))) return rc;
                 if (hs.done) {
+                    tim_end(c, evv);
+                    if (c->tim.on) c->tim.noop[4]++;  // a head that returned at once is not a V-cycle
                     it++;
                     break;
                 }
-                tim_begin(c, 4, &ev);
-                rc = mg_vcycle(c);
-                tim_end(c, ev);
+                rc = mg_vcycle_rest(c);
+                tim_end(c, evv);
                 if (rc) return rc;
                 hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
                                    (const double2 *)c->z, P_rz[cur]);
