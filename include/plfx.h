@@ -19,6 +19,7 @@
 #ifndef PLFX_H
 #define PLFX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -216,6 +217,11 @@ int plfx_set_bc_sources(plfx_ctx *ctx, int nseg, const int32_t *src, const int32
                         const int32_t *fk, const int32_t *flen, const int32_t *fidx, const double *fshare);
 int plfx_load_step(plfx_ctx *ctx, plfx_step *step, double *u_at, double *f_at, double *sums18);
 
+/* Host-staged transport for the same collectives (tests on a single GPU, hosts without RCCL): every in-place all-reduce
+ * the library needs is staged through host memory and handed to `fn` (dtype 0 = double, 1 = int32; op 0 = sum, 3 = min;
+ * return 0 on success).  Slow by construction -- the product transport is plfx_comm_init (RCCL). */
+typedef int (*plfx_allreduce_fn)(void *user, void *buf, size_t count, int dtype, int op);
+int plfx_comm_init_callback(plfx_ctx *ctx, int rank, int nranks, plfx_allreduce_fn fn, void *user);
 /* device_collectives = 1: this context shards the elements over an RCCL communicator; plfx_sweep (flags),
  * plfx_scf_all (statistics) and plfx_finish_step (element sums) then return values of the WHOLE mesh (all-reduced on
  * the device, on the library's stream) and the caller needs no collective of its own. */

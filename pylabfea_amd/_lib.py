@@ -46,7 +46,8 @@ SYMBOLS = [
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
     'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
-    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_set_bc_sources',
+    'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
+    'plfx_set_bc_sources',
     'plfx_load_step',
 ]
 
@@ -437,6 +438,24 @@ class Context(object):
     def comm_init(self, uid, rank, nranks):
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(self.lib.plfx_comm_init(self.h, buf, int(rank), int(nranks)))
+
+    _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+
+    def comm_init_callback(self, rank, nranks, fn):
+        """host-staged collectives (tests on one GPU, hosts without RCCL): ``fn(array, op)`` all-reduces the NumPy
+        array in place (op 0 = sum, 3 = min) across the ranks"""
+        def trampoline(user, buf, count, dtype, op):
+            try:
+                ct = C.c_int32 if dtype == 1 else C.c_double
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ct)), shape=(count,))
+                fn(arr, op)
+                return 0
+            except Exception:  # noqa: BLE001 - reported as an error code across the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ar_cb = self._ALLREDUCE_FN(trampoline)   # keep alive as long as the context
+        self._chk(self.lib.plfx_comm_init_callback(self.h, int(rank), int(nranks), self._ar_cb, None))
 
     # -- instrumentation
     def timing_enable(self, on=True):

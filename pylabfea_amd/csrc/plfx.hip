@@ -227,6 +227,9 @@ struct plfx_ctx {
 
     // multi-GPU
     ncclComm_t comm = nullptr;
+    plfx_allreduce_fn host_ar = nullptr;  // host-staged collective transport (plfx_comm_init_callback: tests, hosts without RCCL)
+    void *host_ar_user = nullptr;
+    std::vector<char> host_ar_buf;
     int rank = 0, nranks = 1;
 
     Timing tim;
@@ -667,17 +670,40 @@ int plain_spmv(plfx_ctx *c, const double *in, double *out)
     return 0;  // the matrix is replicated on every rank: no collective here
 }
 
+bool comm_active(const plfx_ctx *c) { return c->comm != nullptr || c->host_ar != nullptr; }
+
+// in-place all-reduce of a device buffer on the library's stream: RCCL, or the host-staged callback transport
+int allreduce(plfx_ctx *c, void *dev, size_t count, int nccl_dtype, int nccl_op, const char *what)
+{
+    if (c->comm) {
+        if (g_rccl.AllReduce(dev, dev, count, nccl_dtype, nccl_op, c->comm, c->stream) != 0)
+            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(%s) failed", what);
+        return 0;
+    }
+    if (c->host_ar) {
+        const size_t bytes = count * (nccl_dtype == NCCL_INT32 ? 4 : 8);
+        if (c->host_ar_buf.size() < bytes) c->host_ar_buf.resize(bytes);
+        HIPCHK(c, hipMemcpyAsync(c->host_ar_buf.data(), dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->host_ar(c->host_ar_user, c->host_ar_buf.data(), count, nccl_dtype == NCCL_INT32 ? 1 : 0,
+                       nccl_op == NCCL_MIN ? 3 : 0) != 0)
+            return fail(c, PLFX_ERR_HIP, "host all-reduce callback failed (%s)", what);
+        HIPCHK(c, hipMemcpyAsync(dev, c->host_ar_buf.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    return 0;
+}
+
 // Sharded runs: make the stiffness generators of the whole mesh consistent on every rank after a sweep
 // changed the owned ones (own part + exact zeros elsewhere, summed by one all-reduce).
 int sync_M(plfx_ctx *c)
 {
-    if (!c->comm || !c->sharded) return 0;
+    if (!comm_active(c) || !c->sharded) return 0;
     hipLaunchKernelGGL(k_zero_foreign_M, dim3(grid_for((size_t)6 * c->nel_total)), dim3(BLOCK), 0, c->stream,
                        c->nel_total, c->e0, c->e0 + c->nel, c->Mel);
     HIPCHK(c, hipGetLastError());
-    if (g_rccl.AllReduce(c->Mel, c->Mel, (size_t)6 * c->nel_total, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
-        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(M) failed");
-    return 0;
+    return allreduce(c, c->Mel, (size_t)6 * c->nel_total, NCCL_FLOAT64, NCCL_SUM, "M");
 }
 
 
@@ -2218,10 +2244,9 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     }
     hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
-    if (c->comm &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
-        g_rccl.AllReduce(c->fin_dev + 2 * (size_t)n, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, c->comm,
-                         c->stream) != 0)
-        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(sums) failed");
+    if (comm_active(c) &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
+        (rc = allreduce(c, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, "sums")))
+        return rc;
     if ((rc = fetch_results(c, c->fin_dev, 2 * n + 18, c->fin_host))) return rc;
     if (u_at && n > 0) memcpy(u_at, c->fin_host, (size_t)8 * n);
     if (f_at && n > 0) memcpy(f_at, c->fin_host + n, (size_t)8 * n);
@@ -2279,7 +2304,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // several times less than all-reducing 16.8 MB over xGMI -- so the product is computed redundantly and the solve has
     // no collective at all (PLFX_SHARD_SPMV=1 restores the sharded rows + all-reduce).
     static const bool force_shard_spmv = getenv("PLFX_SHARD_SPMV") && atoi(getenv("PLFX_SHARD_SPMV")) != 0;
-    const bool multi = c->comm != nullptr && (!matfree(c) || force_shard_spmv);
+    const bool multi = comm_active(c) && (!matfree(c) || force_shard_spmv);
     // x0
     // x0: the previous solution restricted to the free DOFs is still in c->x when neither du nor the Dirichlet set changed
     if (!(warm && c->x_is_du))
@@ -2337,8 +2362,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->own_n0,
                                    c->own_n1, (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew,
                                    (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, c->sc);
-                if (g_rccl.AllReduce(c->q, c->q, nd, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
-                    return fail(c, PLFX_ERR_HIP, "ncclAllReduce(q) failed");
+                if ((rc = allreduce(c, c->q, nd, NCCL_FLOAT64, NCCL_SUM, "q"))) return rc;
                 hipLaunchKernelGGL(k_dot_pq, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
                                    (const double2 *)c->q, P_pq, c->sc);
             }
@@ -2488,9 +2512,9 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
         int rcm = sync_M(c);
         if (rcm) return rcm;
     }
-    if (c->comm) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
-        if (g_rccl.AllReduce(c->flags, c->flags, 3, NCCL_INT32, NCCL_SUM, c->comm, c->stream) != 0)
-            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(flags) failed");
+    if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
+        const int rca = allreduce(c, c->flags, 3, NCCL_INT32, NCCL_SUM, "flags");
+        if (rca) return rca;
     }
     int h[4];
     {
@@ -2552,19 +2576,20 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr);
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 0, c->small + 40);
-    if (c->comm) {  // statistics of the whole mesh: sum, count (SUM) and minimum (MIN), then the global mean
-        if (g_rccl.AllReduce(c->small + 40, c->small + 40, 2, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0 ||
-            g_rccl.AllReduce(c->small + 42, c->small + 42, 1, NCCL_FLOAT64, NCCL_MIN, c->comm, c->stream) != 0)
-            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
+    if (comm_active(c)) {  // statistics of the whole mesh: sum, count (SUM) and minimum (MIN), then the global mean
+        int rca = allreduce(c, c->small + 40, 2, NCCL_FLOAT64, NCCL_SUM, "scf sums");
+        if (!rca) rca = allreduce(c, c->small + 42, 1, NCCL_FLOAT64, NCCL_MIN, "scf min");
+        if (rca) return rca;
         hipLaunchKernelGGL(k_scf_mean, dim3(1), dim3(64), 0, c->stream, c->small + 40);
     }
     // second pass with the mean taken from device memory: no host round trip between the passes
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 1,
                        c->part_g, (const double *)(c->small + 43));
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 1, c->small + 40);
-    if (c->comm &&
-        g_rccl.AllReduce(c->small + 44, c->small + 44, 1, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream) != 0)
-        return fail(c, PLFX_ERR_HIP, "ncclAllReduce(scf) failed");
+    if (comm_active(c)) {
+        const int rca = allreduce(c, c->small + 44, 1, NCCL_FLOAT64, NCCL_SUM, "scf squares");
+        if (rca) return rca;
+    }
     HIPCHK(c, hipGetLastError());
     double h[5];
     {
@@ -2627,7 +2652,7 @@ int plfx_comm_info(plfx_ctx *c, int *rank, int *nranks, int *device_collectives)
     if (!c) return PLFX_ERR_ARG;
     if (rank) *rank = c->rank;
     if (nranks) *nranks = c->nranks;
-    if (device_collectives) *device_collectives = c->comm ? 1 : 0;
+    if (device_collectives) *device_collectives = comm_active(c) ? 1 : 0;
     return PLFX_OK;
 }
 
@@ -2650,6 +2675,18 @@ int plfx_comm_init(plfx_ctx *c, const char id[128], int rank, int nranks)
     memcpy(u.internal, id, 128);
     HIPCHK(c, hipSetDevice(c->device));
     if (g_rccl.CommInitRank(&c->comm, nranks, u, rank) != 0) return fail(c, PLFX_ERR_HIP, "ncclCommInitRank failed");
+    c->rank = rank;
+    c->nranks = nranks;
+    return PLFX_OK;
+}
+
+int plfx_comm_init_callback(plfx_ctx *c, int rank, int nranks, plfx_allreduce_fn fn, void *user)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    if (!fn || rank < 0 || rank >= nranks) return fail(c, PLFX_ERR_ARG, "bad rank/nranks/callback");
+    if (c->comm) return fail(c, PLFX_ERR_STATE, "an RCCL communicator is already active");
+    c->host_ar = fn;
+    c->host_ar_user = user;
     c->rank = rank;
     c->nranks = nranks;
     return PLFX_OK;

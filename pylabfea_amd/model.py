@@ -394,11 +394,13 @@ class Model(object):
                              [0., 0., 0., 0., 0., mat.C44]])
         return np.array(mat.CV, dtype=float)
 
-    def distribute(self, rank, nranks, uid):
+    def distribute(self, rank, nranks, uid, host_allreduce=None):
         """Shard the elements into ``nranks`` x-strips (contiguous element-column blocks); this
         process owns strip ``rank`` on GPU ``self.device``.  ``uid`` is the RCCL unique id created on
-        rank 0 (``_lib.Context.comm_unique_id``) and broadcast by the caller."""
+        rank 0 (``_lib.Context.comm_unique_id``) and broadcast by the caller.  ``uid=None`` with
+        ``host_allreduce=fn(array, op)`` selects the host-staged transport instead (tests on one GPU)."""
         self._shard = (int(rank), int(nranks), uid)
+        self._host_allreduce = host_allreduce
         self._drop_engine()
 
     def strip_range(self, rank, nranks):
@@ -423,7 +425,10 @@ class Model(object):
         e0, e1 = 0, self.Nel
         if self._shard is not None:
             rank, nranks, uid = self._shard
-            eng.comm_init(uid, rank, nranks)
+            if uid is not None:
+                eng.comm_init(uid, rank, nranks)
+            elif getattr(self, '_host_allreduce', None) is not None:
+                eng.comm_init_callback(rank, nranks, self._host_allreduce)
             e0, e1 = self.strip_range(rank, nranks)
         eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
         eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible

@@ -1,0 +1,133 @@
+"""Sharded runs with 2 and 3 ranks on ONE GPU: every rank is a process with its own libplfx context on cuda:0 and owns
+one x-strip of elements; the collectives (stiffness generators after a sweep, sweep flags, calc_scf statistics,
+calc_global sums) go through the host-staged transport (plfx_comm_init_callback) over a gloo process group, because RCCL
+refuses two ranks on one device.  Everything else -- strip ownership inside the kernels, zeroing of the foreign
+generators, the replicated solve, the native load step -- is the code that runs with RCCL on N GPUs.
+Reference: traces of the reference's solve (tests/golden/solve.npz) and the single-rank run of the same model."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def build(case, golden_dir):
+    import pylabfea_amd as FE
+    mat = FE.Material()
+    mat.elasticity(E=200.e3, nu=0.3)
+    mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+    fe = FE.Model(dim=2, planestress=False)
+    if case == 'hill6_12':          # golden trace of the reference
+        fe.geom([4.], LY=4.)
+        fe.assign([mat])
+        n, eps, ms = 12, 0.003, 8
+    elif case == 'inclusion':       # heterogeneous: strips see different branches
+        soft = FE.Material(num=2)
+        soft.elasticity(E=1.e3, nu=0.27)
+        fe.geom(sect=2, LX=4., LY=4.)
+        fe.assign([mat, soft])
+        n, eps, ms = 24, 0.002, 6
+    else:                           # J2 + SVC laminate: wave-per-element SVC kernels on strips
+        z = np.load(os.path.join(golden_dir, 'svc_shear.npz'))
+        mb = FE.Material(name='ML', num=2)
+        mb.elasticity(CV=z['par_CV'])
+        mb.plasticity(sy=float(z['par_sy']), sdim=6)
+        mb.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']),
+                   float(z['par_scale_seq']))
+        fe.geom([1, 1, 1, 1], LY=2.)
+        fe.assign([mat, mb, mat, mb])
+        n, eps, ms = 16, 0.0015, 4
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    if case == 'inclusion':
+        el = np.ones((n, n))
+        el[8:16, 8:16] = 2
+        fe.mesh(elmts=el, NX=n, NY=n)
+    elif case == 'hill6_12':
+        fe.mesh(NX=n, NY=n)
+    else:
+        fe.mesh(NX=n, NY=8)
+    return fe, ms
+
+
+def _worker(rank, world, port, case, golden_dir, q):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        def allreduce(arr, op):
+            t = torch.from_numpy(arr)           # shares memory with the library's staging buffer
+            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 3 else dist.ReduceOp.SUM)
+        fe, ms = build(case, golden_dir)
+        fe.distribute(rank, world, None, host_allreduce=allreduce)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=ms)
+        eng = fe._engine
+        assert eng.comm_info() == (rank, world, True)
+        e0, e1 = fe._e0, fe._e1
+        q.put((rank, dict(nsteps=fe.nsteps, niter=list(fe.niter), u=fe.u, f=fe.f, sgl=fe.sgl, e0=e0, e1=e1,
+                          sig=eng.state_get(0), epl=eng.state_get(2), native=fe._native_step and fe._dev_coll)))
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'ERROR: ' + traceback.format_exc()))
+        raise exc
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case,world', [('hill6_12', 2), ('inclusion', 3), ('laminate_svc', 2)])
+def test_sharded_ranks_on_one_gpu(golden_dir, case, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, d = q.get(timeout=600)
+        assert not isinstance(d, str), d
+        res[r] = d
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-rank run of the same model in this process
+    fe, ms = build(case, golden_dir)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=ms)
+    sig1, epl1 = fe._state('sig'), fe._state('epl')
+    assert np.max(epl1) > 0.
+    for r in range(world):
+        d = res[r]
+        assert d['native']                                    # the native load step ran with device-side collectives
+        assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
+        assert np.max(np.abs(d['u'] - fe.u)) <= 1e-9 * np.max(np.abs(fe.u))
+        assert np.max(np.abs(d['f'] - fe.f)) <= 1e-8 * np.max(np.abs(fe.f))
+        assert np.max(np.abs(d['sgl'] - fe.sgl)) <= 1e-9 * np.max(np.abs(fe.sgl))
+        e0, e1 = d['e0'], d['e1']
+        assert e1 > e0
+        assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * np.max(np.abs(sig1))
+        assert np.max(np.abs(d['epl'] - epl1[e0:e1])) <= 1e-8 * max(np.max(np.abs(epl1)), 1e-30)
+    assert sorted(res[r]['e0'] for r in res) == sorted(fe.strip_range(r, world)[0] for r in range(world))
+    if case == 'hill6_12':   # and the reference's own trace
+        g = np.load(os.path.join(golden_dir, 'solve.npz'))
+        assert res[0]['nsteps'] == int(g['hill6_12_nsteps']) and res[0]['niter'] == list(g['hill6_12_niter'])
+        assert np.max(np.abs(res[0]['u'] - g['hill6_12_u'])) <= 1e-6 * np.max(np.abs(g['hill6_12_u']))
