@@ -19,6 +19,7 @@ SpMV are sharded, the global vector is all-reduced over RCCL at each CG step, th
 hierarchy is replicated.  Strong scaling: the mesh is fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -29,7 +30,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PREROLL = 6          # untimed elastic increments before warm-up (part of set-up)
+PREROLL = 6          # untimed elastic increments before warm-up (part of set-up) of the 50-increment schedule
+
+
+def schedule(K, W):
+    """(number of load increments, untimed pre-roll increments): BASELINE's 50 increments with 6 elastic pre-roll steps;
+    when more steps are requested than that schedule holds, the same total strain is applied in proportionally more
+    increments (pre-roll = 12 % of them, i.e. the timed region still starts just before the onset of yielding)."""
+    ninc, pre = 50, PREROLL
+    if pre + W + K > ninc:
+        ninc = int(np.ceil((W + K + 1) / 0.88))
+        pre = int(round(0.12 * ninc))
+        while pre + W + K > ninc:
+            ninc += 1
+    return ninc, pre
+
 HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
 # calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
@@ -67,30 +82,32 @@ def cpu_baseline(n, steps, warmup):
     ref = RefSolver(fe, nthreads=0)
     marks = {}
 
+    ninc, pre = schedule(steps, warmup)
+
     def hook(il):
-        if il == PREROLL + warmup:
+        if il == pre + warmup:
             marks['t0'] = time.perf_counter()
             marks['s0'] = ref.timers['n_sweeps']
-        if il == PREROLL + warmup + steps:
+        if il == pre + warmup + steps:
             marks['t1'] = time.perf_counter()
             marks['s1'] = ref.timers['n_sweeps']
 
-    ref.solve(min_step=50, max_load_steps=PREROLL + warmup + steps, step_hook=hook)
+    ref.solve(min_step=ninc, max_load_steps=pre + warmup + steps, step_hook=hook)
     dt = marks['t1'] - marks['t0']
     sweeps = marks['s1'] - marks['s0']
     return {'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'cores': os.cpu_count(),
             'kind': 'port',
             'sample': '%dx%d mesh, same material/loading/schedule, load steps %d..%d, %d sweeps in %.1f s '
                       '(OpenMP sweep on all cores, scipy sparse assembly + SuperLU solve on 1 core)'
-                      % (n, n, PREROLL + warmup, PREROLL + warmup + steps, sweeps, dt),
+                      % (n, n, pre + warmup, pre + warmup + steps, sweeps, dt),
             'ms_per_step': 1e3 * dt / steps}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--mesh', type=int, default=1024)
     ap.add_argument('--cpu-mesh', type=int, default=224)
     ap.add_argument('--no-cpu', action='store_true')
@@ -134,27 +151,43 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # torch initialises its HIP context lazily on the first CUDA call (a few ms that would otherwise land inside the
+    # timed region after the first barrier): do it now
+    torch.zeros(1, device='cuda:%d' % local)
+    barrier()
+
     marks = {}
+    ninc, pre = schedule(K, W)
+
+    dbg = [] if os.environ.get('BENCH_DEBUG') else None
 
     def hook(il):
-        if il == PREROLL + W:
+        if dbg is not None:
+            dbg.append((il, time.perf_counter()))
+        if il == pre + W:
             eng.timing_reset()
             eng.timing_enable(True)
+            gc.collect()
+            gc.disable()   # no collector pauses inside the timed steps (a full collection of this process takes 2-3 ms)
             barrier()
             marks['t0'] = time.perf_counter()
             marks['sw0'] = fe.n_sweeps
             marks['so0'] = len(fe.solver_stats)
-        if il == PREROLL + W + K:
+        if il == pre + W + K:
             barrier()
             marks['t1'] = time.perf_counter()
+            gc.enable()
             marks['sw1'] = fe.n_sweeps
             marks['so1'] = len(fe.solver_stats)
             eng.timing_enable(False)
 
     fe._step_hook = hook
-    fe._max_load_steps = PREROLL + W + K
-    fe.solve(min_step=50)
+    fe._max_load_steps = pre + W + K
+    fe.solve(min_step=ninc)
 
+    if dbg:
+        print('hook times (ms since t0):', [(i, round(1e3 * (t - marks['t0']), 3)) for i, t in dbg if i >= pre + W],
+              't1', round(1e3 * (marks['t1'] - marks['t0']), 3), file=sys.stderr)
     dt = marks['t1'] - marks['t0']
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -216,9 +249,9 @@ def main():
         'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%dx%d Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
-                               'plane strain, uniaxial tension eps=0.005, min_step=50; timed load steps %d..%d '
-                               'of 50 (after %d untimed elastic pre-roll steps)'
-                               % (n, n, PREROLL + W, PREROLL + W + K, PREROLL),
+                               'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
+                               'of %d (after %d untimed elastic pre-roll steps)'
+                               % (n, n, ninc, pre + W, pre + W + K, ninc, pre),
                    'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': ('single GPU' if world == 1 else 'x-strip element shard x%d: sweep + CG SpMV rows sharded, '
                                    'RCCL all-reduce per CG step, replicated multigrid hierarchy' % world),
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1

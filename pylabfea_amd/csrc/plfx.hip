@@ -2697,6 +2697,21 @@ int plfx_timing_enable(plfx_ctx *c, int on)
 {
     if (!c) return PLFX_ERR_STATE;
     c->tim.on = on != 0;
+    if (c->tim.on && c->tim.ring.empty()) {  // create the event ring now, not inside the first timed launch
+        c->tim.ring.resize(2048);
+        for (auto &e : c->tim.ring) {
+            hipEventCreate(&e.a);
+            hipEventCreate(&e.b);
+            e.pending = false;
+        }
+        // first use of an event makes the runtime allocate its completion signal (pool growth costs milliseconds when
+        // it happens in the middle of a timed region): touch every event once now
+        for (auto &e : c->tim.ring) {
+            hipEventRecord(e.a, c->stream);
+            hipEventRecord(e.b, c->stream);
+        }
+        hipStreamSynchronize(c->stream);
+    }
     return PLFX_OK;
 }
 

@@ -665,6 +665,21 @@ class Model(object):
 
     # ------------------------------------------------------------------ solution
     def solve(self, min_step=None, verb=False):
+        """Solve the (non-linear) boundary-value problem (model.py:979-1450); see `_solve_steps`.
+
+        The cyclic garbage collector is paused for the duration of the load-step loop: the loop allocates no reference
+        cycles, while a full collection of a process holding a large mesh (node / element lists of ~1e6 entries) stalls
+        the loop for milliseconds -- as long as a whole load step on the GPU."""
+        import gc
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._solve_steps(min_step=min_step, verb=verb)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _solve_steps(self, min_step=None, verb=False):
         """Solve the (non-linear) boundary-value problem (model.py:979-1450).
 
         Same load-step control as the reference: elastic predictor, load-step scaling ``calc_scf``
