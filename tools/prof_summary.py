@@ -26,10 +26,11 @@ def main(d, out):
         dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     lines.append('')
     lines.append('== fine-level / productive launches only (coarse-level and post-convergence no-op launches filtered by duration) ==')
-    FINE = ('k_mg_smooth<1,1>', 'k_mg_smooth2_zero<1,1>', 'k_mg_residual<1,1>', 'k_spmv<1,1>', 'k_spmv<0,1>',
-            'k_mg_smooth<1,0>', 'k_mg_smooth2_zero<1,0>', 'k_mg_residual<1,0>', 'k_spmv<1,0>', 'k_spmv<0,0>',
-            'k_cg_update', 'k_cg_update_mg', 'k_sweep_light<1>', 'k_sweep_heavy<1>', 'k_grid_diag', 'k_assemble',
-            'k_mg_tail_lds', 'k_update_state', 'k_scf_elements', 'k_axpy_uf')
+    FINE = ('k_mg_smooth<1,1>', 'k_mg_smooth2_zero<1,1>', 'k_mg_residual<1,1>', 'k_spmv<1,1>', 'k_spmv<2,1>',
+            'k_spmv<0,1>', 'k_cg_start<1>', 'k_mg_smooth<1,0>', 'k_mg_smooth2_zero<1,0>', 'k_mg_residual<1,0>',
+            'k_spmv<1,0>', 'k_spmv<0,0>', 'k_cg_update', 'k_cg_update_mg', 'k_sweep_light<1>', 'k_sweep_light<0>',
+            'k_sweep_heavy<1>', 'k_grid_setup', 'k_grid_diag', 'k_assemble', 'k_mg_tail_mf', 'k_mg_tail_lds',
+            'k_update_state<1>', 'k_update_state<0>', 'k_update_state', 'k_scf_elements', 'k_axpy_uf', 'k_bc_finish')
     for k in FINE:
         v = [x for x in dur.get(k, []) if x > 15.]
         if v:
