@@ -870,7 +870,7 @@ def gen_fullyf_ld():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld,scaled_input')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -890,6 +890,35 @@ def main():
         gen_basic()
     if 'fullyf_ld' in todo:
         gen_fullyf_ld()
+    if 'scaled_input' in todo:
+        gen_scaled_input()
+
+
+# ----------------------------------------------------------------------------
+# 9. create_scaled_input (material.py:2301-2346, stress features) and the Barlat maps (material.py:2578-2591)
+# ----------------------------------------------------------------------------
+def gen_scaled_input():
+    rng = np.random.default_rng(11)
+    sig = rand_unit6(rng, 64) * rng.uniform(10., 120., size=64)[:, None]
+    rec = {'sig': sig}
+    for tag, sdim, dev_only, ndof in (('full6', 6, False, 6), ('dev6', 6, True, 6), ('cyl3', 3, False, 2)):
+        m = FE.Material(name='features-' + tag)
+        m.elasticity(E=200000., nu=0.3)
+        m.plasticity(sy=60., sdim=sdim)
+        m.scale_seq, m.Ndof, m.dev_only = 60., ndof, dev_only
+        rec[tag] = m.create_scaled_input(sig)
+        rec[tag + '_single'] = m.create_scaled_input(sig[5])
+    rec['cyl3_princ'] = m.create_scaled_input(sig[:, 0:3])
+    bar = [0.81766, -0.36431, 0.86993, 1.07052, 0.85640, 1.22269, 0.47370, 0.49740, 0.52740,
+           0.27328, 0.56924, 0.66140, 0.40440, 1.30700, 0.98900, 0.49500, 1.27500, 0.53400]
+    mb = FE.Material(name='barlat')
+    mb.elasticity(E=151220., nu=0.3)
+    mb.plasticity(sy=46.76, barlat=bar, barlat_exp=8, sdim=6)
+    rec['barlat_par'] = np.array(bar)
+    rec['Bar_m1'], rec['Bar_m2'] = mb.Bar_m1, mb.Bar_m2
+    rec['seqB'] = np.array([mb.calc_seqB(v) for v in sig])
+    np.savez_compressed(os.path.join(OUT, 'scaled_input.npz'), **rec)
+    print('scaled_input done')
 
 
 if __name__ == '__main__':

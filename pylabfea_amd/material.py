@@ -18,7 +18,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from .basic import eps_eq, sig_eq_j2, yf_tolerance
+from .basic import eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, yf_tolerance
 
 _point_ctx = None      # shared context for point evaluations
 _point_key = None
@@ -181,6 +181,12 @@ class Material(object):
             self.barlat = True
             self.barlat_par = np.array(barlat, dtype=float)
             self.barlat_exp = barlat_exp
+            b = self.barlat_par  # the two linear maps of the stress deviator (material.py:2578-2591)
+            for name, c in (('Bar_m1', b[0:9]), ('Bar_m2', b[9:18])):
+                m = np.zeros((6, 6))
+                m[0, 1], m[0, 2], m[1, 0], m[1, 2], m[2, 0], m[2, 1] = -c[0], -c[1], -c[2], -c[3], -c[4], -c[5]
+                m[3, 3], m[4, 4], m[5, 5] = c[6], c[7], c[8]
+                setattr(self, name, m)
         else:
             self.barlat = False
         self._version += 1
@@ -409,6 +415,36 @@ class Material(object):
             self.msg['equiv'] = ('6-parameter Hill, full Voigt stress'
                                  if self.sdim == 6 and not (self.tresca or self.barlat) else '3-parameter Hill')
         return seq[0] if single else seq
+
+    def calc_seqB(self, sv):
+        """Yld2004-18p (Barlat et al.) equivalent stress of Voigt stresses (material.py:678-702), evaluated by the device
+        routine that `calc_seq` uses for Barlat materials (closed-form principal values of the two transformed
+        deviators)."""
+        if not self.barlat:
+            raise AttributeError('calc_seqB: material has no Barlat parameters (plasticity(barlat=..., barlat_exp=...))')
+        s, single = self._voigt(sv, 'calc_seqB')
+        if s.shape[1] != 6:
+            raise ValueError('calc_seqB: Voigt stress (6,) or (N,6) expected')
+        seq = self._load(ana=True).seq(0, s)
+        return seq[0] if single else seq
+
+    def create_scaled_input(self, sig, epl=None, acc_strain=None, max_stress=None, flag=None, tex=None):
+        """Feature vectors of the SVC yield function for stresses (material.py:2301-2346, the branch without texture and
+        work-hardening features — the ones this engine evaluates): principal-stress cylinder coordinates for sdim=3,
+        (deviatoric) Voigt stress / scale_seq for sdim=6.  Host-side helper for scripts; the kernels build the same
+        features in registers."""
+        if tex is not None or getattr(self, 'txdat', False) or getattr(self, 'whdat', False):
+            raise NotImplementedError('create_scaled_input: texture / work-hardening features are outside this engine')
+        s, _ = self._voigt(sig, 'create_scaled_input')
+        x = np.zeros((len(s), self.Ndof))
+        if self.sdim == 3:
+            x[:, 0] = sig_eq_j2(s) / self.scale_seq - 1.
+            x[:, 1] = sig_polar_ang(s) / np.pi
+        else:
+            if self.dev_only:
+                s = sig_dev(s)
+            x[:, 0:s.shape[1]] = s / self.scale_seq
+        return x
 
     def get_sflow(self, epl):
         """Scalar flow stress for a plastic strain tensor or PEEQ (material.py:974-1007)."""

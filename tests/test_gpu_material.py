@@ -166,6 +166,10 @@ def test_tresca_barlat_seq(ctx, golden_dir):
     mb.elasticity(E=151220., nu=0.3)
     mb.plasticity(sy=46.76, barlat=list(z['barlat_par']), barlat_exp=int(z['barlat_exp']), sdim=6)
     assert np.max(np.abs(mb.calc_seq(z['sig']) - z['barlat_seq']) / z['barlat_seq']) < 1e-11
+    assert np.max(np.abs(mb.calc_seqB(z['sig']) - z['barlat_seq']) / z['barlat_seq']) < 1e-11   # material.py:678-702
+    assert abs(mb.calc_seqB(z['sig'][3]) - z['barlat_seq'][3]) < 1e-11 * z['barlat_seq'][3]
+    zs = np.load(os.path.join(golden_dir, 'scaled_input.npz'))   # calc_seqB called directly in the reference
+    assert np.max(np.abs(mb.calc_seqB(zs['sig']) - zs['seqB']) / zs['seqB']) < 1e-11
     with pytest.raises(ValueError):          # same error as the reference (material.py:822-825)
         mb.calc_fgrad(z['sig'][0])
     with pytest.raises(ValueError):
