@@ -172,6 +172,8 @@ struct plfx_ctx {
         std::vector<int32_t> inv;       // entry -> position in presc
         std::vector<double> first, w;   // scratch
         bool valid = false;
+        int32_t *seg4 = nullptr;        // device: up to 4 segments per prescribed DOF in entry order (-1 = unused); null when
+                                        // a DOF has more entries or there are more than BcSegVals::N segments
         // plfx_set_bc_sources: where each segment's value comes from, and the force-controlled segments
         std::vector<int32_t> src, k, fsrc, fk, flen, fidx;
         std::vector<double> fshare, fext;
@@ -1048,6 +1050,7 @@ void plfx_destroy(plfx_ctx *c)
     for (int h = 0; h < 2; h++)
         if (c->stage_ev[h]) hipEventDestroy(c->stage_ev[h]);
     dfree(c->bc_idx_dev);
+    dfree(c->plan.seg4);
     dfree(c->bc_rows);
     dfree(c->kw);
     dfree(c->fin_idx);
@@ -1907,13 +1910,12 @@ int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, do
 }
 
 // ------------------------------------------------------------------------------ BC + solve
-int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc, const double *w,
-                  const double *fext)
+namespace {
+// calc_BC on the device.  Values of the prescribed DOFs come either from host arrays (du_presc, w: one staged copy) or,
+// for a registered plan, from the per-segment values passed as kernel arguments (seg4 != null: no copy at all).
+int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc, const double *w, const double *fext,
+                  const int32_t *seg4, const BcSegVals *segv)
 {
-    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
-    if (n < 0 || (n > 0 && (!idx || !du_presc || !w))) return fail(c, PLFX_ERR_ARG, "bad argument");
-    for (int k = 0; k < n; k++)
-        if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "presc_idx[%d] out of range", k);
     const size_t nd = c->ndof;
     int rc = ensure_tmp(c, std::max(n, 1));
     if (rc) return rc;
@@ -1960,7 +1962,11 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
         }
         c->bc_valid = true;
     }
-    if (n > 0) {
+    if (n > 0 && seg4) {
+        hipLaunchKernelGGL(k_scatter_bc_plan, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->bc_idx_dev,
+                           seg4, *segv, c->dup, c->wv, c->is_presc, same_set ? 0 : 1);
+        HIPCHK(c, hipGetLastError());
+    } else if (n > 0) {
         if ((size_t)n > c->stage_cap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->stage) hipHostFree(c->stage);
@@ -2005,6 +2011,17 @@ int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     c->bc_set = true;
     return PLFX_OK;
 }
+}  // namespace
+
+int plfx_apply_bc(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc, const double *w,
+                  const double *fext)
+{
+    if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
+    if (n < 0 || (n > 0 && (!idx || !du_presc || !w))) return fail(c, PLFX_ERR_ARG, "bad argument");
+    for (int k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "presc_idx[%d] out of range", k);
+    return apply_bc_impl(c, n, idx, du_presc, w, fext, nullptr, nullptr);
+}
 
 int plfx_set_bc_plan(plfx_ctx *c, int nseg, const int32_t *seg_len, const int32_t *idx)
 {
@@ -2041,6 +2058,26 @@ int plfx_set_bc_plan(plfx_ctx *c, int nseg, const int32_t *seg_len, const int32_
     }
     P.first.assign(P.presc.size(), 0.);
     P.w.assign(P.presc.size(), 0.);
+    dfree(P.seg4);
+    if (nseg <= BcSegVals::N && !P.presc.empty()) {  // entries of every DOF in entry order (= the host's summation order)
+        const size_t np = P.presc.size();
+        std::vector<int32_t> t(4 * np, -1);
+        std::vector<int> cnt(np, 0);
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++) {
+            const int k = P.inv[i];
+            if (cnt[k] == 4)
+                ok = false;
+            else
+                t[4 * (size_t)k + cnt[k]++] = P.seg_of[i];
+        }
+        if (ok) {
+            int rc = dalloc(c, &P.seg4, t.size());
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(P.seg4, t.data(), t.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
     P.valid = true;
     return PLFX_OK;
 }
@@ -2062,6 +2099,12 @@ int plfx_apply_bc_plan(plfx_ctx *c, const double *seg_val, const double *fext, i
         if (bad < 0 && v != P.first[P.inv[i]]) bad = i;
     }
     if (inconsistent_entry) *inconsistent_entry = bad;
+    if (P.seg4) {  // first = value of the first entry, w = sum over the entries: formed on the device from the segment values
+        if (!c->assembled) return fail(c, PLFX_ERR_STATE, "assemble first");
+        BcSegVals sv;
+        for (int i = 0; i < BcSegVals::N; i++) sv.v[i] = i < P.nseg ? seg_val[i] : 0.;
+        return apply_bc_impl(c, np, P.presc.data(), nullptr, nullptr, fext, P.seg4, &sv);
+    }
     return plfx_apply_bc(c, np, P.presc.data(), P.first.data(), P.w.data(), fext);
 }
 

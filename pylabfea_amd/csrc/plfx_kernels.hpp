@@ -1153,6 +1153,37 @@ k_scatter_bc(int n, const int32_t *idx, const double *a, const double *b, double
     if (flag) m[i] = 1.;
 }
 
+// the same for a registered BC plan: every prescribed DOF takes the value of its first entry's segment (y) and the sum
+// over the segments of all its entries in entry order (z; a DOF on two edges counts twice, model.py:1115-1122); the
+// per-segment values travel as kernel arguments
+struct BcSegVals {
+    static constexpr int N = 16;
+    double v[N];
+};
+
+__global__ void __launch_bounds__(BLOCK)
+k_scatter_bc_plan(int n, const int32_t *__restrict__ idx, const int32_t *__restrict__ seg4, BcSegVals sv,
+                  double *__restrict__ y, double *__restrict__ z, double *__restrict__ m, int flag)
+{
+    __shared__ double val[BcSegVals::N];
+    if (threadIdx.x < BcSegVals::N) val[threadIdx.x] = sv.v[threadIdx.x];
+    __syncthreads();
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    const double first = val[seg4[4 * k]];
+    double w = 0.;
+    w += first;
+#pragma unroll
+    for (int q = 1; q < 4; q++) {
+        const int sg = seg4[4 * k + q];
+        if (sg >= 0) w += val[sg];
+    }
+    y[i] = first;
+    z[i] = w;
+    if (flag) m[i] = 1.;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, const double *y, double *v)
 {
     const int k = blockIdx.x * BLOCK + threadIdx.x;
