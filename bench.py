@@ -173,12 +173,14 @@ def main():
             marks['t0'] = time.perf_counter()
             marks['sw0'] = fe.n_sweeps
             marks['so0'] = len(fe.solver_stats)
+            marks['ru0'] = eng.reuse_info()
         if il == pre + W + K:
             barrier()
             marks['t1'] = time.perf_counter()
             gc.enable()
             marks['sw1'] = fe.n_sweeps
             marks['so1'] = len(fe.solver_stats)
+            marks['ru1'] = eng.reuse_info()
             eng.timing_enable(False)
 
     fe._step_hook = hook
@@ -257,6 +259,10 @@ def main():
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
                               else 'Jacobi-PCG') + ' rtol=%g, %s operator' % (fe.cg_rtol, 'matrix-free' if mf else 'block-ELL'), 'device': devname},
         'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
+        # solves / assemblies / BC applications of the timed steps whose inputs were bit-identical to the previous call's and
+        # were therefore not recomputed (plfx_reuse_info; PLFX_REUSE=0 recomputes them) -- included in 'solves' above
+        'unchanged_inputs_reused': dict(zip(('assemblies', 'bc_applications', 'solves'),
+                                            [int(b - a) for a, b in zip(marks['ru0'], marks['ru1'])])),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items()},

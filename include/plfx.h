@@ -126,6 +126,13 @@ int plfx_set_operator(plfx_ctx *ctx, int kind);
 /* y = K x over all DOFs with the current operator (the product of model.py:1384, `K @ du`); host arrays [ndof] */
 int plfx_matvec(plfx_ctx *ctx, const double *x, double *y);
 int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free);
+/* Unchanged inputs are not recomputed (environment PLFX_REUSE=0 switches it off): plfx_assemble returns at once when no
+ * sweep reported a changed tangent and nothing was written into the tangents since the last assembly (Model.setupK of an
+ * unchanged model, model.py:1333); plfx_apply_bc_plan with the values of the previous call on the same operator keeps the
+ * right-hand side; plfx_solve(warm=1) of the system the previous converged solve solved returns that solution with 0
+ * iterations (the reference repeats the last solve of a load step as predictor and first stiffness iteration of the next,
+ * model.py:1291/1335).  Counters of the three cases since plfx_create. */
+int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *solves);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
 int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);
 /* element stiffness of element e from its current tangent (Element.calc_Kel, model.py:365), [64] */

@@ -163,6 +163,19 @@ struct plfx_ctx {
     double *kw = nullptr;           // K w, zero outside bc_rows
     int last_heavy = 0;  // elements that needed the sub-divided corrector in the last sweep
     bool x_is_du = false;  // c->x still holds the last solution on the free DOFs (0 on the prescribed ones) = the warm start
+    // Unchanged inputs are not recomputed (PLFX_REUSE=0 switches this off): the generators are re-snapshotted only when a
+    // sweep reported a changed tangent (or they were written from outside) since the last plfx_assemble; a registered BC
+    // plan with the same segment values on the same operator is not re-applied; and a solve of the system that the previous
+    // converged solve already solved returns that solution (the reference repeats the last solve of a load step as the
+    // predictor and as the first stiffness iteration of the next one whenever the increments are equal).
+    bool reuse = true;
+    bool M_dirty = true;             // generators (or anything plfx_assemble depends on) changed since the last assembly
+    unsigned long long op_epoch = 0; // counts executed assemblies
+    bool bc_memo = false, bc_memo_fext = false;
+    unsigned long long bc_epoch = 0;
+    BcSegVals bc_last{};
+    struct { bool valid = false; double rtol = 0., relres = 0.; } memo;
+    int n_reuse_assemble = 0, n_reuse_bc = 0, n_reuse_solve = 0;
     // registered boundary-condition plan (plfx_set_bc_plan): calc_BC's index structure, fixed for a load history
     struct BcPlan {
         int nseg = 0;
@@ -607,6 +620,7 @@ void free_mesh(plfx_ctx *c)
     c->mg_tail = -1;
     c->gx = c->gy = 0;
     c->assembled = c->bc_set = false;
+    c->M_dirty = true;
     c->x_is_du = false;
     c->bc_valid = false;
     c->bc_idx.clear();
@@ -998,6 +1012,7 @@ int plfx_create(int device, plfx_ctx **out)
     if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
     if (const char *e3 = getenv("PLFX_SVC_WAVE")) c->want_svc_wave = atoi(e3) ? 1 : 0;
     if (const char *e4 = getenv("PLFX_MG_GRAPH")) c->want_mg_graph = atoi(e4) ? 1 : 0;
+    if (const char *e8 = getenv("PLFX_REUSE")) c->reuse = atoi(e8) != 0;
     {
         const char *e5 = getenv("PLFX_MAILBOX");
         if (!e5 || atoi(e5)) {
@@ -1187,6 +1202,8 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_scf_elements, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
+    c->M_dirty = true;
+    c->memo.valid = false;
     return PLFX_OK;
 }
 
@@ -1658,7 +1675,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         HIPCHK(c, hipMemcpyAsync(c->mg_dev, hd.data(), hd.size() * sizeof(MgLevDev), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    c->assembled = false;
+    c->assembled = false, c->M_dirty = true;
     return PLFX_OK;
 }
 
@@ -1669,7 +1686,7 @@ int plfx_set_operator(plfx_ctx *c, int kind)
     if (kind != c->want_matfree) {
         mg_graph_drop(c);
         c->want_matfree = kind;
-        c->assembled = false;  // diagonal / matrix values of the other form have to be rebuilt
+        c->assembled = false, c->M_dirty = true;  // diagonal / matrix values of the other form have to be rebuilt
         c->bc_set = false;
     }
     return PLFX_OK;
@@ -1688,6 +1705,15 @@ int plfx_operator_info(plfx_ctx *c, int *matrix_free, int *levels_matrix_free)
     return PLFX_OK;
 }
 
+int plfx_reuse_info(plfx_ctx *c, int *assemblies, int *bc_applications, int *solves)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (assemblies) *assemblies = c->n_reuse_assemble;
+    if (bc_applications) *bc_applications = c->n_reuse_bc;
+    if (solves) *solves = c->n_reuse_solve;
+    return PLFX_OK;
+}
+
 int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
 {
     if (!c) return PLFX_ERR_STATE;
@@ -1696,6 +1722,7 @@ int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
     if (omega > 0.) c->mg_omega = omega;
     if (nu > 0) c->mg_nu = nu;
     mg_graph_drop(c);  // the captured launches carry omega / nu
+    c->M_dirty = true;  // the next plfx_assemble (re)builds what this preconditioner needs
     return PLFX_OK;
 }
 
@@ -1728,7 +1755,7 @@ int plfx_state_reset(plfx_ctx *c)
         hipLaunchKernelGGL(k_init_M_all, dim3((c->nel_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
                            c->dmat, c->dcls, c->nel_total, c->dcls_all, c->Mel);
     HIPCHK(c, hipGetLastError());
-    c->assembled = false;
+    c->assembled = false, c->M_dirty = true;
     c->x_is_du = false;
     return PLFX_OK;
 }
@@ -1815,6 +1842,7 @@ int plfx_state_set(plfx_ctx *c, int which, const double *in)
     }
     HIPCHK(c, hipMemcpyAsync(p, t.data(), 8 * comps * n, hipMemcpyHostToDevice, c->stream));
     if (which == 5) {
+        c->M_dirty = true;
         hipLaunchKernelGGL(k_refresh_M, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
                            c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel + c->e0, c->nel_total);
         HIPCHK(c, hipGetLastError());
@@ -1848,6 +1876,10 @@ int plfx_gather(plfx_ctx *c, int which, int n, const int32_t *idx, double *out)
 int plfx_assemble(plfx_ctx *c)
 {
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (c->reuse && c->assembled && !c->M_dirty) {  // no tangent changed since the last assembly: K is what it was
+        c->n_reuse_assemble++;
+        return PLFX_OK;
+    }
     EvPair *ev;
     tim_begin(c, 3, &ev);
     if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
@@ -1868,6 +1900,9 @@ int plfx_assemble(plfx_ctx *c)
         if (rc) return rc;
     }
     c->assembled = true;
+    c->M_dirty = false;
+    c->op_epoch++;
+    c->memo.valid = false;
     return PLFX_OK;
 }
 
@@ -1961,6 +1996,18 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
             HIPCHK(c, hipStreamSynchronize(c->stream));  // `rows` goes out of scope
         }
         c->bc_valid = true;
+    }
+    if (c->reuse && seg4 && same_set && c->bc_set && c->bc_memo && c->bc_epoch == c->op_epoch && !fext && !c->bc_memo_fext &&
+        memcmp(&c->bc_last, segv, sizeof(BcSegVals)) == 0) {
+        c->n_reuse_bc++;  // same plan, same values, same operator: rhs, prescribed values and masks are what they were
+        return PLFX_OK;
+    }
+    c->memo.valid = false;  // another system
+    c->bc_memo = seg4 != nullptr;
+    if (seg4) {
+        c->bc_last = *segv;
+        c->bc_epoch = c->op_epoch;
+        c->bc_memo_fext = fext != nullptr;
     }
     if (n > 0 && seg4) {
         hipLaunchKernelGGL(k_scatter_bc_plan, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->bc_idx_dev,
@@ -2339,6 +2386,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 {
     if (!c || !c->bc_set) return c ? fail(c, PLFX_ERR_STATE, "apply_bc first") : PLFX_ERR_STATE;
     if (maxit < 1) maxit = 1;
+    if (c->reuse && warm && c->x_is_du && c->memo.valid && c->memo.rtol == rtol) {
+        // the system of the previous converged solve (no assembly, no other boundary values since): du is its solution
+        c->n_reuse_solve++;
+        if (iters) *iters = 0;
+        if (relres) *relres = c->memo.relres;
+        return PLFX_OK;
+    }
     const size_t nd = c->ndof;
     const int nn = c->nnode;
     const int gn = c->grid_nodes;
@@ -2480,9 +2534,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         c->tim.noop[2] += it - hs.iters;
 
     }
-    if (relres) {
+    {
         const double bb = hs.thresh2 / (rtol * rtol);
-        *relres = (bb > 0. && hs.rr_final >= 0.) ? std::sqrt(hs.rr_final / bb) : 0.;
+        const double rl = (bb > 0. && hs.rr_final >= 0.) ? std::sqrt(hs.rr_final / bb) : 0.;
+        if (relres) *relres = rl;
+        c->memo.valid = done == 1;
+        c->memo.rtol = rtol;
+        c->memo.relres = rl;
     }
     return done ? PLFX_OK : 1;  // 1 = iteration limit reached (soft failure, like co_nconv)
 }
@@ -2568,6 +2626,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     }
     if (changed) *changed = h[0];
     if (conv) *conv = h[1] ? 0 : 1;
+    if (h[0]) c->M_dirty = true;  // generators are rewritten exactly where a tangent changed (finish_element)
     c->last_heavy = h[2];
     return PLFX_OK;
 }

@@ -29,7 +29,7 @@ def wrap(name):
     setattr(_lib.Context, name, g)
 
 
-for name in ('assemble', 'apply_bc', 'apply_bc_plan', 'solve', 'sweep', 'scf_all', 'scf_stats', 'scf_sumsq', 'update_state',
+for name in ('load_step', 'set_bc_plan', 'set_bc_sources', 'set_finish_set', 'assemble', 'apply_bc', 'apply_bc_plan', 'solve', 'sweep', 'scf_all', 'scf_stats', 'scf_sumsq', 'update_state',
              'finish_step', 'gather', 'global_sums', 'state_get'):
     wrap(name)
 fe = bench.tension_model(FE, bench.hill_material(FE), n, 0.005, device=0)
