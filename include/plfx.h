@@ -247,6 +247,9 @@ int plfx_comm_init(plfx_ctx *ctx, const char id[128], int rank, int nranks);
 int plfx_timing_get(plfx_ctx *ctx, int which, double *ms, int64_t *launches);
 int plfx_timing_reset(plfx_ctx *ctx);
 int plfx_timing_enable(plfx_ctx *ctx, int on);
+/* Bit f of mask = time family f (default: all).  Every timed launch costs two hipEventRecord calls (about 4 us of host time
+ * each and a bubble on the stream); bench.py times only the two kernels its roofline objects need. */
+int plfx_timing_select(plfx_ctx *ctx, unsigned mask);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step',
@@ -466,6 +466,11 @@ class Context(object):
     # -- instrumentation
     def timing_enable(self, on=True):
         self._chk(self.lib.plfx_timing_enable(self.h, int(bool(on))))
+
+    def timing_select(self, families=None):
+        """time only the given families (T_* constants); None = all"""
+        mask = 0xFF if families is None else sum(1 << int(f) for f in set(families))
+        self._chk(self.lib.plfx_timing_select(self.h, C.c_uint(mask)))
 
     def timing_reset(self):
         self._chk(self.lib.plfx_timing_reset(self.h))

@@ -35,6 +35,7 @@ struct EvPair {
 
 struct Timing {
     bool on = false;
+    unsigned mask = 0xFFu;  // families that are timed (plfx_timing_select)
     std::vector<EvPair> ring;
     size_t head = 0;
     double ms[8] = {0};
@@ -311,7 +312,7 @@ void tim_begin(plfx_ctx *c, int which, EvPair **out)
 {
     *out = nullptr;
     Timing &t = c->tim;
-    if (!t.on) return;
+    if (!t.on || !((t.mask >> which) & 1u)) return;
     if (t.ring.empty()) {
         t.ring.resize(2048);
         for (auto &e : t.ring) {
@@ -2816,6 +2817,13 @@ int plfx_timing_enable(plfx_ctx *c, int on)
         }
         hipStreamSynchronize(c->stream);
     }
+    return PLFX_OK;
+}
+
+int plfx_timing_select(plfx_ctx *c, unsigned mask)
+{
+    if (!c) return PLFX_ERR_STATE;
+    c->tim.mask = mask;
     return PLFX_OK;
 }
 
