@@ -203,7 +203,10 @@ int plfx_global_sums(plfx_ctx *ctx, double *out18);
  * Segment source codes: 0 left (value bcl0[k]), 1 bottom (bcb0[k]), 2 right (dbcr[k]), 3 top (dbct[k]), 4 node set (dbcn[k]). */
 typedef struct plfx_step {
     /* in */
-    int32_t il, nonlin, has_nodeset, warm, maxit, _pad;
+    int32_t il, nonlin, has_nodeset, warm, maxit;
+    int32_t defer_slot; /* 0: the call returns the end-of-step data; 1 or 2: it returns as soon as the end-of-step kernels are
+                         * enqueued, the data are collected later with plfx_finish_fetch(slot - 1) -- the caller's bookkeeping
+                         * and the predictor of the next step overlap the state update of this one */
     double rtol;
     double bcl0[2], bcb0[2];
     double max_dbcr[2], max_dbct[2], max_dbcn[2]; /* increments planned for this step (max_dbcn is updated like the reference's alias, :1285) */
@@ -223,6 +226,7 @@ typedef struct plfx_step {
 int plfx_set_bc_sources(plfx_ctx *ctx, int nseg, const int32_t *src, const int32_t *k, int nf, const int32_t *fsrc,
                         const int32_t *fk, const int32_t *flen, const int32_t *fidx, const double *fshare);
 int plfx_load_step(plfx_ctx *ctx, plfx_step *step, double *u_at, double *f_at, double *sums18);
+int plfx_finish_fetch(plfx_ctx *ctx, int slot, double *u_at, double *f_at, double *sums18);
 
 /* Host-staged transport for the same collectives (tests on a single GPU, hosts without RCCL): every in-place all-reduce
  * the library needs is staged through host memory and handed to `fn` (dtype 0 = double, 1 = int32; op 0 = sum, 3 = min;

@@ -45,7 +45,7 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step',
@@ -74,7 +74,7 @@ def load():
 class CStep(C.Structure):
     """plfx_step of include/plfx.h: one load step of Model.solve"""
     _fields_ = [('il', C.c_int32), ('nonlin', C.c_int32), ('has_nodeset', C.c_int32), ('warm', C.c_int32),
-                ('maxit', C.c_int32), ('_pad', C.c_int32), ('rtol', C.c_double),
+                ('maxit', C.c_int32), ('defer_slot', C.c_int32), ('rtol', C.c_double),
                 ('bcl0', C.c_double * 2), ('bcb0', C.c_double * 2),
                 ('max_dbcr', C.c_double * 2), ('max_dbct', C.c_double * 2), ('max_dbcn', C.c_double * 2),
                 ('bcr', C.c_double * 2), ('bct', C.c_double * 2), ('bcn', C.c_double * 2),
@@ -372,6 +372,17 @@ class Context(object):
         """one load step (plfx_load_step); returns the data of finish_step"""
         uu, ff, sums = self._fin
         self._chk(self.lib.plfx_load_step(self.h, C.byref(step), _dp(uu), _dp(ff), _dp(sums)))
+        return uu, ff, sums.reshape(3, 6)
+
+    @staticmethod
+    def lib_has_mailbox():
+        """the pinned host mailbox is on unless PLFX_MAILBOX=0 (deferred end-of-step results need it)"""
+        return os.environ.get('PLFX_MAILBOX', '1') != '0'
+
+    def finish_fetch(self, slot):
+        """end-of-step data of a load step that ran with step.defer_slot = slot + 1"""
+        uu, ff, sums = self._fin
+        self._chk(self.lib.plfx_finish_fetch(self.h, int(slot), _dp(uu), _dp(ff), _dp(sums)))
         return uu, ff, sums.reshape(3, 6)
 
     def set_finish_set(self, idx):

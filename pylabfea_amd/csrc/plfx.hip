@@ -198,6 +198,14 @@ struct plfx_ctx {
     int fin_n = 0;
     double *fin_dev = nullptr;      // [2 n + 18] gathered u, f and the 18 element sums
     double *fin_host = nullptr;     // pinned mirror
+    // deferred end-of-step results (plfx_step.defer_slot): two pinned slots, posted by the device, collected by
+    // plfx_finish_fetch while the next load step is already running
+    CgMbox *fin_box[2] = {nullptr, nullptr};
+    double *fin_pin[2] = {nullptr, nullptr};
+    unsigned long long fin_seq[2] = {0, 0};
+    bool fin_pending[2] = {false, false};
+    int fin_pin_n = 0;
+    int fin_defer = -1;             // slot the next plfx_finish_step posts into instead of waiting
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int grid_nodes = 0, grid_el = 0;
 
@@ -358,13 +366,14 @@ void tim_flush(plfx_ctx *c)
 }
 
 // wait until a kernel has posted `seq` to the pinned mailbox (a failed launch or a hung queue must not spin forever)
-int mbox_wait(plfx_ctx *c, unsigned long long seq)
+int mbox_wait(plfx_ctx *c, unsigned long long seq, CgMbox *box = nullptr)
 {
+    if (!box) box = c->mbox;
     // waits as long as the stream has work in flight (like hipStreamSynchronize would: a corrector sweep over millions
     // of SVC elements takes seconds); fails on a stream error, or when the stream has drained and the post never arrived
     unsigned spins = 0;
     int idle_seen = 0;
-    while (__atomic_load_n(&c->mbox->seq, __ATOMIC_ACQUIRE) != seq) {
+    while (__atomic_load_n(&box->seq, __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {
             const hipError_t e = hipStreamQuery(c->stream);
@@ -1072,6 +1081,10 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->fin_idx);
     dfree(c->fin_dev);
     if (c->fin_host) hipHostFree(c->fin_host);
+    for (int q = 0; q < 2; q++) {
+        if (c->fin_pin[q]) hipHostFree(c->fin_pin[q]);
+        if (c->fin_box[q]) hipHostFree(c->fin_box[q]);
+    }
     if (c->mbox) hipHostFree(c->mbox);
     if (c->mb_buf) hipHostFree(c->mb_buf);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -2293,6 +2306,10 @@ int plfx_load_step(plfx_ctx *c, plfx_step *st, double *u_at, double *f_at, doubl
         st->dbct[k] = dbct[k];
         st->dbcn[k] = dbcn[k];
     }
+    if (st->defer_slot == 1 || st->defer_slot == 2) {
+        if (!c->mbox) return fail(c, PLFX_ERR_UNSUPPORTED, "deferred results need the pinned mailbox (PLFX_MAILBOX=0 is set)");
+        c->fin_defer = st->defer_slot - 1;
+    }
     return plfx_finish_step(c, u_at, f_at, sums18);
 }
 
@@ -2305,6 +2322,8 @@ int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dfree(c->fin_idx);
     dfree(c->fin_dev);
+    c->fin_pin_n = 0;  // slots are re-allocated for the new set at the next deferred step
+    c->fin_pending[0] = c->fin_pending[1] = false;
     if (c->fin_host) hipHostFree(c->fin_host);
     c->fin_host = nullptr;
     int rc;
@@ -2340,10 +2359,51 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     if (comm_active(c) &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
         (rc = allreduce(c, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, "sums")))
         return rc;
+    if (c->fin_defer >= 0) {  // post into the pinned slot and return without waiting (plfx_finish_fetch collects)
+        const int sl = c->fin_defer;
+        c->fin_defer = -1;
+        const int tot = 2 * n + 18;
+        if (c->fin_pin_n < tot) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int q = 0; q < 2; q++) {
+                if (c->fin_pin[q]) hipHostFree(c->fin_pin[q]);
+                c->fin_pin[q] = nullptr;
+                HIPCHK(c, hipHostMalloc((void **)&c->fin_pin[q], (size_t)8 * tot, hipHostMallocMapped | hipHostMallocCoherent));
+                if (!c->fin_box[q]) {
+                    HIPCHK(c, hipHostMalloc((void **)&c->fin_box[q], sizeof(CgMbox), hipHostMallocMapped | hipHostMallocCoherent));
+                    memset(c->fin_box[q], 0, sizeof(CgMbox));
+                }
+                c->fin_pending[q] = false;
+            }
+            c->fin_pin_n = tot;
+        }
+        // a slot that was never collected (caller left its loop early) is simply overwritten: the sequence number tells
+        // plfx_finish_fetch which post it is waiting for
+        const unsigned long long seq = ++c->fin_seq[sl];
+        hipLaunchKernelGGL(k_mbox_post, dim3(1), dim3(BLOCK), 0, c->stream, c->fin_dev, tot, c->fin_pin[sl], c->fin_box[sl], seq);
+        HIPCHK(c, hipGetLastError());
+        c->fin_pending[sl] = true;
+        return PLFX_OK;
+    }
     if ((rc = fetch_results(c, c->fin_dev, 2 * n + 18, c->fin_host))) return rc;
     if (u_at && n > 0) memcpy(u_at, c->fin_host, (size_t)8 * n);
     if (f_at && n > 0) memcpy(f_at, c->fin_host + n, (size_t)8 * n);
     if (sums18) memcpy(sums18, c->fin_host + 2 * (size_t)n, 18 * 8);
+    return PLFX_OK;
+}
+
+int plfx_finish_fetch(plfx_ctx *c, int slot, double *u_at, double *f_at, double *sums18)
+{
+    if (!c || !c->fin_dev) return c ? fail(c, PLFX_ERR_STATE, "set_finish_set first") : PLFX_ERR_STATE;
+    if (slot < 0 || slot > 1 || !c->fin_pending[slot]) return fail(c, PLFX_ERR_STATE, "no deferred results in slot %d", slot);
+    int rc = mbox_wait(c, c->fin_seq[slot], c->fin_box[slot]);
+    if (rc) return rc;
+    c->fin_pending[slot] = false;
+    const int n = c->fin_n;
+    const double *h = c->fin_pin[slot];
+    if (u_at && n > 0) memcpy(u_at, h, (size_t)8 * n);
+    if (f_at && n > 0) memcpy(f_at, h + n, (size_t)8 * n);
+    if (sums18) memcpy(sums18, h + 2 * (size_t)n, 18 * 8);
     return PLFX_OK;
 }
 

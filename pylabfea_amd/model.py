@@ -188,6 +188,7 @@ class Model(object):
         self._dev_coll = False
         self._native_step = os.environ.get('PLFX_NATIVE_STEP', '1') != '0'
         self._step_io = _lib.CStep()
+        self._defer_finish = os.environ.get('PLFX_DEFER_FINISH', '1') != '0'
         self._shard = None  # (rank, nranks, uid)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
@@ -734,6 +735,14 @@ class Model(object):
         niter = []
         co_nconv = []
         bc_inc = True
+        pending = None   # slot of a load step whose end-of-step data are still to be collected
+        defer = self._defer_finish and eng.lib_has_mailbox()
+
+        def record_global(fin_data):
+            self._calc_global_device(eng, fin_data)
+            sgl.append(self.glob['sig'])
+            egl.append(self.glob['eps'])
+            epgl.append(self.glob['epl'])
         nconv = 0
         warm = not first_call
         dbcn = None
@@ -768,6 +777,10 @@ class Model(object):
                                                               [float(v) for v in bcn0])
                 st.sld[:] = [float(v) for v in sld]
                 self._bc_register(eng)
+                # end-of-step data (boundary u, f and the element sums of calc_global) are not waited for: the library
+                # posts them into one of two pinned slots and this loop collects them one step later, so its own
+                # bookkeeping and the next predictor overlap the state update on the GPU
+                st.defer_slot = (il & 1) + 1 if defer else 0
                 fin = eng.load_step(st)
                 warm = True
                 dbcr, dbct = np.array(st.dbcr[:]), np.array(st.dbct[:])
@@ -850,10 +863,12 @@ class Model(object):
                 hr0 = hr0 or (np.abs(bcn0[0] - self.bcn[0]) > 1.e-6 and np.abs(self.bcn[0]) > 1.e-9)
                 hr1 = hr1 or (np.abs(bcn0[1] - self.bcn[1]) > 1.e-6 and np.abs(self.bcn[1]) > 1.e-9)
             bc_inc = bool(hr0 or hr1 or hl0 or hl1)
-            self._calc_global_device(eng, fin)
-            sgl.append(self.glob['sig'])
-            egl.append(self.glob['eps'])
-            epgl.append(self.glob['epl'])
+            if native and defer:
+                if pending is not None:
+                    record_global(eng.finish_fetch(pending))
+                pending = (il - 1) & 1
+            else:
+                record_global(fin)
             if self._step_hook is not None:
                 self._step_hook(il)
             if self._max_load_steps is not None and il >= self._max_load_steps:
@@ -866,6 +881,8 @@ class Model(object):
                 print('Global stress: ', np.around(self.glob['sig'], decimals=3))
                 print('Global plastic strain: ', np.around(self.glob['epl'], decimals=6))
                 print('----------------------------')
+        if pending is not None:
+            record_global(eng.finish_fetch(pending))
         self.sgl, self.egl, self.epgl = np.array(sgl), np.array(egl), np.array(epgl)
         self.bct_mem = bct0
         self.bcr_mem = bcr0
