@@ -2672,10 +2672,6 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #undef WAVE_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
-    {
-        int rcm = sync_M(c);
-        if (rcm) return rcm;
-    }
     if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
         const int rca = allreduce(c, c->flags, 3, NCCL_INT32, NCCL_SUM, "flags");
         if (rca) return rca;
@@ -2684,6 +2680,10 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     {
         const int rcf = fetch_results(c, reinterpret_cast<const double *>(c->flags), 2, reinterpret_cast<double *>(h));
         if (rcf) return rcf;
+    }
+    if (h[0] || !c->reuse) {  // the replicated generators are exchanged only when some rank rewrote some of its own
+        int rcm = sync_M(c);
+        if (rcm) return rcm;
     }
     if (changed) *changed = h[0];
     if (conv) *conv = h[1] ? 0 : 1;
