@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -228,6 +229,7 @@ struct plfx_ctx {
     int mg_cheby = 0;            // > 0: Chebyshev steps that solve the coarsest level (no dense inverse: odd coarse sizes)
     double mg_cheby_kappa = 1.;  // assumed condition number of D^-1 K on the coarsest level
     int mg_tail_E = 0;           // elements of the tail levels without the coarsest; > 0: the matrix-free tail is usable
+    size_t mg_tail_lds = 0;      // dynamic LDS of k_mg_tail_mf
     bool mg_inv_valid = false;   // the dense coarse inverse matches the current coarse matrix and Dirichlet mask
     bool mg_dinv_current = false; // the matrix-free levels' dinv was written by the last mg_assemble with the current mask
     CgMbox *mbox = nullptr;                // pinned host mailbox of the PCG convergence flag (PLFX_MAILBOX)
@@ -898,7 +900,7 @@ int mg_coarse_part(plfx_ctx *c)
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
         if (lt < nl - 1 && tail_mf(c))
             hipLaunchKernelGGL(k_mg_tail_mf, dim3(1), dim3(MG_TAIL_BLOCK),
-                               (size_t)c->mg_tail_T * 3 * sizeof(double2) + (size_t)c->mg_tail_E * 6 * sizeof(double),
+                               c->mg_tail_lds,
                                c->stream, c->mg_dev, lt, nl, c->mg_tail_T, c->mg_tail_E, c->dtab, om, c->sc);
         else if (lt < nl - 1 && c->mg_tail_T > 0 && c->mg_nu == 2)
             hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(MG_TAIL_BLOCK),
@@ -1657,8 +1659,9 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             int E = 0;
             for (size_t m = c->mg_tail; m + 1 < c->mg.size(); m++) E += c->mg[m].nel;
             const size_t bytes_mf = (size_t)T * 3 * sizeof(double2) + (size_t)E * 6 * sizeof(double);
+            c->mg_tail_lds = bytes_mf;
             c->mg_tail_E = 0;
-            if (c->grid_ok && bytes_mf <= 156 * 1024 && E > 0) {
+            if (c->grid_ok && bytes_mf <= 154 * 1024 && E > 0 && c->mg.size() <= 16) {  // + 2 KB static LDS (level table)
                 c->mg_tail_E = E;
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_mf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)bytes_mf));
@@ -2839,7 +2842,16 @@ int plfx_comm_init(plfx_ctx *c, const char id[128], int rank, int nranks)
     ncclUniqueId u;
     memcpy(u.internal, id, 128);
     HIPCHK(c, hipSetDevice(c->device));
-    if (g_rccl.CommInitRank(&c->comm, nranks, u, rank) != 0) return fail(c, PLFX_ERR_HIP, "ncclCommInitRank failed");
+    int nrc = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    // a communicator without peers can be retried safely (the bootstrap of RCCL occasionally fails right after another
+    // process on the box released its sockets); with peers a retry on one rank would dead-lock the others
+    for (int attempt = 0; nrc != 0 && nranks == 1 && attempt < 3; attempt++) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(300));
+        ncclUniqueId u2;
+        if (g_rccl.GetUniqueId(&u2) != 0) break;
+        nrc = g_rccl.CommInitRank(&c->comm, 1, u2, 0);
+    }
+    if (nrc != 0) return fail(c, PLFX_ERR_HIP, "ncclCommInitRank failed (RCCL result %d)", nrc);
     c->rank = rank;
     c->nranks = nranks;
     return PLFX_OK;

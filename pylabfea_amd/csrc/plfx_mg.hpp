@@ -216,6 +216,7 @@ k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ di
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
 constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel
+static_assert(MG_TAIL_NODES <= 2 * MG_TAIL_BLOCK, "k_mg_tail_mf: a thread owns at most two nodes of a level");
 constexpr int MG_DENSE_MAX = 128;    // coarsest grids up to this many DOFs are solved with a dense inverse
 
 struct MgLevDev {
@@ -731,49 +732,70 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
 {
     if (sc->done) return;
     extern __shared__ double2 arena[];  // 3 T double2 + 6 E double
+    __shared__ MgLevDev slev[16];       // level descriptors: one global read at the start instead of one per visit
     double2 *X = arena, *Bv = arena + T, *W = arena + 2 * (size_t)T;
     double *Ms = reinterpret_cast<double *>(arena + 3 * (size_t)T);
     const int nt = blockDim.x;
+    const int tid = threadIdx.x;
+    if (tid >= l0 && tid < nl && tid < 16) slev[tid] = lev[tid];
+    __syncthreads();
+    const double2 zero2 = make_double2(0., 0.);
     for (int l = l0; l < nl - 1; l++) {  // the coarsest level is solved with the dense inverse: no generators needed
-        const MgLevDev L = lev[l];
+        const MgLevDev &L = slev[l];
         double *dst = Ms + 6 * (size_t)L.elem_off;
-        for (int q = threadIdx.x; q < 6 * L.nel; q += nt) dst[q] = L.Mel[q];
+        for (int q = tid; q < 6 * L.nel; q += nt) dst[q] = L.Mel[q];
     }
     {
-        const MgLevDev L = lev[l0];
-        for (int i = threadIdx.x; i < L.nnode; i += nt) Bv[L.tail_off + i] = L.b[i];
+        const MgLevDev &L = slev[l0];
+        for (int i = tid; i < L.nnode; i += nt) Bv[L.tail_off + i] = L.b[i];
     }
     __syncthreads();
     for (int l = l0; l < nl - 1; l++) {  // down
-        const MgLevDev L = lev[l];
-        const MgLevDev Cc = lev[l + 1];
+        const MgLevDev &L = slev[l];
+        const MgLevDev &Cc = slev[l + 1];
         double2 *x = X + L.tail_off, *b = Bv + L.tail_off, *w = W + L.tail_off, *bc = Bv + Cc.tail_off;
         const double *Ml = Ms + 6 * (size_t)L.elem_off;
-        const int nxn = L.nx + 1, nyn = L.ny + 1;
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = x1 = omega D^-1 b
-            const double2 di = L.dinv[i], bi = b[i];
-            w[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+        const int nxn = L.nx + 1, nyn = L.ny + 1, nn = L.nnode, nel = L.nel;
+        // a thread owns nodes tid and tid + nt of a level in every phase (MG_TAIL_NODES <= 2 * MG_TAIL_BLOCK): the Jacobi
+        // scaling of its nodes -- the only global data of a phase -- is read once per visit of a level
+        const double2 dA = tid < nn ? L.dinv[tid] : zero2, dB = tid + nt < nn ? L.dinv[tid + nt] : zero2;
+        const double2 dC = tid < Cc.nnode ? Cc.dinv[tid] : zero2;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // w = x1 = omega D^-1 b
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 di = r ? dB : dA, bi = b[i];
+                w[i] = make_double2(omega * di.x * bi.x, omega * di.y * bi.y);
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = x1 + omega D^-1 (b - K x1)
-            const double2 di = L.dinv[i];
-            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
-                                           [&](int j) { return w[j]; });
-            const double2 bi = b[i], x1 = w[i];
-            x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // x = x1 + omega D^-1 (b - K x1)
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 di = r ? dB : dA;
+                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                                               [&](int j) { return w[j]; });
+                const double2 bi = b[i], x1 = w[i];
+                x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = res = P (b - K x)
-            const double2 di = L.dinv[i];
-            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
-                                           [&](int j) { return x[j]; });
-            const double2 bi = b[i];
-            w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // w = res = P (b - K x)
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 di = r ? dB : dA;
+                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                                               [&](int j) { return x[j]; });
+                const double2 bi = b[i];
+                w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
+            }
         }
         __syncthreads();
         const int nyc = Cc.ny + 1;
-        for (int i = threadIdx.x; i < Cc.nnode; i += nt) {  // b_c = P^T res
-            const double2 d = Cc.dinv[i];
+        if (tid < Cc.nnode) {  // b_c = P^T res   (a coarse level of the tail has at most nt nodes)
+            const int i = tid;
             const int J = i / nyc, K = i - J * nyc;
             double sx = 0., sy = 0.;
             for (int dj = -1; dj <= 1; dj++) {
@@ -783,21 +805,21 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
                     const int kf = 2 * K + dk;
                     if (kf < 0 || kf >= nyn) continue;
                     const double wt = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
-                    const double2 r = w[jf * nyn + kf];
-                    sx = fma(wt, r.x, sx);
-                    sy = fma(wt, r.y, sy);
+                    const double2 rr = w[jf * nyn + kf];
+                    sx = fma(wt, rr.x, sx);
+                    sy = fma(wt, rr.y, sy);
                 }
             }
-            bc[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+            bc[i] = make_double2(dC.x != 0. ? sx : 0., dC.y != 0. ? sy : 0.);
         }
         __syncthreads();
     }
     {   // coarsest grid: x = Ainv b
-        const MgLevDev L = lev[nl - 1];
+        const MgLevDev &L = slev[nl - 1];
         const int n = 2 * L.nnode;
         const double *bv = reinterpret_cast<const double *>(Bv + L.tail_off);
         double *xv = reinterpret_cast<double *>(X + L.tail_off);
-        for (int i = threadIdx.x; i < n; i += nt) {
+        for (int i = tid; i < n; i += nt) {
             double acc = 0.;
             for (int j = 0; j < n; j++) acc = fma(L.ainv[(size_t)i * n + j], bv[j], acc);
             xv[i] = acc;
@@ -805,60 +827,73 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
         __syncthreads();
     }
     for (int l = nl - 2; l >= l0; l--) {  // up: prolongation + two post-smoothing sweeps
-        const MgLevDev L = lev[l];
-        const MgLevDev Cc = lev[l + 1];
+        const MgLevDev &L = slev[l];
+        const MgLevDev &Cc = slev[l + 1];
         double2 *x = X + L.tail_off, *b = Bv + L.tail_off, *w = W + L.tail_off;
         const double2 *xc = X + Cc.tail_off;
         const double *Ml = Ms + 6 * (size_t)L.elem_off;
-        const int nxn = L.nx + 1, nyn = L.ny + 1, nyc = Cc.ny + 1;
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {
-            const double2 d = L.dinv[i];
-            const int j = i / nyn, k = i - j * nyn;
-            const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
-            double2 c = xc[J0 * nyc + K0];
-            double cx = c.x, cy = c.y;
-            if (oj) {
-                c = xc[(J0 + 1) * nyc + K0];
-                cx += c.x;
-                cy += c.y;
+        const int nxn = L.nx + 1, nyn = L.ny + 1, nyc = Cc.ny + 1, nn = L.nnode, nel = L.nel;
+        const double2 dA = tid < nn ? L.dinv[tid] : zero2, dB = tid + nt < nn ? L.dinv[tid + nt] : zero2;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 d = r ? dB : dA;
+                const int j = i / nyn, k = i - j * nyn;
+                const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
+                double2 c = xc[J0 * nyc + K0];
+                double cx = c.x, cy = c.y;
+                if (oj) {
+                    c = xc[(J0 + 1) * nyc + K0];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                if (ok) {
+                    c = xc[J0 * nyc + K0 + 1];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                if (oj && ok) {
+                    c = xc[(J0 + 1) * nyc + K0 + 1];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                const double wt = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+                double2 xf = x[i];
+                if (d.x != 0.) xf.x = fma(wt, cx, xf.x);
+                if (d.y != 0.) xf.y = fma(wt, cy, xf.y);
+                x[i] = xf;
             }
-            if (ok) {
-                c = xc[J0 * nyc + K0 + 1];
-                cx += c.x;
-                cy += c.y;
-            }
-            if (oj && ok) {
-                c = xc[(J0 + 1) * nyc + K0 + 1];
-                cx += c.x;
-                cy += c.y;
-            }
-            const double wt = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
-            double2 xf = x[i];
-            if (d.x != 0.) xf.x = fma(wt, cx, xf.x);
-            if (d.y != 0.) xf.y = fma(wt, cy, xf.y);
-            x[i] = xf;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // w = x + omega D^-1 (b - K x)
-            const double2 di = L.dinv[i];
-            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
-                                           [&](int j) { return x[j]; });
-            const double2 bi = b[i], xi = x[i];
-            w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // w = x + omega D^-1 (b - K x)
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 di = r ? dB : dA;
+                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                                               [&](int j) { return x[j]; });
+                const double2 bi = b[i], xi = x[i];
+                w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L.nnode; i += nt) {  // x = w + omega D^-1 (b - K w)
-            const double2 di = L.dinv[i];
-            const double2 q = grid_apply_g(nxn, nyn, L.nel, tab, i, [&](int m) { return Ml[m]; },
-                                           [&](int j) { return w[j]; });
-            const double2 bi = b[i], wi = w[i];
-            x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // x = w + omega D^-1 (b - K w)
+            const int i = tid + r * nt;
+            if (i < nn) {
+                const double2 di = r ? dB : dA;
+                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                                               [&](int j) { return w[j]; });
+                const double2 bi = b[i], wi = w[i];
+                x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));
+            }
         }
         __syncthreads();
     }
     {
-        const MgLevDev L = lev[l0];
-        for (int i = threadIdx.x; i < L.nnode; i += nt) L.x[i] = X[L.tail_off + i];
+        const MgLevDev &L = slev[l0];
+        for (int i = tid; i < L.nnode; i += nt) L.x[i] = X[L.tail_off + i];
     }
 }
 
