@@ -179,6 +179,7 @@ def main():
             marks['sw0'] = fe.n_sweeps
             marks['so0'] = len(fe.solver_stats)
             marks['ru0'] = eng.reuse_info()
+            marks['si0'] = eng.sweep_info()
         if il == pre + W + K:
             barrier()
             marks['t1'] = time.perf_counter()
@@ -186,6 +187,7 @@ def main():
             marks['sw1'] = fe.n_sweeps
             marks['so1'] = len(fe.solver_stats)
             marks['ru1'] = eng.reuse_info()
+            marks['si1'] = eng.sweep_info()
             eng.timing_enable(False)
 
     fe._step_hook = hook
@@ -216,11 +218,14 @@ def main():
     #     k_mg_smooth<1,1> (fine level): x_in, dinv, b, x_out 4x16 = 64 B
     #   assembled operator (PLFX_MATFREE=0): block-ELL values 288 + column ids 36 + the same 64 B = 388 B per node
     #   k_sweep_light: conn 16 + cls 4 + du 16 + sig 48 + epl 48 + tangent 168 read; res_sig 48 + res_depl 48
-    #              + fyn 8 + max_steps 4 written = 412 B (+216 B when the tangent / M is rewritten; not counted)
+    #              + fyn 8 + max_steps 4 written = 412 B per element, + 216 B (tangent 168 + generator 48 written) for every
+    #              element whose tangent changed (counted on the device: plfx_sweep_info)
     mf = eng.operator_info()[0] == 1
     op_bytes = (64. * fe.Nnode + 48. * fe.Nel) if mf else 388. * fe.Nnode
+    n_sw = marks['si1'][0] - marks['si0'][0]
+    rewritten = (marks['si1'][1] - marks['si0'][1]) / world      # this rank's share of the rewritten tangents
     bytes_per = {'spmv': op_bytes / world,
-                 'sweep': 412. * nel_rank, 'cg_update': 128. * fe.Nnode, 'assemble': 0.,
+                 'sweep': 412. * nel_rank + 216. * rewritten / max(n_sw, 1), 'cg_update': 128. * fe.Nnode, 'assemble': 0.,
                  'mg_smooth': op_bytes}
     # dominant kernel: with multigrid the fine-level operator kernels of the V-cycle (k_mg_smooth, k_mg_smooth2_zero,
     # k_mg_residual: same structure, same bytes, ~26-30 us each, 4 per cycle); family 'mg_smooth' times the two
@@ -240,8 +245,9 @@ def main():
         traffic = pmc.get(k) if (world == 1 and n == 1024) else None
         opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + %s + p.q)' % opname,
-                           'sweep': 'k_sweep_light<1> (strain gather + return mapping + tangent test / refresh; the compacted 50-sub-step '
-                                    'list of k_sweep_heavy is empty on this workload and timed separately)',
+                           'sweep': 'k_sweep_light<1> (strain gather + return mapping + tangent test / refresh; 412 B per element + 216 B per '
+                                    'rewritten tangent, %.0f %% of the elements per sweep here; the compacted 50-sub-step list of '
+                                    'k_sweep_heavy is empty on this workload and timed separately)' % (100. * rewritten / max(n_sw * nel_rank, 1)),
                            'cg_update': 'k_cg_update',
                            'mg_smooth': 'k_mg_smooth<1,%d> (fine-level damped-Jacobi post-smoothing sweep of the '
                                         'multigrid V-cycle: %s + update)' % (1 if mf else 0, opname)}[k],

@@ -133,6 +133,10 @@ int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free)
  * iterations (the reference repeats the last solve of a load step as predictor and first stiffness iteration of the next,
  * model.py:1291/1335).  Counters of the three cases since plfx_create. */
 int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *solves);
+/* Sweeps since plfx_create and the number of element tangents they rewrote (model.py:1346-1355: a tangent is stored, and
+ * Kel refreshed, only where it changed by more than 1e-3) -- whole mesh in sharded runs.  A sweep moves 412 B per element
+ * plus 216 B per rewritten tangent. */
+int plfx_sweep_info(plfx_ctx *ctx, int64_t *sweeps, int64_t *tangents_rewritten);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
 int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);
 /* element stiffness of element e from its current tangent (Element.calc_Kel, model.py:365), [64] */

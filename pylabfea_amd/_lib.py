@@ -45,7 +45,7 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_sweep_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step',
@@ -257,6 +257,12 @@ class Context(object):
 
     def set_grid(self, nx, ny):
         self._chk(self.lib.plfx_set_grid(self.h, int(nx), int(ny)))
+
+    def sweep_info(self):
+        """(sweeps, element tangents rewritten by them) since the context was created"""
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_sweep_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def reuse_info(self):
         """(assemblies, BC applications, solves) answered from unchanged inputs since the context was created"""

@@ -146,6 +146,7 @@ struct plfx_ctx {
     double *part_g = nullptr;
     CgScalars *sc = nullptr;
     int *flags = nullptr;
+    int *bflags = nullptr;  // per-block result slots of the sweep kernels (post_block_flags)
     double *small = nullptr;  // [64] scratch outputs
     int32_t *idx_tmp = nullptr;
     double *val_tmp = nullptr;
@@ -178,6 +179,7 @@ struct plfx_ctx {
     BcSegVals bc_last{};
     struct { bool valid = false; double rtol = 0., relres = 0.; } memo;
     int n_reuse_assemble = 0, n_reuse_bc = 0, n_reuse_solve = 0;
+    long long n_sweeps = 0, n_tangents_rewritten = 0;  // plfx_sweep_info
     // registered boundary-condition plan (plfx_set_bc_plan): calc_BC's index structure, fixed for a load history
     struct BcPlan {
         int nseg = 0;
@@ -1050,6 +1052,7 @@ int plfx_create(int device, plfx_ctx **out)
     if ((rc = dalloc(c, &c->part_g, (size_t)18 * MAXPART))) return rc;
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
     if ((rc = dalloc(c, &c->flags, 4))) return rc;
+    if ((rc = dalloc(c, &c->bflags, (size_t)2 * SWEEP_SLOTS))) return rc;
     if ((rc = dalloc(c, &c->small, 64))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PLFX_OK;
@@ -1070,6 +1073,7 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->part_g);
     dfree(c->sc);
     dfree(c->flags);
+    dfree(c->bflags);
     dfree(c->small);
     dfree(c->idx_tmp);
     dfree(c->val_tmp);
@@ -1719,6 +1723,14 @@ int plfx_operator_info(plfx_ctx *c, int *matrix_free, int *levels_matrix_free)
             for (auto &L : c->mg) n += L.matfree ? 1 : 0;
         *levels_matrix_free = n;
     }
+    return PLFX_OK;
+}
+
+int plfx_sweep_info(plfx_ctx *c, int64_t *sweeps, int64_t *tangents_rewritten)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (sweeps) *sweeps = c->n_sweeps;
+    if (tangents_rewritten) *tangents_rewritten = c->n_tangents_rewritten;
     return PLFX_OK;
 }
 
@@ -2614,11 +2626,12 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     HIPCHK(c, hipMemsetAsync(c->flags, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->bflags, 0, (size_t)8 * SWEEP_SLOTS, c->stream));
     EvPair *ev;
     tim_begin(c, 0, &ev);
 #define SWEEP_ARGS(lds) c->dmat, c->nmat, c->dcls, c->ncls, lds, c->nel, c->e0, c->dconn, c->dcls_id,          \
                         (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total,   \
-                        c->res_sig, c->res_depl, c->fyn, c->max_steps, nit, c->flags, c->heavy_list
+                        c->res_sig, c->res_depl, c->fyn, c->max_steps, nit, c->flags, c->bflags, c->heavy_list
     // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
     int first = 1;
     const int wm = c->svc_wave_mat;  // this SVC material runs wave-per-element, the thread-per-element kernels skip it
@@ -2627,7 +2640,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     const int grid_w = std::max(1, std::min((c->nel + 3) / 4, 1024));
 #define WAVE_ARGS c->dmat, c->nmat, c->dcls, c->ncls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,  \
                   c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl, c->fyn,         \
-                  c->max_steps, nit, c->flags, c->heavy_list
+                  c->max_steps, nit, c->flags, c->bflags, c->heavy_list
     if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), first, -1);
@@ -2674,9 +2687,10 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
     tim_end(c, ev);
+    hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags);
     HIPCHK(c, hipGetLastError());
     if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
-        const int rca = allreduce(c, c->flags, 3, NCCL_INT32, NCCL_SUM, "flags");
+        const int rca = allreduce(c, c->flags, 4, NCCL_INT32, NCCL_SUM, "flags");
         if (rca) return rca;
     }
     int h[4];
@@ -2691,6 +2705,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     if (changed) *changed = h[0];
     if (conv) *conv = h[1] ? 0 : 1;
     if (h[0]) c->M_dirty = true;  // generators are rewritten exactly where a tangent changed (finish_element)
+    c->n_sweeps++;
+    c->n_tangents_rewritten += h[3];
     c->last_heavy = h[2];
     return PLFX_OK;
 }

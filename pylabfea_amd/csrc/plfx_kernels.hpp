@@ -331,7 +331,7 @@ __device__ __forceinline__ void sweep_epilogue(const ClassDev &c, const MatDev &
         tangent_to_M(Ct, c.kappa, M);
 #pragma unroll
         for (int k = 0; k < 6; k++) Mel[(size_t)k * mel_stride + e] = M[k];
-        changed = 1;
+        changed += 1;  // counts the elements whose tangent (and generator) this thread rewrote
     }
     if (ns > max_steps[e]) max_steps[e] = ns;  // stat_nlin['max_steps'] (model.py:1356)
 }
@@ -351,10 +351,72 @@ __device__ __forceinline__ void stage_tables(SweepTables &t, const MatDev *gmat,
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
 }
 
+// Result flags of a sweep without atomics on one address (4096 per-wave atomics on one cache line cost ~40 us of the
+// streaming sweep): every block adds its counts to its own slot of `bflags` (blocks of consecutive launches on the stream
+// share slots, memset once per sweep), k_sweep_flags reduces the slots after the last launch of the sweep.
+constexpr int SWEEP_SLOTS = 1024;  // >= every sweep grid (grid_xcd / grid_w cap their grids at MAXPART = 1024)
+static_assert(SWEEP_SLOTS >= MAXPART, "one slot per block of a sweep grid");
+
+__device__ __forceinline__ void post_block_flags(int changed, int nconv, int *__restrict__ bflags)
+{
+    __shared__ int sh_c[16], sh_n[16];
+    int cw = changed, nw = nconv ? 1 : 0;
+    for (int o = 32; o; o >>= 1) {
+        cw += __shfl_xor(cw, o, 64);
+        nw |= __shfl_xor(nw, o, 64);
+    }
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh_c[wave] = cw;
+        sh_n[wave] = nw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c2 = 0, n2 = 0;
+        for (int w = 0; w < nwaves; w++) {
+            c2 += sh_c[w];
+            n2 |= sh_n[w];
+        }
+        if (c2) bflags[2 * blockIdx.x] += c2;
+        if (n2) bflags[2 * blockIdx.x + 1] = 1;
+    }
+}
+
+// flags[0] = any tangent changed, flags[1] = any element not converged, flags[3] = tangents rewritten (flags[2], the length
+// of the compacted list, is maintained by the kernels themselves)
+__global__ void __launch_bounds__(BLOCK) k_sweep_flags(const int *__restrict__ bflags, int *__restrict__ flags)
+{
+    __shared__ int sc[BLOCK / 64], sn[BLOCK / 64];
+    int cw = 0, nw = 0;
+    for (int b = threadIdx.x; b < SWEEP_SLOTS; b += BLOCK) {
+        cw += bflags[2 * b];
+        nw |= bflags[2 * b + 1];
+    }
+    for (int o = 32; o; o >>= 1) {
+        cw += __shfl_xor(cw, o, 64);
+        nw |= __shfl_xor(nw, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sc[threadIdx.x >> 6] = cw;
+        sn[threadIdx.x >> 6] = nw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c2 = 0, n2 = 0;
+        for (int w = 0; w < BLOCK / 64; w++) {
+            c2 += sc[w];
+            n2 |= sn[w];
+        }
+        flags[0] = c2 ? 1 : 0;
+        flags[1] = n2;
+        flags[3] = c2;
+    }
+}
+
 // Material sweep over the owned elements (model.py:1340-1359), phase 1: elastic and one-step plastic
 // elements are finished here (streaming, HBM-bound); elements whose increment must be sub-divided are
 // appended to `list` (one atomic per wave) for k_sweep_heavy.  SoA state: component c of element e at
-// [c*nel + e].  flags[0] |= changed, flags[1] |= not converged, flags[2] = length of `list`.
+// [c*nel + e].  flags[0] |= changed, flags[1] |= not converged, flags[2] = length of `list`, flags[3] = tangents rewritten.
 // Material / class tables are staged in LDS (wave-uniform addresses -> broadcast reads); holding them
 // in SGPRs instead (scalar loads + waterfall over classes) was measured 35 % slower (SGPR spills).
 template <int KIND>
@@ -364,7 +426,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind, int skip_mat)
+              int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int skip_mat)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
@@ -414,8 +476,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             if (heavy) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
         }
     }
-    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
-    if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+    post_block_flags(changed, nconv, bflags);
 }
 
 // Phase 2: the sub-divided plastic corrector for the compacted element list.  Every lane runs the
@@ -427,7 +488,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, const int32_t *__restrict__ list, int skip_mat)
+              int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, int skip_mat)
 {
     const int count = flags[2];
     if (count == 0) return;
@@ -461,8 +522,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
                        res_depl, fyn, max_steps, nit, changed, nconv);
     }
-    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
-    if (__any(nconv) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+    post_block_flags(changed, nconv, bflags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -496,7 +556,7 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
                  int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
                  const double2 *__restrict__ du2, const double *__restrict__ sig, const double *__restrict__ epl,
                  double *elstiff, double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-                 int32_t *max_steps, int nit, int *flags, int32_t *list, int first_kind, int wave_mat)
+                 int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int wave_mat)
 {
     const int count = HEAVY ? flags[2] : nel;
     if (count == 0) return;
@@ -538,8 +598,7 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
                            max_steps, nit, changed, nconv);
         }
     }
-    if (lane == 0 && changed) atomicOr(&flags[0], 1);
-    if (lane == 0 && nconv) atomicOr(&flags[1], 1);
+    post_block_flags(lane == 0 ? changed : 0, lane == 0 ? nconv : 0, bflags);
 }
 
 // elstiff = CV, M from CV for all owned elements (model.py:1219-1221)
