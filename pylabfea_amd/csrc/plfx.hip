@@ -2105,6 +2105,8 @@ int plfx_set_bc_plan(plfx_ctx *c, int nseg, const int32_t *seg_len, const int32_
     if (nseg < 0 || (nseg > 0 && (!seg_len || !idx))) return fail(c, PLFX_ERR_ARG, "bad argument");
     auto &P = c->plan;
     P.valid = false;
+    c->bc_memo = false;  // values are compared per segment: another plan, another meaning
+    c->memo.valid = false;
     P.nseg = nseg;
     P.seg_of.clear();
     std::vector<int32_t> all;
