@@ -758,8 +758,12 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
         const int nxn = L.nx + 1, nyn = L.ny + 1, nn = L.nnode, nel = L.nel;
         // a thread owns nodes tid and tid + nt of a level in every phase (MG_TAIL_NODES <= 2 * MG_TAIL_BLOCK): the Jacobi
         // scaling of its nodes -- the only global data of a phase -- is read once per visit of a level
-        const double2 dA = tid < nn ? L.dinv[tid] : zero2, dB = tid + nt < nn ? L.dinv[tid + nt] : zero2;
-        const double2 dC = tid < Cc.nnode ? Cc.dinv[tid] : zero2;
+        // (clamped index + value select: a conditional load would become a pointer select through scratch memory)
+        double2 dA = L.dinv[tid < nn ? tid : 0], dB = L.dinv[tid + nt < nn ? tid + nt : 0];
+        double2 dC = Cc.dinv[tid < Cc.nnode ? tid : 0];
+        if (tid >= nn) dA = zero2;
+        if (tid + nt >= nn) dB = zero2;
+        if (tid >= Cc.nnode) dC = zero2;
 #pragma unroll
         for (int r = 0; r < 2; r++) {  // w = x1 = omega D^-1 b
             const int i = tid + r * nt;
@@ -833,7 +837,9 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
         const double2 *xc = X + Cc.tail_off;
         const double *Ml = Ms + 6 * (size_t)L.elem_off;
         const int nxn = L.nx + 1, nyn = L.ny + 1, nyc = Cc.ny + 1, nn = L.nnode, nel = L.nel;
-        const double2 dA = tid < nn ? L.dinv[tid] : zero2, dB = tid + nt < nn ? L.dinv[tid + nt] : zero2;
+        double2 dA = L.dinv[tid < nn ? tid : 0], dB = L.dinv[tid + nt < nn ? tid + nt : 0];
+        if (tid >= nn) dA = zero2;
+        if (tid + nt >= nn) dB = zero2;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int i = tid + r * nt;
