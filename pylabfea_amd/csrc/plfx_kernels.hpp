@@ -71,6 +71,41 @@ __device__ __forceinline__ double sum_partials(const double *part, int n, double
     return t;
 }
 
+// the same for up to three arrays at once: one round of loads and one set of barriers instead of one per scalar
+// (identical operation order per array, hence bit-identical results)
+template <int NA>
+__device__ __forceinline__ void sum_partials_n(const double *const (&part)[NA], int n, double (&out)[NA])
+{
+    __shared__ double shn[NA][BLOCK / 64];
+    __shared__ double bcn[NA];
+    double v[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) v[a] = 0.;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+#pragma unroll
+        for (int a = 0; a < NA; a++) v[a] += part[a][i];
+    }
+#pragma unroll
+    for (int a = 0; a < NA; a++) v[a] = wave_sum(v[a]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NA; a++) shn[a][w] = v[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        double t = 0.;
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; i++) t += shn[threadIdx.x][i];
+        bcn[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NA; a++) out[a] = bcn[a];
+    __syncthreads();
+}
+
 __host__ __device__ constexpr bool kind_is_svc(int k) { return k == 3 || k == 6; }
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
@@ -924,7 +959,17 @@ k_spmv(KOp op, int n_begin, int n_end,
     double beta = 0.;
     if (MODE >= 1) {
         if (sc->done) return;
-        const double rr = sum_partials(part_rr, npart_prev, sh);
+        double rr, rzn = 0., rzo = 1.;
+        if (MODE == 1) {  // MODE 2 = first iteration: p = z (beta = 0, p_old is not initialised and never read)
+            const double *const arr[3] = {part_rr, part_rz_new, part_rz_old};
+            double o[3];
+            sum_partials_n<3>(arr, npart_prev, o);
+            rr = o[0];
+            rzn = o[1];
+            rzo = o[2];
+        } else {
+            rr = sum_partials(part_rr, npart_prev, sh);
+        }
         if (rr <= sc->thresh2 || !(rr == rr)) {  // all blocks take the same decision from the same partials
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 sc->done = (rr == rr) ? 1 : 2;   // 2 = breakdown (NaN residual)
@@ -933,11 +978,7 @@ k_spmv(KOp op, int n_begin, int n_end,
             }
             return;
         }
-        if (MODE == 1) {  // MODE 2 = first iteration: p = z (beta = 0, p_old is not initialised and never read)
-            const double rzn = sum_partials(part_rz_new, npart_prev, sh);
-            const double rzo = sum_partials(part_rz_old, npart_prev, sh);
-            beta = rzn / rzo;
-        }
+        if (MODE == 1) beta = rzn / rzo;
     }
     double acc_pq = 0.;
     const int nb = gridDim.x;

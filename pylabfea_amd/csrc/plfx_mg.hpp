@@ -912,8 +912,17 @@ k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restri
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
-    const double pq = sum_partials(part_pq, npart_pq, sh);
-    const double rz = sum_partials(part_rz, npart_prev, sh);
+    double pq, rz;
+    if (npart_pq == npart_prev) {  // both scalars in one round of loads / barriers
+        const double *const arr[2] = {part_pq, part_rz};
+        double o[2];
+        sum_partials_n<2>(arr, npart_pq, o);
+        pq = o[0];
+        rz = o[1];
+    } else {
+        pq = sum_partials(part_pq, npart_pq, sh);
+        rz = sum_partials(part_rz, npart_prev, sh);
+    }
     if (!(pq > 0.)) {  // breakdown: stop and keep the last iterate (the host falls back to Jacobi-PCG)
         if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 2;
         return;
