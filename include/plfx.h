@@ -102,6 +102,12 @@ int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const doubl
                         const double *epl, const double *deps, double *fy, double *sig_out,
                         double *depl, double *ct /* [n*36] */, int32_t *nsteps);
 
+/* Index products of Model.mesh for the reference's structured NX x NY grid, computed on the host (no context, no GPU):
+ * conn[NX*NY*4] = [n1, n1+1, n1+NnodeY, n1+NnodeY+1] with n1 = (ih / NY) * NnodeY + ih % NY for element ih = j*NY + k
+ * (model.py:935-948); node sets noleft (j = 0), noright (j = NX), nobot (k = 0), notop (k = NY) in ascending node order
+ * (model.py:897-911), each [NY+1] or [NX+1] long.  Any output pointer may be NULL.  Integer work: bit-exact. */
+int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t *noright, int32_t *nobot, int32_t *notop);
+
 /* ---------------------------------------------------------------- mesh (Model.mesh products, model.py:758-952)
  * conn[nel*4]: Q4 connectivity in the reference's node order; mat_id[nel]; lxy[nel*2] element
  * sizes (Lelx, Lely).  Elements are rectangles aligned with the axes (model.py:262).

@@ -45,7 +45,7 @@ SYMBOLS = [
     'plfx_assemble', 'plfx_get_csr', 'plfx_apply_bc', 'plfx_solve', 'plfx_sweep', 'plfx_scf_stats',
     'plfx_update_state', 'plfx_global_sums', 'plfx_comm_unique_id', 'plfx_comm_init',
     'plfx_timing_get', 'plfx_timing_reset', 'plfx_timing_enable', 'plfx_set_grid', 'plfx_set_precond',
-    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_sweep_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
+    'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_gen_structured', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_sweep_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step',
@@ -97,6 +97,19 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def gen_structured(NX, NY):
+    """(conn[Nel,4], noleft, noright, nobot, notop) of the reference's structured grid from the library's own index
+    generator (plfx_gen_structured; host-only, works without a GPU)"""
+    lib = load()
+    conn = np.empty((NX * NY, 4), dtype=np.int32)
+    le, ri = np.empty(NY + 1, dtype=np.int32), np.empty(NY + 1, dtype=np.int32)
+    bo, to = np.empty(NX + 1, dtype=np.int32), np.empty(NX + 1, dtype=np.int32)
+    rc = lib.plfx_gen_structured(int(NX), int(NY), _dp(conn), _dp(le), _dp(ri), _dp(bo), _dp(to))
+    if rc:
+        raise PlfxError('plfx_gen_structured(%d, %d): error %d' % (NX, NY, rc))
+    return conn, le, ri, bo, to
 
 
 def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None, barlat=None,

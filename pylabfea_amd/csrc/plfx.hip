@@ -1743,6 +1743,29 @@ int plfx_reuse_info(plfx_ctx *c, int *assemblies, int *bc_applications, int *sol
     return PLFX_OK;
 }
 
+int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t *noright, int32_t *nobot, int32_t *notop)
+{
+    if (NX < 1 || NY < 1 || (int64_t)(NX + 1) * (NY + 1) > INT32_MAX) return PLFX_ERR_ARG;
+    const int nyn = NY + 1;
+    if (conn)
+        for (int ih = 0; ih < NX * NY; ih++) {
+            const int n1 = (ih / NY) * nyn + ih % NY;
+            conn[4 * (size_t)ih + 0] = n1;
+            conn[4 * (size_t)ih + 1] = n1 + 1;
+            conn[4 * (size_t)ih + 2] = n1 + nyn;
+            conn[4 * (size_t)ih + 3] = n1 + nyn + 1;
+        }
+    for (int k = 0; k <= NY; k++) {
+        if (noleft) noleft[k] = k;
+        if (noright) noright[k] = NX * nyn + k;
+    }
+    for (int j = 0; j <= NX; j++) {
+        if (nobot) nobot[j] = j * nyn;
+        if (notop) notop[j] = j * nyn + NY;
+    }
+    return PLFX_OK;
+}
+
 int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
 {
     if (!c) return PLFX_ERR_STATE;

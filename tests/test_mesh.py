@@ -59,6 +59,22 @@ def test_mesh_products(golden_dir, name):
     assert fe.element[3].nodes == list(g('conn')[3])
 
 
+@pytest.mark.parametrize('name,nx,ny', [('sq4', 4, 4), ('sq18', 18, 18), ('sq32', 32, 32), ('lam16x4', 16, 4), ('lam13x3', 13, 3)])
+def test_library_index_generator_bit_exact(golden_dir, name, nx, ny):
+    """plfx_gen_structured (host-only entry point of the C-ABI): connectivity and boundary node sets of the reference's
+    structured grid, bit-exact against Model.mesh of the reference (fixture) and against the facade's generator."""
+    from pylabfea_amd import _lib
+    z = np.load(os.path.join(golden_dir, 'mesh.npz'))
+    conn, le, ri, bo, to = _lib.gen_structured(nx, ny)
+    assert np.array_equal(conn, z[name + '_conn'])
+    for arr, k in ((le, 'noleft'), (ri, 'noright'), (bo, 'nobot'), (to, 'notop')):
+        assert np.array_equal(arr, z['%s_%s' % (name, k)]), k
+    fe = build(name, z)
+    assert np.array_equal(conn, fe._conn)
+    with pytest.raises(_lib.PlfxError):
+        _lib.gen_structured(0, 3)
+
+
 def test_api_errors():
     with pytest.raises(ValueError):
         FE.Model(dim=3)
