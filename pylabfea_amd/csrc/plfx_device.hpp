@@ -1042,7 +1042,10 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
                 R[sym_idx(0, 2)] += d2 * y0 + d0 * y2;  // x4
                 R[sym_idx(0, 1)] += d1 * y0 + d0 * y1;  // x5
             }
-            fy1 = yf.full(sig, eplt);
+            // "update yield function" (:339-342): inside the loop the value is overwritten by the next sub-step's :303-306
+            // before anything reads it -- only the one of the last sub-step is returned, so only that one is evaluated
+            // (for an SVC this is a whole ML_full_yf ray search per scaled-back sub-step)
+            if (it == nsteps - 1) fy1 = yf.full(sig, eplt);
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) depl[i] += ddepl[i];  // :344
