@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_spmv(KOp op, int n_begin, int n_end,
        const double2 *__restrict__ p, const double2 *__restrict__ z, double2 *__restrict__ pnew,
        double2 *__restrict__ q, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
-       const double *__restrict__ part_rr, int npart_prev, double *__restrict__ part_pq, CgScalars *sc, int it)
+       const double *__restrict__ part_rr, int npart_prev, double *__restrict__ part_pq, CgScalars *__restrict__ sc, int it)
 {
     __shared__ double sh[BLOCK / 64];
     double beta = 0.;
