@@ -72,35 +72,66 @@ def tension_model(FE, mat, n, eps, device=0):
     return fe
 
 
-def cpu_baseline(n, steps, warmup):
-    """Same hot path on the host cores: the pinned CPU oracle (oracle/solve_ref.py: OpenMP sweep,
-    sparse assembly, sparse direct solve) on a bounded sample of the same workload."""
+def cpu_run(n, steps, warmup, nthreads, linear):
+    """One timed run of the pinned CPU oracle (oracle/solve_ref.py) on an n x n sample of the bench workload."""
     import pylabfea_amd as FE
     from oracle.solve_ref import RefSolver
     mat = hill_material(FE)
     fe = tension_model(FE, mat, n, 0.005)
-    ref = RefSolver(fe, nthreads=0)
+    ref = RefSolver(fe, nthreads=nthreads, linear=linear)
     marks = {}
-
     ninc, pre = schedule(steps, warmup)
 
     def hook(il):
         if il == pre + warmup:
             marks['t0'] = time.perf_counter()
-            marks['s0'] = ref.timers['n_sweeps']
+            marks['tm0'] = dict(ref.timers)
         if il == pre + warmup + steps:
             marks['t1'] = time.perf_counter()
-            marks['s1'] = ref.timers['n_sweeps']
+            marks['tm1'] = dict(ref.timers)
 
     ref.solve(min_step=ninc, max_load_steps=pre + warmup + steps, step_hook=hook)
     dt = marks['t1'] - marks['t0']
-    sweeps = marks['s1'] - marks['s0']
-    return {'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'cores': os.cpu_count(),
-            'kind': 'port',
-            'sample': '%dx%d mesh, same material/loading/schedule, load steps %d..%d, %d sweeps in %.1f s '
-                      '(OpenMP sweep on all cores, scipy sparse assembly + SuperLU solve on 1 core)'
-                      % (n, n, pre + warmup, pre + warmup + steps, sweeps, dt),
-            'ms_per_step': 1e3 * dt / steps}
+    d = {k: marks['tm1'][k] - marks['tm0'][k] for k in marks['tm0']}
+    return {'value': fe.Nel * d['n_sweeps'] / dt, 'ms_per_step': 1e3 * dt / steps, 'mesh': '%dx%d' % (n, n),
+            'sweeps': int(d['n_sweeps']), 'solves': int(d['n_solves']), 'seconds': dt,
+            'seconds_sweep': d['sweep'], 'seconds_solve': d['solve'], 'seconds_assemble': d['assemble'],
+            'sweep_only_value': fe.Nel * d['n_sweeps'] / max(d['sweep'], 1e-9),
+            'load_steps': '%d..%d of %d' % (pre + warmup, pre + warmup + steps, ninc)}
+
+
+def reference_python():
+    """The reference as-is (unmodified pyLabFEA 4.4.2, one Python thread): it cannot travel to the GPU box, so its rate is
+    the one measured in the build container while oracle/gen_golden.py:gen_configs produced the config-3 trace on the 8x8
+    mesh (the largest the dense solve allows is ~175^2) -- stored with that fixture."""
+    try:
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'solve_configs.npz'))
+        calls, t = int(z['cfg3_hill6_8_ncalls']), float(z['cfg3_hill6_8_tsolve'])
+    except Exception:
+        return None
+    return {'value': calls / t, 'unit': 'element-updates/s', 'cores': 1, 'host': 'build container (8 cores, no GPU), not this host',
+            'sample': 'Model.solve(min_step=50) of config 3 on 8x8 elements: %d Material.response calls in %.2f s '
+                      '(whole solve incl. the dense LU of the 162-DOF system)' % (calls, t)}
+
+
+def cpu_baseline(n, steps, warmup, n1=128):
+    """Same hot path on the host cores (baseline 2): the pinned CPU oracle -- OpenMP material sweep,
+    CSR assembly, OpenMP Jacobi-PCG (oracle/plfx_oracle.c:plfo_pcg_csr) -- on a bounded sample of the same workload,
+    on all cores and on one thread, with the sweep-only rates and the reference-as-is figure beside it."""
+    cores = os.cpu_count()
+    allc = cpu_run(n, steps, warmup, 0, 'pcg')
+    one = cpu_run(n1, max(1, min(steps, 2)), 0, 1, 'pcg')
+    out = {'value': allc['value'], 'unit': 'element-updates/s', 'cores': cores, 'kind': 'port',
+           'sample': '%s mesh, same material/loading/schedule, load steps %s, %d sweeps + %d Jacobi-PCG solves in %.1f s '
+                     '(OpenMP sweep and PCG rows on %d threads; CSR assembly numpy)'
+                     % (allc['mesh'], allc['load_steps'], allc['sweeps'], allc['solves'], allc['seconds'], cores),
+           'ms_per_step': allc['ms_per_step'],
+           'all_cores': dict(allc, cores=cores),
+           'one_thread': dict(one, cores=1),
+           'sweep_only': {'all_cores': allc['sweep_only_value'], 'one_thread': one['sweep_only_value'],
+                          'unit': 'element-updates/s', 'note': 'material sweep alone (strain gather + response), no assembly / solve'},
+           'reference_python': reference_python()}
+    return out
 
 
 def main():

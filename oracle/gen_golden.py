@@ -870,7 +870,7 @@ def gen_fullyf_ld():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld,scaled_input')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld,scaled_input,configs')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -892,6 +892,8 @@ def main():
         gen_fullyf_ld()
     if 'scaled_input' in todo:
         gen_scaled_input()
+    if 'configs' in todo:
+        gen_configs()
 
 
 # ----------------------------------------------------------------------------
@@ -919,6 +921,137 @@ def gen_scaled_input():
     rec['seqB'] = np.array([mb.calc_seqB(v) for v in sig])
     np.savez_compressed(os.path.join(OUT, 'scaled_input.npz'), **rec)
     print('scaled_input done')
+
+
+# ----------------------------------------------------------------------------
+# 10. the schedules BASELINE.json's configs are quoted on, on meshes the reference can hold
+#     (VERDICT r1 item 1 / 6): config 2 (J2, eps 0.004, min_step 20), config 3 (Hill-6p, eps 0.005, min_step 50),
+#     config 4 (train_hill SVC, eps 0.001, min_step 10), config 5 (laminate J2 + Goss-Barlat-trained SVC, eps 0.003,
+#     min_step 20).  Homogeneous tension is mesh-size independent, so the full-size GPU runs must reproduce these traces.
+# ----------------------------------------------------------------------------
+GOSS_BARLAT = [0.81766901, -0.36431565, 0.31238124, 0.84321164, -0.01812166, 0.8320893, 0.35952332,
+               0.08127502, 1.29314957, 1.0956107, 0.90916744, 0.27655112, 1.090482, 1.18282173,
+               -0.01897814, 0.90539357, 1.88256105, 0.0127306]
+
+
+def train_goss_barlat():
+    """examples/train_goss_barlat.py:36-41, 44-49, 70-83 without the plotting."""
+    from scipy.optimize import fsolve
+
+    def find_yloc(x, sig, mat):
+        return mat.calc_seq(sig * x[:, None]) - mat.sy
+    mat_GB = FE.Material(name='Yld2004-18p_from_Goss')
+    mat_GB.elasticity(E=151220., nu=0.3)
+    mat_GB.plasticity(sy=46.76, barlat=GOSS_BARLAT[0:18], barlat_exp=8)
+    sunit = FE.load_cases(number_3d=100, number_6d=200)
+    x1 = fsolve(find_yloc, np.ones(len(sunit)) * mat_GB.sy, args=(sunit, mat_GB), xtol=1.e-5)
+    sig = sunit * x1[:, None]
+    data_GS = FE.Data(sig, mat_name="Goss-Barlat", wh_data=False)
+    ml = FE.Material('ML-Goss-Barlat_C3.0_G1.5', num=1)
+    ml.from_data(data_GS.mat_data)
+    ml.elasticity(C11=mat_GB.C11, C12=mat_GB.C12, C44=mat_GB.C44)
+    ml.train_SVC(C=3.0, gamma=1.5, Ce=0.99, Fe=0.1, Nseq=25, gridsearch=False)
+    return ml, mat_GB, sig
+
+
+def svc6_point_record(name, ml, rec):
+    """calc_yf / calc_fgrad / calc_seq / ML_full_yf / response vectors of a 6-feature SVC material (as in gen_svc)."""
+    rng = np.random.default_rng(7 + len(name))
+    N = 400
+    u = rand_unit6(rng, N)
+    sig = u * (ml.sy * rng.uniform(0.2, 1.6, size=N))[:, None]
+    sig[:40, 3:5] = 0.
+    rec['b_sig'] = sig
+    rec['b_yf'] = ml.calc_yf(sig)
+    rec['b_fgrad'] = ml.calc_fgrad(sig)
+    rec['b_seq'] = ml.calc_seq(sig)
+    nf = 120
+    rec['b_full_yf'] = np.array([ml.ML_full_yf(sig[i], verb=False) for i in range(nf)])
+    for tag, ps in (('pe', False), ('ps', True)):
+        CVr = element_CV(ml, ps)
+        s, e, d = gen_response_inputs(ml, CVr, rng, 64, True)
+        e[:] = 0.
+        fy, so, dp, ct, ns = run_response(ml, s, e, d, CVr)
+        print('svc', name, tag, np.bincount(ns))
+        for k, v in (('CV', CVr), ('sig', s), ('epl', e), ('deps', d), ('fy', fy), ('sig_out', so), ('depl', dp),
+                     ('ct', ct), ('nsteps', ns)):
+            rec['r%s_%s' % (tag, k)] = v
+
+
+def gen_configs():
+    rec = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # configs 2 and 3 on 8x8
+        for name, mname, eps, ms in (('cfg2_j2_8', 'j2', 0.004, 20), ('cfg3_hill6_8', 'hill6', 0.005, 50)):
+            mat = make_material(mname)
+            rr = ResponseRecorder(mat)
+            fe = tension_model(mat, 8, eps)
+            t = time.time()
+            with SolveTracer() as tr:
+                fe.solve(min_step=ms)
+            dt = time.time() - t
+            solve_record(fe, name, rec, dt)
+            tr.store(rec, name)
+            rec[name + '_ncalls'] = np.array(rr.n)
+            print(name, '%.1fs' % dt, fe.nsteps, fe.niter, rr.n, fe.sgl[-1][1], '%.1f updates/s' % (rr.n / dt))
+        # config 4: train_hill SVC on 4x4
+        mat_h = FE.Material(name='Hill-reference', num=1)
+        mat_h.elasticity(E=200.e3, nu=0.3)
+        mat_h.plasticity(sy=50., rv=[1.2, 1.0, 0.8, 1.0, 1.0, 1.0], sdim=6)
+        ml = FE.Material('ML-Hill-p1', num=2)
+        ml.train_SVC(C=2.0, gamma=1.0, mat_ref=mat_h, Nseq=25, Nlc=300, Fe=0.1, Ce=0.99, gridsearch=False)
+        old = np.load(os.path.join(OUT, 'svc_hill.npz'))
+        same = (old['par_sv'].shape == ml.svm_yf.support_vectors_.shape
+                and np.array_equal(old['par_sv'], ml.svm_yf.support_vectors_)
+                and np.array_equal(old['par_dual'], ml.svm_yf.dual_coef_[0, :]))
+        print('train_hill SVC retrained: %d SVs, identical to tests/golden/svc_hill.npz: %s'
+              % (len(ml.svm_yf.support_vectors_), same))
+        rec['cfg4_same_as_svc_hill'] = np.array(same)
+        if not same:
+            for k, v in svc_params(ml).items():
+                rec['cfg4_par_' + k] = v
+        rr = ResponseRecorder(ml)
+        fe = tension_model(ml, 4, 0.001)
+        t = time.time()
+        with SolveTracer() as tr:
+            fe.solve(min_step=10)
+        dt = time.time() - t
+        solve_record(fe, 'cfg4_svc_4', rec, dt)
+        tr.store(rec, 'cfg4_svc_4')
+        rec['cfg4_svc_4_ncalls'] = np.array(rr.n)
+        print('cfg4_svc_4 %.1fs' % dt, fe.nsteps, fe.niter, rr.n, fe.sgl[-1][1], '%.2f updates/s' % (rr.n / dt))
+        np.savez_compressed(os.path.join(OUT, 'solve_configs.npz'), **rec)
+
+        # config 5 materials: J2 + SVC trained on Barlat Yld2004-18p (Goss texture)
+        mlb, mat_GB, sig_train = train_goss_barlat()
+        print('Goss-Barlat SVC: %d SVs' % len(mlb.svm_yf.support_vectors_))
+        recb = {('par_' + k): v for k, v in svc_params(mlb).items()}
+        recb['barlat_par'] = np.array(GOSS_BARLAT)
+        recb['yield_stresses_barlat'] = sig_train          # 300 yield points of the Barlat reference material
+        recb['yf_at_barlat_yield'] = mlb.calc_yf(sig_train)
+        svc6_point_record('gossbarlat', mlb, recb)
+        np.savez_compressed(os.path.join(OUT, 'svc_gossbarlat.npz'), **recb)
+        matj = make_material('j2')
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom([2, 1, 2, 1, 2], LY=8.)
+        fe.assign([matj, mlb, matj, mlb, matj])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.003 * fe.leny, 'disp')
+        fe.mesh(NX=8, NY=4)
+        rr1, rr2 = ResponseRecorder(matj), ResponseRecorder(mlb)
+        t = time.time()
+        with SolveTracer() as tr:
+            fe.solve(min_step=20)
+        dt = time.time() - t
+        solve_record(fe, 'cfg5_lam_8x4', rec, dt)
+        tr.store(rec, 'cfg5_lam_8x4')
+        rec['cfg5_lam_8x4_ncalls'] = np.array([rr1.n, rr2.n])
+        print('cfg5_lam_8x4 %.1fs' % dt, fe.nsteps, fe.niter, rr1.n, rr2.n, fe.sgl[-1][1])
+    np.savez_compressed(os.path.join(OUT, 'solve_configs.npz'), **rec)
+    print('configs done')
 
 
 if __name__ == '__main__':

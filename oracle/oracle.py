@@ -215,3 +215,19 @@ def strain_batch(conn, lxy, mat_id, planestress, CVs, Es, nus, u):
                             int(planestress), _p(_c(CVs).reshape(-1, 36)), _p(_c(Es)), _p(_c(nus)),
                             _p(_c(u)), _p(eps))
     return eps
+
+
+def pcg_csr(K, b, free, x0, rtol=1.e-10, maxit=200000, nthreads=0):
+    """Jacobi-PCG on a scipy CSR matrix restricted to the free DOFs (plfo_pcg_csr); returns (x, iterations, relres)"""
+    n = K.shape[0]
+    indptr = _c(K.indptr, np.int32)
+    indices = _c(K.indices, np.int32)
+    data = _c(K.data)
+    x = np.array(x0, dtype=np.float64, copy=True)
+    fm = _c(free, np.uint8)
+    rel = C.c_double(0.)
+    f = lib().plfo_pcg_csr
+    f.restype = C.c_int
+    its = f(int(n), _p(indptr), _p(indices), _p(data), _p(_c(b)), _p(fm), _p(x), C.c_double(rtol), int(maxit),
+            int(nthreads), C.byref(rel))
+    return x, int(its), float(rel.value)

@@ -834,3 +834,82 @@ void plfo_strain_batch(int nel, const int *conn, const double *lxy, const int *m
                     eps + 6 * (size_t)e);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Jacobi-preconditioned CG on a CSR matrix, projected onto the free DOFs (free[i] != 0): the iterative counterpart of
+ * the reference's `Kred = K[ind][:, ind]; np.linalg.solve(Kred, df[ind])` (model.py:1028-1033, 1291).  Rows and
+ * columns of prescribed DOFs are skipped, x stays 0 there.  OpenMP over rows; the same-host CPU baseline of
+ * BASELINE.md section 3 ("CSR assembly, Jacobi-PCG, OpenMP material sweep").  Returns the iteration count. */
+int plfo_pcg_csr(int n, const int *indptr, const int *indices, const double *data, const double *b,
+                 const unsigned char *free_mask, double *x, double rtol, int maxit, int nthreads, double *relres)
+{
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
+    double *p = (double *)malloc(sizeof(double) * n), *q = (double *)malloc(sizeof(double) * n);
+    double *dinv = (double *)malloc(sizeof(double) * n);
+    int it = 0;
+    double bb = 0., rr = 0., rz = 0.;
+#ifdef _OPENMP
+    const int nt = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+    const int nt = 1;
+    (void)nthreads;
+#endif
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : bb, rr, rz)
+    for (int i = 0; i < n; i++) {
+        double d = 0., s = 0.;
+        if (free_mask[i]) {
+            for (int k = indptr[i]; k < indptr[i + 1]; k++) {
+                const int j = indices[k];
+                if (j == i) d = data[k];
+                if (free_mask[j]) s += data[k] * x[j];
+            }
+            dinv[i] = (fabs(d) > 1e-300) ? 1. / fabs(d) : 1.;
+            r[i] = b[i] - s;
+            bb += b[i] * b[i];
+        } else {
+            dinv[i] = 0.;
+            r[i] = 0.;
+            x[i] = 0.;
+        }
+        z[i] = dinv[i] * r[i];
+        p[i] = z[i];
+        rr += r[i] * r[i];
+        rz += r[i] * z[i];
+    }
+    const double thresh2 = rtol * rtol * bb;
+    while (it < maxit && rr > thresh2) {
+        double pq = 0.;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : pq)
+        for (int i = 0; i < n; i++) {
+            double s = 0.;
+            if (free_mask[i])
+                for (int k = indptr[i]; k < indptr[i + 1]; k++) s += data[k] * p[indices[k]];  /* p = 0 on prescribed DOFs */
+            q[i] = s;
+            pq += p[i] * s;
+        }
+        if (!(pq > 0.)) break;
+        const double alpha = rz / pq;
+        double rr2 = 0., rz2 = 0.;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : rr2, rz2)
+        for (int i = 0; i < n; i++) {
+            x[i] += alpha * p[i];
+            r[i] -= alpha * q[i];
+            z[i] = dinv[i] * r[i];
+            rr2 += r[i] * r[i];
+            rz2 += r[i] * z[i];
+        }
+        const double beta = rz2 / rz;
+#pragma omp parallel for num_threads(nt) schedule(static)
+        for (int i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
+        rr = rr2;
+        rz = rz2;
+        it++;
+    }
+    if (relres) *relres = bb > 0. ? sqrt(rr / bb) : 0.;
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+    free(dinv);
+    return it;
+}

@@ -102,6 +102,10 @@ void plfo_strain_batch(int nel, const int *conn /* [nel*4] */, const double *lxy
                        int planestress, const double *CV, const double *E, const double *nu,
                        const double *u /* [ndof] */, double *eps /* [nel*6] */);
 
+/* Kred + np.linalg.solve (model.py:1028-1033, 1291) as Jacobi-PCG on the CSR matrix, free DOFs only (OpenMP rows) */
+int plfo_pcg_csr(int n, const int *indptr, const int *indices, const double *data, const double *b,
+                 const unsigned char *free_mask, double *x, double rtol, int maxit, int nthreads, double *relres);
+
 /* scipy 1.15.3 optimize.brentq (Brent 1973) on a scalar callback */
 typedef double (*plfo_fn)(double x, void *ctx);
 double plfo_brentq(plfo_fn f, void *ctx, double xa, double xb, double xtol, double rtol,

@@ -8,10 +8,16 @@ sparse direct solve, using the pinned C oracle for every per-element routine:
     scipy.sparse.linalg.spsolve (Kred + np.linalg.solve) -> plfo_response_batch (the material sweep)
 
 It is used (a) by tests to check the GPU path at sizes beyond the reference's reach and (b) by
-bench.py as the same-host ``cpu_baseline`` (kind "port").  Mesh arrays and boundary-condition
-*definitions* are taken from a ``pylabfea_amd.Model`` that has been meshed but not solved (its index
-generation is pinned bit-exactly against the reference by tests/test_mesh.py); nothing here touches
-libplfx or a GPU.
+bench.py as the same-host ``cpu_baseline`` (kind "port").  Only *definitions* are taken from a
+``pylabfea_amd.Model`` that has been meshed but not solved: the BC flags and values, the material parameters,
+the geometry numbers, and the mesh index arrays (connectivity, material ids, element sizes -- pinned bit-exactly
+against the reference by tests/test_mesh.py).  The element elastic matrix (model.py:272-303), the boundary node
+sets (model.py:897-911) and calc_BC (model.py:1070-1206) are restated HERE, independently of the product's
+``Model._element_CV`` / ``Model._bc_data``; nothing here touches libplfx or a GPU.
+
+Linear solve: ``linear='lu'`` SuperLU (sparse direct, one core -- the parity checker) or ``linear='pcg'``
+Jacobi-preconditioned CG on the CSR matrix with OpenMP rows (plfo_pcg_csr; the same-host CPU baseline of
+BASELINE.md section 3: CSR assembly, Jacobi-PCG, OpenMP material sweep).
 """
 import time
 
@@ -25,9 +31,12 @@ YF_TOL = 5.e-3
 
 
 class RefSolver(object):
-    def __init__(self, model, nthreads=0):
+    def __init__(self, model, nthreads=0, linear='lu', pcg_rtol=1.e-10):
         m = self.m = model
         self.nthreads = nthreads
+        self.linear = linear
+        self.pcg_rtol = pcg_rtol
+        self.pcg_iters = []
         self.conn = np.ascontiguousarray(m._conn, dtype=np.int32)
         self.mat_id = np.ascontiguousarray(m._mat_id, dtype=np.int32)
         self.lxy = np.ascontiguousarray(m._lxy, dtype=float)
@@ -38,7 +47,7 @@ class RefSolver(object):
         self.mats = []
         self.CVs = []
         for mat in m.mat:
-            CV = m._element_CV(mat)
+            CV = self.element_CV(mat)
             self.CVs.append(CV.reshape(36))
             if mat.sy is None:
                 self.mats.append(O.Material(kind=O.ELASTIC, E=mat.E, nu=mat.nu))
@@ -59,31 +68,123 @@ class RefSolver(object):
         self.rows = np.repeat(dofs, 8, axis=1).ravel()
         self.cols = np.tile(dofs, (1, 8)).ravel()
         self.timers = {'assemble': 0., 'solve': 0., 'sweep': 0., 'n_sweeps': 0, 'n_solves': 0}
+        # boundary node sets of the structured grid (model.py:897-911: node j*NnodeY + k, j outer, k inner)
+        nxn, nyn = m.NnodeX, m.NnodeY
+        self.noleft = [k for k in range(nyn)]
+        self.noright = [(nxn - 1) * nyn + k for k in range(nyn)]
+        self.nobot = [j * nyn for j in range(nxn)]
+        self.notop = [j * nyn + nyn - 1 for j in range(nxn)]
+        self._csr = None
+
+    def element_CV(self, mat):
+        """Element.__init__ (model.py:270-303): plane-stress matrix from E, nu and C44, else the material's CV"""
+        if self.ps:
+            hh = mat.E / (1 - mat.nu * mat.nu)
+            C12 = mat.nu * hh
+            C11 = hh
+            CV = np.zeros((6, 6))
+            CV[0, 0] = CV[1, 1] = C11
+            CV[0, 1] = CV[1, 0] = C12
+            CV[5, 5] = mat.C44
+            return CV
+        if mat.CV is not None:
+            return np.array(mat.CV, dtype=float)
+        C11, C12, C44 = mat.C11, mat.C12, mat.C44
+        return np.array([[C11, C12, C12, 0., 0., 0.], [C12, C11, C12, 0., 0., 0.], [C12, C12, C11, 0., 0., 0.],
+                         [0., 0., 0., C44, 0., 0.], [0., 0., 0., 0., C44, 0.], [0., 0., 0., 0., 0., C44]])
+
+    def calc_BC(self, bcl0, bcb0, dbcr, dbct, dbcn):
+        """calc_BC (model.py:1070-1206) walked in the reference's order.  The reference subtracts K[:, i] * value from
+        the force vector at EVERY application of a displacement BC -- a DOF on two edges is applied twice (:1115-1122,
+        1163-1170) -- and writes du[i] at the first one.  Returned: prescribed DOFs (ascending), du on them, the summed
+        applied values wv (df = fext - K wv on the free DOFs) and the external force vector."""
+        m = self.m
+        nd = self.ndof
+        du = np.zeros(nd)
+        wv = np.zeros(nd)
+        fext = np.zeros(nd)
+        fixed = np.zeros(nd, dtype=bool)
+
+        def disp(nodes, k, val):
+            for j in nodes:
+                i = 2 * j + k
+                if not fixed[i]:
+                    fixed[i] = True
+                    du[i] = val
+                wv[i] += val
+
+        for k in range(2):
+            if m.ubcleft[k]:
+                disp(self.noleft, k, bcl0[k])
+        for k in range(2):
+            if m.ubcbot[k]:
+                disp(self.nobot, k, bcb0[k])
+        for k in range(2):
+            if m.ubcright[k]:
+                disp(self.noright, k, dbcr[k])
+            else:
+                for j in self.noright:
+                    hh = 1. / (m.NnodeY - 1)
+                    hy = m.npos[2 * j + 1]
+                    if hy < 1.e-3 or hy > m.leny - 1.e-3:
+                        hh *= 0.5
+                    fext[2 * j + k] += dbcr[k] * hh
+        for k in range(2):
+            if m.ubctop[k]:
+                disp(self.notop, k, dbct[k])
+            else:
+                for j in self.notop:
+                    hh = 1. / (m.NnodeX - 1)
+                    hx = m.npos[2 * j]
+                    if hx < 1.e-3 or hx > m.lenx - 1.e-3:
+                        hh *= 0.5
+                    fext[2 * j + k] += dbct[k] * hh
+        if m.noset is not None:
+            if dbcn is None:
+                raise ValueError('No BC for selected node set given.')
+            for k in range(2):
+                if m.ubcn[k]:
+                    disp(m.noset, k, dbcn[k])
+                else:
+                    for j in m.noset:
+                        fext[2 * j + k] += dbcn[k]
+        return fixed, du, wv, fext
 
     # model.py:954-977
     def setupK(self):
         t = time.perf_counter()
         Kel = O.kel_batch(self.lxy, self.mat_id, self.thick, self.ps, self.CVs, self.Es, self.nus, self.elstiff)
-        K = sp.coo_matrix((Kel.ravel(), (self.rows, self.cols)), shape=(self.ndof, self.ndof)).tocsr()
+        if self._csr is None:   # pattern and scatter map once; later assemblies only sum the element values into place
+            C = sp.coo_matrix((np.ones(self.rows.size), (self.rows, self.cols)), shape=(self.ndof, self.ndof)).tocsr()
+            C.sort_indices()
+            # position of every (row, col) contribution in the CSR data array
+            key = self.rows.astype(np.int64) * self.ndof + self.cols
+            rr = np.repeat(np.arange(self.ndof, dtype=np.int64), np.diff(C.indptr))
+            ckey = rr * self.ndof + C.indices
+            self._csr = (C.indptr.copy(), C.indices.copy(), np.searchsorted(ckey, key), len(ckey))
+        indptr, indices, pos, nnz = self._csr
+        data = np.bincount(pos, weights=Kel.ravel(), minlength=nnz)
+        K = sp.csr_matrix((data, indices, indptr), shape=(self.ndof, self.ndof))
         self.timers['assemble'] += time.perf_counter() - t
         return K
 
     # model.py:1070-1206 + 1028-1033 + 1291
     def lin_solve(self, K, bcl0, bcb0, dbcr, dbct, dbcn):
-        presc, first, w, fext = self.m._bc_data(bcl0, bcb0, dbcr, dbct, dbcn)
+        fixed, du, wv, fext = self.calc_BC(bcl0, bcb0, dbcr, dbct, dbcn)
         t = time.perf_counter()
-        wv = np.zeros(self.ndof)
-        wv[presc] = w
-        df = -(K @ wv)
-        if fext is not None:
-            df += fext
-        mask = np.ones(self.ndof, dtype=bool)
-        mask[presc] = False
-        ind = np.nonzero(mask)[0]
-        du = np.zeros(self.ndof)
-        du[presc] = first
-        Kred = K[ind][:, ind].tocsc()
-        du[ind] = spla.spsolve(Kred, df[ind])
+        df = fext - K @ wv
+        if self.linear == 'pcg':
+            # projected system on the free DOFs (rows / columns of prescribed DOFs are skipped inside the C routine)
+            x0 = self._x_prev if getattr(self, '_x_prev', None) is not None else np.zeros(self.ndof)
+            x, its, relres = O.pcg_csr(K, df, (~fixed), x0, self.pcg_rtol, 200000, self.nthreads)
+            self._x_prev = x
+            self.pcg_iters.append(its)
+            free = ~fixed
+            du[free] = x[free]
+        else:
+            ind = np.nonzero(~fixed)[0]
+            Kred = K[ind][:, ind].tocsc()
+            du[ind] = spla.spsolve(Kred, df[ind])
         self.timers['solve'] += time.perf_counter() - t
         self.timers['n_solves'] += 1
         return du

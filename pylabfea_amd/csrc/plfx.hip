@@ -1530,8 +1530,13 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     c->mg.clear();
     c->grid_ok = false;
     c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, 0, 0, c->nel_total, c->Mel);
-    for (int e = 1; e < c->nel_total; e++)  // coarse re-assembly and the matrix-free operator need one element shape
-        if (c->hlxy[2 * (size_t)e] != c->hlxy[0] || c->hlxy[2 * (size_t)e + 1] != c->hlxy[1]) return PLFX_OK;
+    // coarse re-assembly and the matrix-free operator need one element shape.  Laminate meshes compute dx = LS[i]/nes[i]
+    // per section (model.py:847), so nominally uniform sections can differ by an ulp: compare with a relative tolerance and
+    // use element 0's shape for the operator tables (the strain operator keeps each class's own lx, ly).
+    for (int e = 1; e < c->nel_total; e++)
+        if (std::fabs(c->hlxy[2 * (size_t)e] - c->hlxy[0]) > 1e-12 * std::fabs(c->hlxy[0]) ||
+            std::fabs(c->hlxy[2 * (size_t)e + 1] - c->hlxy[1]) > 1e-12 * std::fabs(c->hlxy[1]))
+            return PLFX_OK;
     int rc;
     {   // geometry table of grid_apply: position p = pj*2+pk <-> element (j-1+pj, k-1+pk), in which node (j,k) has the
         // local number a = (1-pj)*2 + (1-pk) (connectivity order model.py:936-948)

@@ -13,6 +13,7 @@ sdim=3 flow rules use the reference's axis-tracking principal stresses (exact fo
 Tresca and Barlat Yld2004-18p are equivalent stresses only (the reference has no normal for them).
 ML materials: 6 stress features (sdim=6) or the 2 features (seq, polar angle) of ``setup_yf_SVM_3D`` (sdim=3).
 """
+import os
 import warnings
 
 import numpy as np
@@ -20,15 +21,33 @@ import numpy as np
 from . import _lib
 from .basic import eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, yf_tolerance
 
-_point_ctx = None      # shared context for point evaluations
+_point_ctx = {}        # shared contexts for point evaluations, one per GPU
 _point_key = None
 
 
+def point_device():
+    """GPU of the point-evaluation context: PLFX_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else 0"""
+    for var in ('PLFX_DEVICE', 'LOCAL_RANK'):
+        v = os.environ.get(var)
+        if v is not None and v.strip().lstrip('-').isdigit():
+            return int(v)
+    return 0
+
+
 def _ctx():
-    global _point_ctx
-    if _point_ctx is None:
-        _point_ctx = _lib.Context(0)
-    return _point_ctx
+    dev = point_device()
+    if dev not in _point_ctx:
+        _point_ctx[dev] = _lib.Context(dev)
+    return _point_ctx[dev]
+
+
+def close_point_contexts():
+    """release the shared point-evaluation contexts (HBM of the support-vector tables, streams)"""
+    global _point_key
+    for c in _point_ctx.values():
+        c.close()
+    _point_ctx.clear()
+    _point_key = None
 
 
 class Material(object):
@@ -383,8 +402,8 @@ class Material(object):
         cv = np.asarray(self.CV if CV is None else CV, dtype=float)
         if cv.shape != (6, 6):
             raise ValueError('CV must be a (6,6) array')
-        key = (id(self), self._version, bool(ana), cv.tobytes(), self.khard, self.sy)
         ctx = _ctx()
+        key = (id(ctx), id(self), self._version, bool(ana), cv.tobytes(), self.khard, self.sy)
         if key != _point_key:
             ctx.set_materials([self._record(cv, ana=ana)])
             _point_key = key

@@ -1,0 +1,162 @@
+"""GPU parity on the schedules BASELINE.json's configs are quoted on.
+
+``tests/golden/solve_configs.npz`` (oracle/gen_golden.py:gen_configs) holds traces of the UNMODIFIED reference for
+  config 2: 8x8 J2 (sy=150, khard=500), eps=0.004, min_step=20
+  config 3: 8x8 Hill-6p (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), eps=0.005, min_step=50
+  config 4: 4x4 SVC of examples/train_hill.py (1585 support vectors), eps=0.001, min_step=10
+  config 5: 8x4 laminate [2,1,2,1,2] (LY=8) of J2 and the SVC trained on Barlat Yld2004-18p / Goss texture
+            (examples/train_goss_barlat.py), eps=0.003, min_step=20
+The small meshes are compared field by field; the full-size runs (256^2, 1024^2, 512^2) of the homogeneous configs must
+reproduce the small-mesh traces (uniform solution: mesh-size independent), which puts the regime the bench times
+(load steps >= 10, scale_bc = 1, unchanged-input reuse of assemblies / solves) under the reference.
+Bar: identical load-step / K-iteration / non-convergence counts, 1e-6 relative on fields (north star)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from test_gpu_model import FE, check_fields, close, make_material, svc_material, tension_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cfg(golden_dir):
+    return np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+
+
+def homogeneous_check(fe, g, p, rtol=1e-6):
+    """full-size run against the small-mesh reference trace of the same homogeneous problem"""
+    assert fe.nsteps == int(g[p + '_nsteps'])
+    assert list(fe.niter) == list(g[p + '_niter'])
+    assert list(fe.co_nconv) == list(g[p + '_co_nconv'])
+    assert close(fe.sgl, g[p + '_sgl'], rtol=rtol)
+    assert close(fe.egl, g[p + '_egl'], rtol=rtol)
+    assert close(fe.epgl, g[p + '_epgl'], scale=np.max(np.abs(g[p + '_egl'])), rtol=rtol)
+    sig, epl, eps = fe._state('sig'), fe._state('epl'), fe._state('eps')
+    assert np.max(np.abs(sig - sig[0])) < rtol * np.max(np.abs(sig))           # every element carries the same state
+    assert np.max(np.abs(epl - epl[0])) < rtol * np.max(np.abs(eps))
+    assert close(sig[0], g[p + '_sig'][0], rtol=rtol)
+    assert close(epl[0], g[p + '_epl'][0], scale=np.max(np.abs(g[p + '_eps'])), rtol=rtol)
+    assert close(fe._state('elstiff')[0], g[p + '_elstiff'][0], rtol=10 * rtol)
+    gb = g[p + '_globbc']
+    mine = np.array([fe.glob[k] for k in ('ebc1', 'ebc2', 'sbc1', 'sbc2')])
+    assert close(mine[:2], gb[:2], scale=np.max(np.abs(g[p + '_egl'])), rtol=rtol)
+    assert close(mine[2:], gb[2:4], scale=np.max(np.abs(g[p + '_sgl'])), rtol=rtol)
+    free = fe.free_dofs()
+    assert np.max(np.abs(fe.f[free])) < rtol * np.max(np.abs(fe.f))             # equilibrium
+
+
+# ------------------------------------------------------------------ config 2: J2, eps 0.004, min_step 20
+def test_config2_schedule_8x8(cfg):
+    fe = tension_model(make_material('j2'), 8, 0.004)
+    fe.solve(min_step=20)
+    check_fields(fe, cfg, 'cfg2_j2_8')
+
+
+def test_config2_full_size_256(cfg):
+    """BASELINE.json configs[1]: 256x256 Q4, isotropic J2 plasticity, 20 load increments — exact workload."""
+    fe = tension_model(make_material('j2'), 256, 0.004)
+    fe.solve(min_step=20)
+    homogeneous_check(fe, cfg, 'cfg2_j2_8')
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+
+
+# ------------------------------------------------------------------ config 3: Hill-6p, eps 0.005, min_step 50
+def test_config3_schedule_8x8(cfg):
+    fe = tension_model(make_material('hill6'), 8, 0.005)
+    fe.solve(min_step=50)
+    check_fields(fe, cfg, 'cfg3_hill6_8')
+    # the regime bench.py times: from load step 10 on the increments are equal and the library answers repeated solves /
+    # assemblies from the previous ones (plfx_reuse_info) -- pinned here against the reference's trace
+    ra, rb, rs = fe._engine.reuse_info()
+    assert ra > 0 and rs > 0
+
+
+def test_config3_full_size_1024(cfg):
+    """BASELINE.json configs[2] = the bench workload: 1024x1024 Q4, Hill-48, eps=0.005, 50 increments."""
+    fe = tension_model(make_material('hill6'), 1024, 0.005)
+    fe.solve(min_step=50)
+    homogeneous_check(fe, cfg, 'cfg3_hill6_8')
+    ra, rb, rs = fe._engine.reuse_info()
+    assert ra >= 20 and rs >= 20     # the il >= 10 reuse path ran (BENCH_r01: 20 of 40 assemblies, 25 of 60 solves per 10 steps)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+
+
+def test_config3_reuse_off_is_the_same_trace(cfg):
+    """PLFX_REUSE=0 (every assembly / solve recomputed, like the reference does) gives the same trace at 128^2."""
+    os.environ['PLFX_REUSE'] = '0'
+    try:
+        fe = tension_model(make_material('hill6'), 128, 0.005)
+        fe.solve(min_step=50)
+    finally:
+        del os.environ['PLFX_REUSE']
+    homogeneous_check(fe, cfg, 'cfg3_hill6_8')
+    assert fe._engine.reuse_info() == (0, 0, 0)
+
+
+# ------------------------------------------------------------------ config 4: train_hill SVC, eps 0.001, min_step 10
+def test_config4_schedule_4x4(cfg, golden_dir):
+    assert bool(cfg['cfg4_same_as_svc_hill'])        # the trace was made with the SVC stored in svc_hill.npz
+    fe = tension_model(svc_material(golden_dir, 'hill'), 4, 0.001)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=10)
+    check_fields(fe, cfg, 'cfg4_svc_4', rtol=2e-6)   # SVC: bounded by brentq's xtol = 1e-5 MPa in ML_full_yf
+
+
+def test_config4_full_size_512(cfg, golden_dir):
+    """BASELINE.json configs[3]: 512x512 mesh, SVC yield function with 1585 support vectors — exact workload."""
+    fe = tension_model(svc_material(golden_dir, 'hill'), 512, 0.001)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=10)
+    homogeneous_check(fe, cfg, 'cfg4_svc_4', rtol=2e-6)
+    assert np.max(fe._state('max_steps')) == 49       # the 50-sub-step corrector ran (wave-per-element SVC kernels)
+
+
+# ------------------------------------------------------------------ config 5: J2 + Goss-Barlat-trained SVC laminate
+def laminate_cfg5(golden_dir, NX, NY):
+    ma = make_material('j2')
+    mb = svc_material(golden_dir, 'gossbarlat')
+    ma.num, mb.num = 1, 2
+    fe = FE().Model(dim=2, planestress=False)
+    fe.geom([2, 1, 2, 1, 2], LY=8.)
+    fe.assign([ma, mb, ma, mb, ma])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.003 * fe.leny, 'disp')
+    fe.mesh(NX=NX, NY=NY)
+    return fe
+
+
+def test_config5_real_materials_8x4(cfg, golden_dir):
+    """BASELINE config 5's materials (J2 + SVC trained on Barlat Yld2004-18p, examples/train_goss_barlat.py:36-41, 70-83)
+    on the laminate geometry, 8x4 elements, against the reference's trace."""
+    fe = laminate_cfg5(golden_dir, 8, 4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=20)
+    check_fields(fe, cfg, 'cfg5_lam_8x4', rtol=2e-6)
+    assert np.max(fe._state('epl')[fe._mat_id == 1]) > 0. and np.max(fe._state('epl')[fe._mat_id == 0]) > 0.
+
+
+def test_config5_real_materials_64x32_vs_oracle(golden_dir):
+    """the same laminate on 64x32 elements (multigrid + matrix-free operator, wave-per-element SVC kernels, material jumps)
+    against the pinned oracle's sparse direct solve, first 6 load steps of the 20-increment schedule"""
+    from oracle.solve_ref import RefSolver
+    fe = laminate_cfg5(golden_dir, 64, 32)
+    fe._max_load_steps = 6
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=20)
+        ref = RefSolver(laminate_cfg5(golden_dir, 64, 32)).solve(min_step=20, max_load_steps=6)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+    assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
+    s = np.max(np.abs(ref.sig))
+    assert np.max(np.abs(fe.u - ref.u)) < 2e-6 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 2e-6 * s
+    assert np.max(np.abs(fe._state('epl') - ref.epl)) < 2e-6 * np.max(np.abs(ref.eps))
+    assert np.max(np.abs(fe.sgl - ref.sgl)) < 2e-6 * s

@@ -81,7 +81,7 @@ def test_response_vs_oracle_large(ctx, golden_dir):
     assert np.max(np.abs(ct[ok] - ct2[ok])) < 1e-6 * CV[0, 0]
 
 
-@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train'])
+@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train', 'gossbarlat'])
 def test_svc(ctx, golden_dir, name):
     from pylabfea_amd import _lib
     z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))

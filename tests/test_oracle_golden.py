@@ -57,7 +57,7 @@ def test_element(golden_dir):
         assert rel(K, z['e%d_KelD' % k], 1e-6) < 1e-12
 
 
-@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train'])
+@pytest.mark.parametrize('name', ['hill', 'shear', 'j2train', 'gossbarlat'])
 def test_svc(golden_dir, name):
     z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))
     m = O.Material.from_golden(z)

@@ -82,3 +82,62 @@ def test_elastic32(golden_dir):
     fe = tension_model(m, 32, 0.001)
     r = RefSolver(fe).solve()
     check(r, g, 'el32')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the schedules BASELINE.json's configs are quoted on (tests/golden/solve_configs.npz, oracle/gen_golden.py:gen_configs)
+def svc_material(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, 'svc_%s.npz' % name))
+    m = FE.Material(name='ML-' + name)
+    m.elasticity(CV=z['par_CV'])
+    m.plasticity(sy=float(z['par_sy']), sdim=int(z['par_sdim']))
+    m.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']),
+              float(z['par_scale_seq']), dev_only=bool(z['par_dev_only']))
+    return m
+
+
+@pytest.mark.parametrize('name,mat,eps,ms', [('cfg2_j2_8', 'j2', 0.004, 20), ('cfg3_hill6_8', 'hill6', 0.005, 50)])
+def test_config_schedules(golden_dir, name, mat, eps, ms):
+    g = np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+    r = RefSolver(tension_model(make_material(mat), 8, eps)).solve(min_step=ms)
+    check(r, g, name)
+
+
+def test_config_schedule_pcg_variant(golden_dir):
+    """the OpenMP Jacobi-PCG of the CPU baseline (linear='pcg') gives the same trace as the sparse direct solve"""
+    g = np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+    r = RefSolver(tension_model(make_material('hill6'), 8, 0.005), linear='pcg', pcg_rtol=1e-12).solve(min_step=50)
+    check(r, g, 'cfg3_hill6_8')
+    assert max(r.pcg_iters) > 0
+
+
+def check_svc(r, g, p, tol=2e-6):
+    assert r.nsteps == int(g[p + '_nsteps'])
+    assert list(r.niter) == list(g[p + '_niter'])
+    assert list(r.co_nconv) == list(g[p + '_co_nconv'])
+    for a, k in ((r.u, '_u'), (r.sig, '_sig'), (r.eps, '_eps'), (r.sgl, '_sgl'), (r.egl, '_egl')):
+        ref = g[p + k]
+        assert np.max(np.abs(a - ref)) < tol * np.max(np.abs(ref)), k
+    assert np.max(np.abs(r.epl - g[p + '_epl'])) < tol * np.max(np.abs(g[p + '_eps']))
+
+
+def test_config4_svc_schedule(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+    r = RefSolver(tension_model(svc_material(golden_dir, 'hill'), 4, 0.001)).solve(min_step=10)
+    check_svc(r, g, 'cfg4_svc_4')
+
+
+def test_config5_laminate_real_materials(golden_dir):
+    """J2 + the SVC trained on Barlat Yld2004-18p (Goss texture), laminate [2,1,2,1,2], 8x4 elements"""
+    g = np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+    ma, mb = make_material('j2'), svc_material(golden_dir, 'gossbarlat')
+    fe = FE.Model(dim=2)
+    fe.geom([2, 1, 2, 1, 2], LY=8.)
+    fe.assign([ma, mb, ma, mb, ma])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.003 * fe.leny, 'disp')
+    fe.mesh(NX=8, NY=4)
+    r = RefSolver(fe).solve(min_step=20)
+    check_svc(r, g, 'cfg5_lam_8x4')
