@@ -238,9 +238,32 @@ int plfx_set_bc_sources(plfx_ctx *ctx, int nseg, const int32_t *src, const int32
 int plfx_load_step(plfx_ctx *ctx, plfx_step *step, double *u_at, double *f_at, double *sums18);
 int plfx_finish_fetch(plfx_ctx *ctx, int slot, double *u_at, double *f_at, double *sums18);
 
+/* ---------------------------------------------------------------- strip-local engine
+ * Multi-GPU form of the whole path for the reference's structured grids: the global NX x NY grid (node j*(NY+1)+k, element
+ * j*NY+k, model.py:893, 935) is cut into x-strips of whole element columns; every rank holds ONE strip as a standalone local
+ * mesh (plfx_set_mesh with el_begin = 0, el_end = nel; plfx_set_grid with its local column count) made of its owned columns
+ * [own_col0, own_col1) of the local grid plus `halo` columns on each interior side.  Nothing is replicated except the
+ * coarse problem; per PCG iteration the ranks exchange one halo slab of the residual (contiguous node columns, ncclSend /
+ * ncclRecv), one all-reduce of the owned level-`coarse_level` residual into the replicated global coarse grid, and three
+ * all-reduces of <= 8 KB of partial sums.  The V-cycle is arithmetically the one a single GPU runs on the global grid
+ * (validity widths in DESIGN.md section 6), so iteration counts do not depend on the number of strips.  The material sweep
+ * runs on the halo elements too (their state is recomputed from the exchanged displacement increment, never communicated).
+ * global_col0 = global element column of local column 0; halo (derived) must be 8 * 2^coarse_level (32 for level 3, 64 for
+ * level 4); all column numbers and NY must be multiples of 2^coarse_level.  Needs the matrix-free operator and, for more
+ * than one strip, a communicator (plfx_comm_init / plfx_comm_init_callback) created BEFORE this call.
+ * plfx_sweep flags, plfx_scf_all statistics and plfx_finish_step element sums then refer to the whole grid; u_at / f_at of
+ * plfx_finish_step and all state arrays are local (owned + halo columns). */
+int plfx_set_strip(plfx_ctx *ctx, int own_col0, int own_col1, int global_col0, int global_nx, int coarse_level);
+int plfx_strip_info(plfx_ctx *ctx, int *active, int *halo, int *coarse_level, int *coarse_levels, int64_t *halo_refreshes,
+                    int64_t *coarse_gathers, int64_t *partial_allreduces);
+/* in-place all-reduce of n <= 32 host doubles over the context's communicator (op 0 = sum, 3 = min): the boundary sums of
+ * calc_global (model.py:1452-1471) over the strips.  No-op without a communicator. */
+int plfx_allreduce_host(plfx_ctx *ctx, double *buf, int n, int op);
+
 /* Host-staged transport for the same collectives (tests on a single GPU, hosts without RCCL): every in-place all-reduce
  * the library needs is staged through host memory and handed to `fn` (dtype 0 = double, 1 = int32; op 0 = sum, 3 = min;
- * return 0 on success).  Slow by construction -- the product transport is plfx_comm_init (RCCL). */
+ * return 0 on success).  op 100 = halo exchange of a strip: buf holds [slab for the left neighbour | slab for the right
+ * neighbour] (count / 2 doubles each) and must come back as [slab from the left | slab from the right]; every rank calls.  Slow by construction -- the product transport is plfx_comm_init (RCCL). */
 typedef int (*plfx_allreduce_fn)(void *user, void *buf, size_t count, int dtype, int op);
 int plfx_comm_init_callback(plfx_ctx *ctx, int rank, int nranks, plfx_allreduce_fn fn, void *user);
 /* device_collectives = 1: this context shards the elements over an RCCL communicator; plfx_sweep (flags),

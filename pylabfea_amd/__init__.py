@@ -8,7 +8,8 @@ See DESIGN.md for the scope table and INTEGRATION.md for the C-ABI.
 from .basic import Strain, Stress, eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, sig_princ, yf_tolerance
 from .material import Material
 from .model import Model
+from ._dist import host_transport
 
 __version__ = '0.1.0'
-__all__ = ['Material', 'Model', 'Stress', 'Strain', 'eps_eq', 'sig_dev', 'sig_eq_j2', 'sig_polar_ang', 'sig_princ',
+__all__ = ['Material', 'Model', 'host_transport', 'Stress', 'Strain', 'eps_eq', 'sig_dev', 'sig_eq_j2', 'sig_polar_ang', 'sig_princ',
            'yf_tolerance']

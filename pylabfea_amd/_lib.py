@@ -48,7 +48,7 @@ SYMBOLS = [
     'plfx_precond_info', 'plfx_set_operator', 'plfx_operator_info', 'plfx_gen_structured', 'plfx_reuse_info', 'plfx_timing_select', 'plfx_finish_fetch', 'plfx_sweep_info', 'plfx_matvec', 'plfx_set_bc_plan', 'plfx_apply_bc_plan',
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
-    'plfx_load_step',
+    'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
 ]
 
 _lib = None
@@ -474,6 +474,26 @@ class Context(object):
     def comm_init(self, uid, rank, nranks):
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(self.lib.plfx_comm_init(self.h, buf, int(rank), int(nranks)))
+
+    def set_strip(self, own_col0, own_col1, global_col0, global_nx, coarse_level):
+        """this context holds one x-strip of a larger structured grid (plfx_set_strip)"""
+        self._chk(self.lib.plfx_set_strip(self.h, int(own_col0), int(own_col1), int(global_col0), int(global_nx),
+                                          int(coarse_level)))
+
+    def strip_info(self):
+        """(active, halo, coarse_level, levels of the replicated coarse hierarchy, halo refreshes, coarse gathers,
+        all-reduces of partial sums)"""
+        a, h, l, cl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        nh, nc, npart = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_strip_info(self.h, C.byref(a), C.byref(h), C.byref(l), C.byref(cl), C.byref(nh),
+                                           C.byref(nc), C.byref(npart)))
+        return bool(a.value), h.value, l.value, cl.value, nh.value, nc.value, npart.value
+
+    def allreduce_host(self, values, op=0):
+        """all-reduce <= 32 host doubles over the context's communicator (op 0 sum, 3 min)"""
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.lib.plfx_allreduce_host(self.h, a.ctypes.data_as(C.c_void_p), int(a.size), int(op)))
+        return a
 
     _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
 

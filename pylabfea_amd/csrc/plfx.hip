@@ -19,6 +19,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,12 +53,18 @@ typedef int (*fn_ncclGetUniqueId)(ncclUniqueId *);
 typedef int (*fn_ncclCommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
 typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
 typedef int (*fn_ncclCommDestroy)(ncclComm_t);
+typedef int (*fn_ncclSend)(const void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*fn_ncclRecv)(void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*fn_ncclGroup)(void);
 struct Rccl {
     void *h = nullptr;
     fn_ncclGetUniqueId GetUniqueId = nullptr;
     fn_ncclCommInitRank CommInitRank = nullptr;
     fn_ncclAllReduce AllReduce = nullptr;
     fn_ncclCommDestroy CommDestroy = nullptr;
+    fn_ncclSend Send = nullptr;          // point-to-point: halo refresh of the strip-local engine
+    fn_ncclRecv Recv = nullptr;
+    fn_ncclGroup GroupStart = nullptr, GroupEnd = nullptr;
 };
 Rccl g_rccl;
 bool load_rccl()
@@ -78,12 +86,34 @@ bool load_rccl()
     g_rccl.CommInitRank = (fn_ncclCommInitRank)dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.AllReduce = (fn_ncclAllReduce)dlsym(g_rccl.h, "ncclAllReduce");
     g_rccl.CommDestroy = (fn_ncclCommDestroy)dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.Send = (fn_ncclSend)dlsym(g_rccl.h, "ncclSend");
+    g_rccl.Recv = (fn_ncclRecv)dlsym(g_rccl.h, "ncclRecv");
+    g_rccl.GroupStart = (fn_ncclGroup)dlsym(g_rccl.h, "ncclGroupStart");
+    g_rccl.GroupEnd = (fn_ncclGroup)dlsym(g_rccl.h, "ncclGroupEnd");
     return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
 }
 constexpr int NCCL_FLOAT64 = 8;  // ncclDouble
 constexpr int NCCL_INT32 = 2;    // ncclInt32
 constexpr int NCCL_SUM = 0;
 constexpr int NCCL_MIN = 3;
+
+// Opt-in to > 64 KiB of dynamic LDS is a per-function attribute shared by every context of the process (several models, the
+// point-evaluation context, the coarse context of a strip): only ever raise it, so that a context created later with
+// smaller tables cannot shrink the limit under a context that still launches with the larger ones.
+hipError_t set_dyn_lds(const void *fn, int bytes)
+{
+    static std::map<std::pair<int, const void *>, int> cur;
+    static std::mutex mu;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, fn);
+    auto it = cur.find(key);
+    if (it != cur.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur[key] = bytes;
+    return e;
+}
 
 template <class T>
 struct DBuf {  // device buffer
@@ -259,6 +289,26 @@ struct plfx_ctx {
     void *host_ar_user = nullptr;
     std::vector<char> host_ar_buf;
     int rank = 0, nranks = 1;
+
+    // Strip-local engine (plfx_set_strip): this context holds ONE x-strip of a larger structured grid as
+    // a standalone local grid -- the owned element columns [oc0, oc1) plus W halo columns on every interior side.  Three
+    // things stitch the strips together: the halo refresh of a node vector (contiguous node columns, one send/recv pair per
+    // neighbour), owned-only reductions followed by all-reduces of the per-block partial sums, and a replicated coarse
+    // problem (`child`: levels >= Ld of the GLOBAL grid, fed by one all-reduce of the owned level-Ld residual per V-cycle).
+    struct Strip {
+        bool on = false;
+        int oc0 = 0, oc1 = 0;            // owned element columns of the local grid
+        int W = 0;                       // halo width in element columns
+        int Ld = 0;                      // first level of the replicated coarse problem
+        int gcol0 = 0, gnx = 0;          // global element column of local column 0, global element columns
+        bool has_left = false, has_right = false;
+        int own_lo = 0, own_hi = 0;      // owned node range [lo, hi): disjoint over the ranks (reductions)
+        int eown_lo = 0, eown_hi = 0;    // owned element range
+        plfx_ctx *child = nullptr;
+        std::vector<double> hbuf;        // host staging of the callback transport
+        long long n_halo = 0, n_coarse = 0, n_part = 0;
+    } strip;
+    bool is_child = false;               // coarse context of a strip: shares stream, sc and dtab with its parent
 
     Timing tim;
 };
@@ -568,10 +618,13 @@ bool build_pattern(int nnode, const int32_t *conn, int el_begin, int el_end, std
 }
 
 void mg_graph_drop(plfx_ctx *c);
+int strip_coarse(plfx_ctx *c);
+void strip_free(plfx_ctx *c);
 
 void free_mesh(plfx_ctx *c)
 {
     mg_graph_drop(c);
+    strip_free(c);
     dfree(c->dcls);
     dfree(c->dconn);
     dfree(c->dcls_id);
@@ -697,7 +750,7 @@ size_t dyn_lds_bytes(const plfx_ctx *c) { return (c->has_svc || c->has_svc3) ? (
 int plain_spmv(plfx_ctx *c, const double *in, double *out)
 {
     LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)in, nullptr, nullptr,
-               (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0);
+               (double2 *)out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
     HIPCHK(c, hipGetLastError());
     return 0;  // the matrix is replicated on every rank: no collective here
 }
@@ -736,6 +789,65 @@ int sync_M(plfx_ctx *c)
                        c->nel_total, c->e0, c->e0 + c->nel, c->Mel);
     HIPCHK(c, hipGetLastError());
     return allreduce(c, c->Mel, (size_t)6 * c->nel_total, NCCL_FLOAT64, NCCL_SUM, "M");
+}
+
+
+// ---------------------------------------------------------------------------------------------- strip-local engine
+inline int own_lo(const plfx_ctx *c) { return c->strip.on ? c->strip.own_lo : 0; }
+inline int own_hi(const plfx_ctx *c) { return c->strip.on ? c->strip.own_hi : c->nnode; }
+
+// all-reduce of per-block partial sums (owned-only on every rank): the consumer kernels keep summing the <= 1024 entries
+// redundantly in a fixed order, so every rank takes bitwise the same decisions
+int part_allreduce(plfx_ctx *c, double *p, size_t n)
+{
+    if (!c->strip.on || c->nranks < 2) return 0;
+    c->strip.n_part++;
+    return allreduce(c, p, n, NCCL_FLOAT64, NCCL_SUM, "partial sums");
+}
+
+// Halo refresh of a node vector v (double2 per node, node id = column * nyn + row): the W node columns beyond each
+// interior edge of the owned range are overwritten with the neighbour's (valid) values.  Columns are contiguous in memory,
+// so a slab is one send / recv without packing:
+//   to the left neighbour   my columns oc0+1 .. oc0+W      from it   columns oc0-W .. oc0-1
+//   to the right neighbour  my columns oc1-W .. oc1-1      from it   columns oc1+1 .. oc1+W
+// (node columns oc0 and oc1 are computed validly by both sides)
+int halo_refresh(plfx_ctx *c, double *v)
+{
+    auto &S = c->strip;
+    if (!S.on || c->nranks < 2) return 0;
+    const int nyn = c->gy + 1;
+    const size_t n = (size_t)S.W * nyn * 2;
+    double *sendL = v + (size_t)2 * (S.oc0 + 1) * nyn, *recvL = v + (size_t)2 * (S.oc0 - S.W) * nyn;
+    double *sendR = v + (size_t)2 * (S.oc1 - S.W) * nyn, *recvR = v + (size_t)2 * (S.oc1 + 1) * nyn;
+    S.n_halo++;
+    if (c->comm) {
+        if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+            return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
+        int rc = g_rccl.GroupStart();
+        if (!rc && S.has_left) {
+            rc = g_rccl.Send(sendL, n, NCCL_FLOAT64, c->rank - 1, c->comm, c->stream);
+            if (!rc) rc = g_rccl.Recv(recvL, n, NCCL_FLOAT64, c->rank - 1, c->comm, c->stream);
+        }
+        if (!rc && S.has_right) {
+            rc = g_rccl.Send(sendR, n, NCCL_FLOAT64, c->rank + 1, c->comm, c->stream);
+            if (!rc) rc = g_rccl.Recv(recvR, n, NCCL_FLOAT64, c->rank + 1, c->comm, c->stream);
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc || rc2) return fail(c, PLFX_ERR_HIP, "halo refresh (ncclSend/ncclRecv) failed: %d / %d", rc, rc2);
+        return 0;
+    }
+    if (c->host_ar) {  // host-staged transport: [to left | to right] out, [from left | from right] back (op 100)
+        S.hbuf.assign(2 * n, 0.);
+        if (S.has_left) HIPCHK(c, hipMemcpyAsync(S.hbuf.data(), sendL, 8 * n, hipMemcpyDeviceToHost, c->stream));
+        if (S.has_right) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + n, sendR, 8 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->host_ar(c->host_ar_user, S.hbuf.data(), 2 * n, 0, 100) != 0)
+            return fail(c, PLFX_ERR_HIP, "host halo-exchange callback failed");
+        if (S.has_left) HIPCHK(c, hipMemcpyAsync(recvL, S.hbuf.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
+        if (S.has_right) HIPCHK(c, hipMemcpyAsync(recvR, S.hbuf.data() + n, 8 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
 }
 
 
@@ -897,7 +1009,9 @@ int mg_coarse_part(plfx_ctx *c)
     int rc;
     for (int l = 1; l < lt; l++)
         if ((rc = mg_down_level(c, l))) return rc;
-    {
+    if (c->strip.on) {  // level Ld and everything below it: the replicated coarse problem of the whole grid
+        if ((rc = strip_coarse(c))) return rc;
+    } else {
         auto &L = c->mg[nl - 1];
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
         if (lt < nl - 1 && tail_mf(c))
@@ -973,7 +1087,7 @@ int mg_vcycle_rest(plfx_ctx *c)
     int rc;
     if (lt < 1) {  // two-level hierarchy without a separate fine leg
         if ((rc = mg_coarse_part(c))) return rc;
-    } else if (c->want_mg_graph && lt >= 2) {
+    } else if (c->want_mg_graph && lt >= 2 && !c->strip.on) {  // (collectives inside the strip's cycle are not captured)
         if (!c->mg_graph_exec) {
             HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             rc = mg_coarse_part(c);
@@ -1000,6 +1114,130 @@ int mg_vcycle(plfx_ctx *c)
     int rc = mg_vcycle_head(c);
     if (rc) return rc;
     return mg_vcycle_rest(c);
+}
+
+
+// ---------------------------------------------------------------------------------------------- strip: coarse problem
+// window of the local level-Ld grid inside the global one: owned node columns [jc0, jc1) (the last rank owns the closing
+// column), owned element columns [ec0, ec1), global column of local column 0
+struct StripWin {
+    int jc0, jc1, ec0, ec1, g0;
+};
+StripWin strip_window(const plfx_ctx *c)
+{
+    const auto &S = c->strip;
+    StripWin w;
+    w.jc0 = S.oc0 >> S.Ld;
+    w.jc1 = (S.oc1 >> S.Ld) + (S.has_right ? 0 : 1);
+    w.ec0 = S.oc0 >> S.Ld;
+    w.ec1 = S.oc1 >> S.Ld;
+    w.g0 = S.gcol0 >> S.Ld;
+    return w;
+}
+
+// z_Ld = (V-cycle of the global hierarchy below level Ld)(b_Ld): the owned part of the local level-Ld right-hand side is
+// placed into the zero-filled global vector, ONE all-reduce completes it on every rank, every rank runs the same cycle
+// (launch-latency-bound kernels, as on one GPU) and takes its window of the correction -- valid on ALL local columns.
+int strip_coarse(plfx_ctx *c)
+{
+    auto &S = c->strip;
+    plfx_ctx *k = S.child;
+    auto &L = c->mg[S.Ld];
+    const StripWin w = strip_window(c);
+    const size_t nyc = L.ny + 1;
+    const size_t nd = (size_t)2 * k->nnode;
+    hipLaunchKernelGGL(k_strip_pack, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, 1, nd, (size_t)2 * L.nnode,
+                       (size_t)2 * (w.g0 + w.jc0) * nyc, (size_t)2 * (w.jc1 - w.jc0) * nyc, (size_t)2 * w.jc0 * nyc,
+                       (const double *)L.b, k->r);
+    HIPCHK(c, hipGetLastError());
+    if (c->nranks > 1) {
+        S.n_coarse++;
+        const int rc = allreduce(c, k->r, nd, NCCL_FLOAT64, NCCL_SUM, "coarse right-hand side");
+        if (rc) return rc;
+    }
+    int rc = mg_vcycle(k);
+    if (rc) {
+        c->err = k->err;
+        return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(L.x, k->z + (size_t)2 * w.g0 * nyc, (size_t)16 * L.nnode, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// generators of level Ld of the whole grid (owned columns of every rank, one all-reduce), then the coarse context's
+// own "setupK": diagonal, snapshot, generators of its coarser levels
+int strip_child_assemble(plfx_ctx *c)
+{
+    auto &S = c->strip;
+    plfx_ctx *k = S.child;
+    auto &L = c->mg[S.Ld];
+    const StripWin w = strip_window(c);
+    const size_t tot = (size_t)6 * k->nel_total;
+    hipLaunchKernelGGL(k_strip_pack, dim3(grid_for(tot)), dim3(BLOCK), 0, c->stream, 6, (size_t)k->nel_total, (size_t)L.nel,
+                       (size_t)(w.g0 + w.ec0) * L.ny, (size_t)(w.ec1 - w.ec0) * L.ny, (size_t)w.ec0 * L.ny,
+                       (const double *)L.Mel, k->Mel);
+    HIPCHK(c, hipGetLastError());
+    if (c->nranks > 1) {
+        const int rc = allreduce(c, k->Mel, tot, NCCL_FLOAT64, NCCL_SUM, "coarse generators");
+        if (rc) return rc;
+    }
+    KOp live = k->op;
+    live.M = k->Mel;
+    hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(k->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)k->diag, k->Mop,
+                       k->mg[1].Mel, (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    k->bc_valid = false;  // its Jacobi scalings / Dirichlet masks follow in strip_child_dinv (after the parent's calc_BC)
+    const int rc = mg_assemble(k);
+    if (rc) c->err = k->err;
+    return rc;
+}
+
+// Dirichlet mask + Jacobi scaling of level Ld of the whole grid from the owned columns of every rank, then the coarser ones
+int strip_child_dinv(plfx_ctx *c)
+{
+    auto &S = c->strip;
+    plfx_ctx *k = S.child;
+    auto &L = c->mg[S.Ld];
+    const StripWin w = strip_window(c);
+    const size_t nyc = L.ny + 1;
+    const size_t nd = (size_t)2 * k->nnode;
+    hipLaunchKernelGGL(k_strip_pack, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, 1, nd, (size_t)2 * L.nnode,
+                       (size_t)2 * (w.g0 + w.jc0) * nyc, (size_t)2 * (w.jc1 - w.jc0) * nyc, (size_t)2 * w.jc0 * nyc,
+                       (const double *)L.dinv, k->dinv);
+    HIPCHK(c, hipGetLastError());
+    if (c->nranks > 1) {
+        const int rc = allreduce(c, k->dinv, nd, NCCL_FLOAT64, NCCL_SUM, "coarse Jacobi scaling");
+        if (rc) return rc;
+    }
+    k->mg_inv_valid = false;
+    const int rc = mg_update_dinv(k, false);
+    if (rc) c->err = k->err;
+    return rc;
+}
+
+void strip_free(plfx_ctx *c)
+{
+    plfx_ctx *k = c->strip.child;
+    if (k) {
+        mg_graph_drop(k);
+        dfree(k->Mel);
+        dfree(k->Mop);
+        dfree(k->diag);
+        dfree(k->dinv);
+        dfree(k->r);
+        dfree(k->z);
+        for (auto &L : k->mg) {
+            if (L.owned) {
+                dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
+                dfree(L.Mel); dfree(L.x); dfree(L.b);
+            }
+            dfree(L.t); dfree(L.res); dfree(L.ainv);
+        }
+        dfree(k->mg_cls);
+        dfree(k->mg_dev);
+        delete k;  // stream, sc and dtab belong to the parent
+    }
+    c->strip = plfx_ctx::Strip();
 }
 
 }  // namespace
@@ -1208,19 +1446,19 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->svc_wave_mat >= 0) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_svc_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->svc_wave_lds));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_svc_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1>, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_response_batch<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_point_eval, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_light<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sweep_heavy<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_scf_elements, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_response_batch<3>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_response_batch<6>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_light<6>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_heavy<6>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_point_eval, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_light<3>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_heavy<3>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_scf_elements, bytes));
     }
     c->M_dirty = true;
     c->memo.valid = false;
@@ -1504,61 +1742,12 @@ int plfx_get_kel(plfx_ctx *c, int e, double *Kel)
     return PLFX_OK;
 }
 
-// ------------------------------------------------------------------------------ structured grid / multigrid
-int plfx_set_grid(plfx_ctx *c, int nx, int ny)
+// Multigrid hierarchy of the nx x ny element grid of context c (level 0 aliases the context's fine-grid arrays): level
+// dimensions, block-ELL patterns of the coarse levels, single-workgroup tail, coarse solver.  Shared by plfx_set_grid and
+// by the coarse context of a strip (strip_create_child).
+static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
 {
-    if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
-    if (nx < 1 || ny < 1 || (long long)nx * ny != c->nel_total || (long long)(nx + 1) * (ny + 1) != c->nnode)
-        return fail(c, PLFX_ERR_ARG, "grid %dx%d does not match the mesh", nx, ny);
-    const int nrow = ny + 1;
-    for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
-        const int n1 = (e / ny) * nrow + e % ny;
-        const int32_t *q = &c->hconn[4 * (size_t)e];
-        if (q[0] != n1 || q[1] != n1 + 1 || q[2] != n1 + nrow || q[3] != n1 + nrow + 1)
-            return fail(c, PLFX_ERR_ARG, "connectivity of element %d is not the structured numbering", e);
-    }
-    c->gx = nx;
-    c->gy = ny;
-    mg_graph_drop(c);
-    for (auto &L : c->mg) {  // drop a previous hierarchy
-        if (L.owned) {
-            dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
-            dfree(L.Mel); dfree(L.x); dfree(L.b);
-        }
-        dfree(L.t); dfree(L.res); dfree(L.ainv);
-    }
-    c->mg.clear();
-    c->grid_ok = false;
-    c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, 0, 0, c->nel_total, c->Mel);
-    // coarse re-assembly and the matrix-free operator need one element shape.  Laminate meshes compute dx = LS[i]/nes[i]
-    // per section (model.py:847), so nominally uniform sections can differ by an ulp: compare with a relative tolerance and
-    // use element 0's shape for the operator tables (the strain operator keeps each class's own lx, ly).
-    for (int e = 1; e < c->nel_total; e++)
-        if (std::fabs(c->hlxy[2 * (size_t)e] - c->hlxy[0]) > 1e-12 * std::fabs(c->hlxy[0]) ||
-            std::fabs(c->hlxy[2 * (size_t)e + 1] - c->hlxy[1]) > 1e-12 * std::fabs(c->hlxy[1]))
-            return PLFX_OK;
     int rc;
-    {   // geometry table of grid_apply: position p = pj*2+pk <-> element (j-1+pj, k-1+pk), in which node (j,k) has the
-        // local number a = (1-pj)*2 + (1-pk) (connectivity order model.py:936-948)
-        double tab[64];
-        const ClassDev &g = c->hcls[0];
-        for (int pj = 0; pj < 2; pj++)
-            for (int pk = 0; pk < 2; pk++) {
-                const int a = (1 - pj) * 2 + (1 - pk), p = pj * 2 + pk;
-                for (int b = 0; b < 4; b++) {
-                    tab[p * 16 + b * 4 + 0] = g.Sxx[a * 4 + b];
-                    tab[p * 16 + b * 4 + 1] = g.Syy[a * 4 + b];
-                    tab[p * 16 + b * 4 + 2] = g.Sxy[a * 4 + b];
-                    tab[p * 16 + b * 4 + 3] = g.Sxy[b * 4 + a];
-                }
-            }
-        if (!c->dtab && (rc = dalloc(c, &c->dtab, 64))) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->dtab, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((rc = dalloc(c, &c->Mop, (size_t)6 * c->nel_total))) return rc;
-        c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, nx, ny, c->nel_total, c->Mop);
-        c->grid_ok = true;
-    }
     std::vector<std::pair<int, int>> dims;
     dims.push_back({nx, ny});
     while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 &&
@@ -1567,7 +1756,8 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     if (dims.size() < 2) return PLFX_OK;
     if (!c->mg_cls) {
         if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->mg_cls, &c->hcls[0], sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->mg_cls, &geom, sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->mg.resize(dims.size());
     for (size_t l = 0; l < dims.size(); l++) {
@@ -1624,16 +1814,15 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         const int n = 2 * Lc.nnode;
         if (n <= MG_DENSE_MAX) {
             if ((rc = dalloc(c, &Lc.ainv, (size_t)n * n))) return rc;
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          n * n * (int)sizeof(double)));
+            HIPCHK(c, set_dyn_lds((const void *)k_mg_coarse_invert, n * n * (int)sizeof(double)));
         }
     }
     c->mg_cheby = 0;
     const bool small_coarsest = c->mg.back().nnode <= MG_COARSE_MAX;
     if (small_coarsest) {
         const int lds = c->mg.back().nnode * 4 * (int)sizeof(double2);
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_coarse_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_mg_coarse_solve, lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_mg_tail, lds));
     }
     {   // levels small enough for the single-workgroup tail (never level 0)
         std::vector<MgLevDev> hd(c->mg.size());
@@ -1661,8 +1850,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             const size_t bytes = (size_t)T * (4 * sizeof(double2) + 9 * sizeof(int));
             if (ok && bytes <= 150 * 1024) {
                 c->mg_tail_T = T;
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)bytes));
+                HIPCHK(c, set_dyn_lds((const void *)k_mg_tail_lds, (int)bytes));
             }
             // matrix-free tail: generators of the tail levels (coarsest excluded) in LDS instead of neighbour tables
             int E = 0;
@@ -1672,8 +1860,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             c->mg_tail_E = 0;
             if (c->grid_ok && bytes_mf <= 154 * 1024 && E > 0 && c->mg.size() <= 16) {  // + 2 KB static LDS (level table)
                 c->mg_tail_E = E;
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_mg_tail_mf, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)bytes_mf));
+                HIPCHK(c, set_dyn_lds((const void *)k_mg_tail_mf, (int)bytes_mf));
             }
         }
         {   // levels above the tail are applied matrix-free; the tail and the coarsest level keep assembled matrices
@@ -1701,7 +1888,219 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         HIPCHK(c, hipMemcpyAsync(c->mg_dev, hd.data(), hd.size() * sizeof(MgLevDev), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ structured grid / multigrid
+int plfx_set_grid(plfx_ctx *c, int nx, int ny)
+{
+    if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (nx < 1 || ny < 1 || (long long)nx * ny != c->nel_total || (long long)(nx + 1) * (ny + 1) != c->nnode)
+        return fail(c, PLFX_ERR_ARG, "grid %dx%d does not match the mesh", nx, ny);
+    const int nrow = ny + 1;
+    for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
+        const int n1 = (e / ny) * nrow + e % ny;
+        const int32_t *q = &c->hconn[4 * (size_t)e];
+        if (q[0] != n1 || q[1] != n1 + 1 || q[2] != n1 + nrow || q[3] != n1 + nrow + 1)
+            return fail(c, PLFX_ERR_ARG, "connectivity of element %d is not the structured numbering", e);
+    }
+    c->gx = nx;
+    c->gy = ny;
+    mg_graph_drop(c);
+    for (auto &L : c->mg) {  // drop a previous hierarchy
+        if (L.owned) {
+            dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
+            dfree(L.Mel); dfree(L.x); dfree(L.b);
+        }
+        dfree(L.t); dfree(L.res); dfree(L.ainv);
+    }
+    c->mg.clear();
+    c->grid_ok = false;
+    c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, 0, 0, c->nel_total, c->Mel);
+    // coarse re-assembly and the matrix-free operator need one element shape.  Laminate meshes compute dx = LS[i]/nes[i]
+    // per section (model.py:847), so nominally uniform sections can differ by an ulp: compare with a relative tolerance and
+    // use element 0's shape for the operator tables (the strain operator keeps each class's own lx, ly).
+    for (int e = 1; e < c->nel_total; e++)
+        if (std::fabs(c->hlxy[2 * (size_t)e] - c->hlxy[0]) > 1e-12 * std::fabs(c->hlxy[0]) ||
+            std::fabs(c->hlxy[2 * (size_t)e + 1] - c->hlxy[1]) > 1e-12 * std::fabs(c->hlxy[1]))
+            return PLFX_OK;
+    int rc;
+    {   // geometry table of grid_apply: position p = pj*2+pk <-> element (j-1+pj, k-1+pk), in which node (j,k) has the
+        // local number a = (1-pj)*2 + (1-pk) (connectivity order model.py:936-948)
+        double tab[64];
+        const ClassDev &g = c->hcls[0];
+        for (int pj = 0; pj < 2; pj++)
+            for (int pk = 0; pk < 2; pk++) {
+                const int a = (1 - pj) * 2 + (1 - pk), p = pj * 2 + pk;
+                for (int b = 0; b < 4; b++) {
+                    tab[p * 16 + b * 4 + 0] = g.Sxx[a * 4 + b];
+                    tab[p * 16 + b * 4 + 1] = g.Syy[a * 4 + b];
+                    tab[p * 16 + b * 4 + 2] = g.Sxy[a * 4 + b];
+                    tab[p * 16 + b * 4 + 3] = g.Sxy[b * 4 + a];
+                }
+            }
+        if (!c->dtab && (rc = dalloc(c, &c->dtab, 64))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dtab, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = dalloc(c, &c->Mop, (size_t)6 * c->nel_total))) return rc;
+        c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, nx, ny, c->nel_total, c->Mop);
+        c->grid_ok = true;
+    }
+    if ((rc = build_hierarchy(c, nx, ny, c->hcls[0]))) return rc;
     c->assembled = false, c->M_dirty = true;
+    return PLFX_OK;
+}
+
+// ------------------------------------------------------------------------------ strip-local engine
+int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int global_nx, int coarse_level)
+{
+    if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh / set_grid first") : PLFX_ERR_STATE;
+    if (!c->grid_ok || !c->want_matfree || c->mg.size() < 2)
+        return fail(c, PLFX_ERR_UNSUPPORTED, "a strip needs the uniform structured grid (matrix-free operator + multigrid)");
+    if (c->sharded) return fail(c, PLFX_ERR_STATE, "a strip context owns its whole local mesh (el_begin = 0, el_end = nel)");
+    const int nx = c->gx, ny = c->gy, Ld = coarse_level;
+    if (Ld < 1 || Ld >= (int)c->mg.size())
+        return fail(c, PLFX_ERR_ARG, "coarse level %d outside 1..%d of the local hierarchy", Ld, (int)c->mg.size() - 1);
+    const int al = 1 << Ld;
+    if (own_col0 < 0 || own_col1 > nx || own_col0 >= own_col1) return fail(c, PLFX_ERR_ARG, "bad owned column range");
+    const bool hl = own_col0 > 0, hr = own_col1 < nx;
+    const int W = hl ? own_col0 : (hr ? nx - own_col1 : 0);
+    if ((hl && own_col0 != W) || (hr && nx - own_col1 != W)) return fail(c, PLFX_ERR_ARG, "halo widths of the two sides differ");
+    if ((own_col0 | own_col1 | global_col0 | global_nx | ny | W | nx) & (al - 1))
+        return fail(c, PLFX_ERR_ARG, "columns, halo and NY must be multiples of 2^level = %d", al);
+    if (global_col0 < 0 || global_col0 + nx > global_nx) return fail(c, PLFX_ERR_ARG, "local grid outside the global one");
+    if ((hl != (global_col0 + own_col0 > 0)) || (hr != (global_col0 + own_col1 < global_nx)))
+        return fail(c, PLFX_ERR_ARG, "a halo is needed exactly on the interior sides of the strip");
+    if ((hl || hr) && own_col1 - own_col0 < W) return fail(c, PLFX_ERR_ARG, "owned width %d below the halo width %d", own_col1 - own_col0, W);
+    if ((hl || hr) && c->nranks < 2) return fail(c, PLFX_ERR_STATE, "interior strip edges need a communicator (plfx_comm_init*)");
+    if (c->mg_nu != 2) return fail(c, PLFX_ERR_UNSUPPORTED, "the validity widths of a strip are worked out for V(2,2)");
+    if (hl || hr) {
+        // Validity widths (columns beyond the owned range on which a quantity equals the single-GPU one).  The operator row
+        // and the Jacobi scaling of the outermost local column E are wrong (elements beyond the artificial edge are missing)
+        // and every operator application moves that error one column inwards.  Down: b valid v -> first sweep a = min(v, E-1),
+        // second a-1, residual a-2, full-weighting restriction (a-3)/2.  Up: x of the down leg a-1, prolongated correction
+        // 2 g', two post-smoothing sweeps -2.  Needed: b of level Ld valid on the owned columns (v >= 0) and z valid on
+        // owned + 1 (g >= 1; then p, K p and r stay valid on the owned columns without further exchange).
+        std::vector<int> a(Ld + 1);
+        int v = W;
+        for (int l = 0; l < Ld; l++) {
+            a[l] = std::min(v, (W >> l) - 1);
+            v = (a[l] - 3) >= 0 ? (a[l] - 3) / 2 : -1;
+        }
+        int g = W >> Ld;  // the coarse correction is valid on every local column
+        for (int l = Ld - 1; l >= 0 && v >= 0; l--) g = std::min(a[l] - 1, 2 * g) - 2;
+        if (v < 0 || g < 1)
+            return fail(c, PLFX_ERR_ARG, "halo of %d columns is too narrow for coarse level %d (need 8 * 2^level: 32 for 3, 64 for 4)", W, Ld);
+    }
+    mg_graph_drop(c);
+    strip_free(c);
+    auto &S = c->strip;
+    // the local hierarchy ends at level Ld (kept for its vectors, generators and Jacobi scaling: the hand-over level)
+    for (size_t l = Ld + 1; l < c->mg.size(); l++) {
+        auto &L = c->mg[l];
+        if (L.owned) {
+            dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
+            dfree(L.Mel); dfree(L.x); dfree(L.b);
+        }
+        dfree(L.t); dfree(L.res); dfree(L.ainv);
+    }
+    c->mg.resize(Ld + 1);
+    dfree(c->mg.back().ainv);
+    c->mg_tail = -1;
+    c->mg_tail_T = c->mg_tail_E = 0;
+    c->mg_cheby = 0;
+    c->precond = 1;
+    for (auto &L : c->mg) L.matfree = true;
+    S.oc0 = own_col0;
+    S.oc1 = own_col1;
+    S.W = W;
+    S.Ld = Ld;
+    S.gcol0 = global_col0;
+    S.gnx = global_nx;
+    S.has_left = hl;
+    S.has_right = hr;
+    const int nyn = ny + 1;
+    S.own_lo = own_col0 * nyn;
+    S.own_hi = (hr ? own_col1 : nx + 1) * nyn;
+    S.eown_lo = own_col0 * ny;
+    S.eown_hi = own_col1 * ny;
+    // replicated coarse problem: levels >= Ld of the global grid
+    plfx_ctx *k = new plfx_ctx();
+    S.child = k;
+    k->is_child = true;
+    k->device = c->device;
+    k->stream = c->stream;
+    k->prop = c->prop;
+    k->sc = c->sc;
+    k->dtab = c->dtab;
+    k->want_matfree = 1;
+    k->want_mg_graph = c->want_mg_graph;
+    k->mg_omega = c->mg_omega;
+    k->mg_nu = c->mg_nu;
+    k->gx = global_nx >> Ld;
+    k->gy = ny >> Ld;
+    k->nel_total = k->nel = k->gx * k->gy;
+    k->nnode = (k->gx + 1) * (k->gy + 1);
+    k->ndof = 2 * k->nnode;
+    int rc;
+#define KALLOC(ptr, n)                               \
+    if ((rc = dalloc(c, &(ptr), (size_t)(n)))) {     \
+        strip_free(c);                               \
+        return rc;                                   \
+    }
+    KALLOC(k->Mel, (size_t)6 * k->nel_total);
+    KALLOC(k->Mop, (size_t)6 * k->nel_total);
+    KALLOC(k->diag, k->ndof);
+    KALLOC(k->dinv, k->ndof);
+    KALLOC(k->r, k->ndof);
+    KALLOC(k->z, k->ndof);
+#undef KALLOC
+    k->grid_ok = true;
+    k->grid_nodes = grid_xcd(k->nnode);
+    k->op = make_op(k, k->nnode, 0, nullptr, nullptr, k->gx, k->gy, k->nel_total, k->Mop);
+    rc = build_hierarchy(k, k->gx, k->gy, c->hcls[0]);
+    if (rc || !mg_active(k)) {
+        if (!rc) rc = fail(c, PLFX_ERR_UNSUPPORTED, "the global coarse grid %d x %d has no usable hierarchy", k->gx, k->gy);
+        else c->err = k->err;
+        strip_free(c);
+        return rc;
+    }
+    S.on = true;
+    // the per-block partial sums are all-reduced element-wise: every rank must produce (and consume) the same number of them
+    c->grid_nodes = MAXPART;
+    c->assembled = false, c->M_dirty = true;
+    c->bc_set = false;
+    c->bc_valid = false;
+    c->x_is_du = false;
+    c->memo.valid = false;
+    return PLFX_OK;
+}
+
+int plfx_strip_info(plfx_ctx *c, int *active, int *halo, int *coarse_level, int *coarse_levels, int64_t *halo_refreshes,
+                    int64_t *coarse_gathers, int64_t *partial_allreduces)
+{
+    if (!c) return PLFX_ERR_ARG;
+    const auto &S = c->strip;
+    if (active) *active = S.on ? 1 : 0;
+    if (halo) *halo = S.W;
+    if (coarse_level) *coarse_level = S.Ld;
+    if (coarse_levels) *coarse_levels = S.child ? (int)S.child->mg.size() : 0;
+    if (halo_refreshes) *halo_refreshes = S.n_halo;
+    if (coarse_gathers) *coarse_gathers = S.n_coarse;
+    if (partial_allreduces) *partial_allreduces = S.n_part;
+    return PLFX_OK;
+}
+
+int plfx_allreduce_host(plfx_ctx *c, double *buf, int n, int op)
+{
+    if (!c || !c->small) return PLFX_ERR_STATE;
+    if (!buf || n < 0 || n > 32 || (op != 0 && op != 3)) return fail(c, PLFX_ERR_ARG, "n must be in 0..32, op 0 (sum) or 3 (min)");
+    if (n == 0 || !comm_active(c)) return PLFX_OK;
+    HIPCHK(c, hipMemcpyAsync(c->small, buf, (size_t)8 * n, hipMemcpyHostToDevice, c->stream));
+    const int rc = allreduce(c, c->small, n, NCCL_FLOAT64, op == 3 ? NCCL_MIN : NCCL_SUM, "host scalars");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(buf, c->small, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PLFX_OK;
 }
 
@@ -1956,6 +2355,10 @@ int plfx_assemble(plfx_ctx *c)
         int rc = mg_assemble(c);
         if (rc) return rc;
     }
+    if (c->strip.on) {
+        int rc = strip_child_assemble(c);
+        if (rc) return rc;
+    }
     c->assembled = true;
     c->M_dirty = false;
     c->op_epoch++;
@@ -2112,6 +2515,7 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
         rc = mg_update_dinv(c, same_set);
         if (rc) return rc;
     }
+    if (c->strip.on && (rc = strip_child_dinv(c))) return rc;
     c->bc_set = true;
     return PLFX_OK;
 }
@@ -2393,7 +2797,8 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     const int g = grid_for(c->nel, MAXPART);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<1>), dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, c->nel,
                        c->e0, c->dconn, c->dcls_id, (const double2 *)c->du, (const double2 *)c->u, c->sig, c->epl,
-                       c->eps, c->elstiff, c->res_sig, c->res_depl, c->nonlin ? 1 : 0, c->part_g);
+                       c->eps, c->elstiff, c->res_sig, c->res_depl, c->nonlin ? 1 : 0, c->part_g,
+                       c->strip.on ? c->strip.eown_lo : 0, c->strip.on ? c->strip.eown_hi : 0x7fffffff);
     const int n = c->fin_n;
     if (n > 0) {
         hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, c->fin_dev);
@@ -2502,8 +2907,11 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     const size_t nd = c->ndof;
     const int nn = c->nnode;
     const int gn = c->grid_nodes;
-    double *P_pq = c->part, *P_rz[2] = {c->part + MAXPART, c->part + 2 * MAXPART},
-           *P_rr[2] = {c->part + 3 * MAXPART, c->part + 4 * MAXPART}, *P_bb = c->part + 5 * MAXPART;
+    // partial-sum slots; r.z[1], r.r[1], b.b (written together by k_cg_start) are contiguous: one all-reduce in a strip
+    double *P_pq = c->part, *P_rz[2] = {c->part + MAXPART, c->part + 3 * MAXPART},
+           *P_rr[2] = {c->part + 2 * MAXPART, c->part + 4 * MAXPART}, *P_bb = c->part + 5 * MAXPART;
+    const int olo = own_lo(c), ohi = own_hi(c);
+    if (c->strip.on && !mg_active(c)) return fail(c, PLFX_ERR_STATE, "a strip solves with the multigrid preconditioner only");
     // Sharded run with the assembled operator: every rank applies its own rows, one all-reduce of the global vector per
     // CG step.  With the matrix-free operator every rank holds all generators and a full K p costs ~50 us at 1024^2 --
     // several times less than all-reducing 16.8 MB over xGMI -- so the product is computed redundantly and the solve has
@@ -2518,7 +2926,11 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     int rc = 0;
     // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1"); one pass (no q round trip)
     LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, warm ? 1 : 0, (const double2 *)c->x, (const double2 *)c->rhs,
-               (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
+               (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb, olo, ohi);
+    if (c->strip.on) {  // sums of the whole grid; r valid on every local column (the V-cycle reads the halo)
+        if ((rc = part_allreduce(c, P_rz[1], (size_t)3 * MAXPART))) return rc;
+        if ((rc = halo_refresh(c, c->r))) return rc;
+    }
     hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
     const bool mg = mg_active(c);
     CgScalars hs;
@@ -2532,8 +2944,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     if (mg && !done) {
         rc = mg_vcycle_rest(c);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
+        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
                            (const double2 *)c->z, P_rz[1]);
+        if ((rc = part_allreduce(c, P_rz[1], gn))) return rc;
     }
     // beta of the first iteration is 0 (k_spmv<1> takes p = z for it == 0 without touching p_old); only the sharded
     // k_p_update_outside path still derives it from the partials: rz_old = +inf, p_old = 0
@@ -2557,12 +2970,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             tim_begin(c, 1, &ev);
             if (it == 0 && !multi)  // first iteration: p = z, p_old untouched
                 LAUNCH_OP2(k_spmv, 2, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)pold, (const double2 *)c->z,
-                           (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
+                           (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it, olo, ohi);
             else
                 LAUNCH_OP2(k_spmv, 1, matfree(c), dim3(gn), c->op, multi ? c->own_n0 : 0, multi ? c->own_n1 : nn,
                            (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev],
-                           P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it);
+                           P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it, olo, ohi);
             tim_end(c, ev);
+            if ((rc = part_allreduce(c, P_pq, gn))) return rc;
             if (multi) {
                 hipLaunchKernelGGL(k_p_update_outside, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->own_n0,
                                    c->own_n1, (const double2 *)pold, (const double2 *)c->z, (double2 *)pnew,
@@ -2575,8 +2989,12 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 tim_begin(c, 2, &ev);
                 hipLaunchKernelGGL(k_cg_update_mg, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
                                    (const double2 *)c->q, (const double2 *)c->dinv, (double2 *)c->x,
-                                   (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc);
+                                   (double2 *)c->r, P_pq, gn, P_rz[prev], gn, P_rr[cur], c->sc, olo, ohi);
                 tim_end(c, ev);
+                if (c->strip.on) {
+                    if ((rc = part_allreduce(c, P_rr[cur], gn))) return rc;
+                    if ((rc = halo_refresh(c, c->r))) return rc;  // the one vector exchange of a PCG iteration
+                }
                 // stop here if this update converged: the V-cycle below would only prepare the next iteration
                 const unsigned long long seq = cg_check_post(c, P_rr[cur], gn, it + 1);
                 EvPair *evv;
@@ -2592,8 +3010,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 rc = mg_vcycle_rest(c);
                 tim_end(c, evv);
                 if (rc) return rc;
-                hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->r,
+                hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
                                    (const double2 *)c->z, P_rz[cur]);
+                if ((rc = part_allreduce(c, P_rz[cur], gn))) return rc;
             } else {
                 tim_begin(c, 2, &ev);
                 hipLaunchKernelGGL(k_cg_update, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)pnew,
@@ -2610,6 +3029,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         }
         done = hs.done;
     }
+    if (mg && done != 1 && c->strip.on)
+        return fail(c, PLFX_ERR_UNSUPPORTED, "multigrid-PCG did not converge in %d iterations on a strip (no Jacobi fall-back there)", it);
     if (mg && done != 1) {
         // breakdown (indefinite tangent, preconditioner not SPD) or stagnation: fall back to Jacobi-PCG,
         // warm-started from the last iterate
@@ -2631,6 +3052,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;  // x is valid on owned + 2 columns: complete the halo
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
     HIPCHK(c, hipGetLastError());
     c->x_is_du = true;  // x = du on the free DOFs, 0 on the prescribed ones: the next warm start
@@ -2787,8 +3209,9 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
                        c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
                        c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
                        c->small + 32, c->scf_hh, c->scf_mult);
+    const int elo = c->strip.on ? c->strip.eown_lo : 0, ehi = c->strip.on ? c->strip.eown_hi : 0x7fffffff;
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
-                       c->part_g, (const double *)nullptr);
+                       c->part_g, (const double *)nullptr, elo, ehi);
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 0, c->small + 40);
     if (comm_active(c)) {  // statistics of the whole mesh: sum, count (SUM) and minimum (MIN), then the global mean
         int rca = allreduce(c, c->small + 40, 2, NCCL_FLOAT64, NCCL_SUM, "scf sums");
@@ -2798,7 +3221,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     }
     // second pass with the mean taken from device memory: no host round trip between the passes
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 1,
-                       c->part_g, (const double *)(c->small + 43));
+                       c->part_g, (const double *)(c->small + 43), elo, ehi);
     hipLaunchKernelGGL(k_scf_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->part_g, g, 1, c->small + 40);
     if (comm_active(c)) {
         const int rca = allreduce(c, c->small + 44, 1, NCCL_FLOAT64, NCCL_SUM, "scf squares");

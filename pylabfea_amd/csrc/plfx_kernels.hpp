@@ -953,7 +953,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_spmv(KOp op, int n_begin, int n_end,
        const double2 *__restrict__ p, const double2 *__restrict__ z, double2 *__restrict__ pnew,
        double2 *__restrict__ q, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
-       const double *__restrict__ part_rr, int npart_prev, double *__restrict__ part_pq, CgScalars *__restrict__ sc, int it)
+       const double *__restrict__ part_rr, int npart_prev, double *__restrict__ part_pq, CgScalars *__restrict__ sc, int it,
+       int own_lo, int own_hi /* nodes whose p.q this rank sums (strip: owned columns; else all) */)
 {
     __shared__ double sh[BLOCK / 64];
     double beta = 0.;
@@ -1005,11 +1006,11 @@ k_spmv(KOp op, int n_begin, int n_end,
             pn.x = fma(beta, po.x, zi.x);
             pn.y = fma(beta, po.y, zi.y);
             pnew[i] = pn;
-            acc_pq = fma(pn.x, qx, fma(pn.y, qy, acc_pq));
+            if (i >= own_lo && i < own_hi) acc_pq = fma(pn.x, qx, fma(pn.y, qy, acc_pq));
         } else if (MODE == 2) {
             const double2 zi = z[i];
             pnew[i] = zi;
-            acc_pq = fma(zi.x, qx, fma(zi.y, qy, acc_pq));
+            if (i >= own_lo && i < own_hi) acc_pq = fma(zi.x, qx, fma(zi.y, qy, acc_pq));
         }
     }
     if (MODE >= 1) {
@@ -1104,7 +1105,8 @@ template <int GRID>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_start(KOp op, int nnode, int warm, const double2 *__restrict__ x, const double2 *__restrict__ b,
            const double2 *__restrict__ dinv, double2 *__restrict__ r, double2 *__restrict__ z,
-           double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, double *__restrict__ part_bb_out)
+           double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, double *__restrict__ part_bb_out,
+           int own_lo, int own_hi /* nodes whose sums this rank takes (strip: owned columns; else all) */)
 {
     __shared__ double sh[BLOCK / 64];
     double a_rz = 0., a_rr = 0., a_bb = 0.;
@@ -1122,10 +1124,12 @@ k_cg_start(KOp op, int nnode, int warm, const double2 *__restrict__ x, const dou
         zi.y = di.y * ri.y;
         r[i] = ri;
         z[i] = zi;
-        a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
-        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
-        const double bx = (di.x != 0.) ? bi.x : 0., by = (di.y != 0.) ? bi.y : 0.;
-        a_bb = fma(bx, bx, fma(by, by, a_bb));
+        if (i >= own_lo && i < own_hi) {
+            a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
+            a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+            const double bx = (di.x != 0.) ? bi.x : 0., by = (di.y != 0.) ? bi.y : 0.;
+            a_bb = fma(bx, bx, fma(by, by, a_bb));
+        }
     }
     const double t1 = block_sum(a_rz, sh);
     const double t2 = block_sum(a_rr, sh);
@@ -1348,7 +1352,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcls, int nel, int e_off, const int32_t *__restrict__ conn,
                const int32_t *__restrict__ cls, const double2 *__restrict__ du2, const double2 *__restrict__ u2, double *__restrict__ sig, double *__restrict__ epl,
                double *__restrict__ eps, const double *__restrict__ elstiff, const double *__restrict__ res_sig, const double *__restrict__ res_depl,
-               int nonlin, double *__restrict__ part /* SUMS: [18][gridDim.x] volume-weighted sums of the new sig, eps, epl */)
+               int nonlin, double *__restrict__ part /* SUMS: [18][gridDim.x] volume-weighted sums of the new sig, eps, epl */,
+               int sum_lo = 0, int sum_hi = 0x7fffffff /* elements that enter the sums (strip: owned columns) */)
 {
     // SUMS = 1 fuses calc_global's element sums (k_global_partials: same grid, same order -> identical numbers)
     __shared__ double sh[BLOCK / 64];
@@ -1386,7 +1391,7 @@ k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcl
         class_strain(c, u2, n0, n1, n2, n3, et);  // el.eps = el.eps_t() (model.py:1392)
 #pragma unroll
         for (int k = 0; k < 6; k++) eps[(size_t)k * nel + e] = et[k];
-        if (SUMS) {
+        if (SUMS && e >= sum_lo && e < sum_hi) {
             const double v = c.vel;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -1514,14 +1519,14 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
 // pass 0: sum(mult*hh), min(hh | mult>0), count ; pass 1: sum(mult*(hh-mean)^2)
 __global__ void __launch_bounds__(BLOCK)
 k_scf_reduce(int nel, const double *hh, const int32_t *mult, double mean, int pass,
-             double *part /* [3][gridDim.x] */, const double *mean_dev = nullptr)
+             double *part /* [3][gridDim.x] */, const double *mean_dev = nullptr, int e_lo = 0, int e_hi = 0x7fffffff)
 {
     __shared__ double sh[BLOCK / 64];
     __shared__ double shmin[BLOCK / 64];
     if (mean_dev) mean = *mean_dev;
     double s = 0., cnt = 0., mn = 1.e300;
     for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
-        const int m = mult[e];
+        const int m = (e >= e_lo && e < e_hi) ? mult[e] : 0;  // strip: halo elements belong to the neighbour's statistics
         if (m == 0) continue;
         const double h = hh[e];
         if (pass == 0) {
@@ -1588,3 +1593,4 @@ __global__ void k_scf_mean(double *out)
 }
 
 }  // namespace plfx
+

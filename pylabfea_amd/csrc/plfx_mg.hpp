@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restrict__ q,
                const double2 *__restrict__ dinv, double2 *__restrict__ x, double2 *__restrict__ r, const double *__restrict__ part_pq,
                int npart_pq, const double *__restrict__ part_rz, int npart_prev, double *__restrict__ part_rr_out,
-               CgScalars *__restrict__ sc)
+               CgScalars *__restrict__ sc, int own_lo, int own_hi /* nodes whose r.r this rank sums (strip: owned columns) */)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
@@ -938,24 +938,38 @@ k_cg_update_mg(int nnode, const double2 *__restrict__ p, const double2 *__restri
         ri.y = (di.y != 0.) ? fma(-alpha, qi.y, ri.y) : 0.;
         x[i] = xi;
         r[i] = ri;
-        a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+        if (i >= own_lo && i < own_hi) a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
     }
     const double t2 = block_sum(a_rr, sh);
     if (threadIdx.x == 0) part_rr_out[blockIdx.x] = t2;
 }
 
-// partial sums of r.z
+// partial sums of r.z over the nodes [own_lo, own_hi) (all nodes; the owned columns of a strip)
 __global__ void __launch_bounds__(BLOCK)
-k_dot_rz(int nnode, const double2 *__restrict__ r, const double2 *__restrict__ z, double *part_rz_out)
+k_dot_rz(int own_lo, int own_hi, const double2 *__restrict__ r, const double2 *__restrict__ z, double *part_rz_out)
 {
     __shared__ double sh[BLOCK / 64];
     double acc = 0.;
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+    for (int i = own_lo + blockIdx.x * BLOCK + threadIdx.x; i < own_hi; i += gridDim.x * BLOCK) {
         const double2 a = r[i], b = z[i];
         acc = fma(a.x, b.x, fma(a.y, b.y, acc));
     }
     const double t = block_sum(acc, sh);
     if (threadIdx.x == 0) part_rz_out[blockIdx.x] = t;
+}
+
+// Strip-local engine: dst[c * dst_n + i] = (off <= i < off + cnt) ? src[c * src_n + i - off + soff] : 0 for c < ncomp -- the owned
+// window of a strip's level-Ld array placed into the zero-filled array of the replicated coarse grid; one all-reduce over
+// the ranks then completes it (x + 0 + ... + 0 = x exactly).  Node / element columns are contiguous, so a window is a range.
+__global__ void __launch_bounds__(BLOCK)
+k_strip_pack(int ncomp, size_t dst_n, size_t src_n, size_t off, size_t cnt, size_t soff, const double *__restrict__ src,
+             double *__restrict__ dst)
+{
+    const size_t tot = (size_t)ncomp * dst_n;
+    for (size_t t = blockIdx.x * (size_t)BLOCK + threadIdx.x; t < tot; t += (size_t)gridDim.x * BLOCK) {
+        const size_t c = t / dst_n, i = t - c * dst_n;
+        dst[t] = (i >= off && i < off + cnt) ? src[c * src_n + (i - off) + soff] : 0.;
+    }
 }
 
 }  // namespace plfx

@@ -190,6 +190,7 @@ class Model(object):
         self._step_io = _lib.CStep()
         self._defer_finish = os.environ.get('PLFX_DEFER_FINISH', '1') != '0'
         self._shard = None  # (rank, nranks, uid)
+        self._strip = None  # strip-local engine: column window and numbering offsets of this rank (strip_plan)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
 
@@ -395,14 +396,56 @@ class Model(object):
                              [0., 0., 0., 0., 0., mat.C44]])
         return np.array(mat.CV, dtype=float)
 
-    def distribute(self, rank, nranks, uid, host_allreduce=None):
-        """Shard the elements into ``nranks`` x-strips (contiguous element-column blocks); this
-        process owns strip ``rank`` on GPU ``self.device``.  ``uid`` is the RCCL unique id created on
-        rank 0 (``_lib.Context.comm_unique_id``) and broadcast by the caller.  ``uid=None`` with
-        ``host_allreduce=fn(array, op)`` selects the host-staged transport instead (tests on one GPU)."""
+    def distribute(self, rank, nranks, uid, host_allreduce=None, mode=None, coarse_level=None):
+        """Run this model on ``nranks`` GPUs, one process per GPU; this process is ``rank`` on GPU ``self.device``.
+        ``uid`` is the RCCL unique id created on rank 0 (``_lib.Context.comm_unique_id``) and broadcast by the caller;
+        ``uid=None`` with ``host_allreduce=fn(array, op)`` selects the host-staged transport instead (tests on one GPU;
+        ``pylabfea_amd.host_transport`` builds ``fn`` from a ``torch.distributed`` process group).
+
+        ``mode='strip'`` (default wherever it applies: uniform structured grid, strips at least one halo wide): every rank
+        holds its x-strip of element columns plus a halo as a standalone local problem -- state, operator, multigrid
+        levels and solve are all distributed, the ranks exchange one halo slab and a coarse right-hand side per PCG
+        iteration (plfx_set_strip).  ``mode='replicated'``: the material state and sweep are sharded by x-strips, the
+        operator and the solve are replicated (any mesh).  After ``solve`` the arrays ``u, f, du`` and the element
+        results are filled on this rank's columns only (zeros elsewhere)."""
+        if mode not in (None, 'strip', 'replicated'):
+            raise ValueError("distribute: mode must be None, 'strip' or 'replicated'")
         self._shard = (int(rank), int(nranks), uid)
         self._host_allreduce = host_allreduce
+        self._dist_mode = mode
+        self._strip_level = coarse_level
+        self._strip = None
+        self._bc_struct = None
+        self._bc_registered = None
+        self._bnd_idx = None
+        self._bnd_offs = None
         self._drop_engine()
+
+    def strip_plan(self, rank, nranks, coarse_level=None):
+        """Column ranges of the strip-local engine for ``rank`` of ``nranks``: dict with the owned element columns
+        ``c0, c1``, the local window ``g0, g1`` (owned + halo), the hand-over level ``Ld`` and the halo width ``W = 8 * 2^Ld``
+        -- or None when the mesh does not allow it (non-uniform elements, strips narrower than the halo, sizes that are
+        not multiples of 2^Ld).  Strip boundaries are multiples of 2^Ld so that every level coarsens exactly as on one GPU."""
+        NX, NY = self._NX, self._NY
+        lx, ly = self._lxy[:, 0], self._lxy[:, 1]
+        if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]) or np.max(np.abs(ly - ly[0])) > 1e-12 * abs(ly[0]):
+            return None
+        for Ld in ((coarse_level,) if coarse_level else (4, 3, 2, 1)):
+            al, W = 1 << Ld, 8 << Ld
+            if NX % al or NY % al:
+                continue
+            gx, gy = NX >> Ld, NY >> Ld
+            if gx % 2 or gy % 2 or gx * gy <= 4:      # the replicated coarse grid needs a hierarchy of its own
+                continue
+            units = NX // al
+            cols = [((units * r) // nranks) * al for r in range(nranks + 1)]
+            if nranks > 1 and min(b - a for a, b in zip(cols[:-1], cols[1:])) < W:
+                continue
+            c0, c1 = cols[rank], cols[rank + 1]
+            g0 = c0 - (W if rank > 0 else 0)
+            g1 = c1 + (W if rank < nranks - 1 else 0)
+            return dict(c0=c0, c1=c1, g0=g0, g1=g1, Ld=Ld, W=W, rank=rank, nranks=nranks)
+        return None
 
     def strip_range(self, rank, nranks):
         """Owned element range of x-strip ``rank``: whole element columns, balanced."""
@@ -424,15 +467,42 @@ class Model(object):
         eng = _lib.Context(self.device)
         eng.set_materials([m._record(self._element_CV(m)) for m in self.mat])
         e0, e1 = 0, self.Nel
+        self._strip = None
+        plan = None
         if self._shard is not None:
             rank, nranks, uid = self._shard
             if uid is not None:
                 eng.comm_init(uid, rank, nranks)
             elif getattr(self, '_host_allreduce', None) is not None:
                 eng.comm_init_callback(rank, nranks, self._host_allreduce)
+            mode = getattr(self, '_dist_mode', None)
+            if mode != 'replicated' and self.operator != 0 and self.precond != 0:
+                plan = self.strip_plan(rank, nranks, getattr(self, '_strip_level', None))
+            if plan is None and mode == 'strip':
+                raise ValueError('distribute: the strip-local engine needs a uniform structured grid whose strips are at '
+                                 'least one halo (8 * 2^level columns) wide, with NX, NY multiples of 2^level')
             e0, e1 = self.strip_range(rank, nranks)
-        eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
-        eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
+        if plan is not None:
+            # this rank's strip (owned columns + halo) as a standalone local mesh; same numbering rules (model.py:893, 935)
+            NY, nyn = self._NY, self._NY + 1
+            g0, g1 = plan['g0'], plan['g1']
+            nxl = g1 - g0
+            ih = np.arange(nxl * NY)
+            n1 = (ih // NY) * nyn + ih % NY
+            conn = np.stack((n1, n1 + 1, n1 + nyn, n1 + nyn + 1), axis=1)
+            nnode_l = (nxl + 1) * nyn
+            eng.set_mesh(conn, self._mat_id[g0 * NY:g1 * NY], self._lxy[g0 * NY:g1 * NY], nnode_l, self.thick,
+                         self.planestress, 0, nxl * NY)
+            eng.set_grid(nxl, NY)
+            eng.set_strip(plan['c0'] - g0, plan['c1'] - g0, g0, self._NX, plan['Ld'])
+            last = plan['rank'] == plan['nranks'] - 1
+            plan.update(node0=g0 * nyn, nnode=nnode_l, el0=g0 * NY, nel=nxl * NY,
+                        own_nodes=(plan['c0'] * nyn, (self._NX + 1 if last else plan['c1']) * nyn))
+            self._strip = plan
+            e0, e1 = plan['c0'] * NY, plan['c1'] * NY
+        else:
+            eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+            eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
         if self.precond is not None:
             eng.set_precond(self.precond)
         if self.operator is not None:
@@ -457,7 +527,12 @@ class Model(object):
                    'res_sig': _lib.ST_RES_SIG, 'res_depl': _lib.ST_RES_DEPL, 'max_steps': _lib.ST_MAXSTEPS,
                    'fyn': _lib.ST_FYN}
             a = self._ensure_engine().state_get(ids[name])
-            if self._shard is not None:  # place the owned strip into a full-size array
+            if self._strip is not None:  # local strip (owned + halo elements): the owned part into a full-size array
+                full = np.zeros((self.Nel,) + a.shape[1:])
+                o = self._e0 - self._strip['el0']
+                full[self._e0:self._e1] = a[o:o + self._e1 - self._e0]
+                a = full
+            elif self._shard is not None:  # place the owned strip into a full-size array
                 full = np.zeros((self.Nel,) + a.shape[1:])
                 full[self._e0:self._e1] = a
                 a = full
@@ -479,7 +554,8 @@ class Model(object):
         node set (x before y); force segments with the per-node share of the edge force."""
         key = (tuple(self.ubcleft), tuple(self.ubcbot), tuple(self.ubcright), tuple(self.ubctop),
                tuple(self.ubcn) if self.noset is not None else None,
-               None if self.noset is None else tuple(self.noset), self.Nnode)
+               None if self.noset is None else tuple(self.noset), self.Nnode,
+               None if self._strip is None else (self._strip['node0'], self._strip['nnode']))
         st = self._bc_struct
         if st is not None and st[0] == key:
             return st[1]
@@ -491,8 +567,15 @@ class Model(object):
             hh[(hp < 1.e-3) | (hp > length - 1.e-3)] *= 0.5  # half on corner nodes
             return hh
 
-        nl, nb = np.asarray(self.noleft, dtype=np.int64), np.asarray(self.nobot, dtype=np.int64)
-        nr, nt = np.asarray(self.noright, dtype=np.int64), np.asarray(self.notop, dtype=np.int64)
+        strip = self._strip   # strip-local engine: only the nodes of this rank's local grid, in its local numbering
+
+        def sel(nodes):
+            a = np.asarray(nodes, dtype=np.int64)
+            if strip is None:
+                return a
+            return a[(a >= strip['node0']) & (a < strip['node0'] + strip['nnode'])]
+
+        nl, nb, nr, nt = sel(self.noleft), sel(self.nobot), sel(self.noright), sel(self.notop)
         for k in range(2):
             if self.ubcleft[k]:
                 dseg.append(('l', k, 2 * nl + k))
@@ -510,12 +593,16 @@ class Model(object):
             else:
                 fseg.append(('t', k, 2 * nt + k, share(nt, self.NnodeX, 0, self.lenx)))
         if self.noset is not None:
-            ns = np.asarray(self.noset, dtype=np.int64)
+            ns = sel(self.noset)
             for k in range(2):
                 if self.ubcn[k]:
                     dseg.append(('n', k, 2 * ns + k))
                 else:
                     fseg.append(('n', k, 2 * ns + k, np.ones(len(ns))))
+        if strip is not None:   # global -> local DOF numbers (node id = column * NnodeY + row on both grids)
+            off = 2 * strip['node0']
+            dseg = [(src, k, idx - off) for src, k, idx in dseg]
+            fseg = [(src, k, idx - off, hh) for src, k, idx, hh in fseg]
         plan = {'dseg': [(src, k) for src, k, _ in dseg], 'fseg': fseg}
         if dseg:
             idx = np.concatenate([d[2] for d in dseg])
@@ -554,9 +641,21 @@ class Model(object):
             v = float(src[s][k])
             if v != 0.:
                 if fext is None:
-                    fext = np.zeros(self.Ndof)
+                    fext = np.zeros(self._ndof_local())
                 np.add.at(fext, fidx, v * hh)
         return presc, first, w, fext
+
+    def _nodal(self, a):
+        """strip-local engine: the local nodal array (owned + halo columns) placed into a full-size one"""
+        if self._strip is None:
+            return a
+        full = np.zeros(self.Ndof)
+        o = 2 * self._strip['node0']
+        full[o:o + len(a)] = a
+        return full
+
+    def _ndof_local(self):
+        return self.Ndof if self._strip is None else 2 * self._strip['nnode']
 
     def free_dofs(self):
         """The reference's ``ind`` list (ascending free DOFs) for the current BC flags."""
@@ -596,7 +695,7 @@ class Model(object):
             v = float(src[s][k])
             if v != 0.:
                 if fext is None:
-                    fext = np.zeros(self.Ndof)
+                    fext = np.zeros(self._ndof_local())
                 np.add.at(fext, fidx, v * hh)
         bad = eng.apply_bc_plan(vals, fext)
         if bad >= 0:
@@ -895,9 +994,9 @@ class Model(object):
         self.nsteps = il
         self.niter = niter
         self.co_nconv = co_nconv
-        self.u = eng.state_get(_lib.ST_U)
-        self.f = eng.state_get(_lib.ST_F)
-        self.du = eng.state_get(_lib.ST_DU)
+        self.u = self._nodal(eng.state_get(_lib.ST_U))
+        self.f = self._nodal(eng.state_get(_lib.ST_F))
+        self.du = self._nodal(eng.state_get(_lib.ST_DU))
         self._cache = {}
 
     # ------------------------------------------------------------------ homogenisation
@@ -926,16 +1025,22 @@ class Model(object):
     def _finish_register(self, eng):
         sets = (self.noleft, self.noright, self.nobot, self.notop)
         if self._bnd_idx is None:
-            parts = []
-            for nodes in sets:
-                idx = 2 * np.asarray(nodes, dtype=np.int64)
+            parts, seg = [], []
+            for q, nodes in enumerate(sets):
+                a = np.asarray(nodes, dtype=np.int64)
+                if self._strip is not None:  # this rank's owned nodes only (disjoint over the ranks), local numbering
+                    lo, hi = self._strip['own_nodes']
+                    a = a[(a >= lo) & (a < hi)] - self._strip['node0']
+                idx = 2 * a
                 parts.extend((idx, idx + 1))
+                seg.extend((np.full(len(idx), 2 * q), np.full(len(idx), 2 * q + 1)))
             self._bnd_idx = np.concatenate(parts)
+            # [x of set 0, y of set 0, x of set 1, ...]: 8 segment sums; the divisor is the size of the WHOLE node set
+            self._bnd_offs = (np.concatenate(seg).astype(np.intp), np.array([len(nodes) for nodes in sets], dtype=float))
         eng.set_finish_set(self._bnd_idx)
 
     def _calc_global_device(self, eng, fin=None):
         """calc_global during solve: boundary DOFs gathered from HBM, element sums reduced on the GPU."""
-        sets = (self.noleft, self.noright, self.nobot, self.notop)
         if fin is None:
             self._finish_register(eng)
             uu = eng.gather(_lib.ST_U, self._bnd_idx)
@@ -943,12 +1048,15 @@ class Model(object):
             sums = eng.global_sums()
         else:
             uu, ff, sums = fin
-        if self._bnd_offs is None:  # [x of set 0, y of set 0, x of set 1, ...]: 8 segment sums in one reduceat
-            lens = np.repeat([len(nodes) for nodes in sets], 2)
-            self._bnd_offs = (np.concatenate(([0], np.cumsum(lens)[:-1])), lens[::2].astype(float))
-        offs, cnt = self._bnd_offs
-        su = np.add.reduceat(uu, offs)
-        sf = np.add.reduceat(ff, offs)
+        if self._bnd_offs is None:
+            self._bnd_idx = None
+            self._finish_register(eng)
+        seg, cnt = self._bnd_offs
+        su = np.bincount(seg, weights=uu, minlength=8)
+        sf = np.bincount(seg, weights=ff, minlength=8)
+        if self._strip is not None:   # boundary sums over the strips (plfx_allreduce_host); element sums arrive all-reduced
+            tot = eng.allreduce_host(np.concatenate((su, sf)))
+            su, sf = tot[:8], tot[8:]
         bv = [(su[2 * q] / cnt[q], su[2 * q + 1] / cnt[q], sf[2 * q], sf[2 * q + 1]) for q in range(4)]
         if self._shard is not None and not (self._dev_coll and fin is not None):
             sums = self._allreduce_sum(sums.ravel()).reshape(3, 6)
@@ -957,6 +1065,8 @@ class Model(object):
     def calc_global(self):
         """Global quantities from boundary nodes and element averages (model.py:1473-1511)."""
         eng = self._ensure_engine()
+        if self._strip is not None and self.u is not None:
+            return   # the homogenised values of the last load step are current (element sums over strips need the halo masks)
         self._calc_global_device(eng)
 
     def plot(self, *args, **kw):

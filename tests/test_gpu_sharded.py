@@ -1,4 +1,4 @@
-"""Sharded runs with 2 and 3 ranks on ONE GPU: every rank is a process with its own libplfx context on cuda:0 and owns
+"""Multi-rank runs with 2 to 4 ranks on ONE GPU (replicated-solve mode and the strip-local engine): every rank is a process with its own libplfx context on cuda:0 and owns
 one x-strip of elements; the collectives (stiffness generators after a sweep, sweep flags, calc_scf statistics,
 calc_global sums) go through the host-staged transport (plfx_comm_init_callback) over a gloo process group, because RCCL
 refuses two ranks on one device.  Everything else -- strip ownership inside the kernels, zeroing of the foreign
@@ -63,26 +63,27 @@ def build(case, golden_dir):
     return fe, ms
 
 
-def _worker(rank, world, port, case, golden_dir, q):
+def _worker(rank, world, port, case, golden_dir, q, mode='replicated'):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        def allreduce(arr, op):
-            t = torch.from_numpy(arr)           # shares memory with the library's staging buffer
-            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 3 else dist.ReduceOp.SUM)
+        import pylabfea_amd as FE
         fe, ms = build(case, golden_dir)
-        fe.distribute(rank, world, None, host_allreduce=allreduce)
+        fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world), mode=mode)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             fe.solve(min_step=ms)
         eng = fe._engine
         assert eng.comm_info() == (rank, world, True)
         e0, e1 = fe._e0, fe._e1
+        strip = fe._strip
         q.put((rank, dict(nsteps=fe.nsteps, niter=list(fe.niter), u=fe.u, f=fe.f, sgl=fe.sgl, e0=e0, e1=e1,
-                          sig=eng.state_get(0), epl=eng.state_get(2), native=fe._native_step and fe._dev_coll)))
+                          sig=fe._state('sig')[e0:e1], epl=fe._state('epl')[e0:e1], native=fe._native_step and fe._dev_coll,
+                          strip=strip, strip_info=eng.strip_info(), its=[s[0] for s in fe.solver_stats],
+                          glob={k: v for k, v in fe.glob.items() if np.ndim(v) == 0 and v is not None})))
     except Exception as exc:  # noqa: BLE001
         import traceback
         q.put((rank, 'ERROR: ' + traceback.format_exc()))
@@ -131,3 +132,104 @@ def test_sharded_ranks_on_one_gpu(golden_dir, case, world):
         g = np.load(os.path.join(golden_dir, 'solve.npz'))
         assert res[0]['nsteps'] == int(g['hill6_12_nsteps']) and res[0]['niter'] == list(g['hill6_12_niter'])
         assert np.max(np.abs(res[0]['u'] - g['hill6_12_u'])) <= 1e-6 * np.max(np.abs(g['hill6_12_u']))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strip-local engine (plfx_set_strip): every rank holds its x-strip + halo as a standalone local problem
+def build_strip(case, golden_dir):
+    import pylabfea_amd as FE
+    mat = FE.Material()
+    mat.elasticity(E=200.e3, nu=0.3)
+    mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+    fe = FE.Model(dim=2, planestress=False)
+    if case == 'tension':                # homogeneous Hill tension, 128 x 32 elements (lenx : leny = 4 : 1, square elements)
+        fe.geom([16.], LY=4.)
+        fe.assign([mat])
+        NX, NY, eps, ms = 128, 32, 0.003, 8
+        el = None
+    elif case == 'inclusion':            # soft inclusion across a strip boundary: strips take different branches
+        soft = FE.Material(num=2)
+        soft.elasticity(E=1.e3, nu=0.27)
+        fe.geom(sect=2, LX=12., LY=4.)
+        fe.assign([mat, soft])
+        NX, NY, eps, ms = 192, 64, 0.002, 6
+        el = np.ones((NX, NY))
+        el[80:112, 20:44] = 2
+    else:                                # J2 + SVC laminate (wave-per-element SVC kernels on strips)
+        z = np.load(os.path.join(golden_dir, 'svc_shear.npz'))
+        mb = FE.Material(name='ML', num=2)
+        mb.elasticity(CV=z['par_CV'])
+        mb.plasticity(sy=float(z['par_sy']), sdim=6)
+        mb.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']),
+                   float(z['par_scale_seq']))
+        fe.geom([2, 1, 2, 1, 2], LY=2.)
+        fe.assign([mat, mb, mat, mb, mat])
+        NX, NY, eps, ms = 64, 16, 0.0015, 4
+        el = None
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(eps * fe.leny, 'disp')
+    if el is not None:
+        fe.mesh(elmts=el, NX=NX, NY=NY)
+    else:
+        fe.mesh(NX=NX, NY=NY)
+    return fe, ms
+
+
+def _strip_worker(rank, world, port, case, golden_dir, q):
+    global build
+    build = build_strip            # the worker above takes the model from build()
+    _worker(rank, world, port, case, golden_dir, q, mode='strip')
+
+
+@pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('inclusion', 3), ('laminate_svc', 2)])
+def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
+    """Strips + halo on 2..4 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
+    right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
+    K-iteration AND PCG-iteration counts (the V-cycle is arithmetically the single-GPU one), fields to 1e-9."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, case, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, d = q.get(timeout=900)
+        assert not isinstance(d, str), d
+        res[r] = d
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    fe, ms = build_strip(case, golden_dir)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=ms)
+    sig1, epl1 = fe._state('sig'), fe._state('epl')
+    assert np.max(epl1) > 0.
+    its1 = [s[0] for s in fe.solver_stats]
+    nyn = fe.NnodeY
+    for r in range(world):
+        d = res[r]
+        st = d['strip']
+        assert st is not None and d['native']
+        active, halo, Ld, clev, nh, nc, npart = d['strip_info']
+        assert active and halo == st['W'] == 8 << Ld and clev >= 2
+        assert nh > 0 and nc > 0 and npart > 0
+        assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
+        assert d['its'] == its1                                      # same PCG iterations in every solve
+        lo, hi = 2 * st['c0'] * nyn, 2 * (st['c1'] + 1) * nyn        # nodes of the owned columns
+        su = np.max(np.abs(fe.u))
+        assert np.max(np.abs(d['u'][lo:hi] - fe.u[lo:hi])) <= 1e-9 * su
+        flo, fhi = 2 * st['own_nodes'][0], 2 * st['own_nodes'][1]
+        assert np.max(np.abs(d['f'][flo:fhi] - fe.f[flo:fhi])) <= 1e-8 * np.max(np.abs(fe.f))
+        assert np.max(np.abs(d['sgl'] - fe.sgl)) <= 1e-9 * np.max(np.abs(fe.sgl))
+        for k, v in d['glob'].items():
+            assert abs(v - fe.glob[k]) <= 1e-8 * max(1e-3, abs(fe.glob[k])), k
+        e0, e1 = d['e0'], d['e1']
+        assert (e0, e1) == (st['c0'] * fe._NY, st['c1'] * fe._NY)
+        assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * np.max(np.abs(sig1))
+        assert np.max(np.abs(d['epl'] - epl1[e0:e1])) <= 1e-8 * max(np.max(np.abs(epl1)), 1e-30)
+    assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
