@@ -14,9 +14,13 @@ are run untimed as set-up so that warm-up and timed steps lie in the plastic reg
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: the elements are sharded into N x-strips (one rank per GPU): material sweep and the rows of the CG
-SpMV are sharded, the global vector is all-reduced over RCCL at each CG step, the matrix / multigrid
-hierarchy is replicated.  Strong scaling: the mesh is fixed.  Rank 0 prints ONE JSON line.
+N>1 (one rank per GPU over RCCL): WEAK scaling -- every GPU holds a 1024-column strip of a (N*1024) x 1024 mesh of the
+same square elements (the domain grows in x: LX = 4 N) and runs the strip-local engine (plfx_set_strip, DESIGN.md
+section 6): state, sweep, operator, multigrid levels and solve are all distributed; per PCG iteration the ranks exchange
+one halo slab of the residual (ncclSend/ncclRecv), one all-reduce of the coarse right-hand side and three all-reduces of
+8 KB of partial sums.  `value` = elements of the whole mesh x sweeps / wall-clock.  Rank 0 prints ONE JSON line.
+PLFX_BENCH_TRANSPORT=host runs the same path over gloo with the host-staged transport (several ranks on ONE GPU: a
+functional check, not a measurement).
 """
 import argparse
 import gc
@@ -60,15 +64,16 @@ def hill_material(FE):
     return mat
 
 
-def tension_model(FE, mat, n, eps, device=0):
+def tension_model(FE, mat, n, eps, device=0, strips=1):
+    """n x n elements per strip; `strips` of them side by side in x (same square elements, LX = 4 * strips)"""
     fe = FE.Model(dim=2, planestress=False, device=device)
-    fe.geom([4.], LY=4.)
+    fe.geom([4. * strips], LY=4.)
     fe.assign([mat])
     fe.bcleft(0.)
     fe.bcbot(0.)
     fe.bcright(0., 'force')
     fe.bctop(eps * fe.leny, 'disp')
-    fe.mesh(NX=n, NY=n)
+    fe.mesh(NX=n * strips, NY=n)
     return fe
 
 
@@ -134,6 +139,61 @@ def cpu_baseline(n, steps, warmup, n1=128):
     return out
 
 
+# FP64 VALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 FP64 instruction per SIMD every 4 cycles (16 FP64 lanes per
+# SIMD) = 614 G wave-instructions/s = 78.6 TFLOP/s when every one is an FMA (MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s)
+VALU_FP64_PEAK_TFLOPS = 78.6
+# VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
+# same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
+SVC_VALU_PER_ELEMENT = {'corrector': 1727838., 'streaming': 804363926.5 / 16384.}
+SVC_PROFILE = 'profiles/r02_svc_rocprofv3_summary.txt'
+
+
+def svc_sample(FE, _lib, n=128, device=0):
+    """Bounded sample of BASELINE config 4 (SVC yield function of examples/train_hill.py, 1585 support vectors, eps=0.001,
+    min_step=10) on an n x n mesh: ten elastic load steps + the eleventh with 16 stiffness iterations whose sweeps run the
+    50-sub-step corrector on every element.  Times the wave-per-element SVC kernels with HIP events."""
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'svc_hill.npz'))
+    m = FE.Material(name='ML-Hill-p1')
+    m.elasticity(CV=z['par_CV'])
+    m.plasticity(sy=float(z['par_sy']), sdim=6)
+    m.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']))
+    fe = tension_model(FE, m, n, 0.001, device=device)
+    eng = fe._ensure_engine()
+    eng.timing_reset()
+    eng.timing_select((_lib.T_SWEEP, _lib.T_SWEEP_HEAVY))
+    eng.timing_enable(True)
+    import warnings
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=10)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    eng.timing_enable(False)
+    ms_l, n_l = eng.timing_get(_lib.T_SWEEP)
+    ms_h, n_h = eng.timing_get(_lib.T_SWEEP_HEAVY)
+    nsv = len(z['par_dual'])
+    out = {'workload': '%dx%d Q4, SVC yield function (%d support vectors x 6 features, examples/train_hill.py), eps=0.001, '
+                       'min_step=10: whole solve, %d load steps, %d sweeps' % (n, n, nsv, fe.nsteps, fe.n_sweeps),
+           'seconds': dt, 'value': fe.Nel * fe.n_sweeps / dt, 'unit': 'element-updates/s', 'sweeps': int(fe.n_sweeps),
+           'pcg_iterations': int(sum(q[0] for q in fe.solver_stats)),
+           'kernel_ms': {'k_sweep_svc_wave<0> (streaming phase)': round(ms_l, 3), 'k_sweep_svc_wave<1> (50-sub-step corrector)': round(ms_h, 3)},
+           'launches': {'streaming': int(n_l), 'corrector': int(n_h)}}
+    heavy_el = fe.Nel  # on this workload every sweep of the last load step puts every element on the corrector list
+    vc = SVC_VALU_PER_ELEMENT['corrector']
+    if n_h > 0 and vc:
+        per_launch_s = ms_h * 1e-3 / n_h
+        ach = vc * heavy_el * 128. / per_launch_s / 1e12     # wave-instructions x 64 lanes x 2 flop (FMA-equivalent issue slots)
+        out['roofline'] = {'kernel': 'k_sweep_svc_wave<1> (one wave per element: 50 sub-steps of the plastic corrector, support-'
+                                     'vector sums split over the lanes, tables in LDS)',
+                           'bound': 'valu_fp64', 'achieved': ach, 'peak': VALU_FP64_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s (FP64 VALU issue slots x 128 flop)', 'frac': ach / VALU_FP64_PEAK_TFLOPS,
+                           'valu_wave_instructions_per_element': vc, 'valu_source': 'rocprofv3 --pmc SQ_INSTS_VALU, ' + SVC_PROFILE,
+                           'avg_launch_ms': per_launch_s * 1e3, 'elements_per_launch': heavy_el, 'traffic': None,
+                           'us_per_element_update': per_launch_s * 1e6 / heavy_el * 1.0}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -142,6 +202,8 @@ def main():
     ap.add_argument('--mesh', type=int, default=1024)
     ap.add_argument('--cpu-mesh', type=int, default=224)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-svc', action='store_true', help='skip the bounded config-4 (SVC) sample behind roofline_svc')
+    ap.add_argument('--svc-mesh', type=int, default=128)
     ap.add_argument('--all-families', action='store_true',
                     help='HIP-event timing of every kernel family (kernel_ms table) instead of only the two roofline kernels; '
                          'costs about 0.1 ms per load step')
@@ -157,22 +219,31 @@ def main():
     import pylabfea_amd as FE
     from pylabfea_amd import _lib
 
-    force_dist = os.environ.get('PLFX_FORCE_DIST') == '1'  # exercise the sharded path with a single rank
+    force_dist = os.environ.get('PLFX_FORCE_DIST') == '1'  # exercise the distributed path with a single rank
+    host_transport = os.environ.get('PLFX_BENCH_TRANSPORT') == 'host'
+    ngpu = max(1, torch.cuda.device_count())
+    local = local % ngpu if host_transport else local
     dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if host_transport:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     K, W, n = args.steps, args.warmup, args.mesh
     mat = hill_material(FE)
-    fe = tension_model(FE, mat, n, 0.005, device=local)
+    fe = tension_model(FE, mat, n, 0.005, device=local, strips=world)
     if dist is not None:
-        uid = [None]
-        if rank == 0:
-            uid[0] = _lib.Context(local).comm_unique_id()
-        dist.broadcast_object_list(uid, src=0)
-        fe.distribute(rank, world, uid[0])
+        if host_transport:
+            fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world))
+        else:
+            uid = [None]
+            if rank == 0:
+                uid[0] = _lib.Context(local).comm_unique_id()
+            dist.broadcast_object_list(uid, src=0)
+            fe.distribute(rank, world, uid[0])
     eng = fe._ensure_engine()
     if os.environ.get('MG_NU'):  # experiment knob: smoothing sweeps / damping of the multigrid preconditioner
         eng.set_precond(1, float(os.environ.get('MG_OMEGA', '0.65')), int(os.environ['MG_NU']))
@@ -184,6 +255,8 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    strip = fe._strip            # strip-local engine in use (None: single GPU, or the replicated-solve fall-back)
 
     # torch initialises its HIP context lazily on the first CUDA call (a few ms that would otherwise land inside the
     # timed region after the first barrier): do it now
@@ -230,7 +303,7 @@ def main():
               't1', round(1e3 * (marks['t1'] - marks['t0']), 3), file=sys.stderr)
     dt = marks['t1'] - marks['t0']
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if host_transport else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sweeps = marks['sw1'] - marks['sw0']
@@ -252,17 +325,28 @@ def main():
     #              + fyn 8 + max_steps 4 written = 412 B per element, + 216 B (tangent 168 + generator 48 written) for every
     #              element whose tangent changed (counted on the device: plfx_sweep_info)
     mf = eng.operator_info()[0] == 1
-    op_bytes = (64. * fe.Nnode + 48. * fe.Nel) if mf else 388. * fe.Nnode
+    # nodes / elements one launch of this rank's kernels passes over: the local grid of a strip (owned + halo columns)
+    nn_l = strip['nnode'] if strip else fe.Nnode
+    ne_l = strip['nel'] if strip else fe.Nel
+    op_bytes = (64. * nn_l + 48. * ne_l) if mf else 388. * nn_l
     n_sw = marks['si1'][0] - marks['si0'][0]
-    rewritten = (marks['si1'][1] - marks['si0'][1]) / world      # this rank's share of the rewritten tangents
-    bytes_per = {'spmv': op_bytes / world,
-                 'sweep': 412. * nel_rank + 216. * rewritten / max(n_sw, 1), 'cg_update': 128. * fe.Nnode, 'assemble': 0.,
+    if strip:
+        nel_rank = ne_l
+        rewritten = float(marks['si1'][1] - marks['si0'][1])     # counted on this rank's local elements
+    else:
+        rewritten = (marks['si1'][1] - marks['si0'][1]) / world  # whole mesh (all-reduced): this rank's share
+    bytes_per = {'spmv': op_bytes if strip else op_bytes / world,
+                 'sweep': 412. * nel_rank + 216. * rewritten / max(n_sw, 1), 'cg_update': 128. * nn_l, 'assemble': 0.,
                  'mg_smooth': op_bytes}
     # dominant kernel: with multigrid the fine-level operator kernels of the V-cycle (k_mg_smooth, k_mg_smooth2_zero,
     # k_mg_residual: same structure, same bytes, ~26-30 us each, 4 per cycle); family 'mg_smooth' times the two
     # post-smoothing launches of every cycle, i.e. half of that class
-    mg_on = eng.precond_info()[0] == 1 and tim['mg_smooth'][1] > 0
-    dominant = 'mg_smooth' if mg_on else max(('spmv', 'sweep', 'cg_update'), key=lambda k: tim[k][0])
+    # family 'mg_smooth' times the two post-smoothing launches of every cycle = half of the class of fine-level operator
+    # kernels of the V-cycle (k_mg_smooth, k_mg_smooth2_zero, k_mg_residual: same structure, same bytes, 4 per cycle):
+    # the class is weighted accordingly when the dominant kernel is chosen by accumulated time
+    weight = {'mg_smooth': 2.0, 'spmv': 1.0, 'sweep': 1.0, 'cg_update': 1.0}
+    cands = [k for k in ('mg_smooth', 'spmv', 'sweep', 'cg_update') if tim[k][1] > 0]
+    dominant = max(cands, key=lambda k: weight[k] * tim[k][0]) if cands else 'sweep'
 
     def roof(k):
         ms, cnt = tim[k]
@@ -273,7 +357,7 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled and
         # WRITE_SIZE as calibrated there, MI355X_MICROARCH.md 'HBM'); measured on this workload (1 GPU, 1024^2)
         pmc = PMC_TRAFFIC['matfree' if mf else 'assembled']
-        traffic = pmc.get(k) if (world == 1 and n == 1024) else None
+        traffic = pmc.get(k) if (world == 1 and n == 1024) else None   # from the committed profile of this workload, not this run
         opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
         return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + %s + p.q)' % opname,
                            'sweep': 'k_sweep_light<1> (strain gather + return mapping + tangent test / refresh; 412 B per element + 216 B per '
@@ -284,20 +368,27 @@ def main():
                                         'multigrid V-cycle: %s + update)' % (1 if mf else 0, opname)}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                'traffic_source': PMC_SOURCE['matfree' if mf else 'assembled'] if traffic else None,
+                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload committed as ' + PMC_SOURCE['matfree' if mf else 'assembled'] + ' (not measured in this run)') if traffic else None,
                 'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
 
     out = {
         'metric': 'integration-point updates/sec (wall-clock per load step in ms_per_step)',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'strong',
+        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak' if (strip or world == 1) else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%dx%d Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
+        'config': {'workload': '%s Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
                                'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
                                'of %d (after %d untimed elastic pre-roll steps)'
-                               % (n, n, ninc, pre + W, pre + W + K, ninc, pre),
-                   'elements': fe.Nel, 'dofs': fe.Ndof, 'parallelism': ('single GPU' if world == 1 else 'x-strip element shard x%d: sweep + CG SpMV rows sharded, '
-                                   'RCCL all-reduce per CG step, replicated multigrid hierarchy' % world),
+                               % ('%dx%d' % (fe._NX, fe._NY), ninc, pre + W, pre + W + K, ninc, pre),
+                   'elements': fe.Nel, 'dofs': fe.Ndof,
+                   'parallelism': ('single GPU' if world == 1 else
+                                   ('strip-local engine x%d: %d owned + %d halo element columns per GPU, halo refresh of the residual '
+                                    '(ncclSend/ncclRecv) + coarse right-hand-side all-reduce (level %d, replicated %d-level coarse '
+                                    'hierarchy) + 3 all-reduces of 8 KB partial sums per PCG iteration; weak scaling, %d x %d mesh'
+                                    % (world, strip['c1'] - strip['c0'], strip['W'], strip['Ld'], eng.strip_info()[3], fe._NX, fe._NY))
+                                   if strip else
+                                   ('x-strip element shard x%d: material state and sweep sharded, operator + multigrid solve '
+                                    'replicated, one all-reduce of the stiffness generators per changed sweep' % world)),
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
                               else 'Jacobi-PCG') + ' rtol=%g, %s operator' % (fe.cg_rtol, 'matrix-free' if mf else 'block-ELL'), 'device': devname},
         'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
@@ -310,6 +401,12 @@ def main():
         'roofline_spmv': roof('spmv'),
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items() if v[1] > 0},
     }
+    if strip:
+        si = eng.strip_info()
+        out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'note': 'since the start of the run (rank 0)'}
+    if rank == 0 and world == 1 and not args.no_svc:
+        fe._drop_engine()        # release the 1024^2 model's HBM and stream before the SVC sample
+        out['roofline_svc'] = svc_sample(FE, _lib, args.svc_mesh, device=local)
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 3)), 0)
     elif rank == 0:

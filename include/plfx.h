@@ -248,7 +248,7 @@ int plfx_finish_fetch(plfx_ctx *ctx, int slot, double *u_at, double *f_at, doubl
  * all-reduces of <= 8 KB of partial sums.  The V-cycle is arithmetically the one a single GPU runs on the global grid
  * (validity widths in DESIGN.md section 6), so iteration counts do not depend on the number of strips.  The material sweep
  * runs on the halo elements too (their state is recomputed from the exchanged displacement increment, never communicated).
- * global_col0 = global element column of local column 0; halo (derived) must be 8 * 2^coarse_level (32 for level 3, 64 for
+ * global_col0 = global element column of local column 0; halo (derived) must be at least 4 * 2^coarse_level (32 for level 3, 64 for
  * level 4); all column numbers and NY must be multiples of 2^coarse_level.  Needs the matrix-free operator and, for more
  * than one strip, a communicator (plfx_comm_init / plfx_comm_init_callback) created BEFORE this call.
  * plfx_sweep flags, plfx_scf_all statistics and plfx_finish_step element sums then refer to the whole grid; u_at / f_at of

@@ -793,6 +793,13 @@ int sync_M(plfx_ctx *c)
 
 
 // ---------------------------------------------------------------------------------------------- strip-local engine
+// collectives of a strip run whenever there are peers -- and with a single rank when PLFX_STRIP_FORCE_COLL=1 (exercises the
+// RCCL calls of the path on a 1-rank communicator: tests)
+inline bool strip_coll(const plfx_ctx *c)
+{
+    static const bool force = getenv("PLFX_STRIP_FORCE_COLL") && atoi(getenv("PLFX_STRIP_FORCE_COLL")) != 0;
+    return c->nranks > 1 || (force && (c->comm || c->host_ar));
+}
 inline int own_lo(const plfx_ctx *c) { return c->strip.on ? c->strip.own_lo : 0; }
 inline int own_hi(const plfx_ctx *c) { return c->strip.on ? c->strip.own_hi : c->nnode; }
 
@@ -800,7 +807,7 @@ inline int own_hi(const plfx_ctx *c) { return c->strip.on ? c->strip.own_hi : c-
 // redundantly in a fixed order, so every rank takes bitwise the same decisions
 int part_allreduce(plfx_ctx *c, double *p, size_t n)
 {
-    if (!c->strip.on || c->nranks < 2) return 0;
+    if (!c->strip.on || !strip_coll(c)) return 0;
     c->strip.n_part++;
     return allreduce(c, p, n, NCCL_FLOAT64, NCCL_SUM, "partial sums");
 }
@@ -814,7 +821,7 @@ int part_allreduce(plfx_ctx *c, double *p, size_t n)
 int halo_refresh(plfx_ctx *c, double *v)
 {
     auto &S = c->strip;
-    if (!S.on || c->nranks < 2) return 0;
+    if (!S.on || !strip_coll(c)) return 0;
     const int nyn = c->gy + 1;
     const size_t n = (size_t)S.W * nyn * 2;
     double *sendL = v + (size_t)2 * (S.oc0 + 1) * nyn, *recvL = v + (size_t)2 * (S.oc0 - S.W) * nyn;
@@ -1150,7 +1157,7 @@ int strip_coarse(plfx_ctx *c)
                        (size_t)2 * (w.g0 + w.jc0) * nyc, (size_t)2 * (w.jc1 - w.jc0) * nyc, (size_t)2 * w.jc0 * nyc,
                        (const double *)L.b, k->r);
     HIPCHK(c, hipGetLastError());
-    if (c->nranks > 1) {
+    if (strip_coll(c)) {
         S.n_coarse++;
         const int rc = allreduce(c, k->r, nd, NCCL_FLOAT64, NCCL_SUM, "coarse right-hand side");
         if (rc) return rc;
@@ -1177,7 +1184,7 @@ int strip_child_assemble(plfx_ctx *c)
                        (size_t)(w.g0 + w.ec0) * L.ny, (size_t)(w.ec1 - w.ec0) * L.ny, (size_t)w.ec0 * L.ny,
                        (const double *)L.Mel, k->Mel);
     HIPCHK(c, hipGetLastError());
-    if (c->nranks > 1) {
+    if (strip_coll(c)) {
         const int rc = allreduce(c, k->Mel, tot, NCCL_FLOAT64, NCCL_SUM, "coarse generators");
         if (rc) return rc;
     }
@@ -1205,7 +1212,7 @@ int strip_child_dinv(plfx_ctx *c)
                        (size_t)2 * (w.g0 + w.jc0) * nyc, (size_t)2 * (w.jc1 - w.jc0) * nyc, (size_t)2 * w.jc0 * nyc,
                        (const double *)L.dinv, k->dinv);
     HIPCHK(c, hipGetLastError());
-    if (c->nranks > 1) {
+    if (strip_coll(c)) {
         const int rc = allreduce(c, k->dinv, nd, NCCL_FLOAT64, NCCL_SUM, "coarse Jacobi scaling");
         if (rc) return rc;
     }
@@ -1990,7 +1997,7 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
         int g = W >> Ld;  // the coarse correction is valid on every local column
         for (int l = Ld - 1; l >= 0 && v >= 0; l--) g = std::min(a[l] - 1, 2 * g) - 2;
         if (v < 0 || g < 1)
-            return fail(c, PLFX_ERR_ARG, "halo of %d columns is too narrow for coarse level %d (need 8 * 2^level: 32 for 3, 64 for 4)", W, Ld);
+            return fail(c, PLFX_ERR_ARG, "halo of %d columns is too narrow for coarse level %d (need 4 * 2^level: 32 for level 3, 64 for level 4)", W, Ld);
     }
     mg_graph_drop(c);
     strip_free(c);
@@ -3142,7 +3149,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags);
     HIPCHK(c, hipGetLastError());
     if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
-        const int rca = allreduce(c, c->flags, 4, NCCL_INT32, NCCL_SUM, "flags");
+        // strip: the counts of rewritten tangents / sub-stepped elements stay local (halo elements are replicas)
+        const int rca = allreduce(c, c->flags, c->strip.on ? 2 : 4, NCCL_INT32, NCCL_SUM, "flags");
         if (rca) return rca;
     }
     int h[4];

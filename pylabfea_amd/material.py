@@ -327,7 +327,8 @@ class Material(object):
         material.py:1161) and the SVC yield function.  The reference declares this method but raises
         ``ModuleNotFoundError`` (material.py:2688-2703); the layout read here is the one its ``export_MLparam``
         writes and its Abaqus UMAT reads (examples/UMAT/ml_umat.f:129-151), including the rule
-        ``dev_only = props[16] < 0``.  Files with work-hardening or texture features (Ndof > 6) are refused."""
+        ``dev_only = props[16] < 0``, and the older layout of the files shipped under examples/UMAT/models (see below).
+        Files with work-hardening or texture features (Ndof > 6) are refused."""
         import json
         if path and path[-1] != '/':
             path += '/'
@@ -367,7 +368,17 @@ class Material(object):
             pass
         dual = props[29:29 + nsv]
         sv = props[29 + nsv:29 + nsv * (ndof + 1)].reshape(nsv, ndof)
-        self.set_svc(sv, dual, props[5], props[6], scale_seq, dev_only=bool(props[16] < 0.), C=C)
+        # Layouts.  Current (export_MLparam of v4.4, material.py:2212-2214): slot 16 = -1 / 0 deviatoric-feature flag, slot 17 =
+        # Nset, 18.. = scale_text.  Files shipped with the reference under examples/UMAT/models (written by pyLabFEA 4.3,
+        # "v4.0 layout"): slot 16 = Nset (>= 1), 17.. = scale_text, no flag -- those versions trained the 6-feature SVC on
+        # DEVIATORIC stresses (every support vector is trace-free; with full-stress features the J2 file would yield under
+        # hydrostatic load), so the flag is recovered from the support vectors.  Dual coefficients start at slot 29 in both.
+        self.mlparam_layout = 'v4.0' if props[16] >= 1. else 'v4.4'
+        if self.mlparam_layout == 'v4.0':
+            dev_only = bool(ndof == 6 and np.max(np.abs(sv[:, 0:3].sum(axis=1))) < 1e-9 * max(np.max(np.abs(sv)), 1e-300))
+        else:
+            dev_only = bool(props[16] < 0.)
+        self.set_svc(sv, dual, props[5], props[6], scale_seq, dev_only=dev_only, C=C)
         return self
 
     # ------------------------------------------------------------------ records for libplfx

@@ -423,7 +423,7 @@ class Model(object):
 
     def strip_plan(self, rank, nranks, coarse_level=None):
         """Column ranges of the strip-local engine for ``rank`` of ``nranks``: dict with the owned element columns
-        ``c0, c1``, the local window ``g0, g1`` (owned + halo), the hand-over level ``Ld`` and the halo width ``W = 8 * 2^Ld``
+        ``c0, c1``, the local window ``g0, g1`` (owned + halo), the hand-over level ``Ld`` and the halo width ``W = 4 * 2^Ld``
         -- or None when the mesh does not allow it (non-uniform elements, strips narrower than the halo, sizes that are
         not multiples of 2^Ld).  Strip boundaries are multiples of 2^Ld so that every level coarsens exactly as on one GPU."""
         NX, NY = self._NX, self._NY
@@ -431,7 +431,7 @@ class Model(object):
         if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]) or np.max(np.abs(ly - ly[0])) > 1e-12 * abs(ly[0]):
             return None
         for Ld in ((coarse_level,) if coarse_level else (4, 3, 2, 1)):
-            al, W = 1 << Ld, 8 << Ld
+            al, W = 1 << Ld, 4 << Ld
             if NX % al or NY % al:
                 continue
             gx, gy = NX >> Ld, NY >> Ld
@@ -465,7 +465,17 @@ class Model(object):
             if m.sy is not None:
                 m._no_flow_rule()  # Tresca / Barlat have no normal in the reference either (material.py:822-825)
         eng = _lib.Context(self.device)
-        eng.set_materials([m._record(self._element_CV(m)) for m in self.mat])
+        # one engine material per distinct Material object: a laminate lists the same material for several sections
+        # (assign([A, B, A, B, A])), and the library runs only ONE 6-feature SVC material on its wave-per-element kernels
+        uniq, remap = [], []
+        for m in self.mat:
+            j = next((k for k, q in enumerate(uniq) if q is m), None)
+            if j is None:
+                uniq.append(m)
+                j = len(uniq) - 1
+            remap.append(j)
+        eng.set_materials([m._record(self._element_CV(m)) for m in uniq])
+        self._eng_mat_id = np.asarray(remap, dtype=np.int64)[self._mat_id]
         e0, e1 = 0, self.Nel
         self._strip = None
         plan = None
@@ -480,7 +490,7 @@ class Model(object):
                 plan = self.strip_plan(rank, nranks, getattr(self, '_strip_level', None))
             if plan is None and mode == 'strip':
                 raise ValueError('distribute: the strip-local engine needs a uniform structured grid whose strips are at '
-                                 'least one halo (8 * 2^level columns) wide, with NX, NY multiples of 2^level')
+                                 'least one halo (4 * 2^level columns) wide, with NX, NY multiples of 2^level')
             e0, e1 = self.strip_range(rank, nranks)
         if plan is not None:
             # this rank's strip (owned columns + halo) as a standalone local mesh; same numbering rules (model.py:893, 935)
@@ -491,7 +501,7 @@ class Model(object):
             n1 = (ih // NY) * nyn + ih % NY
             conn = np.stack((n1, n1 + 1, n1 + nyn, n1 + nyn + 1), axis=1)
             nnode_l = (nxl + 1) * nyn
-            eng.set_mesh(conn, self._mat_id[g0 * NY:g1 * NY], self._lxy[g0 * NY:g1 * NY], nnode_l, self.thick,
+            eng.set_mesh(conn, self._eng_mat_id[g0 * NY:g1 * NY], self._lxy[g0 * NY:g1 * NY], nnode_l, self.thick,
                          self.planestress, 0, nxl * NY)
             eng.set_grid(nxl, NY)
             eng.set_strip(plan['c0'] - g0, plan['c1'] - g0, g0, self._NX, plan['Ld'])
@@ -501,7 +511,7 @@ class Model(object):
             self._strip = plan
             e0, e1 = plan['c0'] * NY, plan['c1'] * NY
         else:
-            eng.set_mesh(self._conn, self._mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+            eng.set_mesh(self._conn, self._eng_mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
             eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
         if self.precond is not None:
             eng.set_precond(self.precond)

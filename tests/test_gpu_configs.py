@@ -107,13 +107,47 @@ def test_config4_schedule_4x4(cfg, golden_dir):
 
 
 def test_config4_full_size_512(cfg, golden_dir):
-    """BASELINE.json configs[3]: 512x512 mesh, SVC yield function with 1585 support vectors — exact workload."""
+    """BASELINE.json configs[3]: 512x512 mesh, SVC yield function with 1585 support vectors -- exact workload.
+    The first ten load steps (elastic, scaled by calc_scf) are uniform and must reproduce the reference's 4x4 trace.  The
+    eleventh takes the whole remaining load in one step and does not converge in the reference either (16 stiffness
+    iterations); there the field is NOT uniform -- the trained SVC couples the in-plane stress to small shear components
+    (1.8 % non-uniformity on the reference's 4x4 mesh) -- so that step is mesh dependent (tools/probes/cfg4_probe.py:
+    1.4e-3 at 16^2 ... 1.6e-3 at 256^2, independent of the PCG tolerance) and is pinned by the oracle test below instead;
+    here: identical iteration / non-convergence counts, the homogenised stress within 5e-3, equilibrium."""
+    g, p = cfg, 'cfg4_svc_4'
     fe = tension_model(svc_material(golden_dir, 'hill'), 512, 0.001)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         fe.solve(min_step=10)
-    homogeneous_check(fe, cfg, 'cfg4_svc_4', rtol=2e-6)
+    assert fe.nsteps == int(g[p + '_nsteps']) == 11
+    assert list(fe.niter) == list(g[p + '_niter'])
+    assert list(fe.co_nconv) == list(g[p + '_co_nconv'])
+    s = np.max(np.abs(g[p + '_sgl']))
+    assert np.max(np.abs(fe.sgl[:11] - g[p + '_sgl'][:11])) < 1e-6 * s       # ten uniform steps: strict
+    assert np.max(np.abs(fe.egl[:11] - g[p + '_egl'][:11])) < 1e-6 * np.max(np.abs(g[p + '_egl']))
+    assert np.max(np.abs(fe.sgl[11] - g[p + '_sgl'][11])) < 5e-3 * s         # the non-converged step: mesh dependent
+    assert np.max(np.abs(fe.egl[11][1] - g[p + '_egl'][11][1])) < 1e-9       # prescribed global strain
+    free = fe.free_dofs()
+    assert np.max(np.abs(fe.f[free])) < 1e-6 * np.max(np.abs(fe.f))
     assert np.max(fe._state('max_steps')) == 49       # the 50-sub-step corrector ran (wave-per-element SVC kernels)
+
+
+def test_config4_schedule_32x32_vs_oracle(golden_dir):
+    """config 4's schedule on 32x32 elements (multigrid, matrix-free operator, wave-per-element SVC kernels) against the
+    pinned oracle's sparse direct solve, including the non-converged last step"""
+    from oracle.solve_ref import RefSolver
+    fe = tension_model(svc_material(golden_dir, 'hill'), 32, 0.001)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=10)
+        ref = RefSolver(tension_model(svc_material(golden_dir, 'hill'), 32, 0.001)).solve(min_step=10)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+    assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter) and list(fe.co_nconv) == list(ref.co_nconv)
+    s = np.max(np.abs(ref.sig))
+    assert np.max(np.abs(fe.u - ref.u)) < 5e-6 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 5e-6 * s
+    assert np.max(np.abs(fe._state('epl') - ref.epl)) < 5e-6 * np.max(np.abs(ref.eps))
+    assert np.max(np.abs(fe.sgl - ref.sgl)) < 5e-6 * s
 
 
 # ------------------------------------------------------------------ config 5: J2 + Goss-Barlat-trained SVC laminate

@@ -216,7 +216,7 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         st = d['strip']
         assert st is not None and d['native']
         active, halo, Ld, clev, nh, nc, npart = d['strip_info']
-        assert active and halo == st['W'] == 8 << Ld and clev >= 2
+        assert active and halo == st['W'] == 4 << Ld and clev >= 2
         assert nh > 0 and nc > 0 and npart > 0
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
         assert d['its'] == its1                                      # same PCG iterations in every solve

@@ -79,3 +79,58 @@ def test_loaded_material_on_gpu(gold, golden_dir, tag):
     assert np.max(np.abs(yf - gold[tag + '_yf'])) < 1e-10 * np.max(np.abs(gold[tag + '_yf']))
     a = m.calc_fgrad(sig)
     assert np.max(np.abs(a - gold[tag + '_fgrad'])) < 1e-10 * np.max(np.abs(gold[tag + '_fgrad']))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parameter files SHIPPED with the reference (examples/UMAT/models/*.csv, written by pyLabFEA 4.3: "v4.0 layout" -- slot 16
+# holds Nset instead of the deviatoric-feature flag).  Data files, copied unchanged to tests/golden/mlparam/legacy_v4.3/.
+LEGACY = {'J2': dict(nsv=255, sy=60., E=200000., uniaxial=60.), 'Goss-Barlat': dict(nsv=235, sy=46.78191221811742, E=151220., uniaxial=None)}
+
+
+def legacy_decision(path, sig):
+    """decision function straight from the file's numbers (UMAT rule ml_umat.f:415-440, deviatoric features)"""
+    p = np.loadtxt(path, delimiter=',').ravel()
+    nsv = int(p[0])
+    dual, sv = p[29:29 + nsv], p[29 + nsv:29 + 7 * nsv].reshape(nsv, 6)
+    s = np.array(sig, dtype=float)
+    s[:, :3] -= s[:, :3].mean(axis=1)[:, None]
+    x = s / p[8]
+    d2 = ((x[:, None, :] - sv[None, :, :]) ** 2).sum(axis=2)
+    return (dual[None, :] * np.exp(-p[6] * d2)).sum(axis=1) + p[5]
+
+
+@pytest.mark.parametrize('tag', sorted(LEGACY))
+def test_from_mlparam_reads_shipped_v40_files(golden_dir, tag):
+    import pylabfea_amd as FE
+    src = os.path.join(golden_dir, 'mlparam', 'legacy_v4.3')
+    m = FE.Material(name='shipped').from_MLparam('abq_ML-%s_C15_G25' % tag, path=src)
+    L = LEGACY[tag]
+    assert m.mlparam_layout == 'v4.0' and m.ML_yf and m.sdim == 6 and m.Ndof == 6
+    assert len(m.svc['dual']) == L['nsv'] and abs(np.sum(m.svc['dual'])) < 1e-9      # SVC dual constraint: sum = 0
+    assert m.dev_only                                   # recovered from the trace-free support vectors
+    assert abs(m.sy - L['sy']) < 1e-12 * L['sy'] and m.gam_yf == 2.5 and m.C_yf == 15.0
+    assert abs(m.E - L['E']) < 1e-6 * L['E'] and abs(m.nu - 0.3) < 1e-9
+    # a current-layout file (slot 16 = flag) is still recognised as such
+    cur = FE.Material().from_MLparam('abq_ML-J2dev_C15_G25', path=os.path.join(golden_dir, 'mlparam'))
+    assert cur.mlparam_layout == 'v4.4' and cur.dev_only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', sorted(LEGACY))
+def test_shipped_v40_material_on_gpu(golden_dir, tag):
+    """yield function of the loaded shipped material on the device against the file's own numbers; the J2-trained one
+    yields at its nominal 60 MPa in uniaxial tension and is pressure independent"""
+    import pylabfea_amd as FE
+    src = os.path.join(golden_dir, 'mlparam', 'legacy_v4.3')
+    m = FE.Material(name='shipped').from_MLparam('abq_ML-%s_C15_G25' % tag, path=src)
+    rng = np.random.default_rng(4)
+    sig = rng.normal(size=(300, 6)) * m.sy * rng.uniform(0.2, 1.4, size=(300, 1))
+    ref = legacy_decision(os.path.join(src, 'abq_ML-%s_C15_G25-svm.csv' % tag), sig)
+    yf = m.calc_yf(sig)
+    assert np.max(np.abs(yf - ref)) < 1e-10 * np.max(np.abs(ref))
+    if LEGACY[tag]['uniaxial']:
+        s = np.zeros((2, 6))
+        s[0, 0], s[1, 0] = 0.98 * 60., 1.02 * 60.
+        f = m.calc_yf(s)
+        assert f[0] < 0. < f[1]
+        assert abs(m.calc_yf(s + np.array([500., 500., 500., 0., 0., 0.]))[0] - f[0]) < 1e-9

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes over tools/svc_profile.py: per-kernel time and SQ counters of the SVC sweep kernels.
+Usage: tools/svc_prof_summary.py <dir with trace/ and pmc*/> <elements per corrector launch> <out.txt>"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r'plfx::(k_[a-zA-Z_0-9]+(<[0-9, ]+>)?)', name)
+    return m.group(1).replace(' ', '') if m else name[:40]
+
+
+d, nel, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+L = []
+rows = list(csv.DictReader(open(glob.glob('%s/trace/*kernel_stats.csv' % d)[0])))
+L.append('== rocprofv3 --kernel-trace --stats: python tools/svc_profile.py (bounded config-4 sample) ==')
+L.append('%-28s %8s %12s %12s %8s' % ('kernel', 'calls', 'avg_us', 'total_ms', 'pct'))
+for r in rows[:14]:
+    L.append('%-28s %8s %12.2f %12.3f %8.3f' % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3,
+                                                float(r['TotalDurationNs']) / 1e6, float(r['Percentage'])))
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob('%s/pmc*/*counter_collection.csv' % d):
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name'])
+        if k.startswith('k_sweep_svc_wave'):
+            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+L.append('')
+L.append('== rocprofv3 --pmc (SQ counters, average per dispatch; productive dispatches = those with > 1e6 VALU instructions) ==')
+for k in sorted(acc):
+    c = acc[k]
+    keep = None
+    if 'SQ_INSTS_VALU' in c:
+        keep = [i for i, v in enumerate(c['SQ_INSTS_VALU']) if v > 1e6]
+    L.append(k)
+    for name in sorted(c):
+        v = c[name]
+        if keep is not None and len(v) == len(c['SQ_INSTS_VALU']):
+            v = [v[i] for i in keep]
+        if v:
+            L.append('   %-24s n=%4d  avg %16.1f' % (name, len(v), sum(v) / len(v)))
+    if keep and k.endswith('<1>'):
+        iv = [c['SQ_INSTS_VALU'][i] for i in keep]
+        L.append('   -> VALU wave-instructions per element update: %.1f (%g elements per launch)' % (sum(iv) / len(iv) / nel, nel))
+        if 'SQ_ACTIVE_INST_VALU' in c and 'SQ_WAVE_CYCLES' in c:
+            a = [c['SQ_ACTIVE_INST_VALU'][i] for i in keep]
+            w = [c['SQ_WAVE_CYCLES'][i] for i in keep]
+            L.append('   -> SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.3f (share of the wave cycles in which a VALU instruction issues)'
+                     % (sum(a) / sum(w)))
+open(out, 'w').write('\n'.join(L) + '\n')
+print('\n'.join(L))
