@@ -144,8 +144,8 @@ def cpu_baseline(n, steps, warmup, n1=128):
 VALU_FP64_PEAK_TFLOPS = 78.6
 # VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
 # same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
-SVC_VALU_PER_ELEMENT = {'corrector': 1727838., 'streaming': 804363926.5 / 16384.}
-SVC_PROFILE = 'profiles/r02_svc_rocprofv3_summary.txt'
+SVC_VALU_PER_ELEMENT = {'corrector': 929793., 'streaming': 804363926.5 / 16384.}
+SVC_PROFILE = 'profiles/r02b_svc_rocprofv3_summary.txt'
 
 
 def svc_sample(FE, _lib, n=128, device=0):
@@ -181,8 +181,10 @@ def svc_sample(FE, _lib, n=128, device=0):
            'launches': {'streaming': int(n_l), 'corrector': int(n_h)}}
     heavy_el = fe.Nel  # on this workload every sweep of the last load step puts every element on the corrector list
     vc = SVC_VALU_PER_ELEMENT['corrector']
+    n_prod = int(fe.niter[-1]) + 1     # corrector launches with a non-empty list: the stiffness iterations of the last load step
+    out['launches']['corrector_productive'] = n_prod
     if n_h > 0 and vc:
-        per_launch_s = ms_h * 1e-3 / n_h
+        per_launch_s = ms_h * 1e-3 / n_prod   # (the empty launches of the ten elastic steps take ~5 us each)
         ach = vc * heavy_el * 128. / per_launch_s / 1e12     # wave-instructions x 64 lanes x 2 flop (FMA-equivalent issue slots)
         out['roofline'] = {'kernel': 'k_sweep_svc_wave<1> (one wave per element: 50 sub-steps of the plastic corrector, support-'
                                      'vector sums split over the lanes, tables in LDS)',

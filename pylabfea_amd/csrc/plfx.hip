@@ -1440,9 +1440,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             if (s.kind == PLFX_SVC6) {
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
-                if (c->svc_wave_mat < 0 && c->want_svc_wave && 8 * npad <= c->lds_doubles && npad <= 2048) {
+                if (c->svc_wave_mat < 0 && c->want_svc_wave && 9 * npad <= c->lds_doubles && npad <= 2048) {
                     c->svc_wave_mat = k;
-                    c->svc_wave_lds = 8 * npad * 8;  // v[6], dual, |v|^2
+                    c->svc_wave_lds = 9 * npad * 8;  // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32
                 }
             }
         }

@@ -636,9 +636,14 @@ struct YfSvcT {
     // computed once per ray and kept in registers (one value per vector of this lane), |v_k|^2 is the 8th LDS table:
     // 2 fused multiply-adds and 2 LDS reads per vector and evaluation instead of 12 operations and 7 reads.
     static constexpr int MAXTRIP = 2048 / (64 * NC);   // 64 NC MAXTRIP >= npad: up to 2048 support vectors
+    // FP32 sign screen of the marching bracket (ray_screen): in the corrector kernel (4 vectors per lane and trip, one wave
+    // per SIMD, registers to spare); the streaming kernel (2 waves per SIMD, 256 VGPRs) has no room for the FP32 copies
+    static constexpr bool SCREEN = WAVE >= 4 && NF == 6;
     struct RaySetup {
         double DD;
         double ck[WAVE > 0 ? MAXTRIP : 1][NC];
+        float ck32[SCREEN ? MAXTRIP : 1][NC];    // the same in FP32 for the sign screen of the marching bracket
+        float ckmax, gvvmax;                     // bounds of |D.v_k| and gamma log2(e) |v_k|^2 over the vectors (error margin)
     };
     __device__ __forceinline__ void ray_setup(const double *su, RaySetup &r) const
     {
@@ -649,6 +654,7 @@ struct YfSvcT {
 #pragma unroll
         for (int i = 0; i < 6; i++) r.DD = fma(D[i], D[i], r.DD);
         const int lane = threadIdx.x & 63;
+        float ckm = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXTRIP; t++) {
             if (t * 64 * NC < npad) {  // wave-uniform
@@ -661,9 +667,67 @@ struct YfSvcT {
 #pragma unroll
                     for (int i = 0; i < 6; i++) a = fma(D[i], v[c][i], a);
                     r.ck[t][c] = a;
+                    if (SCREEN) {
+                        r.ck32[t][c] = (float)a;
+                        ckm = fmaxf(ckm, fabsf((float)a));
+                    }
                 }
             }
         }
+        if (!SCREEN) return;
+        // bounds for the error margin of ray_screen (wave maxima; |v_k|^2 table * gamma log2 e)
+        float gm = 0.f;
+        const float2 *t32 = reinterpret_cast<const float2 *>(dyn_lds + 8 * npad);
+        for (int k = lane; k < npad; k += 64) gm = fmaxf(gm, fabsf(t32[k].y));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ckm = fmaxf(ckm, __shfl_xor(ckm, off, 64));
+            gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+        }
+        r.ckmax = ckm;
+        r.gvvmax = gm;
+    }
+    // FP32 estimate of the decision function at x su with a rigorous error margin: the marching bracket of ML_full_yf
+    // (material.py:475-486, ten to thirty-five 2 % steps per call) only needs the SIGN of the yield function at the
+    // intermediate points -- wherever |estimate| > margin the FP64 evaluation is skipped; the points where the march stops,
+    // and every point the estimate cannot decide, are evaluated in FP64 as before, so bracket ends, brentq iterates and the
+    // result are unchanged.  Per vector: arg = (g t^2 |D|^2) + (-2 g t)(D.v_k) + g |v_k|^2 in FP32, v_exp_f32, two
+    // multiply-adds (sum and sum of magnitudes S): 5 FP32 instructions against 21 FP64 ones.
+    // Error of the estimate <= S (ln 2 * d_arg + e_exp + e_sum) with d_arg <= 6 * 2^-24 * M, M = |g t^2 DD| + |2 g t| max|D.v| +
+    // max g|v|^2 (three roundings + the FP32 representation of the three inputs), e_exp <= 2^-22 (v_exp_f32: 1 ulp, table
+    // entry 0.5 ulp), e_sum <= (npad / 64 + 7) 2^-24 (sequential partial sums per lane + wave reduction).  The margin used is
+    // S (1e-6 M + 1e-5): four to five times that bound.
+    __device__ __forceinline__ double ray_screen(const RaySetup &r, double x, double &margin) const
+    {
+        const double g = -m.gamma * LOG2E;
+        const float A = (float)(g * x * x * r.DD), B = (float)(-2. * g * x);
+        const int lane = threadIdx.x & 63;
+        const float2 *t32 = reinterpret_cast<const float2 *>(dyn_lds + 8 * npad);
+        float f[NC], sa[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) f[c] = 0.f, sa[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXTRIP; t++) {
+            if (t * 64 * NC < npad) {
+                const int k = lane + t * 64 * NC;
+                float2 tv[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) tv[c] = t32[k + 64 * c];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(B, r.ck32[SCREEN ? t : 0][c], A) + tv[c].y);
+                    f[c] = fmaf(tv[c].x, e, f[c]);
+                    sa[c] = fmaf(fabsf(tv[c].x), e, sa[c]);
+                }
+            }
+        }
+        float fs = f[0], ss = sa[0];
+#pragma unroll
+        for (int c = 1; c < NC; c++) fs += f[c], ss += sa[c];
+        const double F = wave_allsum((double)fs), S = wave_allsum((double)ss);
+        const double M = fabs((double)A) + fabs((double)B) * (double)r.ckmax + (double)r.gvvmax;
+        margin = S * (1.e-6 * M + 1.e-5) + 1.e-300;
+        return F + m.intercept;
     }
     __device__ __forceinline__ double ray_eval(const double *su, const RaySetup &r, double x) const
     {
@@ -806,6 +870,20 @@ struct YfSvcT {
         int phase = 0;  // 0 first point, 1 marching down (:475-480), 2 marching up (:481-486), 3 brentq
         double xq = x0;
         for (;;) {
+            if (SCREEN && (phase == 1 || phase == 2)) {  // marching: the sign alone decides whether it goes on
+                double mg;
+                const double fe = ray_screen(ray, xq, mg);
+                if (phase == 1 && fe - mg > 0. && x0 > 0.01) {  // certainly f >= 0: :475-480 marches on
+                    x0 *= 0.98;
+                    xq = x0;
+                    continue;
+                }
+                if (phase == 2 && fe + mg < 0. && x1 < 5. * sflow) {  // certainly f < 0: :481-486 marches on
+                    x1 *= 1.02;
+                    xq = x1;
+                    continue;
+                }
+            }
             const double fq = ray_eval(su, ray, xq);
             if (phase == 0) {
                 f0 = f1 = fq;

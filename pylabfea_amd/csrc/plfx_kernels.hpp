@@ -579,6 +579,9 @@ __device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, 
             for (int c = 0; c < 6; c++) vv = fma(m.sv[6 * (size_t)i + c], m.sv[6 * (size_t)i + c], vv);
         }
         dyn_lds[7 * npad + i] = vv;  // |v_k|^2 for the evaluations along a ray (YfSvcT::ray_eval)
+        // FP32 pair (dual, -gamma log2(e) |v_k|^2) for the sign screen of the marching bracket (YfSvcT::ray_screen)
+        reinterpret_cast<float2 *>(dyn_lds + 8 * npad)[i] =
+            make_float2((i < n) ? (float)m.dual[i] : 0.f, (float)(-m.gamma * LOG2E * vv));
     }
     return npad;
 }
