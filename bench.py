@@ -77,13 +77,13 @@ def tension_model(FE, mat, n, eps, device=0, strips=1):
     return fe
 
 
-def cpu_run(n, steps, warmup, nthreads, linear):
+def cpu_run(n, steps, warmup, nthreads, linear, pcg_threads=None):
     """One timed run of the pinned CPU oracle (oracle/solve_ref.py) on an n x n sample of the bench workload."""
     import pylabfea_amd as FE
     from oracle.solve_ref import RefSolver
     mat = hill_material(FE)
     fe = tension_model(FE, mat, n, 0.005)
-    ref = RefSolver(fe, nthreads=nthreads, linear=linear)
+    ref = RefSolver(fe, nthreads=nthreads, linear=linear, pcg_threads=pcg_threads)
     marks = {}
     ninc, pre = schedule(steps, warmup)
 
@@ -124,12 +124,13 @@ def cpu_baseline(n, steps, warmup, n1=128):
     CSR assembly, OpenMP Jacobi-PCG (oracle/plfx_oracle.c:plfo_pcg_csr) -- on a bounded sample of the same workload,
     on all cores and on one thread, with the sweep-only rates and the reference-as-is figure beside it."""
     cores = os.cpu_count()
-    allc = cpu_run(n, steps, warmup, 0, 'pcg')
+    pcg_thr = min(cores, 32)   # 100 k rows do not feed hundreds of OpenMP threads (256 threads: 7x slower than 32 on the GPU host)
+    allc = cpu_run(n, steps, warmup, 0, 'pcg', pcg_threads=pcg_thr)
     one = cpu_run(n1, max(1, min(steps, 2)), 0, 1, 'pcg')
     out = {'value': allc['value'], 'unit': 'element-updates/s', 'cores': cores, 'kind': 'port',
            'sample': '%s mesh, same material/loading/schedule, load steps %s, %d sweeps + %d Jacobi-PCG solves in %.1f s '
-                     '(OpenMP sweep and PCG rows on %d threads; CSR assembly numpy)'
-                     % (allc['mesh'], allc['load_steps'], allc['sweeps'], allc['solves'], allc['seconds'], cores),
+                     '(OpenMP sweep on %d threads, PCG rows on %d threads; CSR assembly numpy)'
+                     % (allc['mesh'], allc['load_steps'], allc['sweeps'], allc['solves'], allc['seconds'], cores, pcg_thr),
            'ms_per_step': allc['ms_per_step'],
            'all_cores': dict(allc, cores=cores),
            'one_thread': dict(one, cores=1),
@@ -196,6 +197,53 @@ def svc_sample(FE, _lib, n=128, device=0):
     return out
 
 
+def inclusion_variant(FE, n, K, W, device=0):
+    """The bench workload with the central soft inclusion of examples/inclusion.py:31-37 scaled to the mesh (SURVEY 8d:
+    heterogeneous states, branch divergence, half of the matrix elements on the 50-sub-step corrector, elastic-plastic
+    tangent fields under the multigrid preconditioner): same material, loading, schedule and timed window."""
+    mat = hill_material(FE)
+    soft = FE.Material(name='soft inclusion', num=2)
+    soft.elasticity(E=1.e3, nu=0.27)
+    fe = FE.Model(dim=2, planestress=False, device=device)
+    fe.geom(sect=2, LX=4., LY=4.)
+    fe.assign([mat, soft])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.005 * fe.leny, 'disp')
+    el = np.ones((n, n))
+    el[n // 3:2 * (n // 3), n // 3:2 * (n // 3)] = 2
+    fe.mesh(elmts=el, NX=n, NY=n)
+    eng = fe._ensure_engine()
+    marks = {}
+    ninc, pre = schedule(K, W)
+
+    def hook(il):
+        if il == pre + W:
+            eng.sync()
+            marks['t0'], marks['sw0'], marks['so0'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
+        if il == pre + W + K:
+            eng.sync()
+            marks['t1'], marks['sw1'], marks['so1'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
+
+    fe._step_hook = hook
+    fe._max_load_steps = pre + W + K
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=ninc)
+    dt = marks['t1'] - marks['t0']
+    its = [q[0] for q in fe.solver_stats[marks['so0']:marks['so1']]]
+    sweeps = marks['sw1'] - marks['sw0']
+    computed = [i for i in its if i > 0]
+    return {'workload': '%dx%d Q4, the bench material and schedule with a soft elastic inclusion (E=1e3) in the central third; '
+                        'timed load steps %d..%d of %d' % (n, n, pre + W, pre + W + K, ninc),
+            'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'ms_per_step': 1e3 * dt / K, 'sweeps': int(sweeps),
+            'solves': len(its), 'pcg_iterations': int(np.sum(its)),
+            'pcg_iterations_per_computed_solve': float(np.mean(computed)) if computed else 0.,
+            'elements_on_50_substep_corrector_last_sweep': int(np.sum(fe._state('max_steps') == 49))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -204,6 +252,7 @@ def main():
     ap.add_argument('--mesh', type=int, default=1024)
     ap.add_argument('--cpu-mesh', type=int, default=224)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-inclusion', action='store_true', help='skip the heterogeneous (soft inclusion) variant of the workload')
     ap.add_argument('--no-svc', action='store_true', help='skip the bounded config-4 (SVC) sample behind roofline_svc')
     ap.add_argument('--svc-mesh', type=int, default=128)
     ap.add_argument('--all-families', action='store_true',
@@ -406,8 +455,11 @@ def main():
     if strip:
         si = eng.strip_info()
         out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'note': 'since the start of the run (rank 0)'}
+    if rank == 0 and world == 1:
+        fe._drop_engine()        # release the homogeneous model's HBM and stream before the other samples
+    if rank == 0 and world == 1 and not args.no_inclusion:
+        out['inclusion_variant'] = inclusion_variant(FE, n, K, W, device=local)
     if rank == 0 and world == 1 and not args.no_svc:
-        fe._drop_engine()        # release the 1024^2 model's HBM and stream before the SVC sample
         out['roofline_svc'] = svc_sample(FE, _lib, args.svc_mesh, device=local)
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 3)), 0)

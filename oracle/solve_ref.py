@@ -31,11 +31,12 @@ YF_TOL = 5.e-3
 
 
 class RefSolver(object):
-    def __init__(self, model, nthreads=0, linear='lu', pcg_rtol=1.e-10):
+    def __init__(self, model, nthreads=0, linear='lu', pcg_rtol=1.e-10, pcg_threads=None):
         m = self.m = model
         self.nthreads = nthreads
         self.linear = linear
         self.pcg_rtol = pcg_rtol
+        self.pcg_threads = nthreads if pcg_threads is None else pcg_threads   # rows of the PCG kernels: fewer threads than the sweep pay off on small systems
         self.pcg_iters = []
         self.conn = np.ascontiguousarray(m._conn, dtype=np.int32)
         self.mat_id = np.ascontiguousarray(m._mat_id, dtype=np.int32)
@@ -176,7 +177,7 @@ class RefSolver(object):
         if self.linear == 'pcg':
             # projected system on the free DOFs (rows / columns of prescribed DOFs are skipped inside the C routine)
             x0 = self._x_prev if getattr(self, '_x_prev', None) is not None else np.zeros(self.ndof)
-            x, its, relres = O.pcg_csr(K, df, (~fixed), x0, self.pcg_rtol, 200000, self.nthreads)
+            x, its, relres = O.pcg_csr(K, df, (~fixed), x0, self.pcg_rtol, 200000, self.pcg_threads)
             self._x_prev = x
             self.pcg_iters.append(its)
             free = ~fixed

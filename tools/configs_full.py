@@ -97,11 +97,11 @@ if '3i' in which:
     print('    elements that ran the 50-sub-step corrector at least once: %d of %d' % (int(np.sum(ms == 49)), fe.Nel))
 if '5' in which:
     # config 5 geometry on ONE GPU: laminate [2,1,2,1,2], J2 + SVC phases, 2048 x 2048, first load steps
-    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'svc_hill.npz'))
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'svc_gossbarlat.npz'))   # the SVC trained on Barlat Yld2004-18p (Goss)
     ma = FE.Material(num=1)
     ma.elasticity(E=200.e3, nu=0.3)
     ma.plasticity(sy=150., khard=500., sdim=6)
-    mb = FE.Material(name='ML-Hill', num=2)
+    mb = FE.Material(name='ML-Goss-Barlat', num=2)
     mb.elasticity(CV=z['par_CV'])
     mb.plasticity(sy=float(z['par_sy']), sdim=6)
     mb.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']))
@@ -114,4 +114,4 @@ if '5' in which:
     fe.bctop(0.003 * fe.leny, 'disp')
     fe.mesh(NX=2048, NY=2048)
     fe._max_load_steps = 8
-    run('config 5 geometry: 2048x2048 J2+SVC laminate, first 8 of 20 steps', fe, 20)
+    run('config 5: 2048x2048 laminate J2 + Goss-Barlat SVC, first 8 of 20 steps', fe, 20)

@@ -11,9 +11,9 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd $ROOT
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu > $O/bench_under_rocprof.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu --no-inclusion --no-svc > $O/bench_under_rocprof.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python bench.py --no-cpu --no-inclusion --no-svc --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python bench.py --no-cpu --no-inclusion --no-svc --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
 python tools/prof_summary.py $O $O/summary.txt
 python tools/trace_gaps.py $O/trace/bench_kernel_trace.csv 18 > $O/timeline.txt 2>&1
 python tools/configs_full.py 1 2 3 4 > $O/configs.txt 2>&1
