@@ -37,7 +37,8 @@ enum {
     PLFX_SVC6 = 3,    /* RBF-SVC yield function on 6 stress features (material.py:398-405, 765-807) */
     PLFX_TRESCA = 4,  /* Tresca equivalent stress (material.py:630-632): calc_seq only, the reference has
                          no flow rule for it (calc_fgrad raises, material.py:824) */
-    PLFX_BARLAT = 5,  /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) */
+    PLFX_BARLAT = 5,  /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) unless
+                         plfx_material.barlat_normal is set (native normal, extension) */
     PLFX_SVC3 = 6     /* sdim=3 ML material: RBF-SVC on 2 features (seq_J2/scale - 1, polar angle/pi) of the
                          principal stresses, gradient through the Jacobian (material.py:779-807, 2331-2333) */
 };
@@ -71,6 +72,12 @@ typedef struct plfx_material {
     const double *dual; /* [nsv] */
     double barlat[18];  /* Yld2004-18p coefficients c'_12.. (material.py:2578-2591) */
     double barlat_exp;  /* exponent a */
+    int32_t barlat_normal; /* PLFX_BARLAT only.  0: like the reference, the material has an equivalent stress but no flow rule
+                            * (calc_fgrad raises, material.py:822-825) -- plfx_fgrad_batch / plfx_response_batch / plfx_sweep
+                            * refuse it.  1 (EXTENSION, north star "Barlat ... with their normals"): the analytic normal
+                            * d seq / d sigma of Yld2004-18p through the eigen-decompositions of the two transformed deviators,
+                            * associated flow rule like the Hill materials. */
+    int32_t _pad2;
 } plfx_material;
 
 /* ---------------------------------------------------------------- context */

@@ -313,8 +313,71 @@ double plfo_calc_yf(const plfo_material *m, const double sig[6], const double ep
     return plfo_calc_seq(m, sig) - plfo_get_sflow(m, epl);
 }
 
+/* EXTENSION (test infrastructure for the product's opt-in Barlat normal; the reference raises for Barlat, material.py:822):
+ * analytic gradient of calc_seqB.  phi = sum_ij |S'_i - S''_j|^a, seq = (phi/4)^(1/a); dS_i = n_i.dT.n_i for the
+ * eigenvector n_i of the transformed deviator T; chain rule through Bar_m1 / Bar_m2 (material.py:2578-2591) and sig_dev. */
+static void barlat_fgrad(const plfo_material *m, const double sv[6], double a[6])
+{
+    const double *b = m->barlat;
+    double sd[6], T[2][6], w[2][3], V[2][9];
+    plfo_sig_dev(sv, sd);
+    for (int q = 0; q < 2; q++) {
+        const double *c = b + 9 * q;
+        T[q][0] = -c[0] * sd[1] - c[1] * sd[2];
+        T[q][1] = -c[2] * sd[0] - c[3] * sd[2];
+        T[q][2] = -c[4] * sd[0] - c[5] * sd[1];
+        T[q][3] = c[6] * sd[3];
+        T[q][4] = c[7] * sd[4];
+        T[q][5] = c[8] * sd[5];
+        double G[9] = {T[q][0], T[q][5], T[q][4], T[q][5], T[q][1], T[q][3], T[q][4], T[q][3], T[q][2]};
+        jacobi3(G, w[q], V[q]);
+    }
+    const double ex = m->barlat_exp;
+    double phi = 0., dw[2][3] = {{0., 0., 0.}, {0., 0., 0.}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double d = w[0][i] - w[1][j];
+            phi += pow(fabs(d), ex);
+            if (d != 0.) {
+                double t = ex * pow(fabs(d), ex - 1.) * (d > 0. ? 1. : -1.);
+                dw[0][i] += t;
+                dw[1][j] -= t;
+            }
+        }
+    for (int i = 0; i < 6; i++) a[i] = 0.;
+    if (!(phi > 0.)) return;
+    double h[6] = {0., 0., 0., 0., 0., 0.};
+    for (int q = 0; q < 2; q++) {
+        const double *c = b + 9 * q;
+        double g[6] = {0., 0., 0., 0., 0., 0.};
+        for (int i = 0; i < 3; i++) { /* eigenvector i = column i of V */
+            double n0 = V[q][0 * 3 + i], n1 = V[q][1 * 3 + i], n2 = V[q][2 * 3 + i];
+            g[0] += dw[q][i] * n0 * n0;
+            g[1] += dw[q][i] * n1 * n1;
+            g[2] += dw[q][i] * n2 * n2;
+            g[3] += dw[q][i] * 2. * n1 * n2; /* Voigt 23 */
+            g[4] += dw[q][i] * 2. * n0 * n2; /* Voigt 13 */
+            g[5] += dw[q][i] * 2. * n0 * n1; /* Voigt 12 */
+        }
+        h[0] += -c[2] * g[1] - c[4] * g[2];
+        h[1] += -c[0] * g[0] - c[5] * g[2];
+        h[2] += -c[1] * g[0] - c[3] * g[1];
+        h[3] += c[6] * g[3];
+        h[4] += c[7] * g[4];
+        h[5] += c[8] * g[5];
+    }
+    const double hm = (h[0] + h[1] + h[2]) / 3.;
+    const double seq = pow(0.25 * phi, 1. / ex), sc = seq / (ex * phi);
+    for (int i = 0; i < 3; i++) a[i] = sc * (h[i] - hm);
+    for (int i = 3; i < 6; i++) a[i] = sc * h[i];
+}
+
 void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]) /* material.py:765-845 */
 {
+    if (m->kind == PLFO_BARLAT) {
+        barlat_fgrad(m, sig, a);
+        return;
+    }
     if (m->kind == PLFO_SVC6) {
         double s[6], x[6], dK[6] = {0., 0., 0., 0., 0., 0.};
         if (m->dev_only)

@@ -57,6 +57,9 @@ class RefSolver(object):
                                             hill=mat.hill, sv=mat.svc['sv'], dual=mat.svc['dual'],
                                             gamma=mat.gam_yf, intercept=mat.svc['intercept'],
                                             scale_seq=mat.scale_seq, dev_only=mat.dev_only))
+            elif getattr(mat, 'barlat', False):   # Barlat with the product's opt-in native normal (extension)
+                self.mats.append(O.Material(kind=O.BARLAT, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
+                                            barlat=mat.barlat_par, barlat_exp=mat.barlat_exp))
             else:
                 self.mats.append(O.Material(kind=O.HILL6, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
                                             hill=mat.hill, drucker=mat.drucker))

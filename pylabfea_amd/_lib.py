@@ -33,7 +33,7 @@ class CMaterial(C.Structure):
                 ('nfeat', C.c_int32), ('dev_only', C.c_int32), ('_pad', C.c_int32),
                 ('gamma', C.c_double), ('intercept', C.c_double), ('scale_seq', C.c_double),
                 ('sv', C.c_void_p), ('dual', C.c_void_p), ('barlat', C.c_double * 18),
-                ('barlat_exp', C.c_double)]
+                ('barlat_exp', C.c_double), ('barlat_normal', C.c_int32), ('_pad2', C.c_int32)]
 
 
 # every symbol include/plfx.h declares (tests/test_abi.py checks the library exports them all)
@@ -113,7 +113,7 @@ def gen_structured(NX, NY):
 
 
 def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None, barlat=None,
-                  barlat_exp=0.):
+                  barlat_exp=0., barlat_normal=False):
     """Build a plfx_material record.  svc = dict(sv, dual, gamma, intercept, scale_seq, dev_only).
     Returns (struct, keepalive) - keepalive holds the arrays the struct points to."""
     m = CMaterial()
@@ -123,6 +123,7 @@ def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0.,
         for i in range(18):
             m.barlat[i] = float(barlat[i])
         m.barlat_exp = float(barlat_exp)
+        m.barlat_normal = int(bool(barlat_normal))
     cv = _f64(CV).reshape(36)
     for i in range(36):
         m.CV[i] = cv[i]

@@ -136,6 +136,8 @@ struct plfx_ctx {
     MatDev *dmat = nullptr;
     std::vector<double *> dsv;  // owned device copies of sv/dual
     bool has_svc = false, has_svc3 = false, has_analytic = false, has_elastic = false, has_princ = false;
+    bool has_barlat = false;     // Barlat material with the native normal (plfx_material.barlat_normal)
+    int n_noflow = 0;            // materials without a flow rule (Tresca, Barlat without the native normal)
     int svc_lds_need = 0;
     int svc_wave_mat = -1;       // 6-feature SVC material run by the wave-per-element sweep kernels (-1: none)
     int svc_wave_lds = 0;        // bytes of its SoA tables (7 x nsv padded to 64)
@@ -1371,6 +1373,8 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (nmat < 1 || nmat > MAXMAT || !mats) return fail(c, PLFX_ERR_ARG, "nmat must be in 1..%d", MAXMAT);
     free_materials(c);
     c->has_svc = c->has_svc3 = c->has_analytic = c->has_elastic = c->has_princ = false;
+    c->has_barlat = false;
+    c->n_noflow = 0;
     c->svc_lds_need = 0;
     c->svc_wave_mat = -1;
     c->svc_wave_lds = 0;
@@ -1412,10 +1416,13 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         m.sdim = (s.kind == PLFX_PRINC3 || s.kind == PLFX_SVC3) ? 3 : 6;
         for (int i = 0; i < 18; i++) m.barlat[i] = s.barlat[i];
         m.barlat_exp = s.barlat_exp;
+        m.barlat_normal = (s.kind == PLFX_BARLAT && s.barlat_normal) ? 1 : 0;
         if (s.kind != PLFX_ELASTIC) c->nonlin = true;
         if (s.kind == PLFX_HILL6) c->has_analytic = true;
         if (s.kind == PLFX_PRINC3) c->has_princ = true;
         if (s.kind == PLFX_ELASTIC) c->has_elastic = true;
+        if (s.kind == PLFX_BARLAT && s.barlat_normal) c->has_barlat = true;
+        if (s.kind == PLFX_TRESCA || (s.kind == PLFX_BARLAT && !s.barlat_normal)) c->n_noflow++;
         if (s.kind == PLFX_SVC6 || s.kind == PLFX_SVC3) {
             const int nf = (s.kind == PLFX_SVC6) ? 6 : 2;
             if (s.nsv < 1 || s.nfeat != nf || !s.sv || !s.dual)
@@ -1514,6 +1521,9 @@ int plfx_seq_batch(plfx_ctx *c, int mat, int n, const double *sig, double *seq)
 }
 int plfx_fgrad_batch(plfx_ctx *c, int mat, int n, const double *sig, double *a)
 {
+    if (c && mat >= 0 && mat < c->nmat &&
+        (c->hmat[mat].kind == PLFX_TRESCA || (c->hmat[mat].kind == PLFX_BARLAT && !c->hmat[mat].barlat_normal)))
+        return fail(c, PLFX_ERR_UNSUPPORTED, "calc_fgrad: no analytical gradient for this Tresca / Barlat material (material.py:822-825)");
     return point_eval(c, 1, mat, n, sig, nullptr, nullptr, a, nullptr);
 }
 int plfx_yf_batch(plfx_ctx *c, int mat, int n, const double *sig, const double *epl, double *yf)
@@ -1533,6 +1543,7 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
     if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
     if (n < 0 || !sig || !epl || !deps || !fy || !sig_out || !depl || !ct || !nsteps)
         return fail(c, PLFX_ERR_ARG, "null argument");
+    if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
     if (n == 0) return PLFX_OK;
     if (mat_id)
         for (int i = 0; i < n; i++)
@@ -1558,6 +1569,8 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<1>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
     if (c->has_princ)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
+    if (c->has_barlat)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<5>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
     if (c->has_svc)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<3>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, RB_ARGS(c->svc_lds_need));
@@ -3084,6 +3097,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
     HIPCHK(c, hipMemsetAsync(c->flags, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->bflags, 0, (size_t)8 * SWEEP_SLOTS, c->stream));
     EvPair *ev;
@@ -3100,13 +3114,18 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #define WAVE_ARGS c->dmat, c->nmat, c->dcls, c->ncls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,  \
                   c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl, c->fyn,         \
                   c->max_steps, nit, c->flags, c->bflags, c->heavy_list
-    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3)) {
+    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3 && !c->has_barlat)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), first, -1);
         first = 0;
     }
     if (c->has_princ) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0), first, -1);
+        first = 0;
+    }
+    if (c->has_barlat) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<5>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), first, -1);
         first = 0;
     }
@@ -3133,6 +3152,9 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            SWEEP_ARGS(0), -1);
     if (c->has_princ)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
+                           SWEEP_ARGS(0), -1);
+    if (c->has_barlat)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<5>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), -1);
     if (svc_thread)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),

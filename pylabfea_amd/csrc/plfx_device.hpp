@@ -95,8 +95,8 @@ struct MatDev {
     double gamma, intercept, scale_seq;
     const double *sv;    // device pointer [nsv*6]
     const double *dual;  // device pointer [nsv]
-    double barlat[18], barlat_exp;  // Yld2004-18p coefficients (calc_seq only)
-    int32_t kind, sdim, nsv, dev_only, nfeat, _pad;
+    double barlat[18], barlat_exp;  // Yld2004-18p coefficients
+    int32_t kind, sdim, nsv, dev_only, nfeat, barlat_normal;  // barlat_normal: the native Barlat normal is enabled (extension)
 };
 
 // y = C x for a symmetric 21-entry matrix
@@ -299,6 +299,81 @@ __device__ inline double barlat_seq(const MatDev &m, const double *s)
     return pow(0.25 * acc, 1. / m.barlat_exp);
 }
 
+// Barlat Yld2004-18p equivalent stress AND its gradient d seq / d sigma (Voigt, shear components carrying both symmetric
+// entries like every normal of the path: the plastic strain increment lam * a has engineering shear strains).  The
+// reference has no flow rule for Barlat (calc_fgrad raises, material.py:822-825); this is the native normal the north star
+// asks for (EXTENSION, opt-in per material: plfx_material.barlat_normal).  With phi = sum_ij |S'_i - S''_j|^a,
+// seq = (phi/4)^(1/a):  d seq/d phi = seq / (a phi);  d phi/d S'_i = a sum_j |.|^(a-1) sgn(.), d phi/d S''_j = - a sum_i ...;
+// d S_i / d s~ = n_i n_i^T of the eigenvector n_i (s~ = M sd the linearly transformed deviator), Voigt form
+// [n0^2, n1^2, n2^2, 2 n1 n2, 2 n0 n2, 2 n0 n1]; then through M^T (18 coefficients) and the deviator projection.
+// Repeated principal values need no special care: the sum over a degenerate pair is invariant under the choice of basis.
+__device__ inline double barlat_seq_grad(const MatDev &m, const double *s, double *a)
+{
+    const double *b = m.barlat;
+    const double ex = m.barlat_exp;
+    const double p = (s[0] + s[1] + s[2]) / 3.;
+    const double sd[6] = {s[0] - p, s[1] - p, s[2] - p, s[3], s[4], s[5]};
+    const double st1[6] = {-b[0] * sd[1] - b[1] * sd[2], -b[2] * sd[0] - b[3] * sd[2], -b[4] * sd[0] - b[5] * sd[1],
+                           b[6] * sd[3], b[7] * sd[4], b[8] * sd[5]};
+    const double st2[6] = {-b[9] * sd[1] - b[10] * sd[2], -b[11] * sd[0] - b[12] * sd[2],
+                           -b[13] * sd[0] - b[14] * sd[1], b[15] * sd[3], b[16] * sd[4], b[17] * sd[5]};
+    double p1[3], p2[3], V1[9], V2[9];
+    jacobi3_dev(st1, p1, V1);
+    jacobi3_dev(st2, p2, V2);
+    double phi = 0., d1[3] = {0., 0., 0.}, d2[3] = {0., 0., 0.};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double df = p1[i] - p2[j], ad = fabs(df);
+            phi += pow(ad, ex);
+            const double w = (ad > 0.) ? ex * pow(ad, ex - 1.) * (df > 0. ? 1. : -1.) : 0.;
+            d1[i] += w;
+            d2[j] -= w;
+        }
+    const double seq = pow(0.25 * phi, 1. / ex);
+    if (!(phi > 0.)) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = 0.;
+        return seq;
+    }
+    double g1[6] = {0., 0., 0., 0., 0., 0.}, g2[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {  // eigenvector i = column i of V
+        const double n0 = V1[0 * 3 + i], n1 = V1[1 * 3 + i], n2 = V1[2 * 3 + i];
+        g1[0] = fma(d1[i], n0 * n0, g1[0]);
+        g1[1] = fma(d1[i], n1 * n1, g1[1]);
+        g1[2] = fma(d1[i], n2 * n2, g1[2]);
+        g1[3] = fma(d1[i], 2. * n1 * n2, g1[3]);
+        g1[4] = fma(d1[i], 2. * n0 * n2, g1[4]);
+        g1[5] = fma(d1[i], 2. * n0 * n1, g1[5]);
+        const double m0 = V2[0 * 3 + i], m1 = V2[1 * 3 + i], m2 = V2[2 * 3 + i];
+        g2[0] = fma(d2[i], m0 * m0, g2[0]);
+        g2[1] = fma(d2[i], m1 * m1, g2[1]);
+        g2[2] = fma(d2[i], m2 * m2, g2[2]);
+        g2[3] = fma(d2[i], 2. * m1 * m2, g2[3]);
+        g2[4] = fma(d2[i], 2. * m0 * m2, g2[4]);
+        g2[5] = fma(d2[i], 2. * m0 * m1, g2[5]);
+    }
+    // M^T g: st_0 = -b0 sd1 - b1 sd2, st_1 = -b2 sd0 - b3 sd2, st_2 = -b4 sd0 - b5 sd1 (and b9.. for the second map)
+    double h[6];
+    h[0] = -b[2] * g1[1] - b[4] * g1[2] - b[11] * g2[1] - b[13] * g2[2];
+    h[1] = -b[0] * g1[0] - b[5] * g1[2] - b[9] * g2[0] - b[14] * g2[2];
+    h[2] = -b[1] * g1[0] - b[3] * g1[1] - b[10] * g2[0] - b[12] * g2[1];
+    h[3] = b[6] * g1[3] + b[15] * g2[3];
+    h[4] = b[7] * g1[4] + b[16] * g2[4];
+    h[5] = b[8] * g1[5] + b[17] * g2[5];
+    const double hm = (h[0] + h[1] + h[2]) / 3.;  // deviator projection (symmetric)
+    const double sc = seq / (ex * phi);
+    a[0] = sc * (h[0] - hm);
+    a[1] = sc * (h[1] - hm);
+    a[2] = sc * (h[2] - hm);
+    a[3] = sc * h[3];
+    a[4] = sc * h[4];
+    a[5] = sc * h[5];
+    return seq;
+}
+
 // ---------------------------------------------------------------------------------------------
 // RBF-SVC yield function (material.py:398-405 decision function, :765-807 gradient).
 // sv/dual point to LDS when the kernel staged them, to global memory otherwise; every lane reads
@@ -380,6 +455,20 @@ struct YfHill {
     __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
     __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { hill_fgrad(m, s, a); }
+};
+
+// Yield-function policy: Barlat Yld2004-18p with the native normal (extension; see barlat_seq_grad).
+struct YfBarlat {
+    const MatDev &m;
+    __device__ YfBarlat(const MatDev &mm) : m(mm) {}
+    __device__ __forceinline__ double seq(const double *s) const { return barlat_seq(m, s); }
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        return barlat_seq(m, s) - sflow_of(m, epl);
+    }
+    __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
+    __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const { barlat_seq_grad(m, s, a); }
 };
 
 // Yield-function policy: sdim = 3, Hill-3p / J2 on principal stresses.

@@ -169,6 +169,11 @@ struct YfOf<3> {
     }
 };
 template <>
+struct YfOf<5> {
+    typedef YfBarlat type;
+    __device__ static YfBarlat make(const MatDev &m, const double *, const double *) { return YfBarlat(m); }
+};
+template <>
 struct YfOf<6> {
     typedef YfSvc3 type;
     __device__ static YfSvc3 make(const MatDev &m, const double *sv, const double *dual)
@@ -273,6 +278,8 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
                 svc_fgrad(m, psv, pdu, s, a);
             else if (kd == 2)
                 princ_fgrad(m, s, a);
+            else if (kd == 5)
+                barlat_seq_grad(m, s, a);
             else
                 hill_fgrad(m, s, a);
 #pragma unroll
@@ -280,7 +287,7 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
         } else if (what == 2) {
             out[i] = svc3 ? svc3_decision(m, psv, pdu, s)
                           : svc ? svc_decision(m, psv, pdu, s)
-                                : (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
+                                : (kd == 2 ? princ_seq(m, s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
         } else {
             int st = 0;
             if (svc3) {
@@ -290,7 +297,7 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
                 YfSvc yf(m, psv, pdu);
                 out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
             } else {
-                out[i] = (kd == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
+                out[i] = (kd == 2 ? princ_seq(m, s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s)) - sflow_of(m, e);
             }
             if (status) status[i] = st;
         }
@@ -1480,7 +1487,8 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
         int mult = 0;
         double hh = 0.;
         if (m.kind != 0) {
-            const double sref = (m.kind == 2 || m.kind == 6) ? princ_seq(m, ds) : hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
+            const double sref = (m.kind == 2 || m.kind == 6) ? princ_seq(m, ds) : m.kind == 5 ? barlat_seq(m, ds)
+                                                                                             : hill_seq(m, ds);  // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
             if (sref > 0.1) {
                 double s[6], ep[6];
 #pragma unroll
@@ -1503,7 +1511,7 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
                         mult = 1;
                     }
                 } else {
-                    yf0 = (m.kind == 2 ? princ_seq(m, s) : hill_seq(m, s)) - sflow_of(m, ep);
+                    yf0 = (m.kind == 2 ? princ_seq(m, s) : m.kind == 5 ? barlat_seq(m, s) : hill_seq(m, s)) - sflow_of(m, ep);
                     if (yf0 < SPLIT_THRESHOLD) {
                         hh = fmin(1., -yf0 / sref);
                         mult = 2;

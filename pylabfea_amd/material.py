@@ -399,10 +399,22 @@ class Material(object):
         return _lib.pack_material(kind, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
                                   hill=self.hill, drucker=self.drucker,
                                   barlat=self.barlat_par if self.barlat else None,
-                                  barlat_exp=self.barlat_exp if self.barlat else 0.)
+                                  barlat_exp=self.barlat_exp if self.barlat else 0.,
+                                  barlat_normal=bool(self.barlat and getattr(self, 'barlat_normal', False)))
+
+    def enable_barlat_normal(self, on=True):
+        """EXTENSION (not in the reference, which has no flow rule for Barlat materials: calc_fgrad raises,
+        material.py:822-825): use the analytic normal of Yld2004-18p -- d seq / d sigma through the eigen-decompositions
+        of the two linearly transformed deviators -- so that ``calc_fgrad``, ``response``, ``calc_properties`` and
+        ``Model.solve`` work for a Barlat material with an associated flow rule, like they do for Hill materials."""
+        if not self.barlat:
+            raise AttributeError('enable_barlat_normal: material has no Barlat parameters')
+        self.barlat_normal = bool(on)
+        self._version += 1
+        return self
 
     def _no_flow_rule(self):
-        if self.barlat:
+        if self.barlat and not getattr(self, 'barlat_normal', False):
             raise ValueError('calc_fgrad: analytical gradient for Barlat not implemented')
         if self.tresca:
             raise ValueError('calc_fgrad: analytical gradient for Tresca not implemented')
