@@ -39,8 +39,11 @@ enum {
                          no flow rule for it (calc_fgrad raises, material.py:824) */
     PLFX_BARLAT = 5,  /* Barlat Yld2004-18p equivalent stress (material.py:678-702): calc_seq only (:822) unless
                          plfx_material.barlat_normal is set (native normal, extension) */
-    PLFX_SVC3 = 6     /* sdim=3 ML material: RBF-SVC on 2 features (seq_J2/scale - 1, polar angle/pi) of the
+    PLFX_SVC3 = 6,    /* sdim=3 ML material: RBF-SVC on 2 features (seq_J2/scale - 1, polar angle/pi) of the
                          principal stresses, gradient through the Jacobian (material.py:779-807, 2331-2333) */
+    PLFX_SVC_WH = 7   /* RBF-SVC with work-hardening features (material.py:2342-2346): 15 features = 6 stress features, the
+                         plastic strain / scale_wh (6), accumulated strain, max. stress / scale_seq, flag (the last three are
+                         zero on the path); the hardening modulus is read off the gradient (material.py:808-814) */
 };
 
 /* error codes */
@@ -78,6 +81,7 @@ typedef struct plfx_material {
                             * d seq / d sigma of Yld2004-18p through the eigen-decompositions of the two transformed deviators,
                             * associated flow rule like the Hill materials. */
     int32_t _pad2;
+    double scale_wh;    /* PLFX_SVC_WH: scaling of the plastic-strain features (Material.scale_wh, material.py:1165-1172) */
 } plfx_material;
 
 /* ---------------------------------------------------------------- context */
@@ -108,6 +112,18 @@ int plfx_full_yf_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const d
 int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig,
                         const double *epl, const double *deps, double *fy, double *sig_out,
                         double *depl, double *ct /* [n*36] */, int32_t *nsteps);
+/* Work-hardening-aware SVC materials (PLFX_SVC_WH).  The reference keeps the hardening modulus in ONE mutable attribute of
+ * the Material object: every calc_fgrad call overwrites it (khard = max(0, -sum dK/dx[wh] scale_seq/scale_wh),
+ * material.py:808-814), every get_sflow / epl_dot / C_tan reads it, and it is carried from call to call.  Here it is an
+ * explicit input and output per point: khard_in[n] (NULL: the material's khard) is what Material.khard holds when
+ * response() is entered, khard_out[n] what it holds on return.  Inside the load-step loop the library carries it per
+ * material point (state 11). */
+int plfx_response_batch_kh(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig, const double *epl,
+                           const double *deps, const double *khard_in, double *fy, double *sig_out, double *depl,
+                           double *ct, int32_t *nsteps, double *khard_out);
+/* calc_fgrad(sig, epl) of a PLFX_SVC_WH material on n points: gradient w.r.t. the stress and, per point, the raw value
+ * -sum_k dK/dx[6+k] * scale_seq / scale_wh whose mean over the points, clipped at 0, the reference stores in khard */
+int plfx_fgrad_batch_wh(plfx_ctx *ctx, int mat, int n, const double *sig, const double *epl, double *fgrad, double *khard_raw);
 
 /* Index products of Model.mesh for the reference's structured NX x NY grid, computed on the host (no context, no GPU):
  * conn[NX*NY*4] = [n1, n1+1, n1+NnodeY, n1+NnodeY+1] with n1 = (ih / NY) * NnodeY + ih % NY for element ih = j*NY + k
@@ -158,7 +174,8 @@ int plfx_get_kel(plfx_ctx *ctx, int e, double *Kel);
 /* ---------------------------------------------------------------- state (el.sig/eps/epl/elstiff, Model.u/f/du)
  * which: 0 sig, 1 eps, 2 epl, 3 res_sig, 4 res_depl  -> [nel_owned*6];  5 elstiff -> [nel_owned*36];
  *        6 u, 7 f, 8 du -> [ndof];  9 fyn (fy/sflow of the last sweep) -> [nel_owned];
- *        10 max_steps (stat_nlin) -> [nel_owned] as double */
+ *        10 max_steps (stat_nlin) -> [nel_owned] as double;  11 hardening modulus of every material point (PLFX_SVC_WH
+ *        materials: carried from sweep to sweep; others: the material's khard) -> [nel_owned] */
 int plfx_state_get(plfx_ctx *ctx, int which, double *out);
 int plfx_state_set(plfx_ctx *ctx, int which, const double *in);
 /* solve() first-call initialisation (model.py:1212-1234): zero u,f,sig,eps,epl; elstiff = CV */

@@ -870,7 +870,7 @@ def gen_fullyf_ld():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld,scaled_input,configs')
+    ap.add_argument('--only', default='material,element,mesh,solve,svc,mlparam,basic,fullyf_ld,scaled_input,configs,wh')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = args.only.split(',')
@@ -894,6 +894,8 @@ def main():
         gen_scaled_input()
     if 'configs' in todo:
         gen_configs()
+    if 'wh' in todo:
+        gen_wh()
 
 
 # ----------------------------------------------------------------------------
@@ -1052,6 +1054,132 @@ def gen_configs():
         print('cfg5_lam_8x4 %.1fs' % dt, fe.nsteps, fe.niter, rr1.n, rr2.n, fe.sgl[-1][1])
     np.savez_compressed(os.path.join(OUT, 'solve_configs.npz'), **rec)
     print('configs done')
+
+
+# ----------------------------------------------------------------------------
+# 11. SVC with work-hardening features: examples/train_hardening.py:23-79, 171-206 on a reduced data set
+#     (40 load cases, 3e-3 plastic strain increments, Nseq = 8 -> ~1000 support vectors x 15 features)
+# ----------------------------------------------------------------------------
+def train_hardening(Nlc=40, epl_max=0.03, depl=3.e-3, Nseq=8, khard=1000.0):
+    from scipy.optimize import fsolve
+    mat_h = FE.Material(name='Hill-reference', num=1)
+    mat_h.elasticity(E=200.e3, nu=0.3)
+    mat_h.plasticity(sy=50., rv=[1.2, 1.0, 0.8, 1.0, 1.0, 1.0], khard=khard, sdim=6)
+    nl3d = int(Nlc / 3)
+    sunit = FE.load_cases(number_3d=nl3d, number_6d=Nlc - nl3d)
+    x1 = fsolve(mat_h.find_yloc, np.ones(Nlc) * mat_h.sy, args=(sunit,), xtol=1.e-5)
+    sig_ideal = sunit * x1[:, None]
+    SV = np.linalg.inv(mat_h.CV)
+    lc_data = dict()
+    for i, st in enumerate(sig_ideal):   # create_data of the example
+        epl = np.zeros(6)
+        peeq = 0.0
+        sig_list, epl_list, etot_list = [], [], []
+        seq = FE.sig_eq_j2(st)
+        su = st / seq
+        ind = np.zeros(6, dtype=int)
+        for j, v in enumerate(su):
+            ind[j] = 1 if v > 0.0 else (2 if v < 0.0 else 0)
+        key = f'Us_A{ind[0]}B{ind[1]}C{ind[2]}D{ind[3]}E{ind[4]}F{ind[5]}_HI{i:03d}_NNNNN_Tx_NN'
+        dsig = seq / 5
+        for j in range(6):
+            sg = su * j * dsig
+            sig_list.append(sg)
+            epl_list.append(np.array(epl))
+            etot_list.append(np.dot(SV, sg))
+        while peeq < epl_max:
+            peeq = FE.eps_eq(epl) + depl
+            sg = su * (seq + peeq * khard)
+            epl += mat_h.calc_fgrad(sig=sg, epl=epl) * depl
+            sig_list.append(sg)
+            epl_list.append(np.array(epl))
+            etot_list.append(epl + np.dot(SV, sg))
+        sig_, epl_, etot_ = np.array(sig_list), np.array(epl_list), np.array(etot_list)
+        lc_data[key] = {"Stress": sig_, "Eq_Stress": FE.sig_eq_j2(sig_), "Strain_Plastic": epl_,
+                        "Eq_Strain_Plastic": FE.eps_eq(epl_), "Shifted_Strain_Plastic": None,
+                        "Strain_Total": etot_, "Eq_Strain_Total": FE.eps_eq(etot_)}
+    dd = FE.Data(lc_data, mat_name='ML_Hill_hardening', epl_start=0.0, epl_crit=0.0, epl_max=epl_max, depl=depl,
+                 wh_data=True)
+    ml = FE.Material(name='ML_Hill_hardening_C2.0_G1.5', num=2)
+    ml.from_data(dd.mat_data)
+    ml.train_SVC(C=2.0, gamma=1.5, Ce=0.99, Fe=0.1, Nseq=Nseq, gridsearch=False)
+    return ml, mat_h
+
+
+def gen_wh():
+    import contextlib
+    import io
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with contextlib.redirect_stdout(io.StringIO()):
+            ml, mat_h = train_hardening()
+        assert ml.whdat and ml.Ndof == 15 and ml.ind_wh == 6 and ml.sdim == 6
+        print('work-hardening SVC: %d SVs x %d features, scale_wh %.5f, scale_seq %.4f'
+              % (len(ml.svm_yf.support_vectors_), ml.Ndof, ml.scale_wh, ml.scale_seq))
+        rec = {('par_' + k): v for k, v in svc_params(ml).items()}
+        rec['par_scale_wh'] = np.array(float(ml.scale_wh))
+        rec['par_ind_wh'] = np.array(int(ml.ind_wh))
+        rec['par_epc'] = np.array(float(ml.epc))
+        rng = np.random.default_rng(21)
+        N = 240
+        u = rand_unit6(rng, N)
+        sig = u * (ml.sy * rng.uniform(0.3, 1.6, size=N))[:, None]
+        e = rng.normal(size=(N, 6))
+        e[:, :3] -= e[:, :3].mean(axis=1)[:, None]
+        e *= (rng.uniform(0., 0.03, size=N) / FE.eps_eq(e))[:, None]
+        e[:40] = 0.
+        rec['b_sig'], rec['b_epl'] = sig, e
+        rec['b_x'] = ml.create_scaled_input(sig, e, 0., 0., 0.)
+        rec['b_yf'] = ml.calc_yf(sig, epl=e)
+        fg, kh = np.zeros((N, 6)), np.zeros(N)
+        for i in range(N):
+            fg[i] = ml.calc_fgrad(sig[i], epl=e[i])
+            kh[i] = ml.khard
+        rec['b_fgrad'], rec['b_khard'] = fg, kh
+        ml.khard = 0.
+        fgb = ml.calc_fgrad(sig[:50], epl=e[:50])       # batched call: khard = mean over the points, clipped
+        rec['b_fgrad_batch50'], rec['b_khard_batch50'] = fgb, np.array(ml.khard)
+        nf = 80
+        kfix = rng.uniform(0., 900., size=nf)
+        fyf = np.zeros(nf)
+        for i in range(nf):
+            ml.khard = kfix[i]
+            fyf[i] = ml.ML_full_yf(sig[i], epl=e[i], verb=False)
+        rec['b_full_yf'], rec['b_full_yf_khard'] = fyf, kfix
+        for tag, ps in (('pe', False), ('ps', True)):
+            CVr = element_CV(ml, ps)
+            n = 72
+            s, ep, d = gen_response_inputs(ml, CVr, rng, n, True)
+            ep = rng.normal(size=(n, 6))
+            ep[:, :3] -= ep[:, :3].mean(axis=1)[:, None]
+            ep[:, 3:5] = 0.
+            ep *= (rng.uniform(0., 0.02, size=n) / FE.eps_eq(ep))[:, None]
+            ep[:24] = 0.
+            kin = rng.uniform(0., 900., size=n)
+            kin[:12] = 0.
+            out = [[], [], [], [], [], []]
+            for i in range(n):
+                ml.khard = kin[i]
+                fy, so, dp, ct = ml.response(s[i], ep[i], d[i], CVr)
+                for q, v in zip(out, (fy, so, dp, np.asarray(ct).reshape(36), ml.msg['nsteps'], ml.khard)):
+                    q.append(v)
+            print('wh response', tag, np.bincount(np.array(out[4])))
+            rec['r%s_CV' % tag], rec['r%s_sig' % tag], rec['r%s_epl' % tag], rec['r%s_deps' % tag] = CVr, s, ep, d
+            rec['r%s_khard_in' % tag] = kin
+            for k, q in zip(('fy', 'sig_out', 'depl', 'ct', 'nsteps', 'khard_out'), out):
+                rec['r%s_%s' % (tag, k)] = np.array(q)
+        # model level: 4x4 plane-strain tension; Material.khard starts at 0 and is carried through the element loop
+        ml.khard = 0.
+        fe = tension_model(ml, 4, 0.004)
+        t = time.time()
+        with SolveTracer() as tr:
+            fe.solve(min_step=8)
+        solve_record(fe, 'wh4', rec, time.time() - t)
+        tr.store(rec, 'wh4')
+        rec['wh4_khard_final'] = np.array(float(ml.khard))
+        print('wh4 %.1fs' % rec['wh4_tsolve'], fe.nsteps, fe.niter, fe.sgl[-1][1], 'khard', ml.khard)
+    np.savez_compressed(os.path.join(OUT, 'svc_workhard.npz'), **rec)
+    print('wh done')
 
 
 if __name__ == '__main__':

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libplfx_oracle.so')
 
-ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3 = 0, 1, 2, 3, 4, 5, 6
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3, SVC_WH = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class _Mat(C.Structure):
@@ -23,7 +23,7 @@ class _Mat(C.Structure):
                 ('dp', C.c_double * 3), ('nsv', C.c_int), ('ndof', C.c_int),
                 ('dev_only', C.c_int), ('gamma', C.c_double), ('intercept', C.c_double),
                 ('scale_seq', C.c_double), ('sv', C.c_void_p), ('dual', C.c_void_p),
-                ('barlat', C.c_double * 18), ('barlat_exp', C.c_double)]
+                ('barlat', C.c_double * 18), ('barlat_exp', C.c_double), ('scale_wh', C.c_double)]
 
 
 def build():
@@ -56,8 +56,9 @@ class Material(object):
 
     def __init__(self, kind=HILL6, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., sdim=6,
                  sv=None, dual=None, gamma=0., intercept=0., scale_seq=1., dev_only=False,
-                 barlat=None, barlat_exp=0.):
+                 barlat=None, barlat_exp=0., scale_wh=1.):
         m = _Mat()
+        m.scale_wh = scale_wh
         m.kind = kind
         m.sdim = sdim
         m.E, m.nu, m.sy, m.khard = E, nu, sy, khard
@@ -84,6 +85,12 @@ class Material(object):
     @classmethod
     def from_golden(cls, z, prefix='par_'):
         """Build from the ``par_*`` entries written by oracle/gen_golden.py."""
+        if prefix + 'sv' in z and z[prefix + 'sv'].shape[1] == 15:   # work-hardening features
+            return cls(kind=SVC_WH, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']), sy=float(z[prefix + 'sy']),
+                       khard=float(z[prefix + 'khard']), hill=z[prefix + 'hill'], sv=z[prefix + 'sv'], dual=z[prefix + 'dual'],
+                       gamma=float(z[prefix + 'gamma']), intercept=float(z[prefix + 'intercept']),
+                       scale_seq=float(z[prefix + 'scale_seq']), dev_only=bool(z[prefix + 'dev_only']),
+                       scale_wh=float(z[prefix + 'scale_wh']))
         if prefix + 'sv' in z:
             return cls(kind=SVC6 if int(z[prefix + 'sdim']) == 6 else SVC3, E=float(z[prefix + 'E']), nu=float(z[prefix + 'nu']),
                        sy=float(z[prefix + 'sy']), khard=float(z[prefix + 'khard']),
@@ -231,3 +238,62 @@ def pcg_csr(K, b, free, x0, rtol=1.e-10, maxit=200000, nthreads=0):
     its = f(int(n), _p(indptr), _p(indices), _p(data), _p(_c(b)), _p(fm), _p(x), C.c_double(rtol), int(maxit),
             int(nthreads), C.byref(rel))
     return x, int(its), float(rel.value)
+
+
+# ---- work-hardening-aware SVC materials (kind SVC_WH): Material.khard is explicit state
+def fgrad_wh(mat, sig, epl=None):
+    """calc_fgrad(sig, epl) point by point: (gradient (N,6), raw hardening value (N,))"""
+    sig = _c(sig).reshape(-1, 6)
+    n = len(sig)
+    e = None if epl is None else _c(epl).reshape(-1, 6)
+    a = np.empty((n, 6))
+    kh = np.empty(n)
+    lib().plfo_fgrad_wh_batch(C.byref(mat.c), n, _p(sig), None if e is None else _p(e), _p(a), _p(kh))
+    return a, kh
+
+
+def full_yf_wh(mat, sig, epl=None, khard=None):
+    sig = _c(sig).reshape(-1, 6)
+    n = len(sig)
+    e = None if epl is None else _c(epl).reshape(-1, 6)
+    k = None if khard is None else _c(np.broadcast_to(np.asarray(khard, dtype=float), (n,)).copy())
+    out = np.empty(n)
+    lib().plfo_full_yf_wh_batch(C.byref(mat.c), n, _p(sig), None if e is None else _p(e), None if k is None else _p(k), _p(out))
+    return out
+
+
+def response_wh(mats, CVs, sig, epl, deps, khard_in=None, mat_id=None, sequential=False, nthreads=0):
+    """response() with the hardening modulus as state.  sequential=False: per point, khard_in / khard_out are (N,).
+    sequential=True: ONE material object per material carried through the points in index order (the reference's loop over
+    the elements); khard_in / khard_out are (nmat,)."""
+    if isinstance(mats, Material):
+        mats = [mats]
+    sig = _c(sig).reshape(-1, 6)
+    n = len(sig)
+    epl = _c(epl).reshape(-1, 6)
+    deps = _c(deps).reshape(-1, 6)
+    CVs = _c(CVs).reshape(len(mats), 36)
+    mid = np.zeros(n, dtype=np.int32) if mat_id is None else _c(mat_id, np.int32)
+    nk = len(mats) if sequential else n
+    kin = None if khard_in is None else _c(np.broadcast_to(np.asarray(khard_in, dtype=float), (nk,)).copy())
+    kout = np.zeros(nk)
+    fy = np.zeros(n)
+    so = np.zeros((n, 6))
+    dp = np.zeros((n, 6))
+    ct = np.zeros((n, 36))
+    ns = np.zeros(n, dtype=np.int32)
+    kpt = np.zeros(n)
+    lib().plfo_response_wh_batch(_mat_array(mats), n, _p(mid), _p(sig), _p(epl), _p(deps), _p(CVs),
+                                 None if kin is None else _p(kin), _p(fy), _p(so), _p(dp), _p(ct), _p(ns), _p(kout),
+                                 int(bool(sequential)), int(nthreads), _p(kpt))
+    if sequential:
+        return fy, so, dp, ct, ns, kout, kpt
+    return fy, so, dp, ct, ns, kout
+
+
+def yf_wh(mat, sig, epl=None):
+    sig = _c(sig).reshape(-1, 6)
+    e = None if epl is None else _c(epl).reshape(-1, 6)
+    out = np.empty(len(sig))
+    lib().plfo_yf_wh_batch(C.byref(mat.c), len(sig), _p(sig), None if e is None else _p(e), _p(out))
+    return out

@@ -306,8 +306,38 @@ static double svc_decision(const plfo_material *m, const double sig[6]) /* mater
     return f + m->intercept;
 }
 
+/* create_scaled_input with work-hardening features (material.py:2334-2346): 6 stress features, epl / scale_wh, then
+ * accumulated strain, max. stress / scale_seq and flag, which response / Model.solve leave at their defaults 0 */
+static void wh_features(const plfo_material *m, const double sig[6], const double epl[6], double x[15])
+{
+    double s[6];
+    if (m->dev_only)
+        plfo_sig_dev(sig, s);
+    else
+        memcpy(s, sig, sizeof(s));
+    for (int i = 0; i < 6; i++) x[i] = s[i] / m->scale_seq;
+    for (int i = 0; i < 6; i++) x[6 + i] = (epl ? epl[i] : 0.) / m->scale_wh;
+    x[12] = 0.;
+    x[13] = 0. / m->scale_seq;
+    x[14] = 0.;
+}
+
+static double svc_wh_decision(const plfo_material *m, const double sig[6], const double epl[6])
+{
+    double x[15], f = 0.;
+    wh_features(m, sig, epl, x);
+    for (int k = 0; k < m->nsv; k++) {
+        const double *v = m->sv + (size_t)k * 15;
+        double hh = 0.;
+        for (int i = 0; i < 15; i++) hh += (x[i] - v[i]) * (x[i] - v[i]);
+        f += m->dual[k] * exp(-m->gamma * hh);
+    }
+    return f + m->intercept;
+}
+
 double plfo_calc_yf(const plfo_material *m, const double sig[6], const double epl[6]) /* material.py:378-411 */
 {
+    if (m->kind == PLFO_SVC_WH) return svc_wh_decision(m, sig, epl);
     if (m->kind == PLFO_SVC6) return svc_decision(m, sig);
     if (m->kind == PLFO_SVC3) return svc3_decision(m, sig);
     return plfo_calc_seq(m, sig) - plfo_get_sflow(m, epl);
@@ -372,8 +402,43 @@ static void barlat_fgrad(const plfo_material *m, const double sv[6], double a[6]
     for (int i = 3; i < 6; i++) a[i] = sc * h[i];
 }
 
+void plfo_calc_fgrad_wh(const plfo_material *m, const double sig[6], const double epl[6], double a[6], double *kh_raw)
+{   /* material.py:797-814 for whdat materials, N = 1 */
+    double x[15], dK[15];
+    wh_features(m, sig, epl, x);
+    for (int i = 0; i < 15; i++) dK[i] = 0.;
+    for (int k = 0; k < m->nsv; k++) { /* grad_rbf, :768-778 */
+        const double *v = m->sv + (size_t)k * 15;
+        double hv[15], hh = 0.;
+        for (int i = 0; i < 15; i++) {
+            hv[i] = x[i] - v[i];
+            hh += hv[i] * hv[i];
+        }
+        double kk = exp(-m->gamma * hh);
+        for (int i = 0; i < 15; i++) dK[i] += m->dual[k] * (kk * (-2. * m->gamma * hv[i]));
+    }
+    for (int i = 0; i < 6; i++) a[i] = dK[i] / m->scale_seq; /* :807 */
+    double hk = 0.;
+    for (int i = 6; i < 12; i++) hk -= dK[i] * m->scale_seq / m->scale_wh; /* :808-809, ind_wh = 6 */
+    if (kh_raw) *kh_raw = hk;
+    ((plfo_material *)m)->khard = hk < 0. ? 0. : hk; /* :811-814: self.khard = ... (the caller owns a private copy) */
+}
+
+/* calc_fgrad(sig, epl=epl) as epl_dot / C_tan call it (material.py:1050, 1082) */
+static void fgrad_epl(const plfo_material *m, const double sig[6], const double epl[6], double a[6])
+{
+    if (m->kind == PLFO_SVC_WH)
+        plfo_calc_fgrad_wh(m, sig, epl, a, NULL);
+    else
+        plfo_calc_fgrad(m, sig, a);
+}
+
 void plfo_calc_fgrad(const plfo_material *m, const double sig[6], double a[6]) /* material.py:765-845 */
 {
+    if (m->kind == PLFO_SVC_WH) { /* epl = None -> zeros (:734-735) */
+        plfo_calc_fgrad_wh(m, sig, NULL, a, NULL);
+        return;
+    }
     if (m->kind == PLFO_BARLAT) {
         barlat_fgrad(m, sig, a);
         return;
@@ -611,13 +676,23 @@ void plfo_epl_dot(const plfo_material *m, const double sig[6], const double epl[
         return;
     }
     double a[6], ca[6];
-    plfo_calc_fgrad(m, sig, a);
+    fgrad_epl(m, sig, epl, a); /* calc_fgrad(sig, epl=epl): a work-hardening SVC overwrites khard here (:1050) */
     matvec6(Cel, a, ca);
     double hh = dot6(a, ca) + m->khard;
     double cd[6];
     matvec6(Cel, deps, cd);
     double lam = dot6(a, cd) / hh;
     for (int i = 0; i < 6; i++) pdot[i] = lam * a[i];
+}
+
+static void C_tan_epl(const plfo_material *m, const double sig[6], const double epl[6], const double Cel[36], double Ct[36])
+{   /* C_tan(sig, CV, epl=epl) as response calls it (material.py:278, 299, 1076-1086) */
+    double a[6], ca[6];
+    fgrad_epl(m, sig, epl, a);
+    matvec6(Cel, a, ca);
+    double hh = dot6(a, ca) + m->khard;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) Ct[i * 6 + j] = Cel[i * 6 + j] - ca[i] * ca[j] / hh;
 }
 
 void plfo_C_tan(const plfo_material *m, const double sig[6], const double Cel[36], double Ct[36]) /* material.py:1076-1086 */
@@ -632,7 +707,7 @@ void plfo_C_tan(const plfo_material *m, const double sig[6], const double Cel[36
 
 static double resp_yf(const plfo_material *m, const double s[6], const double e[6])
 {
-    if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3) return plfo_ML_full_yf(m, s, e, NULL); /* material.py:249-252 */
+    if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3 || m->kind == PLFO_SVC_WH) return plfo_ML_full_yf(m, s, e, NULL); /* material.py:249-252 */
     return plfo_calc_yf(m, s, e);
 }
 
@@ -657,7 +732,7 @@ int plfo_response(const plfo_material *m, const double sig_in[6], const double e
         double deps_r[6];
         double fy0 = plfo_calc_yf(m, sig, epl); /* :259 */
         if (fy0 < -0.15) {
-            if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3) fy0 = plfo_ML_full_yf(m, sig, NULL, NULL); /* :265 */
+            if (m->kind == PLFO_SVC6 || m->kind == PLFO_SVC3 || m->kind == PLFO_SVC_WH) fy0 = plfo_ML_full_yf(m, sig, NULL, NULL); /* :265 */
             st_scal += fy0 / plfo_calc_seq(m, dsig);                             /* :266 */
             double deps_el[6], ds_el[6];
             for (int i = 0; i < 6; i++) deps_el[i] = deps[i] * (1. - st_scal);
@@ -671,7 +746,7 @@ int plfo_response(const plfo_material *m, const double sig_in[6], const double e
         }
         double ddepl[6], T[36], eplt[6];
         plfo_epl_dot(m, sig, epl, CV, deps_r, ddepl); /* :277 */
-        plfo_C_tan(m, sig, CV, T);                    /* :278 */
+        C_tan_epl(m, sig, epl, CV, T);                    /* :278 */
         for (int i = 0; i < 6; i++) eplt[i] = epl[i] + depl[i] + ddepl[i];
         matvec6(T, deps_r, dsig);
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsig[i];
@@ -685,7 +760,7 @@ int plfo_response(const plfo_material *m, const double sig_in[6], const double e
         }
         for (niter = 0; niter < nsteps; niter++) { /* :295 */
             plfo_epl_dot(m, sig, epl, CV, deps_r, ddepl);
-            plfo_C_tan(m, sig, CV, T);
+            C_tan_epl(m, sig, epl, CV, T);
             for (int i = 0; i < 6; i++) eplt[i] = epl[i] + depl[i] + ddepl[i];
             matvec6(T, deps_r, dsig);
             for (int i = 0; i < 6; i++) sig[i] += dsig[i];
@@ -975,4 +1050,82 @@ int plfo_pcg_csr(int n, const int *indptr, const int *indices, const double *dat
     free(q);
     free(dinv);
     return it;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Work-hardening-aware SVC materials (PLFO_SVC_WH): batched drivers with the hardening modulus as explicit state. */
+void plfo_fgrad_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, double *a, double *kh_raw)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        plfo_material mm = *m;
+        plfo_calc_fgrad_wh(&mm, sig + 6 * (size_t)i, epl ? epl + 6 * (size_t)i : NULL, a + 6 * (size_t)i, kh_raw ? kh_raw + i : NULL);
+    }
+}
+
+void plfo_yf_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, double *yf)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) yf[i] = svc_wh_decision(m, sig + 6 * (size_t)i, epl ? epl + 6 * (size_t)i : NULL);
+}
+
+void plfo_full_yf_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, const double *khard, double *yf)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++) {
+        plfo_material mm = *m;
+        if (khard) mm.khard = khard[i];
+        yf[i] = plfo_ML_full_yf(&mm, sig + 6 * (size_t)i, epl ? epl + 6 * (size_t)i : NULL, NULL);
+    }
+}
+
+void plfo_response_wh_batch(const plfo_material *mats, int n, const int *mat_id, const double *sig, const double *epl,
+                            const double *deps, const double *CV, const double *khard_in, double *fy, double *sig_out,
+                            double *depl, double *ct, int *nsteps, double *khard_out, int sequential, int nthreads,
+                            double *kh_point /* [n] or NULL: Material.khard right after each point's call */)
+{
+    if (sequential) { /* one Material object per material, mutated call after call in index order (model.py:1340-1359) */
+        int nmat = 0;
+        for (int i = 0; i < n; i++)
+            if ((mat_id ? mat_id[i] : 0) + 1 > nmat) nmat = (mat_id ? mat_id[i] : 0) + 1;
+        plfo_material *mm = (plfo_material *)malloc(sizeof(plfo_material) * nmat);
+        for (int k = 0; k < nmat; k++) mm[k] = mats[k];
+        if (khard_in)
+            for (int k = 0; k < nmat; k++) mm[k].khard = khard_in[k]; /* [nmat] entry values */
+        for (int i = 0; i < n; i++) {
+            const int mid = mat_id ? mat_id[i] : 0;
+            if (mm[mid].kind == PLFO_ELASTIC) {
+                nsteps[i] = -1;
+                continue;
+            }
+            nsteps[i] = plfo_response(&mm[mid], sig + 6 * (size_t)i, epl + 6 * (size_t)i, deps + 6 * (size_t)i,
+                                      CV + 36 * (size_t)mid, &fy[i], sig_out + 6 * (size_t)i, depl + 6 * (size_t)i,
+                                      ct + 36 * (size_t)i);
+            if (kh_point) kh_point[i] = mm[mid].khard;
+        }
+        if (khard_out)
+            for (int k = 0; k < nmat; k++) khard_out[k] = mm[k].khard; /* [nmat] exit values */
+        free(mm);
+        return;
+    }
+#ifdef _OPENMP
+    const int nt = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+        const int mid = mat_id ? mat_id[i] : 0;
+        plfo_material mm = mats[mid];
+        if (khard_in) mm.khard = khard_in[i];
+        if (mm.kind == PLFO_ELASTIC) {
+            nsteps[i] = -1;
+            if (khard_out) khard_out[i] = mm.khard;
+            continue;
+        }
+        nsteps[i] = plfo_response(&mm, sig + 6 * (size_t)i, epl + 6 * (size_t)i, deps + 6 * (size_t)i, CV + 36 * (size_t)mid,
+                                  &fy[i], sig_out + 6 * (size_t)i, depl + 6 * (size_t)i, ct + 36 * (size_t)i);
+        if (khard_out) khard_out[i] = mm.khard;
+        if (kh_point) kh_point[i] = mm.khard;
+    }
 }

@@ -20,7 +20,8 @@ extern "C" {
 #endif
 
 enum { PLFO_ELASTIC = 0, PLFO_HILL6 = 1, PLFO_PRINC3 = 2, PLFO_SVC6 = 3, PLFO_TRESCA = 4, PLFO_BARLAT = 5,
-       PLFO_SVC3 = 6 /* sdim=3 ML material: 2 features (seq_J2/scale - 1, polar angle/pi), material.py:2330-2333 */ };
+       PLFO_SVC3 = 6, /* sdim=3 ML material: 2 features (seq_J2/scale - 1, polar angle/pi), material.py:2330-2333 */
+       PLFO_SVC_WH = 7 /* 6-feature SVC + work-hardening features (material.py:2342-2346): ndof = 15, khard is mutable state */ };
 
 typedef struct plfo_material {
     int kind;            /* PLFO_* */
@@ -37,6 +38,7 @@ typedef struct plfo_material {
     /* Barlat Yld2004-18p (material.py:2575-2591): 18 coefficients and exponent; calc_seq only */
     double barlat[18];
     double barlat_exp;
+    double scale_wh;     /* PLFO_SVC_WH: scaling of the plastic-strain features (material.py:1165-1172, 2343) */
 } plfo_material;
 
 /* basic.py:304 sig_dev, :328 eps_eq */
@@ -105,6 +107,21 @@ void plfo_strain_batch(int nel, const int *conn /* [nel*4] */, const double *lxy
 /* Kred + np.linalg.solve (model.py:1028-1033, 1291) as Jacobi-PCG on the CSR matrix, free DOFs only (OpenMP rows) */
 int plfo_pcg_csr(int n, const int *indptr, const int *indices, const double *data, const double *b,
                  const unsigned char *free_mask, double *x, double rtol, int maxit, int nthreads, double *relres);
+
+/* PLFO_SVC_WH: the reference's Material.khard is ONE mutable attribute that every calc_fgrad call overwrites
+ * (material.py:808-814) and get_sflow / epl_dot / C_tan read.  plfo_calc_fgrad_wh is calc_fgrad(sig, epl) for a single point: it
+ * writes the new value into m->khard THROUGH the const pointer (callers pass a private copy of the material, exactly like the
+ * Python object is mutated); *kh_raw receives the unclipped value.  plfo_response_wh_batch: response() per point on a private
+ * copy that starts with khard_in[i] (NULL: m->khard) and leaves khard_out[i]; sequential != 0 instead carries ONE copy through
+ * the points in index order -- what a loop of response() calls over the elements does in Model.solve. */
+void plfo_calc_fgrad_wh(const plfo_material *m, const double sig[6], const double epl[6], double a[6], double *kh_raw);
+void plfo_fgrad_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, double *a, double *kh_raw);
+void plfo_yf_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, double *yf);
+void plfo_full_yf_wh_batch(const plfo_material *m, int n, const double *sig, const double *epl, const double *khard, double *yf);
+void plfo_response_wh_batch(const plfo_material *mats, int n, const int *mat_id, const double *sig, const double *epl,
+                            const double *deps, const double *CV, const double *khard_in, double *fy, double *sig_out,
+                            double *depl, double *ct, int *nsteps, double *khard_out, int sequential, int nthreads,
+                            double *kh_point /* [n] or NULL: Material.khard right after each point's call */);
 
 /* scipy 1.15.3 optimize.brentq (Brent 1973) on a scalar callback */
 typedef double (*plfo_fn)(double x, void *ctx);

@@ -47,11 +47,18 @@ class RefSolver(object):
         self.thick = m.thick
         self.mats = []
         self.CVs = []
+        self.has_wh = False
         for mat in m.mat:
             CV = self.element_CV(mat)
             self.CVs.append(CV.reshape(36))
             if mat.sy is None:
                 self.mats.append(O.Material(kind=O.ELASTIC, E=mat.E, nu=mat.nu))
+            elif mat.ML_yf and getattr(mat, 'whdat', False):   # work-hardening-aware SVC: khard is state of the material
+                self.mats.append(O.Material(kind=O.SVC_WH, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
+                                            hill=mat.hill, sv=mat.svc['sv'], dual=mat.svc['dual'],
+                                            gamma=mat.gam_yf, intercept=mat.svc['intercept'],
+                                            scale_seq=mat.scale_seq, dev_only=mat.dev_only, scale_wh=mat.scale_wh))
+                self.has_wh = True
             elif mat.ML_yf:
                 self.mats.append(O.Material(kind=O.SVC6, E=mat.E, nu=mat.nu, sy=mat.sy, khard=mat.khard,
                                             hill=mat.hill, sv=mat.svc['sv'], dual=mat.svc['dual'],
@@ -196,9 +203,11 @@ class RefSolver(object):
     def strain(self, u):
         return O.strain_batch(self.conn, self.lxy, self.mat_id, self.ps, self.CVs, self.Es, self.nus, u)
 
-    def sflow(self, epl, sel=None):
+    def sflow(self, epl, sel=None, kh=None):
         sy = np.array([0. if mm.sy is None else mm.sy for mm in self.m.mat])[self.mat_id]
-        kh = np.array([0. if mm.khard is None else mm.khard for mm in self.m.mat])[self.mat_id]
+        if kh is None:   # per material: the value the material object holds now
+            kh = (self.khard_mat if self.has_wh else
+                  np.array([0. if mm.khard is None else mm.khard for mm in self.m.mat]))[self.mat_id]
         if sel is not None:
             sy, kh = sy[sel], kh[sel]
         e = epl
@@ -219,9 +228,11 @@ class RefSolver(object):
             sel, sref = sel[act], sref[act]
             if len(sel) == 0:
                 continue
+            if om.c.kind == O.SVC_WH:
+                om.c.khard = float(self.khard_mat[k])   # the material object's current (mutable) hardening modulus
             yf0 = O.calc_yf(om, self.sig[sel], self.epl[sel])
             low = yf0 < -0.15
-            if om.c.kind == O.SVC6 and np.any(low):  # model.py:1049-1053: full yield function along the loading direction
+            if om.c.kind in (O.SVC6, O.SVC_WH) and np.any(low):  # model.py:1049-1053: full yield function along the loading direction
                 yf0 = np.array(yf0)
                 yf0[low] = O.ML_full_yf_ld(om, self.sig[sel][low], self.epl[sel][low], sld)
             hh = np.where(low, np.minimum(1., -yf0 / sref),
@@ -243,6 +254,7 @@ class RefSolver(object):
         self.eps = np.zeros((self.nel, 6))
         self.epl = np.zeros((self.nel, 6))
         self.elstiff = np.array(self.CVs[self.mat_id])
+        self.khard_mat = np.array([0. if mm.khard is None else float(mm.khard) for mm in self.m.mat])
         sgl, egl, epgl = [np.zeros(6)], [np.zeros(6)], [np.zeros(6)]
         bcr0 = np.zeros(2)
         bct0 = np.zeros(2)
@@ -301,11 +313,21 @@ class RefSolver(object):
                     du = self.lin_solve(K, m.bcl, m.bcb, dbcr, dbct, dbcn)
                     t = time.perf_counter()
                     deps = self.strain(du)
-                    fy, res_sig, res_depl, ct, ns = O.response(self.mats, self.CVs, self.sig, self.epl, deps,
-                                                               mat_id=self.mat_id, nthreads=self.nthreads)
+                    if self.has_wh:
+                        # the reference's loop over the elements mutates ONE khard per Material object, call after call
+                        # (material.py:808-814): run the points in index order and carry the value from sweep to sweep
+                        fy, res_sig, res_depl, ct, ns, self.khard_mat, kh_pt = O.response_wh(
+                            self.mats, self.CVs, self.sig, self.epl, deps, khard_in=self.khard_mat, mat_id=self.mat_id,
+                            sequential=True)
+                    else:
+                        fy, res_sig, res_depl, ct, ns = O.response(self.mats, self.CVs, self.sig, self.epl, deps,
+                                                                   mat_id=self.mat_id, nthreads=self.nthreads)
                     self.timers['sweep'] += time.perf_counter() - t
                     self.timers['n_sweeps'] += 1
-                    f = np.where(self.plastic, fy / np.where(self.plastic, self.sflow(self.epl), 1.), 0.)
+                    if self.has_wh:   # f = fy / get_sflow(el.epl) inside the loop: khard as the element's call left it (:1345)
+                        f = np.where(self.plastic, fy / np.where(self.plastic, self.sflow(self.epl, kh=kh_pt), 1.), 0.)
+                    else:
+                        f = np.where(self.plastic, fy / np.where(self.plastic, self.sflow(self.epl), 1.), 0.)
                     hh = np.linalg.norm(self.elstiff - ct, axis=1)
                     upd = self.plastic & (hh > 1.e-3)
                     if nit < 15:

@@ -13,10 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PLFX_LIB', os.path.join(_HERE, 'libplfx.so'))  # PLFX_LIB: kernel-variant experiments
 
 # yield-function kinds (include/plfx.h)
-ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3 = 0, 1, 2, 3, 4, 5, 6
+ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3, SVC_WH = 0, 1, 2, 3, 4, 5, 6, 7
 
 # state ids of plfx_state_get/_set
-ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS = range(11)
+ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS, ST_KHARD = range(12)
 
 # timing families
 T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE, T_VCYCLE, T_SMOOTH, T_SWEEP_HEAVY = range(7)
@@ -33,7 +33,8 @@ class CMaterial(C.Structure):
                 ('nfeat', C.c_int32), ('dev_only', C.c_int32), ('_pad', C.c_int32),
                 ('gamma', C.c_double), ('intercept', C.c_double), ('scale_seq', C.c_double),
                 ('sv', C.c_void_p), ('dual', C.c_void_p), ('barlat', C.c_double * 18),
-                ('barlat_exp', C.c_double), ('barlat_normal', C.c_int32), ('_pad2', C.c_int32)]
+                ('barlat_exp', C.c_double), ('barlat_normal', C.c_int32), ('_pad2', C.c_int32),
+                ('scale_wh', C.c_double)]
 
 
 # every symbol include/plfx.h declares (tests/test_abi.py checks the library exports them all)
@@ -49,6 +50,7 @@ SYMBOLS = [
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
+    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh',
 ]
 
 _lib = None
@@ -144,6 +146,7 @@ def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0.,
         m.gamma = float(svc['gamma'])
         m.intercept = float(svc['intercept'])
         m.scale_seq = float(svc['scale_seq'])
+        m.scale_wh = float(svc.get('scale_wh', 1.) or 1.)
         m.sv = sv.ctypes.data
         m.dual = dual.ctypes.data
     return m, keep
@@ -222,6 +225,15 @@ class Context(object):
         self._chk(self.lib.plfx_fgrad_batch(self.h, int(mat), len(sig), _dp(sig), _dp(out)))
         return out
 
+    def fgrad_wh(self, mat, sig, epl=None):
+        """calc_fgrad(sig, epl) of a work-hardening SVC material: (gradient (N,6), raw hardening value per point (N,))"""
+        sig = _f64(sig).reshape(-1, 6)
+        epl = np.zeros_like(sig) if epl is None else _f64(epl).reshape(-1, 6)
+        out = np.empty_like(sig)
+        kh = np.empty(len(sig))
+        self._chk(self.lib.plfx_fgrad_batch_wh(self.h, int(mat), len(sig), _dp(sig), _dp(epl), _dp(out), _dp(kh)))
+        return out, kh
+
     def yf(self, mat, sig, epl=None):
         sig = _f64(sig).reshape(-1, 6)
         epl = np.zeros_like(sig) if epl is None else _f64(epl).reshape(-1, 6)
@@ -239,7 +251,8 @@ class Context(object):
                                               _dp(out), _dp(st)))
         return out, st
 
-    def response(self, sig, epl, deps, mat_id=None):
+    def response(self, sig, epl, deps, mat_id=None, khard_in=None, return_khard=False):
+        """khard_in / return_khard: entry / exit value of Material.khard per point (work-hardening SVC materials)"""
         sig = _f64(sig).reshape(-1, 6)
         n = len(sig)
         epl = _f64(epl).reshape(-1, 6)
@@ -250,6 +263,14 @@ class Context(object):
         dp = np.empty((n, 6))
         ct = np.empty((n, 36))
         ns = np.empty(n, dtype=np.int32)
+        if khard_in is not None or return_khard:
+            kin = None if khard_in is None else _f64(np.broadcast_to(np.asarray(khard_in, dtype=float), (n,)).copy())
+            kout = np.empty(n)
+            self._chk(self.lib.plfx_response_batch_kh(self.h, n, _dp(mid), _dp(sig), _dp(epl), _dp(deps), _dp(kin),
+                                                      _dp(fy), _dp(so), _dp(dp), _dp(ct), _dp(ns), _dp(kout)))
+            if return_khard:
+                return fy, so, dp, ct, ns, kout
+            return fy, so, dp, ct, ns
         self._chk(self.lib.plfx_response_batch(self.h, n, _dp(mid), _dp(sig), _dp(epl), _dp(deps),
                                                _dp(fy), _dp(so), _dp(dp), _dp(ct), _dp(ns)))
         return fy, so, dp, ct, ns
@@ -323,7 +344,7 @@ class Context(object):
     def state_get(self, which):
         if which in (ST_U, ST_F, ST_DU):
             out = np.empty(self.ndof)
-        elif which in (ST_FYN, ST_MAXSTEPS):
+        elif which in (ST_FYN, ST_MAXSTEPS, ST_KHARD):
             out = np.empty(self.nel_owned)
         elif which == ST_ELSTIFF:
             out = np.empty((self.nel_owned, 36))

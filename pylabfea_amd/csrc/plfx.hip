@@ -137,6 +137,7 @@ struct plfx_ctx {
     std::vector<double *> dsv;  // owned device copies of sv/dual
     bool has_svc = false, has_svc3 = false, has_analytic = false, has_elastic = false, has_princ = false;
     bool has_barlat = false;     // Barlat material with the native normal (plfx_material.barlat_normal)
+    bool has_svcwh = false;      // SVC with work-hardening features (PLFX_SVC_WH)
     int n_noflow = 0;            // materials without a flow rule (Tresca, Barlat without the native normal)
     int svc_lds_need = 0;
     int svc_wave_mat = -1;       // 6-feature SVC material run by the wave-per-element sweep kernels (-1: none)
@@ -168,6 +169,7 @@ struct plfx_ctx {
     // element state (owned)
     double *sig = nullptr, *epl = nullptr, *eps = nullptr, *res_sig = nullptr, *res_depl = nullptr;
     double *elstiff = nullptr, *Mel = nullptr, *fyn = nullptr, *scf_hh = nullptr;
+    double *kh_el = nullptr;   // hardening modulus per material point (work-hardening SVC: mutable, carried from sweep to sweep)
     int32_t *max_steps = nullptr, *scf_mult = nullptr, *heavy_list = nullptr;
     // dof vectors
     double *u = nullptr, *f = nullptr, *du = nullptr, *rhs = nullptr, *dinv = nullptr, *diag = nullptr,
@@ -643,6 +645,7 @@ void free_mesh(plfx_ctx *c)
     dfree(c->Mel);
     dfree(c->fyn);
     dfree(c->scf_hh);
+    dfree(c->kh_el);
     dfree(c->max_steps);
     dfree(c->scf_mult);
     dfree(c->heavy_list);
@@ -747,7 +750,7 @@ bool tail_mf(const plfx_ctx *c)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
     } while (0)
 
-size_t dyn_lds_bytes(const plfx_ctx *c) { return (c->has_svc || c->has_svc3) ? (size_t)c->svc_lds_need * 8 : 0; }
+size_t dyn_lds_bytes(const plfx_ctx *c) { return (c->has_svc || c->has_svc3 || c->has_svcwh) ? (size_t)c->svc_lds_need * 8 : 0; }
 
 int plain_spmv(plfx_ctx *c, const double *in, double *out)
 {
@@ -1374,6 +1377,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     free_materials(c);
     c->has_svc = c->has_svc3 = c->has_analytic = c->has_elastic = c->has_princ = false;
     c->has_barlat = false;
+    c->has_svcwh = false;
     c->n_noflow = 0;
     c->svc_lds_need = 0;
     c->svc_wave_mat = -1;
@@ -1385,7 +1389,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         const plfx_material &s = mats[k];
         MatDev &m = c->hmat[k];
         memset(&m, 0, sizeof(m));
-        if (s.kind < PLFX_ELASTIC || s.kind > PLFX_SVC3)
+        if (s.kind < PLFX_ELASTIC || s.kind > PLFX_SVC_WH)
             return fail(c, PLFX_ERR_ARG, "material %d: unknown kind %d", k, s.kind);
         for (int i = 0; i < 6; i++)
             for (int j = i + 1; j < 6; j++)
@@ -1423,8 +1427,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         if (s.kind == PLFX_ELASTIC) c->has_elastic = true;
         if (s.kind == PLFX_BARLAT && s.barlat_normal) c->has_barlat = true;
         if (s.kind == PLFX_TRESCA || (s.kind == PLFX_BARLAT && !s.barlat_normal)) c->n_noflow++;
-        if (s.kind == PLFX_SVC6 || s.kind == PLFX_SVC3) {
-            const int nf = (s.kind == PLFX_SVC6) ? 6 : 2;
+        if (s.kind == PLFX_SVC6 || s.kind == PLFX_SVC3 || s.kind == PLFX_SVC_WH) {
+            const int nf = (s.kind == PLFX_SVC6) ? 6 : (s.kind == PLFX_SVC3) ? 2 : 15;
+            if (s.kind == PLFX_SVC_WH && !(s.scale_wh > 0.)) return fail(c, PLFX_ERR_ARG, "material %d: scale_wh must be positive", k);
             if (s.nsv < 1 || s.nfeat != nf || !s.sv || !s.dual)
                 return fail(c, PLFX_ERR_ARG, "material %d: SVC needs nsv>=1, nfeat==%d, sv and dual", k, nf);
             double *dsv = nullptr, *ddu = nullptr;
@@ -1442,8 +1447,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             m.gamma = s.gamma;
             m.intercept = s.intercept;
             m.scale_seq = s.scale_seq;
+            m.scale_wh = (s.kind == PLFX_SVC_WH) ? s.scale_wh : 1.;
             if (s.nsv * (nf + 1) <= c->lds_doubles) c->svc_lds_need = std::max(c->svc_lds_need, s.nsv * (nf + 1));
-            if (s.kind == PLFX_SVC6) c->has_svc = true; else c->has_svc3 = true;
+            if (s.kind == PLFX_SVC6) c->has_svc = true; else if (s.kind == PLFX_SVC3) c->has_svc3 = true; else c->has_svcwh = true;
             if (s.kind == PLFX_SVC6) {
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
@@ -1463,7 +1469,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1>, c->svc_wave_lds));
     }
-    if (c->has_svc || c->has_svc3) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
+    if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
         HIPCHK(c, set_dyn_lds((const void *)k_response_batch<3>, bytes));
         HIPCHK(c, set_dyn_lds((const void *)k_response_batch<6>, bytes));
@@ -1473,6 +1479,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_light<3>, bytes));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_heavy<3>, bytes));
         HIPCHK(c, set_dyn_lds((const void *)k_scf_elements, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_response_batch<7>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_light<7>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_heavy<7>, bytes));
     }
     c->M_dirty = true;
     c->memo.valid = false;
@@ -1536,9 +1545,9 @@ int plfx_full_yf_batch(plfx_ctx *c, int mat, int n, const double *sig, const dou
     return point_eval(c, 3, mat, n, sig, epl, ld, yf, status);
 }
 
-int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double *sig,
-                        const double *epl, const double *deps, double *fy, double *sig_out,
-                        double *depl, double *ct, int32_t *nsteps)
+static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const double *sig,
+                               const double *epl, const double *deps, double *fy, double *sig_out,
+                               double *depl, double *ct, int32_t *nsteps, const double *kh_in, double *kh_out)
 {
     if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
     if (n < 0 || !sig || !epl || !deps || !fy || !sig_out || !depl || !ct || !nsteps)
@@ -1562,6 +1571,15 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
         HIPCHK(c, hipMemcpyAsync(d_mid, mat_id, N * 4, hipMemcpyHostToDevice, c->stream));
     }
     double *d_fy = d_out, *d_so = d_out + N, *d_dp = d_out + 7 * N, *d_ct = d_out + 13 * N;
+    double *d_kh = nullptr;   // [2N]: entry / exit hardening modulus of the work-hardening SVC points
+    if (c->has_svcwh) {
+        HIPCHK(c, hipMalloc((void **)&d_kh, N * 16));
+        std::vector<double> k0(N);
+        for (size_t i = 0; i < N; i++) k0[i] = kh_in ? kh_in[i] : c->hmat[mat_id ? mat_id[i] : 0].khard;
+        HIPCHK(c, hipMemcpyAsync(d_kh, k0.data(), N * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_kh + N, d_kh, N * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     EvPair *ev;
     tim_begin(c, 0, &ev);
 #define RB_ARGS(lds) c->dmat, c->nmat, lds, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns
@@ -1577,6 +1595,9 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<6>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, RB_ARGS(c->svc_lds_need));
+    if (c->has_svcwh)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<7>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)d_kh, d_kh + N);
 #undef RB_ARGS
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
@@ -1585,11 +1606,60 @@ int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double 
     HIPCHK(c, hipMemcpyAsync(depl, d_dp, N * 48, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ct, d_ct, N * 288, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nsteps, d_ns, N * 4, hipMemcpyDeviceToHost, c->stream));
+    if (kh_out) {
+        if (d_kh)
+            HIPCHK(c, hipMemcpyAsync(kh_out, d_kh + N, N * 8, hipMemcpyDeviceToHost, c->stream));
+        else
+            for (size_t i = 0; i < N; i++) kh_out[i] = kh_in ? kh_in[i] : c->hmat[mat_id ? mat_id[i] : 0].khard;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(d_in);
     hipFree(d_out);
     hipFree(d_ns);
     if (d_mid) hipFree(d_mid);
+    if (d_kh) hipFree(d_kh);
+    return PLFX_OK;
+}
+
+int plfx_response_batch(plfx_ctx *c, int n, const int32_t *mat_id, const double *sig,
+                        const double *epl, const double *deps, double *fy, double *sig_out,
+                        double *depl, double *ct, int32_t *nsteps)
+{
+    return response_batch_impl(c, n, mat_id, sig, epl, deps, fy, sig_out, depl, ct, nsteps, nullptr, nullptr);
+}
+
+int plfx_response_batch_kh(plfx_ctx *c, int n, const int32_t *mat_id, const double *sig, const double *epl,
+                           const double *deps, const double *khard_in, double *fy, double *sig_out, double *depl,
+                           double *ct, int32_t *nsteps, double *khard_out)
+{
+    return response_batch_impl(c, n, mat_id, sig, epl, deps, fy, sig_out, depl, ct, nsteps, khard_in, khard_out);
+}
+
+int plfx_fgrad_batch_wh(plfx_ctx *c, int mat, int n, const double *sig, const double *epl, double *fgrad, double *khard_raw)
+{
+    if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
+    if (mat < 0 || mat >= c->nmat || n < 0 || !sig || !fgrad) return fail(c, PLFX_ERR_ARG, "bad argument");
+    if (c->hmat[mat].kind != PLFX_SVC_WH) return fail(c, PLFX_ERR_ARG, "material %d has no work-hardening features", mat);
+    if (n == 0) return PLFX_OK;
+    double *dsig = nullptr, *depl = nullptr, *dout = nullptr, *dkh = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dsig, (size_t)n * 48));
+    HIPCHK(c, hipMalloc((void **)&dout, (size_t)n * 48));
+    HIPCHK(c, hipMalloc((void **)&dkh, (size_t)n * 8));
+    HIPCHK(c, hipMemcpyAsync(dsig, sig, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    if (epl) {
+        HIPCHK(c, hipMalloc((void **)&depl, (size_t)n * 48));
+        HIPCHK(c, hipMemcpyAsync(depl, epl, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_point_eval, dim3(grid_for(n)), dim3(BLOCK), dyn_lds_bytes(c), c->stream, c->dmat, c->nmat,
+                       c->svc_lds_need, 1, mat, n, dsig, depl, (const double *)nullptr, dout, (int32_t *)nullptr, dkh);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fgrad, dout, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
+    if (khard_raw) HIPCHK(c, hipMemcpyAsync(khard_raw, dkh, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(dsig);
+    hipFree(dout);
+    hipFree(dkh);
+    if (depl) hipFree(depl);
     return PLFX_OK;
 }
 
@@ -1684,6 +1754,7 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     ALLOC(c->Mel, (size_t)6 * nel);  // whole mesh (global element ids)
     ALLOC(c->fyn, nown);
     ALLOC(c->scf_hh, nown);
+    ALLOC(c->kh_el, nown);
     ALLOC(c->max_steps, nown);
     ALLOC(c->scf_mult, nown);
     ALLOC(c->heavy_list, nown);
@@ -2225,6 +2296,12 @@ int plfx_state_reset(plfx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->u, 0, 8 * nd, c->stream));
     HIPCHK(c, hipMemsetAsync(c->f, 0, 8 * nd, c->stream));
     HIPCHK(c, hipMemsetAsync(c->du, 0, 8 * nd, c->stream));
+    {   // hardening modulus of every material point = its material's khard (Material.khard before the first response call)
+        std::vector<double> kh(c->nel);
+        for (int e = 0; e < c->nel; e++) kh[e] = c->hmat[c->hcls[c->hcls_id[c->e0 + e]].mat].khard;
+        HIPCHK(c, hipMemcpyAsync(c->kh_el, kh.data(), (size_t)8 * c->nel, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     hipLaunchKernelGGL(k_init_tangent, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
                        c->dmat, c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel + c->e0, c->nel_total);
     if (c->sharded)
@@ -2251,6 +2328,7 @@ static int state_ptr(plfx_ctx *c, int which, double **p, size_t *comps, size_t *
     case 7: *p = c->f; *comps = 1; *n = c->ndof; *soa = false; break;
     case 8: *p = c->du; *comps = 1; *n = c->ndof; *soa = false; break;
     case 9: *p = c->fyn; *comps = 1; *soa = false; break;
+    case 11: *p = c->kh_el; *comps = 1; *soa = false; break;
     default: return fail(c, PLFX_ERR_ARG, "unknown state id %d", which);
     }
     return 0;
@@ -3114,7 +3192,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #define WAVE_ARGS c->dmat, c->nmat, c->dcls, c->ncls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,  \
                   c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl, c->fyn,         \
                   c->max_steps, nit, c->flags, c->bflags, c->heavy_list
-    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3 && !c->has_barlat)) {
+    if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3 && !c->has_barlat && !c->has_svcwh)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
                            SWEEP_ARGS(0), first, -1);
         first = 0;
@@ -3144,6 +3222,11 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1);
         first = 0;
     }
+    if (c->has_svcwh) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1, c->kh_el);
+        first = 0;
+    }
     tim_end(c, ev);  // family 0: the streaming phase (one launch per material kind present)
     tim_begin(c, 6, &ev);  // family 6: the compacted 50-sub-step corrector
     // phase 2 reads the list length from the device; an empty list costs one empty launch
@@ -3165,6 +3248,9 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), -1);
+    if (c->has_svcwh)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1, c->kh_el);
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
     tim_end(c, ev);
@@ -3204,7 +3290,7 @@ int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c,
         hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                            c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
                            c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                           c->small + 32, c->scf_hh, c->scf_mult);
+                           c->small + 32, c->scf_hh, c->scf_mult, (const double *)c->kh_el);
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult,

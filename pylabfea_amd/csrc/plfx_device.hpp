@@ -93,7 +93,8 @@ struct MatDev {
     double sy, khard, d0;  // d0 = drucker (calc_seq adds d0*tr(sig)/3, calc_fgrad adds d0/3)
     double E, nu;
     double gamma, intercept, scale_seq;
-    const double *sv;    // device pointer [nsv*6]
+    double scale_wh;     // SVC with work-hardening features: scaling of the plastic-strain features (material.py:2343)
+    const double *sv;    // device pointer [nsv*nfeat]
     const double *dual;  // device pointer [nsv]
     double barlat[18], barlat_exp;  // Yld2004-18p coefficients
     int32_t kind, sdim, nsv, dev_only, nfeat, barlat_normal;  // barlat_normal: the native Barlat normal is enabled (extension)
@@ -455,6 +456,11 @@ struct YfHill {
     __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
     __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { hill_fgrad(m, s, a); }
+    // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
+    __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
 
 // Yield-function policy: Barlat Yld2004-18p with the native normal (extension; see barlat_seq_grad).
@@ -469,6 +475,11 @@ struct YfBarlat {
     __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
     __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { barlat_seq_grad(m, s, a); }
+    // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
+    __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
 
 // Yield-function policy: sdim = 3, Hill-3p / J2 on principal stresses.
@@ -483,6 +494,11 @@ struct YfPrinc3 {
     __device__ __forceinline__ double full(const double *s, const double *epl) const { return plain(s, epl); }
     __device__ __forceinline__ double full0(const double *s, double fy0) const { (void)s; return fy0; }
     __device__ __forceinline__ void fgrad(const double *s, double *a) const { princ_fgrad(m, s, a); }
+    // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
+    __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1034,7 +1050,162 @@ struct YfSvcT {
         else
             svc3_fgrad(m, sv, dual, s, a);
     }
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
+    __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
+
+// ---------------------------------------------------------------------------------------------
+// RBF-SVC yield function with WORK-HARDENING features (material.py:2342-2346, 808-814): 15 features
+//   x = [ (dev) sig / scale_seq (6) | epl / scale_wh (6) | accumulated strain | max. stress / scale_seq | flag ]
+// of which the last three are zero on the path (Material.response / Model.solve never pass them, material.py:207-346).
+// The hardening modulus is not a parameter but a by-product of the gradient:
+//   khard = max(0, - sum_k dK/dx[6+k] * scale_seq / scale_wh)                                   (:808-814)
+// and the reference keeps it in ONE mutable attribute of the Material object that every calc_fgrad call overwrites and
+// every get_sflow / epl_dot / C_tan call reads -- carried from call to call, across elements, in index order.  Inside one
+// response() call that is reproduced exactly (K below); across calls the data-parallel engine carries it per material
+// point (k_sweep_*: kh_el[e]) and the single-call entry points take / return it explicitly.
+struct YfSvcWh {
+    const MatDev &m;
+    const double *sv;
+    const double *dual;
+    const double K_in;   // hardening modulus at the entry of the call
+    mutable double K;    // ... as of the last gradient evaluation
+    __device__ YfSvcWh(const MatDev &mm, const double *s, const double *d, double k0) : m(mm), sv(s), dual(d), K_in(k0), K(k0) {}
+    __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
+    __device__ __forceinline__ void features(const double *s, const double *epl, double *x) const
+    {
+        svc_features(m, s, x);
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[6 + i] = epl[i] / m.scale_wh;
+    }
+    // decision function; the three trailing features are zero: their squared distance is |sv[12..14]|^2
+    __device__ inline double decision_x(const double *x) const
+    {
+        double f = 0.;
+        const double g = -m.gamma * LOG2E;
+        for (int k = 0; k < m.nsv; k++) {
+            const double *v = sv + 15 * k;
+            double hh = 0.;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const double d = x[i] - v[i];
+                hh = fma(d, d, hh);
+            }
+#pragma unroll
+            for (int i = 12; i < 15; i++) hh = fma(v[i], v[i], hh);
+            f = fma(dual[k], exp2_neg(g * hh), f);
+        }
+        return f + m.intercept;
+    }
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        double x[12];
+        features(s, epl, x);
+        return decision_x(x);
+    }
+    __device__ __forceinline__ double kh() const { return K; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return m.sy + eps_eq(epl) * K; }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return m.sy + eps_eq(epl) * K_in; }
+    // gradient w.r.t. the stress (:797-807) and the hardening modulus it implies (:808-814, single point)
+    __device__ inline double fgrad_raw(const double *s, const double *epl, double *a) const
+    {
+        double x[12], acc[12];
+        features(s, epl, x);
+#pragma unroll
+        for (int i = 0; i < 12; i++) acc[i] = 0.;
+        const double g = -m.gamma * LOG2E;
+        for (int k = 0; k < m.nsv; k++) {
+            const double *v = sv + 15 * k;
+            double hv[12], hh = 0.;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                hv[i] = x[i] - v[i];
+                hh = fma(hv[i], hv[i], hh);
+            }
+#pragma unroll
+            for (int i = 12; i < 15; i++) hh = fma(v[i], v[i], hh);
+            const double w = dual[k] * exp2_neg(g * hh);
+#pragma unroll
+            for (int i = 0; i < 12; i++) acc[i] = fma(w, hv[i], acc[i]);
+        }
+        const double c2 = -2. * m.gamma;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = acc[i] * c2 / m.scale_seq;
+        double hk = 0.;
+#pragma unroll
+        for (int i = 6; i < 12; i++) hk -= acc[i] * c2 * m.scale_seq / m.scale_wh;
+        return hk;
+    }
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const
+    {
+        const double hk = fgrad_raw(s, epl, a);
+        K = hk < 0. ? 0. : hk;  // strain softening not supported (:813-814)
+    }
+    // ML_full_yf (material.py:414-516) with the plastic strain in the features
+    __device__ inline double full_ld(const double *s, const double *epl, const double *ld, int *status) const
+    {
+        const double seqv = seq(s);
+        const double sfl = sflow(epl);
+        if (status) *status = 0;
+        if (seqv < 0.01 && ld == nullptr) return seqv - 0.85 * sfl;
+        double su[6];
+        if (ld == nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) su[i] = s[i] / seqv;
+        } else {
+            double hh = 0.;
+#pragma unroll
+            for (int i = 0; i < 6; i++) hh += ld[i] * ld[i];
+            hh = sqrt(hh);
+            if (hh < 1.e-3) {
+                su[0] = sqrt(1.5);
+#pragma unroll
+                for (int i = 1; i < 6; i++) su[i] = 0.;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) su[i] = ld[i] * sqrt(1.5) / hh;
+            }
+        }
+        auto f = [&](double x) {
+            double xs[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) xs[i] = x * su[i];
+            return plain(xs, epl);
+        };
+        double x0 = sfl;
+        if (su[0] * su[1] < -1.e-5) x0 *= 0.5;
+        double x1 = x0;
+        double f0 = f(x0);
+        double f1 = f0;
+        while (f0 >= 0. && x0 > 0.01) {  // :475-480
+            x0 *= 0.98;
+            f0 = f(x0);
+        }
+        while (f1 < 0. && x1 < 5. * sfl) {  // :481-486
+            x1 *= 1.02;
+            f1 = f(x1);
+        }
+        if (f0 * f1 > 0.) {
+            if (status) *status = 1;
+            return seqv - 0.85 * sfl;
+        }
+        bool conv = true;
+        const double xs = brentq_dev(f, x0, x1, f0, f1, 1.e-5, 4. * 2.220446049250313e-16, 100, conv);
+        if (conv && xs < 4. * sfl) return seqv - xs * seq(su);
+        if (status) *status = 2;
+        return seqv - 0.85 * sfl;
+    }
+    __device__ __forceinline__ double full(const double *s, const double *epl) const { return full_ld(s, epl, nullptr, nullptr); }
+    __device__ __forceinline__ double full0(const double *s, double fy0) const
+    {
+        (void)fy0;
+        const double z[6] = {0., 0., 0., 0., 0., 0.};
+        return full_ld(s, z, nullptr, nullptr);  // ML_full_yf(sig): epl = None -> zeros (:265, :437-438)
+    }
+};
+
 typedef YfSvcT<6> YfSvc;
 typedef YfSvcT<2> YfSvc3;
 template <int NC>
@@ -1061,7 +1232,7 @@ __device__ inline int response_light(const MatDev &m, const YF &yf, double *sig,
     double dsig[6], tmp[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) depl[i] = 0.;
-    const double sflow0 = sflow_of(m, epl);
+    const double sflow0 = yf.sflow_entry(epl);
     const double toler = YF_TOL * sflow0;  // :243
     symv(CV, deps, dsig);                  // :244
 #pragma unroll
@@ -1098,9 +1269,9 @@ __device__ inline int response_light(const MatDev &m, const YF &yf, double *sig,
     // trial step with the full remaining increment (:277-293)
     {
         symv(CV, deps_r, dsr);
-        yf.fgrad(sig, a);
+        yf.fgrad(sig, epl, a);
         symv(CV, a, ca);
-        const double hh = dot6(a, ca) + m.khard;
+        const double hh = dot6(a, ca) + yf.kh();
 #pragma unroll
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
         const double yfun = yf.plain(tmp, epl);  // epl_dot :1032, absolute tolerance :1041
@@ -1137,7 +1308,7 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
                                       double *Ct)
 {
     const double *CV = m.CV;
-    const double toler = YF_TOL * sflow_of(m, epl);  // :243
+    const double toler = YF_TOL * yf.sflow_entry(epl);  // :243 (with the hardening modulus at the entry of the call)
     double a[6], ca[6], dsr[6], ddepl[6], eplt[6], tmp[6], fy1;
     // sub-divided step (:288-291): nsteps = maxit
     const int nsteps = MAXIT;
@@ -1153,9 +1324,9 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
 #pragma unroll
     for (int i = 0; i < 21; i++) R[i] = 0.;
     for (int it = 0; it < nsteps; it++) {  // :295
-        yf.fgrad(sig, a);
+        yf.fgrad(sig, epl, a);
         symv(CV, a, ca);
-        const double hh = dot6(a, ca) + m.khard;
+        const double hh = dot6(a, ca) + yf.kh();
 #pragma unroll
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
         const double yfun = yf.plain(tmp, epl);  // NB entry epl, absolute tolerance (:299, :1041)

@@ -106,7 +106,7 @@ __device__ __forceinline__ void sum_partials_n(const double *const (&part)[NA], 
     __syncthreads();
 }
 
-__host__ __device__ constexpr bool kind_is_svc(int k) { return k == 3 || k == 6; }
+__host__ __device__ constexpr bool kind_is_svc(int k) { return k == 3 || k == 6 || k == 7; }
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
 // contiguous range of tiles so that the neighbour columns a tile gathers are in the same L2.
@@ -181,6 +181,23 @@ struct YfOf<6> {
         return YfSvc3(m, sv ? sv : m.sv, dual ? dual : m.dual);
     }
 };
+template <>
+struct YfOf<7> {   // SVC with work-hardening features: the hardening modulus is state (YfSvcWh), set by make_wh
+    typedef YfSvcWh type;
+    __device__ static YfSvcWh make(const MatDev &m, const double *sv, const double *dual)
+    {
+        return YfSvcWh(m, sv ? sv : m.sv, dual ? dual : m.dual, m.khard);
+    }
+};
+// policy object of one material point: KIND 7 takes the point's hardening modulus kh0, the others ignore it
+template <int KIND>
+__device__ __forceinline__ typename YfOf<KIND>::type make_policy(const MatDev &m, const double *sv, const double *dual, double kh0)
+{
+    if constexpr (KIND == 7)
+        return YfSvcWh(m, sv ? sv : m.sv, dual ? dual : m.dual, kh0);
+    else
+        return YfOf<KIND>::make(m, sv, dual);
+}
 
 
 
@@ -190,7 +207,8 @@ template <int KIND>
 __global__ void __launch_bounds__(BLOCK)
 k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
                  const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
-                 double *sig_out, double *depl_out, double *ct_out, int32_t *nsteps)
+                 double *sig_out, double *depl_out, double *ct_out, int32_t *nsteps,
+                 const double *kh_in = nullptr, double *kh_out = nullptr)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -220,8 +238,10 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
             for (int c = 0; c < 21; c++) Ct[c] = m.CV[c];
         } else {
             const bool staged = (mid == svc_mat);
-            const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+            const typename YfOf<KIND>::type yf =
+                make_policy<KIND>(m, staged ? sv : nullptr, staged ? dual : nullptr, kh_in ? kh_in[i] : m.khard);
             ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
+            if (KIND == 7 && kh_out) kh_out[i] = yf.kh();
         }
         fy[i] = f;
         nsteps[i] = ns;
@@ -241,7 +261,7 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
 __global__ void __launch_bounds__(BLOCK)
 k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, int n,
              const double *sig_in, const double *epl_in, const double *ld, double *out,
-             int32_t *status)
+             int32_t *status, double *kh_raw = nullptr /* kind 7, what 1: - sum dK/dx[wh] scale_seq / scale_wh per point */)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -268,6 +288,23 @@ k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, i
             e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
         }
         const int kd = m.kind;
+        if (kd == 7 && what >= 1) {  // SVC with work-hardening features: the plastic strain is part of the feature vector
+            const YfSvcWh yf(m, psv, pdu, m.khard);
+            if (what == 1) {
+                double a[6];
+                const double hk = yf.fgrad_raw(s, e, a);
+#pragma unroll
+                for (int c = 0; c < 6; c++) out[6 * (size_t)i + c] = a[c];
+                if (kh_raw) kh_raw[i] = hk;
+            } else if (what == 2) {
+                out[i] = yf.plain(s, e);
+            } else {
+                int st = 0;
+                out[i] = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
+                if (status) status[i] = st;
+            }
+            continue;
+        }
         if (what == 0) {
             out[i] = (kd == 2 || kd == 6) ? princ_seq(m, s) : kd == 4 ? tresca_seq(s) : kd == 5 ? barlat_seq(m, s) : hill_seq(m, s);
         } else if (what == 1) {
@@ -342,14 +379,14 @@ __device__ __forceinline__ void sweep_epilogue(const ClassDev &c, const MatDev &
                                                double *Ct, double fy, int ns, double *elstiff,
                                                double *Mel, int mel_stride, double *res_sig,
                                                double *res_depl, double *fyn, int32_t *max_steps, int nit,
-                                               int &changed, int &nconv)
+                                               int &changed, int &nconv, double kh = -1.)
 {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         res_sig[(size_t)k * nel + e] = s[k];
         res_depl[(size_t)k * nel + e] = depl[k];
     }
-    const double f = fy / sflow_of(m, ep);  // model.py:1345
+    const double f = fy / (kh >= 0. ? m.sy + eps_eq(ep) * kh : sflow_of(m, ep));  // model.py:1345 (kh: the modulus a work-hardening SVC left behind)
     fyn[e] = f;
     if (!(f <= YF_TOL * 1.0001)) nconv = 1;  // model.py:1361
     // Frobenius norm of the tangent change over the full 6x6 (model.py:1346)
@@ -468,7 +505,8 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int skip_mat)
+              int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int skip_mat,
+              double *kh_el = nullptr /* KIND 7: hardening modulus of every material point, carried from sweep to sweep */)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
@@ -499,13 +537,16 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
                     ep[k] = epl[(size_t)k * nel + e];
                 }
                 const bool staged = (c.mat == svc_mat);
-                const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+                const typename YfOf<KIND>::type yf =
+                    make_policy<KIND>(m, staged ? sv : nullptr, staged ? dual : nullptr, (KIND == 7 && kh_el) ? kh_el[e] : m.khard);
                 const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
                 if (st == 2)
-                    heavy = true;
-                else
+                    heavy = true;  // (the corrector kernel repeats the prelude from the same entry modulus)
+                else {
                     sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, mel_stride, res_sig,
-                                   res_depl, fyn, max_steps, nit, changed, nconv);
+                                   res_depl, fyn, max_steps, nit, changed, nconv, KIND == 7 ? yf.kh() : -1.);
+                    if (KIND == 7 && kh_el) kh_el[e] = yf.kh();
+                }
             }
         }
         // compact the elements that need the 50-sub-step corrector: one atomic per wave
@@ -530,7 +571,8 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, int skip_mat)
+              int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, int skip_mat,
+              double *kh_el = nullptr)
 {
     const int count = flags[2];
     if (count == 0) return;
@@ -558,11 +600,13 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             ep[k] = epl[(size_t)k * nel + e];
         }
         const bool staged = (c.mat == svc_mat);
-        const typename YfOf<KIND>::type yf = YfOf<KIND>::make(m, staged ? sv : nullptr, staged ? dual : nullptr);
+        const typename YfOf<KIND>::type yf =
+            make_policy<KIND>(m, staged ? sv : nullptr, staged ? dual : nullptr, (KIND == 7 && kh_el) ? kh_el[e] : m.khard);
         response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);  // recompute the prelude
         response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
         sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
-                       res_depl, fyn, max_steps, nit, changed, nconv);
+                       res_depl, fyn, max_steps, nit, changed, nconv, KIND == 7 ? yf.kh() : -1.);
+        if (KIND == 7 && kh_el) kh_el[e] = yf.kh();
     }
     post_block_flags(changed, nconv, bflags);
 }
@@ -1462,7 +1506,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls, int lds_doubles, int nel,
                int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
                const double *__restrict__ sig, const double *__restrict__ epl, const double *__restrict__ elstiff, const double *__restrict__ sld,
-               double *__restrict__ hh_out, int32_t *__restrict__ mult_out)
+               double *__restrict__ hh_out, int32_t *__restrict__ mult_out, const double *__restrict__ kh_el = nullptr)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -1497,7 +1541,19 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
                     ep[k] = epl[(size_t)k * nel + e];
                 }
                 double yf0;
-                if (kind_is_svc(m.kind)) {
+                if (m.kind == 7) {  // work-hardening SVC: features with the plastic strain, flow stress with the point's modulus
+                    const bool st = (c.mat == svc_mat);
+                    const YfSvcWh yw(m, st ? sv : m.sv, st ? dual : m.dual, kh_el ? kh_el[e] : m.khard);
+                    yf0 = yw.plain(s, ep);
+                    if (yf0 < SPLIT_THRESHOLD) {
+                        yf0 = yw.full_ld(s, ep, ld, nullptr);
+                        hh = fmin(1., -yf0 / sref);
+                        mult = 2;
+                    } else {
+                        hh = fmin(1., sqrt(1.5) * yw.sflow(ep) / sref);
+                        mult = 1;
+                    }
+                } else if (kind_is_svc(m.kind)) {
                     const bool st = (c.mat == svc_mat);
                     const double *psv = st ? sv : m.sv, *pdu = st ? dual : m.dual;
                     yf0 = (m.kind == 3) ? YfSvc(m, psv, pdu).plain(s, ep) : YfSvc3(m, psv, pdu).plain(s, ep);

@@ -210,7 +210,7 @@ class Material(object):
             self.barlat = False
         self._version += 1
 
-    def set_svc(self, support_vectors, dual_coef, intercept, gamma, scale_seq, dev_only=False, C=None):
+    def set_svc(self, support_vectors, dual_coef, intercept, gamma, scale_seq, dev_only=False, C=None, scale_wh=None):
         """Install a trained RBF-SVC yield function (what ``train_SVC`` leaves in ``svm_yf``,
         ``gam_yf`` and ``scale_seq``; material.py:398-405, 797-807).  ``dual_coef``/``intercept`` are
         scikit-learn's public ``dual_coef_[0]`` / ``intercept_[0]``."""
@@ -218,6 +218,15 @@ class Material(object):
             raise ValueError('set_svc: call elasticity() and plasticity(sy=..., sdim=6) first')
         nfeat = 6 if self.sdim == 6 else 2   # sdim=3: (seq_J2/scale - 1, polar angle/pi), material.py:2331-2333
         sv = np.ascontiguousarray(support_vectors, dtype=float)
+        # work-hardening-aware SVC (train_SVC on Data(wh_data=True), material.py:2342-2346): 6 stress features, the plastic
+        # strain / scale_wh (6), accumulated strain, max. stress / scale_seq, flag  ->  Ndof = 15, ind_wh = 6
+        self.whdat = bool(self.sdim == 6 and sv.ndim == 2 and sv.shape[1] == 15)
+        if self.whdat:
+            if scale_wh is None or not scale_wh > 0.:
+                raise ValueError('set_svc: 15-feature support vectors (work-hardening data) need scale_wh > 0')
+            nfeat = 15
+            self.ind_wh = 6
+            self.scale_wh = float(scale_wh)
         if sv.ndim != 2 or sv.shape[1] != nfeat:
             raise ValueError('set_svc: support vectors must have shape (nsv, %d) for sdim=%d' % (nfeat, self.sdim))
         dual = np.ascontiguousarray(dual_coef, dtype=float).reshape(-1)
@@ -230,7 +239,7 @@ class Material(object):
         self.dev_only = bool(dev_only)
         self.ML_yf = True
         self.Ndof = nfeat
-        if self.khard:
+        if self.khard and not self.whdat:
             # calc_fgrad of an ML material resets self.khard to 0 on every call (material.py:812-814)
             warnings.warn('set_svc: khard of an ML material is reset to 0 by the reference flow rule')
             self.khard = 0.
@@ -280,9 +289,9 @@ class Material(object):
         props[4] = self.C44
         props[5] = self.svc['intercept']
         props[6] = self.gam_yf
-        props[7] = 0.          # epc
+        props[7] = float(getattr(self, 'epc', 0.) or 0.)          # epc
         props[8] = self.scale_seq
-        props[9] = 1.          # scale_wh
+        props[9] = self.scale_wh if getattr(self, 'whdat', False) else 1.          # scale_wh
         if self.CV is None:
             props[10:16] = -1
         else:
@@ -341,9 +350,10 @@ class Material(object):
         nsv, ndof = int(round(props[0])), int(round(props[1]))
         if nsv < 1 or 29 + nsv * (ndof + 1) > len(props):
             raise ValueError('from_MLparam: inconsistent header (nsv={}, Ndof={}, {} numbers)'.format(nsv, ndof, len(props)))
-        if ndof not in (2, 6):
-            raise NotImplementedError('from_MLparam: {} features (work-hardening / texture descriptors) are not '
-                                      'supported; only the 6 stress features or the 2 features of sdim=3'.format(ndof))
+        if ndof not in (2, 6, 15):
+            raise NotImplementedError('from_MLparam: {} features (texture descriptors) are not supported; only the 6 '
+                                      'stress features, the 2 features of sdim=3, or 15 = 6 stress + 9 work-hardening '
+                                      'features'.format(ndof))
         C11, C12, C44 = props[2], props[3], props[4]
         if np.all(props[10:16] == -1.):
             self.elasticity(C11=C11, C12=C12, C44=C44)
@@ -356,7 +366,7 @@ class Material(object):
             CV[3, 3], CV[4, 4], CV[5, 5] = C44, props[14], props[15]
             self.elasticity(CV=CV)
         scale_seq = float(props[8])
-        self.plasticity(sy=scale_seq, sdim=6 if ndof == 6 else 3)
+        self.plasticity(sy=scale_seq, sdim=6 if ndof in (6, 15) else 3)
         C = None
         try:
             with open(trunk + '-svm_meta.json') as fp:
@@ -378,7 +388,10 @@ class Material(object):
             dev_only = bool(ndof == 6 and np.max(np.abs(sv[:, 0:3].sum(axis=1))) < 1e-9 * max(np.max(np.abs(sv)), 1e-300))
         else:
             dev_only = bool(props[16] < 0.)
-        self.set_svc(sv, dual, props[5], props[6], scale_seq, dev_only=dev_only, C=C)
+        self.set_svc(sv, dual, props[5], props[6], scale_seq, dev_only=dev_only, C=C,
+                     scale_wh=float(props[9]) if ndof == 15 else None)
+        if ndof == 15:
+            self.epc = float(props[7])
         return self
 
     # ------------------------------------------------------------------ records for libplfx
@@ -388,8 +401,10 @@ class Material(object):
             return _lib.pack_material(_lib.ELASTIC, CV, E=self.E, nu=self.nu)
         if self.ML_yf and not ana:
             svc = dict(sv=self.svc['sv'], dual=self.svc['dual'], intercept=self.svc['intercept'],
-                       gamma=self.gam_yf, scale_seq=self.scale_seq, dev_only=self.dev_only)
-            return _lib.pack_material(_lib.SVC6 if self.sdim == 6 else _lib.SVC3, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
+                       gamma=self.gam_yf, scale_seq=self.scale_seq, dev_only=self.dev_only,
+                       scale_wh=getattr(self, 'scale_wh', None))
+            kind = _lib.SVC_WH if getattr(self, 'whdat', False) else (_lib.SVC6 if self.sdim == 6 else _lib.SVC3)
+            return _lib.pack_material(kind, CV, E=self.E, nu=self.nu, sy=self.sy, khard=self.khard,
                                       hill=self.hill, drucker=self.drucker, svc=svc)
         kind = _lib.HILL6 if self.sdim == 6 else _lib.PRINC3
         if self.tresca:
@@ -475,8 +490,8 @@ class Material(object):
         work-hardening features — the ones this engine evaluates): principal-stress cylinder coordinates for sdim=3,
         (deviatoric) Voigt stress / scale_seq for sdim=6.  Host-side helper for scripts; the kernels build the same
         features in registers."""
-        if tex is not None or getattr(self, 'txdat', False) or getattr(self, 'whdat', False):
-            raise NotImplementedError('create_scaled_input: texture / work-hardening features are outside this engine')
+        if tex is not None or getattr(self, 'txdat', False):
+            raise NotImplementedError('create_scaled_input: texture features are outside this engine')
         s, _ = self._voigt(sig, 'create_scaled_input')
         x = np.zeros((len(s), self.Ndof))
         if self.sdim == 3:
@@ -486,6 +501,12 @@ class Material(object):
             if self.dev_only:
                 s = sig_dev(s)
             x[:, 0:s.shape[1]] = s / self.scale_seq
+        if getattr(self, 'whdat', False):   # material.py:2342-2346
+            iw = self.ind_wh
+            x[:, iw:iw + self.sdim] = (0. if epl is None else np.asarray(epl, dtype=float)) / self.scale_wh
+            x[:, iw + self.sdim] = 0. if acc_strain is None else acc_strain
+            x[:, iw + self.sdim + 1] = (0. if max_stress is None else max_stress) / self.scale_seq
+            x[:, iw + self.sdim + 2] = 0. if flag is None else flag
         return x
 
     def get_sflow(self, epl):
@@ -561,7 +582,14 @@ class Material(object):
             self._no_flow_rule()
         s, single = self._voigt(s0, 'calc_fgrad')
         nout = s0.shape[-1]  # principal stresses in -> gradient w.r.t. principal stresses out
-        if self.ML_yf and not ana:
+        if self.ML_yf and not ana and getattr(self, 'whdat', False):
+            # the plastic strain is part of the feature vector, and the hardening modulus is read off the gradient
+            # w.r.t. the plastic-strain features: mean over the points, no softening (material.py:808-814)
+            e = None if epl is None else np.asarray(epl, dtype=float).reshape(len(s), -1)
+            a, hk = self._load().fgrad_wh(0, s, e)
+            self.khard = max(0., float(np.sum(hk)) / len(s))
+            self.msg['gradient'] = 'gradient to ML_yf'
+        elif self.ML_yf and not ana:
             a = self._load().fgrad(0, s)
             self.khard = 0.  # side effect of the reference (material.py:812-814, no work-hardening data)
             self.msg['gradient'] = 'gradient to ML_yf'
@@ -592,8 +620,15 @@ class Material(object):
             raise NotImplementedError('response: the device kernel is compiled for maxit=50 (reference default)')
         if self.sy is None:
             raise AttributeError('response called for a purely elastic material')
-        fy, so, dp, ct, ns = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
-                                                     np.asarray(deps, dtype=float)[None, :])
+        if getattr(self, 'whdat', False):
+            # Material.khard is state here: read on entry, overwritten by every gradient evaluation inside the call
+            fy, so, dp, ct, ns, kout = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
+                                                               np.asarray(deps, dtype=float)[None, :],
+                                                               khard_in=[self.khard], return_khard=True)
+            self.khard = float(kout[0])
+        else:
+            fy, so, dp, ct, ns = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
+                                                         np.asarray(deps, dtype=float)[None, :])
         self.msg['nsteps'] = int(ns[0])
         return fy[0], so[0], dp[0], ct[0].reshape(6, 6)
 

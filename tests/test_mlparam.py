@@ -55,14 +55,14 @@ def test_mlparam_errors(tmp_path):
     m.plasticity(sy=60., sdim=6)
     with pytest.raises(AttributeError):
         m.export_MLparam('x', path=str(tmp_path))   # no ML flow rule (material.py:2166-2167)
-    props = np.zeros(128)
-    props[0], props[1] = 3, 15                       # 15 features = work-hardening descriptors
-    np.savetxt(str(tmp_path / 'wh-svm.csv'), props.reshape(16, 8), delimiter=', ')
+    props = np.zeros(160)
+    props[0], props[1] = 3, 21                       # 21 features = stress + work hardening + texture descriptors
+    np.savetxt(str(tmp_path / 'wh-svm.csv'), props.reshape(20, 8), delimiter=', ')
     with pytest.raises(NotImplementedError):
         FE.Material().from_MLparam('wh', path=str(tmp_path))
     props[0] = 500                                   # more vectors than the file holds
     props[1] = 6
-    np.savetxt(str(tmp_path / 'bad-svm.csv'), props.reshape(16, 8), delimiter=', ')
+    np.savetxt(str(tmp_path / 'bad-svm.csv'), props.reshape(20, 8), delimiter=', ')
     with pytest.raises(ValueError):
         FE.Material().from_MLparam('bad', path=str(tmp_path))
 
@@ -134,3 +134,20 @@ def test_shipped_v40_material_on_gpu(golden_dir, tag):
         f = m.calc_yf(s)
         assert f[0] < 0. < f[1]
         assert abs(m.calc_yf(s + np.array([500., 500., 500., 0., 0., 0.]))[0] - f[0]) < 1e-9
+
+
+def test_workhardening_parameter_file_round_trip(golden_dir, tmp_path):
+    """15-feature SVC (6 stress + 9 work-hardening features): export_MLparam -> from_MLparam keeps every
+    number (slot 9 = scale_wh, slot 7 = epc, 15 numbers per support vector)"""
+    import pylabfea_amd as FE
+    z = np.load(os.path.join(golden_dir, 'svc_workhard.npz'))
+    m = FE.Material(name='ML-wh')
+    m.elasticity(CV=z['par_CV'])
+    m.plasticity(sy=float(z['par_sy']), sdim=6)
+    m.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']),
+              scale_wh=float(z['par_scale_wh']), C=2.0)
+    m.export_MLparam('tests/test_mlparam.py', path=str(tmp_path))
+    r = FE.Material(name='loaded').from_MLparam('abq_ML-wh', path=str(tmp_path))
+    assert r.whdat and r.Ndof == 15 and r.ind_wh == 6 and r.scale_wh == float(z['par_scale_wh'])
+    assert np.array_equal(r.svc['sv'], z['par_sv']) and np.array_equal(r.svc['dual'], z['par_dual'])
+    assert r.mlparam_layout == 'v4.4' and r.C_yf == 2.0

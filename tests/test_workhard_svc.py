@@ -1,0 +1,169 @@
+"""SVC yield functions with WORK-HARDENING features (material.py:2342-2346 create_scaled_input, :808-814 khard
+from the SVC gradient): 15 features = 6 stress features + plastic strain / scale_wh (6) + accumulated strain, max. stress,
+flag (zero on the path).  Fixture tests/golden/svc_workhard.npz: an SVC trained by the unmodified reference with the
+procedure of examples/train_hardening.py on a reduced data set (oracle/gen_golden.py:gen_wh), its features, yield function,
+gradients, hardening moduli, ML_full_yf and response() outputs, and a 4x4 Model.solve trace.
+
+The reference keeps the hardening modulus in ONE mutable attribute of the Material object (every calc_fgrad call overwrites
+it, get_sflow / epl_dot / C_tan read it, it is carried from call to call).  Single calls are pinned with explicit entry /
+exit values; the CPU oracle additionally reproduces the reference's element loop (one object mutated in index order) and
+is held to the model trace at 1e-8; the data-parallel engine carries the modulus per material point instead."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope='module')
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, 'svc_workhard.npz'))
+
+
+def facade_material(z):
+    import pylabfea_amd as FE
+    m = FE.Material(name='ML-hardening')
+    m.elasticity(CV=z['par_CV'])
+    m.plasticity(sy=float(z['par_sy']), sdim=6)
+    m.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']),
+              dev_only=bool(z['par_dev_only']), scale_wh=float(z['par_scale_wh']))
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle + host logic
+def test_features_host(z):
+    m = facade_material(z)
+    assert m.whdat and m.Ndof == 15 and m.ind_wh == int(z['par_ind_wh']) == 6
+    x = m.create_scaled_input(z['b_sig'], z['b_epl'], 0., 0., 0.)
+    assert x.shape == (len(z['b_sig']), 15) and np.array_equal(x, z['b_x'])
+    with pytest.raises(ValueError):
+        import pylabfea_amd as FE
+        mm = FE.Material()
+        mm.elasticity(E=200.e3, nu=0.3)
+        mm.plasticity(sy=50., sdim=6)
+        mm.set_svc(z['par_sv'], z['par_dual'], 1., 1.5, 50.)          # 15 features need scale_wh
+
+
+def test_oracle_point_functions(z):
+    om = O.Material.from_golden(z)
+    assert om.c.kind == O.SVC_WH
+    assert np.max(np.abs(O.yf_wh(om, z['b_sig'], z['b_epl']) - z['b_yf'])) < 1e-11
+    a, kh = O.fgrad_wh(om, z['b_sig'], z['b_epl'])
+    assert np.max(np.abs(a - z['b_fgrad'])) < 1e-13
+    assert np.max(np.abs(np.maximum(kh, 0.) - z['b_khard'])) < 1e-8 * np.max(z['b_khard'])
+    assert np.max(z['b_khard']) > 100. and np.min(z['b_khard']) == 0.            # hardening and clipped softening both occur
+    # batched call: khard = clipped MEAN of the raw values (material.py:811-814)
+    assert abs(max(0., np.mean(kh[:50])) - float(z['b_khard_batch50'])) < 1e-8 * max(1., float(z['b_khard_batch50']))
+    nf = len(z['b_full_yf'])
+    f = O.full_yf_wh(om, z['b_sig'][:nf], z['b_epl'][:nf], z['b_full_yf_khard'])
+    assert np.max(np.abs(f - z['b_full_yf'])) < 1e-9 * float(z['par_sy'])
+
+
+@pytest.mark.parametrize('tag', ['pe', 'ps'])
+def test_oracle_response_with_explicit_khard(z, tag):
+    om = O.Material.from_golden(z)
+    CV = z['r%s_CV' % tag]
+    fy, so, dp, ct, ns, kout = O.response_wh(om, CV, z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag],
+                                             khard_in=z['r%s_khard_in' % tag])
+    sy = float(z['par_sy'])
+    assert np.array_equal(ns, z['r%s_nsteps' % tag])
+    assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-8 * sy
+    assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-11
+    assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-6 * CV[0, 0]
+    assert np.max(np.abs(kout - z['r%s_khard_out' % tag])) < 1e-7 * max(1., np.max(z['r%s_khard_out' % tag]))
+    assert np.any(kout != z['r%s_khard_in' % tag])                        # the call does overwrite the modulus
+
+
+def test_oracle_model_trace_sequential_khard(z):
+    """Model.solve of the reference on 4x4 elements: the oracle runs the elements in index order on one mutable material"""
+    import pylabfea_amd as FE
+    from oracle.solve_ref import RefSolver
+    m = facade_material(z)
+    fe = FE.Model(dim=2)
+    fe.geom([4.], LY=4.)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.004 * fe.leny, 'disp')
+    fe.mesh(NX=4, NY=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r = RefSolver(fe).solve(min_step=8)
+    assert r.nsteps == int(z['wh4_nsteps']) and list(r.niter) == list(z['wh4_niter'])
+    for a, k in ((r.u, 'wh4_u'), (r.sig, 'wh4_sig'), (r.sgl, 'wh4_sgl')):
+        assert np.max(np.abs(a - z[k])) < 2e-6 * np.max(np.abs(z[k])), k
+    assert np.max(np.abs(r.epl - z['wh4_epl'])) < 2e-6 * np.max(np.abs(z['wh4_eps']))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_point_functions(z):
+    m = facade_material(z)
+    sy = float(z['par_sy'])
+    assert np.max(np.abs(m.calc_yf(z['b_sig'], epl=z['b_epl']) - z['b_yf'])) < 1e-9
+    for i in (0, 45, 100, 200):                                           # single points: gradient and the side effect
+        a = m.calc_fgrad(z['b_sig'][i], epl=z['b_epl'][i])
+        assert np.max(np.abs(a - z['b_fgrad'][i])) < 1e-11
+        assert abs(m.khard - z['b_khard'][i]) < 1e-7 * max(1., z['b_khard'][i])
+    a = m.calc_fgrad(z['b_sig'][:50], epl=z['b_epl'][:50])
+    assert np.max(np.abs(a - z['b_fgrad_batch50'])) < 1e-11
+    assert abs(m.khard - float(z['b_khard_batch50'])) < 1e-7 * max(1., float(z['b_khard_batch50']))
+    nf = len(z['b_full_yf'])
+    for i in range(0, nf, 7):
+        m.khard = float(z['b_full_yf_khard'][i])
+        f = m.ML_full_yf(z['b_sig'][i], epl=z['b_epl'][i], verb=False)
+        assert abs(f - z['b_full_yf'][i]) < 1e-6 * sy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['pe', 'ps'])
+def test_gpu_response_with_explicit_khard(z, tag):
+    from pylabfea_amd import _lib
+    m = facade_material(z)
+    CV = z['r%s_CV' % tag]
+    ctx = _lib.Context(0)
+    ctx.set_materials([m._record(CV)])
+    fy, so, dp, ct, ns, kout = ctx.response(z['r%s_sig' % tag], z['r%s_epl' % tag], z['r%s_deps' % tag],
+                                            khard_in=z['r%s_khard_in' % tag], return_khard=True)
+    sy = float(z['par_sy'])
+    assert np.array_equal(ns, z['r%s_nsteps' % tag])
+    assert np.max(np.abs(so - z['r%s_sig_out' % tag])) < 1e-6 * sy
+    assert np.max(np.abs(dp - z['r%s_depl' % tag])) < 1e-9
+    assert np.max(np.abs(ct - z['r%s_ct' % tag])) < 1e-5 * CV[0, 0]
+    assert np.max(np.abs(kout - z['r%s_khard_out' % tag])) < 1e-6 * max(1., np.max(z['r%s_khard_out' % tag]))
+    # the facade's response() carries Material.khard from call to call like the reference's object does
+    m.khard = float(z['r%s_khard_in' % tag][40])
+    out = m.response(z['r%s_sig' % tag][40], z['r%s_epl' % tag][40], z['r%s_deps' % tag][40], CV)
+    assert abs(m.khard - z['r%s_khard_out' % tag][40]) < 1e-6 * max(1., z['r%s_khard_out' % tag][40])
+    assert np.max(np.abs(out[1] - z['r%s_sig_out' % tag][40])) < 1e-6 * sy
+
+
+@pytest.mark.gpu
+def test_gpu_model_with_workhardening_svc(z):
+    """4x4 tension with the work-hardening SVC through Model.solve: the load-step / iteration counts of the reference's
+    trace, fields within 1e-4 -- the engine carries the hardening modulus per material point, the reference per Material
+    object through its element loop (a sequential dependence a data-parallel sweep cannot reproduce exactly; the oracle
+    test above holds that form to 2e-6).  The per-point moduli are state 11."""
+    import pylabfea_amd as FE
+    from pylabfea_amd import _lib
+    m = facade_material(z)
+    fe = FE.Model(dim=2)
+    fe.geom([4.], LY=4.)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.004 * fe.leny, 'disp')
+    fe.mesh(NX=4, NY=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=8)
+    assert fe.nsteps == int(z['wh4_nsteps'])
+    assert np.max(np.abs(fe.sgl - z['wh4_sgl'])) < 1e-4 * np.max(np.abs(z['wh4_sgl']))
+    assert np.max(np.abs(fe.u - z['wh4_u'])) < 1e-4 * np.max(np.abs(z['wh4_u']))
+    assert np.max(np.abs(fe._state('epl') - z['wh4_epl'])) < 1e-4 * np.max(np.abs(z['wh4_eps']))
+    kh = fe._engine.state_get(_lib.ST_KHARD)
+    assert kh.shape == (16,) and np.all(kh >= 0.)
