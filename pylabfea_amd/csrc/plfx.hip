@@ -311,6 +311,9 @@ struct plfx_ctx {
         plfx_ctx *child = nullptr;
         std::vector<double> hbuf;        // host staging of the callback transport
         long long n_halo = 0, n_coarse = 0, n_part = 0;
+        // launches of the local levels 1 .. Ld-1 before / after the coarse hand-over, captured once and replayed
+        hipGraph_t g_down = nullptr, g_up = nullptr;
+        hipGraphExec_t x_down = nullptr, x_up = nullptr;
     } strip;
     bool is_child = false;               // coarse context of a strip: shares stream, sc and dtab with its parent
 
@@ -1019,6 +1022,30 @@ int mg_coarse_part(plfx_ctx *c)
     const double om = c->mg_omega;
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;  // levels >= lt run inside one workgroup
     int rc;
+    if (c->strip.on && c->want_mg_graph && lt >= 2) {
+        // strip: the collective of the coarse hand-over sits in the middle of the cycle, so the latency-bound launches of the
+        // local levels are replayed from two graphs, one on each side of it
+        auto &S = c->strip;
+        for (int leg = 0; leg < 2; leg++) {
+            hipGraphExec_t &x = leg ? S.x_up : S.x_down;
+            if (!x) {
+                hipGraph_t &g = leg ? S.g_up : S.g_down;
+                HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+                rc = 0;
+                if (leg == 0)
+                    for (int l = 1; l < lt && !rc; l++) rc = mg_down_level(c, l);
+                else
+                    for (int l = lt - 1; l >= 1 && !rc; l--) rc = mg_up_level(c, l);
+                const hipError_t e = hipStreamEndCapture(c->stream, &g);
+                if (rc) return rc;
+                if (e != hipSuccess || !g) return fail(c, PLFX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+                HIPCHK(c, hipGraphInstantiate(&x, g, nullptr, nullptr, 0));
+            }
+            HIPCHK(c, hipGraphLaunch(x, c->stream));
+            if (leg == 0 && (rc = strip_coarse(c))) return rc;
+        }
+        return 0;
+    }
     for (int l = 1; l < lt; l++)
         if ((rc = mg_down_level(c, l))) return rc;
     if (c->strip.on) {  // level Ld and everything below it: the replicated coarse problem of the whole grid
@@ -1076,6 +1103,13 @@ void mg_graph_drop(plfx_ctx *c)
     if (c->mg_graph) hipGraphDestroy(c->mg_graph);
     c->mg_graph_exec = nullptr;
     c->mg_graph = nullptr;
+    auto &S = c->strip;
+    if (S.x_down) hipGraphExecDestroy(S.x_down);
+    if (S.x_up) hipGraphExecDestroy(S.x_up);
+    if (S.g_down) hipGraphDestroy(S.g_down);
+    if (S.g_up) hipGraphDestroy(S.g_up);
+    S.x_down = S.x_up = nullptr;
+    S.g_down = S.g_up = nullptr;
 }
 
 // z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r).  The fine level is launched kernel by kernel
@@ -1229,6 +1263,7 @@ int strip_child_dinv(plfx_ctx *c)
 
 void strip_free(plfx_ctx *c)
 {
+    mg_graph_drop(c);  // the strip's captured launches reference the levels freed below
     plfx_ctx *k = c->strip.child;
     if (k) {
         mg_graph_drop(k);
