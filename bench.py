@@ -251,6 +251,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--mesh', type=int, default=1024)
     ap.add_argument('--cpu-mesh', type=int, default=224)
+    ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-inclusion', action='store_true', help='skip the heterogeneous (soft inclusion) variant of the workload')
     ap.add_argument('--no-svc', action='store_true', help='skip the bounded config-4 (SVC) sample behind roofline_svc')
@@ -326,6 +327,7 @@ def main():
             eng.timing_reset()
             # two hipEventRecord calls per timed launch: by default only the kernels of the two roofline objects
             eng.timing_select(None if args.all_families else (_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV))
+            eng.timing_sample(args.sample)
             eng.timing_enable(True)
             gc.collect()
             gc.disable()   # no collector pauses inside the timed steps (a full collection of this process takes 2-3 ms)

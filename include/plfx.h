@@ -311,6 +311,8 @@ int plfx_timing_enable(plfx_ctx *ctx, int on);
 /* Bit f of mask = time family f (default: all).  Every timed launch costs two hipEventRecord calls (about 4 us of host time
  * each and a bubble on the stream); bench.py times only the two kernels its roofline objects need. */
 int plfx_timing_select(plfx_ctx *ctx, unsigned mask);
+/* time only every n-th launch of a selected family (n >= 1; the averages stay representative, the host cost drops n-fold) */
+int plfx_timing_sample(plfx_ctx *ctx, int every);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,7 @@ SYMBOLS = [
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
-    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh',
+    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample',
 ]
 
 _lib = None
@@ -543,6 +543,10 @@ class Context(object):
         """time only the given families (T_* constants); None = all"""
         mask = 0xFF if families is None else sum(1 << int(f) for f in set(families))
         self._chk(self.lib.plfx_timing_select(self.h, C.c_uint(mask)))
+
+    def timing_sample(self, every=1):
+        """time only every n-th launch of the selected families"""
+        self._chk(self.lib.plfx_timing_sample(self.h, int(every)))
 
     def timing_reset(self):
         self._chk(self.lib.plfx_timing_reset(self.h))

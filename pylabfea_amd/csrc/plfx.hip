@@ -39,6 +39,8 @@ struct EvPair {
 struct Timing {
     bool on = false;
     unsigned mask = 0xFFu;  // families that are timed (plfx_timing_select)
+    int every = 1;          // ... every n-th launch of a family (plfx_timing_sample)
+    long long seen[8] = {0};
     std::vector<EvPair> ring;
     size_t head = 0;
     double ms[8] = {0};
@@ -382,6 +384,7 @@ void tim_begin(plfx_ctx *c, int which, EvPair **out)
     *out = nullptr;
     Timing &t = c->tim;
     if (!t.on || !((t.mask >> which) & 1u)) return;
+    if (t.every > 1 && (t.seen[which]++ % t.every) != 0) return;  // sampled: two event records per timed launch cost host time
     if (t.ring.empty()) {
         t.ring.resize(2048);
         for (auto &e : t.ring) {
@@ -994,9 +997,9 @@ int mg_up_level(plfx_ctx *c, int l)
     auto &L = c->mg[l];
     auto &C = c->mg[l + 1];
     const bool mf = L.matfree && matfree(c);
+    const int nu = c->mg_nu;
     hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
                        C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
-    const int nu = c->mg_nu;
     double *src = L.x, *dst = L.t;
     for (int k = 0; k < nu; k++) {
         EvPair *ev = nullptr;
@@ -1336,7 +1339,7 @@ int plfx_create(int device, plfx_ctx **out)
     if ((rc = dalloc(c, &c->part, (size_t)8 * MAXPART))) return rc;
     if ((rc = dalloc(c, &c->part_g, (size_t)18 * MAXPART))) return rc;
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
-    if ((rc = dalloc(c, &c->flags, 4))) return rc;
+    if ((rc = dalloc(c, &c->flags, 8))) return rc;  // [0..3] working flags of a sweep, [4..7] its results (k_sweep_flags)
     if ((rc = dalloc(c, &c->bflags, (size_t)2 * SWEEP_SLOTS))) return rc;
     if ((rc = dalloc(c, &c->small, 64))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2331,6 +2334,8 @@ int plfx_state_reset(plfx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->u, 0, 8 * nd, c->stream));
     HIPCHK(c, hipMemsetAsync(c->f, 0, 8 * nd, c->stream));
     HIPCHK(c, hipMemsetAsync(c->du, 0, 8 * nd, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, 32, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->bflags, 0, (size_t)8 * SWEEP_SLOTS, c->stream));
     {   // hardening modulus of every material point = its material's khard (Material.khard before the first response call)
         std::vector<double> kh(c->nel);
         for (int e = 0; e < c->nel; e++) kh[e] = c->hmat[c->hcls[c->hcls_id[c->e0 + e]].mat].khard;
@@ -3211,8 +3216,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
-    HIPCHK(c, hipMemsetAsync(c->flags, 0, 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->bflags, 0, (size_t)8 * SWEEP_SLOTS, c->stream));
+    // (flags / bflags are left zeroed by the k_sweep_flags of the previous sweep)
     EvPair *ev;
     tim_begin(c, 0, &ev);
 #define SWEEP_ARGS(lds) c->dmat, c->nmat, c->dcls, c->ncls, lds, c->nel, c->e0, c->dconn, c->dcls_id,          \
@@ -3289,16 +3293,16 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
     tim_end(c, ev);
-    hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags);
+    hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4);
     HIPCHK(c, hipGetLastError());
     if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
         // strip: the counts of rewritten tangents / sub-stepped elements stay local (halo elements are replicas)
-        const int rca = allreduce(c, c->flags, c->strip.on ? 2 : 4, NCCL_INT32, NCCL_SUM, "flags");
+        const int rca = allreduce(c, c->flags + 4, c->strip.on ? 2 : 4, NCCL_INT32, NCCL_SUM, "flags");
         if (rca) return rca;
     }
     int h[4];
     {
-        const int rcf = fetch_results(c, reinterpret_cast<const double *>(c->flags), 2, reinterpret_cast<double *>(h));
+        const int rcf = fetch_results(c, reinterpret_cast<const double *>(c->flags + 4), 2, reinterpret_cast<double *>(h));
         if (rcf) return rcf;
     }
     if (h[0] || !c->reuse) {  // the replicated generators are exchanged only when some rank rewrote some of its own
@@ -3519,6 +3523,13 @@ int plfx_timing_select(plfx_ctx *c, unsigned mask)
     return PLFX_OK;
 }
 
+int plfx_timing_sample(plfx_ctx *c, int every)
+{
+    if (!c) return PLFX_ERR_STATE;
+    c->tim.every = every < 1 ? 1 : every;
+    return PLFX_OK;
+}
+
 int plfx_timing_reset(plfx_ctx *c)
 {
     if (!c) return PLFX_ERR_STATE;
@@ -3527,6 +3538,7 @@ int plfx_timing_reset(plfx_ctx *c)
         c->tim.ms[i] = 0.;
         c->tim.n[i] = 0;
         c->tim.noop[i] = 0;
+        c->tim.seen[i] = 0;
     }
     return PLFX_OK;
 }
@@ -3536,7 +3548,8 @@ int plfx_timing_get(plfx_ctx *c, int which, double *ms, int64_t *launches)
     if (!c || which < 0 || which >= 8) return PLFX_ERR_ARG;
     tim_flush(c);
     if (ms) *ms = c->tim.ms[which];
-    if (launches) *launches = c->tim.n[which] - c->tim.noop[which];
+    // no-op launches (PCG already converged) are counted for every launch, timed ones only for the sampled share
+    if (launches) *launches = c->tim.n[which] - (c->tim.noop[which] + c->tim.every / 2) / c->tim.every;
     return PLFX_OK;
 }
 

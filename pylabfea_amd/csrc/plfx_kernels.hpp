@@ -463,13 +463,17 @@ __device__ __forceinline__ void post_block_flags(int changed, int nconv, int *__
 
 // flags[0] = any tangent changed, flags[1] = any element not converged, flags[3] = tangents rewritten (flags[2], the length
 // of the compacted list, is maintained by the kernels themselves)
-__global__ void __launch_bounds__(BLOCK) k_sweep_flags(const int *__restrict__ bflags, int *__restrict__ flags)
+// The kernel leaves the slots and the list length zeroed for the next sweep (no memset launches between sweeps) and hands the
+// four results over in out[0..3].
+__global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags, int *__restrict__ flags, int *__restrict__ out)
 {
     __shared__ int sc[BLOCK / 64], sn[BLOCK / 64];
     int cw = 0, nw = 0;
     for (int b = threadIdx.x; b < SWEEP_SLOTS; b += BLOCK) {
         cw += bflags[2 * b];
         nw |= bflags[2 * b + 1];
+        bflags[2 * b] = 0;
+        bflags[2 * b + 1] = 0;
     }
     for (int o = 32; o; o >>= 1) {
         cw += __shfl_xor(cw, o, 64);
@@ -486,9 +490,11 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_flags(const int *__restrict__ b
             c2 += sc[w];
             n2 |= sn[w];
         }
-        flags[0] = c2 ? 1 : 0;
-        flags[1] = n2;
-        flags[3] = c2;
+        out[0] = c2 ? 1 : 0;
+        out[1] = n2;
+        out[2] = flags[2];
+        out[3] = c2;
+        flags[2] = 0;
     }
 }
 
