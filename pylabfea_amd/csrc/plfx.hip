@@ -3282,7 +3282,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), wm);
     if (c->has_svc && wm >= 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1>), dim3(grid_w), dim3(256), (size_t)c->svc_wave_lds,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
                            c->stream, WAVE_ARGS, 0, wm);
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),

@@ -19,6 +19,9 @@ constexpr int BLOCK = 256;
 constexpr int MAXMAT = 16;
 constexpr int MAXCLS = 16;
 constexpr int MAXPART = 1024;  // max blocks of a reducing kernel (partials per scalar)
+#ifndef PLFX_HEAVY_THREADS
+#define PLFX_HEAVY_THREADS 512  // threads per workgroup of the wave-per-element SVC corrector: two waves per SIMD at 256 VGPRs + 592 B of scratch beat one wave per SIMD at 424 registers (766 -> 589 ms per 16 x 16384 element updates)
+#endif
 #ifndef PLFX_SWEEP_WAVES
 #define PLFX_SWEEP_WAVES 1  // min waves per SIMD the sweep kernel is compiled for (register budget)
 #endif
@@ -643,10 +646,11 @@ __device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, 
     return npad;
 }
 
-// HEAVY = 0: 512-thread blocks (8 waves share the LDS tables: 2 waves per SIMD, <= 256 VGPRs) with 2 vectors per lane
-// and trip; HEAVY = 1: 256-thread blocks (the sub-stepping loop needs > 256 VGPRs: 1 wave per SIMD) with 4.
+// Both phases run 512-thread workgroups (8 waves share the LDS tables: 2 waves per SIMD, 256 VGPRs).  HEAVY = 0: 2 vectors per
+// lane and trip; HEAVY = 1: 4, with the FP32 sign screen of the marching bracket -- the sub-stepping loop wants 424 registers
+// and ran one wave per SIMD in round 1; two waves per SIMD with 592 B of scratch are 1.3x faster (PLFX_HEAVY_THREADS).
 template <int HEAVY>
-__global__ void __launch_bounds__(HEAVY ? 256 : 512)
+__global__ void __launch_bounds__(HEAVY ? PLFX_HEAVY_THREADS : 512)
 k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
                  int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
                  const double2 *__restrict__ du2, const double *__restrict__ sig, const double *__restrict__ epl,
