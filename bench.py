@@ -145,8 +145,8 @@ def cpu_baseline(n, steps, warmup, n1=128):
 VALU_FP64_PEAK_TFLOPS = 78.6
 # VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
 # same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
-SVC_VALU_PER_ELEMENT = {'corrector': 929793., 'streaming': 804363926.5 / 16384.}
-SVC_PROFILE = 'profiles/r02b_svc_rocprofv3_summary.txt'
+SVC_VALU_PER_ELEMENT = {'corrector': 910606., 'streaming': 804363926.5 / 16384.}
+SVC_PROFILE = 'profiles/r02c_svc_rocprofv3_summary.txt'
 
 
 def svc_sample(FE, _lib, n=128, device=0):
