@@ -238,3 +238,45 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * np.max(np.abs(sig1))
         assert np.max(np.abs(d['epl'] - epl1[e0:e1])) <= 1e-8 * max(np.max(np.abs(epl1)), 1e-30)
     assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
+
+
+def test_bench_two_ranks_weak_scaling_path(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
+    ONE GPU over the host-staged transport (PLFX_BENCH_TRANSPORT=host; RCCL refuses two ranks on a device): the weak-scaling
+    strip path end to end -- JSON contract, honest labels, and the same sweeps / solves / PCG iterations as the single-GPU
+    run of the same (2 x 128) x 128 mesh."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = free_port()
+    env = dict(os.environ, PLFX_BENCH_TRANSPORT='host')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--mesh', '128']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 3 and d['dtype'] == 'f64'
+    assert d['config']['elements'] == 256 * 128 and 'strip-local engine x2' in d['config']['parallelism']
+    assert d['strip_collectives']['halo_refreshes'] > 0 and d['strip_collectives']['coarse_gathers'] > 0
+    assert d['roofline'] is not None and d['cpu_baseline'] is None
+    # the same workload on one rank: identical counts
+    import pylabfea_amd as FE
+    sys.path.insert(0, root)
+    import bench
+    fe = bench.tension_model(FE, bench.hill_material(FE), 128, 0.005, strips=2)
+    ninc, pre = bench.schedule(3, 1)
+    marks = {}
+
+    def hook(il):
+        if il == pre + 1:
+            marks['s0'], marks['q0'] = fe.n_sweeps, len(fe.solver_stats)
+        if il == pre + 4:
+            marks['s1'], marks['q1'] = fe.n_sweeps, len(fe.solver_stats)
+    fe._step_hook = hook
+    fe._max_load_steps = pre + 4
+    fe.solve(min_step=ninc)
+    its = [s[0] for s in fe.solver_stats[marks['q0']:marks['q1']]]
+    assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
