@@ -430,7 +430,20 @@ class Model(object):
         lx, ly = self._lxy[:, 0], self._lxy[:, 1]
         if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]) or np.max(np.abs(ly - ly[0])) > 1e-12 * abs(ly[0]):
             return None
-        for Ld in ((coarse_level,) if coarse_level else (4, 3, 2, 1)):
+        def widths(Ld):
+            al = 1 << Ld
+            units = NX // al
+            cols = [((units * r) // nranks) * al for r in range(nranks + 1)]
+            return min(b - a for a, b in zip(cols[:-1], cols[1:]))
+        # hand-over level: the deepest one whose halo (4 * 2^Ld columns, recomputed redundantly on every interior side) stays
+        # below an eighth of the strip width; failing that, the deepest one that fits at all
+        cands = (coarse_level,) if coarse_level else (4, 3, 2, 1)
+        if not coarse_level and nranks > 1:
+            ok = [Ld for Ld in cands if NX % (1 << Ld) == 0 and NY % (1 << Ld) == 0]
+            lean = [Ld for Ld in ok if (4 << Ld) * 8 <= widths(Ld)]
+            if lean:
+                cands = tuple(lean) + tuple(Ld for Ld in cands if Ld not in lean)
+        for Ld in cands:
             al, W = 1 << Ld, 4 << Ld
             if NX % al or NY % al:
                 continue

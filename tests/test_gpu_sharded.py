@@ -63,7 +63,7 @@ def build(case, golden_dir):
     return fe, ms
 
 
-def _worker(rank, world, port, case, golden_dir, q, mode='replicated'):
+def _worker(rank, world, port, case, golden_dir, q, mode='replicated', level=None):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -72,7 +72,7 @@ def _worker(rank, world, port, case, golden_dir, q, mode='replicated'):
     try:
         import pylabfea_amd as FE
         fe, ms = build(case, golden_dir)
-        fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world), mode=mode)
+        fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world), mode=mode, coarse_level=level)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             fe.solve(min_step=ms)
@@ -182,11 +182,15 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
     build = build_strip            # the worker above takes the model from build()
     if case.endswith('+python'):   # the statement-by-statement Python transcription of the load step over the C-ABI calls
         os.environ['PLFX_NATIVE_STEP'] = '0'
-    _worker(rank, world, port, case.split('+')[0], golden_dir, q, mode='strip')
+    # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on these widths)
+    level = {'tension': 3 if world == 2 else 2, 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
+    if case.endswith('+default'):
+        level = None
+    _worker(rank, world, port, case.split('+')[0], golden_dir, q, mode='strip', level=level)
 
 
 @pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('inclusion', 3), ('laminate_svc', 2),
-                                        ('tension+python', 2)])
+                                        ('tension+python', 2), ('tension+default', 4)])
 def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     """Strips + halo on 2..4 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
@@ -207,6 +211,7 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         p.join(timeout=120)
         assert p.exitcode == 0
     python_driver = case.endswith('+python')
+    default_level = case.endswith('+default')
     case = case.split('+')[0]
     fe, ms = build_strip(case, golden_dir)
     with warnings.catch_warnings():
@@ -222,6 +227,8 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         assert st is not None and d['native'] == (not python_driver)
         active, halo, Ld, clev, nh, nc, npart = d['strip_info']
         assert active and halo == st['W'] == 4 << Ld and clev >= 2
+        if default_level:
+            assert Ld == 1          # 32-column strips: the lean default
         assert nh > 0 and nc > 0 and npart > 0
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
         assert d['its'] == its1                                      # same PCG iterations in every solve

@@ -85,6 +85,8 @@ def test_strip_plan(NX, NY, nranks):
             assert q % (1 << Ld) == 0                   # every level coarsens exactly as on one GPU
     if NX == 8192:
         assert Ld == 4 and W == 64                      # the bench's weak-scaling layout: 1024 owned + 64 halo columns
+    if (NX, NY, nranks) == (2048, 2048, 8):
+        assert Ld == 3 and W == 32                      # config 5: 256-column strips -> halo an eighth of the width
 
 
 def test_strip_plan_refuses_what_cannot_work():
