@@ -182,7 +182,7 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
     build = build_strip            # the worker above takes the model from build()
     if case.endswith('+python'):   # the statement-by-statement Python transcription of the load step over the C-ABI calls
         os.environ['PLFX_NATIVE_STEP'] = '0'
-    # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on these widths)
+    # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on 64-column strips)
     level = {'tension': 3 if world == 2 else 2, 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
     if case.endswith('+default'):
         level = None
@@ -190,7 +190,7 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
 
 
 @pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('inclusion', 3), ('laminate_svc', 2),
-                                        ('tension+python', 2), ('tension+default', 4)])
+                                        ('tension+python', 2), ('tension+default', 2)])
 def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     """Strips + halo on 2..4 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
@@ -228,7 +228,7 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         active, halo, Ld, clev, nh, nc, npart = d['strip_info']
         assert active and halo == st['W'] == 4 << Ld and clev >= 2
         if default_level:
-            assert Ld == 1          # 32-column strips: the lean default
+            assert Ld == 1          # 64-column strips: the lean default (halo 8 columns = width / 8)
         assert nh > 0 and nc > 0 and npart > 0
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
         assert d['its'] == its1                                      # same PCG iterations in every solve
