@@ -267,6 +267,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
+    # watchdog: a rank that waits forever for a peer (a collective that never completes) ends the job with a stack dump instead
+    # of hanging the node until the caller's own limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get('PLFX_BENCH_WATCHDOG', '1500')), exit=True)
+
     import torch
     import pylabfea_amd as FE
     from pylabfea_amd import _lib
