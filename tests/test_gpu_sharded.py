@@ -183,16 +183,16 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
     if case.endswith('+python'):   # the statement-by-statement Python transcription of the load step over the C-ABI calls
         os.environ['PLFX_NATIVE_STEP'] = '0'
     # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on 64-column strips)
-    level = {'tension': 3 if world == 2 else 2, 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
+    level = {'tension': {2: 3, 4: 2, 8: 1}[world], 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
     if case.endswith('+default'):
         level = None
     _worker(rank, world, port, case.split('+')[0], golden_dir, q, mode='strip', level=level)
 
 
-@pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('inclusion', 3), ('laminate_svc', 2),
+@pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('tension', 8), ('inclusion', 3), ('laminate_svc', 2),
                                         ('tension+python', 2), ('tension+default', 2)])
 def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
-    """Strips + halo on 2..4 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
+    """Strips + halo on 2..8 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
     K-iteration AND PCG-iteration counts (the V-cycle is arithmetically the single-GPU one), fields to 1e-9."""
     import torch.multiprocessing as mp
