@@ -389,8 +389,8 @@ def main():
     op_bytes = (64. * nn_l + 48. * ne_l) if mf else 388. * nn_l
     n_sw = marks['si1'][0] - marks['si0'][0]
     if strip:
-        nel_rank = ne_l
-        rewritten = float(marks['si1'][1] - marks['si0'][1])     # counted on this rank's local elements
+        nel_rank = fe._e1 - fe._e0                               # the sweep passes over the owned columns of the strip
+        rewritten = float(marks['si1'][1] - marks['si0'][1])     # counted on this rank's own elements
     else:
         rewritten = (marks['si1'][1] - marks['si0'][1]) / world  # whole mesh (all-reduced): this rank's share
     bytes_per = {'spmv': op_bytes if strip else op_bytes / world,
@@ -442,7 +442,8 @@ def main():
                    'parallelism': ('single GPU' if world == 1 else
                                    ('strip-local engine x%d: %d owned + %d halo element columns per GPU, halo refresh of the residual '
                                     '(ncclSend/ncclRecv) + coarse right-hand-side all-reduce (level %d, replicated %d-level coarse '
-                                    'hierarchy) + 3 all-reduces of 8 KB partial sums per PCG iteration; weak scaling, %d x %d mesh'
+                                    'hierarchy) + 3 all-reduces of 8 KB partial sums per PCG iteration, stiffness generators of the '
+                                    'halo columns from their owners after a sweep that changed a tangent; weak scaling, %d x %d mesh'
                                     % (world, strip['c1'] - strip['c0'], strip['W'], strip['Ld'], eng.strip_info()[3], fe._NX, fe._NY))
                                    if strip else
                                    ('x-strip element shard x%d: material state and sweep sharded, operator + multigrid solve '
@@ -461,7 +462,7 @@ def main():
     }
     if strip:
         si = eng.strip_info()
-        out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'note': 'since the start of the run (rank 0)'}
+        out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'generator_exchanges': si[7], 'note': 'since the start of the run (rank 0)'}
     if rank == 0 and world == 1:
         fe._drop_engine()        # release the homogeneous model's HBM and stream before the other samples
     if rank == 0 and world == 1 and not args.no_inclusion:

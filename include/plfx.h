@@ -270,16 +270,19 @@ int plfx_finish_fetch(plfx_ctx *ctx, int slot, double *u_at, double *f_at, doubl
  * coarse problem; per PCG iteration the ranks exchange one halo slab of the residual (contiguous node columns, ncclSend /
  * ncclRecv), one all-reduce of the owned level-`coarse_level` residual into the replicated global coarse grid, and three
  * all-reduces of <= 8 KB of partial sums.  The V-cycle is arithmetically the one a single GPU runs on the global grid
- * (validity widths in DESIGN.md section 6), so iteration counts do not depend on the number of strips.  The material sweep
- * runs on the halo elements too (their state is recomputed from the exchanged displacement increment, never communicated).
+ * (validity widths in DESIGN.md section 6), so iteration counts do not depend on the number of strips.  Material state and
+ * sweep: when plfx_set_mesh was given exactly the owned columns as its owned element range [el_begin, el_end), the strip
+ * holds and sweeps only those, and the six stiffness generators of the halo columns arrive from the neighbour that owns
+ * them after every sweep that rewrote a tangent anywhere (6 * halo * NY doubles per side); with el_begin = 0, el_end = nel
+ * the sweep runs on the halo elements too (state recomputed from the exchanged displacement increment, nothing else sent).
  * global_col0 = global element column of local column 0; halo (derived) must be at least 4 * 2^coarse_level (32 for level 3, 64 for
  * level 4); all column numbers and NY must be multiples of 2^coarse_level.  Needs the matrix-free operator and, for more
  * than one strip, a communicator (plfx_comm_init / plfx_comm_init_callback) created BEFORE this call.
  * plfx_sweep flags, plfx_scf_all statistics and plfx_finish_step element sums then refer to the whole grid; u_at / f_at of
- * plfx_finish_step and all state arrays are local (owned + halo columns). */
+ * plfx_finish_step and the nodal arrays are local (owned + halo columns); element state arrays hold the owned element range. */
 int plfx_set_strip(plfx_ctx *ctx, int own_col0, int own_col1, int global_col0, int global_nx, int coarse_level);
 int plfx_strip_info(plfx_ctx *ctx, int *active, int *halo, int *coarse_level, int *coarse_levels, int64_t *halo_refreshes,
-                    int64_t *coarse_gathers, int64_t *partial_allreduces);
+                    int64_t *coarse_gathers, int64_t *partial_allreduces, int64_t *generator_exchanges);
 /* in-place all-reduce of n <= 32 host doubles over the context's communicator (op 0 = sum, 3 = min): the boundary sums of
  * calc_global (model.py:1452-1471) over the strips.  No-op without a communicator. */
 int plfx_allreduce_host(plfx_ctx *ctx, double *buf, int n, int op);

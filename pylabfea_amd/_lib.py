@@ -504,12 +504,12 @@ class Context(object):
 
     def strip_info(self):
         """(active, halo, coarse_level, levels of the replicated coarse hierarchy, halo refreshes, coarse gathers,
-        all-reduces of partial sums)"""
+        all-reduces of partial sums, exchanges of the halo elements' stiffness generators)"""
         a, h, l, cl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        nh, nc, npart = C.c_int64(), C.c_int64(), C.c_int64()
+        nh, nc, npart, ng = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._chk(self.lib.plfx_strip_info(self.h, C.byref(a), C.byref(h), C.byref(l), C.byref(cl), C.byref(nh),
-                                           C.byref(nc), C.byref(npart)))
-        return bool(a.value), h.value, l.value, cl.value, nh.value, nc.value, npart.value
+                                           C.byref(nc), C.byref(npart), C.byref(ng)))
+        return bool(a.value), h.value, l.value, cl.value, nh.value, nc.value, npart.value, ng.value
 
     def allreduce_host(self, values, op=0):
         """all-reduce <= 32 host doubles over the context's communicator (op 0 sum, 3 min)"""

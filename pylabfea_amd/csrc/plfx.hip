@@ -312,7 +312,7 @@ struct plfx_ctx {
         int eown_lo = 0, eown_hi = 0;    // owned element range
         plfx_ctx *child = nullptr;
         std::vector<double> hbuf;        // host staging of the callback transport
-        long long n_halo = 0, n_coarse = 0, n_part = 0;
+        long long n_halo = 0, n_coarse = 0, n_part = 0, n_gen = 0;
         // launches of the local levels 1 .. Ld-1 before / after the coarse hand-over, captured once and replayed
         hipGraph_t g_down = nullptr, g_up = nullptr;
         hipGraphExec_t x_down = nullptr, x_up = nullptr;
@@ -793,9 +793,11 @@ int allreduce(plfx_ctx *c, void *dev, size_t count, int nccl_dtype, int nccl_op,
 
 // Sharded runs: make the stiffness generators of the whole mesh consistent on every rank after a sweep
 // changed the owned ones (own part + exact zeros elsewhere, summed by one all-reduce).
+int strip_sync_M(plfx_ctx *c);
 int sync_M(plfx_ctx *c)
 {
     if (!comm_active(c) || !c->sharded) return 0;
+    if (c->strip.on) return strip_sync_M(c);  // strip-local engine: only the halo columns, from the neighbour that owns them
     hipLaunchKernelGGL(k_zero_foreign_M, dim3(grid_for((size_t)6 * c->nel_total)), dim3(BLOCK), 0, c->stream,
                        c->nel_total, c->e0, c->e0 + c->nel, c->Mel);
     HIPCHK(c, hipGetLastError());
@@ -863,6 +865,57 @@ int halo_refresh(plfx_ctx *c, double *v)
             return fail(c, PLFX_ERR_HIP, "host halo-exchange callback failed");
         if (S.has_left) HIPCHK(c, hipMemcpyAsync(recvL, S.hbuf.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
         if (S.has_right) HIPCHK(c, hipMemcpyAsync(recvR, S.hbuf.data() + n, 8 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// Stiffness generators of the halo elements: a strip sweeps (and holds the material state of) its OWNED element columns
+// only; the six generators of the W halo columns on each interior side are received from the neighbour that owns them
+// whenever a sweep rewrote a tangent anywhere (plfx_sweep calls sync_M on the all-reduced flag, so every rank takes part).
+// Generator k of local element e = column * ny + row sits at Mel[k * nel_total + e]: a slab of W columns is contiguous.
+//   to the left neighbour   my element columns oc0 .. oc0+W-1     from it   columns oc0-W .. oc0-1
+//   to the right neighbour  my element columns oc1-W .. oc1-1     from it   columns oc1 .. oc1+W-1
+int strip_sync_M(plfx_ctx *c)
+{
+    auto &S = c->strip;
+    if (!S.on || !strip_coll(c)) return 0;
+    const int ny = c->gy;
+    const size_t n = (size_t)S.W * ny, tot = (size_t)c->nel_total;
+    double *M = c->Mel;
+    const size_t sL = (size_t)S.oc0 * ny, rL = (size_t)(S.oc0 - S.W) * ny, sR = (size_t)(S.oc1 - S.W) * ny, rR = (size_t)S.oc1 * ny;
+    S.n_gen++;
+    if (c->comm) {
+        if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+            return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
+        int rc = g_rccl.GroupStart();
+        for (int k = 0; k < 6 && !rc; k++) {
+            if (S.has_left) {
+                rc = g_rccl.Send(M + k * tot + sL, n, NCCL_FLOAT64, c->rank - 1, c->comm, c->stream);
+                if (!rc) rc = g_rccl.Recv(M + k * tot + rL, n, NCCL_FLOAT64, c->rank - 1, c->comm, c->stream);
+            }
+            if (!rc && S.has_right) {
+                rc = g_rccl.Send(M + k * tot + sR, n, NCCL_FLOAT64, c->rank + 1, c->comm, c->stream);
+                if (!rc) rc = g_rccl.Recv(M + k * tot + rR, n, NCCL_FLOAT64, c->rank + 1, c->comm, c->stream);
+            }
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc || rc2) return fail(c, PLFX_ERR_HIP, "generator halo exchange (ncclSend/ncclRecv) failed: %d / %d", rc, rc2);
+        return 0;
+    }
+    if (c->host_ar) {  // host-staged transport: [6 slabs to the left | 6 slabs to the right] out, [from left | from right] back
+        S.hbuf.assign(12 * n, 0.);
+        for (int k = 0; k < 6; k++) {
+            if (S.has_left) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + k * n, M + k * tot + sL, 8 * n, hipMemcpyDeviceToHost, c->stream));
+            if (S.has_right) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + (6 + k) * n, M + k * tot + sR, 8 * n, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->host_ar(c->host_ar_user, S.hbuf.data(), 12 * n, 0, 100) != 0)
+            return fail(c, PLFX_ERR_HIP, "host halo-exchange callback failed (generators)");
+        for (int k = 0; k < 6; k++) {
+            if (S.has_left) HIPCHK(c, hipMemcpyAsync(M + k * tot + rL, S.hbuf.data() + k * n, 8 * n, hipMemcpyHostToDevice, c->stream));
+            if (S.has_right) HIPCHK(c, hipMemcpyAsync(M + k * tot + rR, S.hbuf.data() + (6 + k) * n, 8 * n, hipMemcpyHostToDevice, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return 0;
@@ -2086,8 +2139,11 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh / set_grid first") : PLFX_ERR_STATE;
     if (!c->grid_ok || !c->want_matfree || c->mg.size() < 2)
         return fail(c, PLFX_ERR_UNSUPPORTED, "a strip needs the uniform structured grid (matrix-free operator + multigrid)");
-    if (c->sharded) return fail(c, PLFX_ERR_STATE, "a strip context owns its whole local mesh (el_begin = 0, el_end = nel)");
     const int nx = c->gx, ny = c->gy, Ld = coarse_level;
+    // material state and sweeps: either the whole local mesh (halo elements swept redundantly) or exactly the owned columns
+    // (el_begin / el_end of plfx_set_mesh; the generators of the halo columns then come from the neighbours: strip_sync_M)
+    if (c->sharded && (c->e0 != own_col0 * ny || c->nel != (own_col1 - own_col0) * ny))
+        return fail(c, PLFX_ERR_STATE, "the owned element range of plfx_set_mesh must be the owned columns of the strip (or the whole local mesh)");
     if (Ld < 1 || Ld >= (int)c->mg.size())
         return fail(c, PLFX_ERR_ARG, "coarse level %d outside 1..%d of the local hierarchy", Ld, (int)c->mg.size() - 1);
     const int al = 1 << Ld;
@@ -2151,8 +2207,8 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
     const int nyn = ny + 1;
     S.own_lo = own_col0 * nyn;
     S.own_hi = (hr ? own_col1 : nx + 1) * nyn;
-    S.eown_lo = own_col0 * ny;
-    S.eown_hi = own_col1 * ny;
+    S.eown_lo = c->sharded ? 0 : own_col0 * ny;  // in the numbering of the state arrays
+    S.eown_hi = c->sharded ? c->nel : own_col1 * ny;
     // replicated coarse problem: levels >= Ld of the global grid
     plfx_ctx *k = new plfx_ctx();
     S.child = k;
@@ -2206,7 +2262,7 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
 }
 
 int plfx_strip_info(plfx_ctx *c, int *active, int *halo, int *coarse_level, int *coarse_levels, int64_t *halo_refreshes,
-                    int64_t *coarse_gathers, int64_t *partial_allreduces)
+                    int64_t *coarse_gathers, int64_t *partial_allreduces, int64_t *generator_exchanges)
 {
     if (!c) return PLFX_ERR_ARG;
     const auto &S = c->strip;
@@ -2217,6 +2273,7 @@ int plfx_strip_info(plfx_ctx *c, int *active, int *halo, int *coarse_level, int 
     if (halo_refreshes) *halo_refreshes = S.n_halo;
     if (coarse_gathers) *coarse_gathers = S.n_coarse;
     if (partial_allreduces) *partial_allreduces = S.n_part;
+    if (generator_exchanges) *generator_exchanges = S.n_gen;
     return PLFX_OK;
 }
 

@@ -514,12 +514,16 @@ class Model(object):
             n1 = (ih // NY) * nyn + ih % NY
             conn = np.stack((n1, n1 + 1, n1 + nyn, n1 + nyn + 1), axis=1)
             nnode_l = (nxl + 1) * nyn
+            # material state and sweep on the owned columns only; the stiffness generators of the halo columns come from
+            # the neighbours that own them (PLFX_STRIP_SWEEP_HALO=1: sweep the halo elements redundantly instead)
+            lean = os.environ.get('PLFX_STRIP_SWEEP_HALO', '0') != '1'
+            eo0, eo1 = ((plan['c0'] - g0) * NY, (plan['c1'] - g0) * NY) if lean else (0, nxl * NY)
             eng.set_mesh(conn, self._eng_mat_id[g0 * NY:g1 * NY], self._lxy[g0 * NY:g1 * NY], nnode_l, self.thick,
-                         self.planestress, 0, nxl * NY)
+                         self.planestress, eo0, eo1)
             eng.set_grid(nxl, NY)
             eng.set_strip(plan['c0'] - g0, plan['c1'] - g0, g0, self._NX, plan['Ld'])
             last = plan['rank'] == plan['nranks'] - 1
-            plan.update(node0=g0 * nyn, nnode=nnode_l, el0=g0 * NY, nel=nxl * NY,
+            plan.update(node0=g0 * nyn, nnode=nnode_l, el0=g0 * NY, nel=nxl * NY, state_el0=g0 * NY + eo0,
                         own_nodes=(plan['c0'] * nyn, (self._NX + 1 if last else plan['c1']) * nyn))
             self._strip = plan
             e0, e1 = plan['c0'] * NY, plan['c1'] * NY
@@ -550,9 +554,9 @@ class Model(object):
                    'res_sig': _lib.ST_RES_SIG, 'res_depl': _lib.ST_RES_DEPL, 'max_steps': _lib.ST_MAXSTEPS,
                    'fyn': _lib.ST_FYN}
             a = self._ensure_engine().state_get(ids[name])
-            if self._strip is not None:  # local strip (owned + halo elements): the owned part into a full-size array
+            if self._strip is not None:  # local strip: the owned part of the state arrays into a full-size array
                 full = np.zeros((self.Nel,) + a.shape[1:])
-                o = self._e0 - self._strip['el0']
+                o = self._e0 - self._strip['state_el0']
                 full[self._e0:self._e1] = a[o:o + self._e1 - self._e0]
                 a = full
             elif self._shard is not None:  # place the owned strip into a full-size array

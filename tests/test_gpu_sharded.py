@@ -22,6 +22,31 @@ def free_port():
     return p
 
 
+def collect(q, procs, world, limit=900.):
+    """results of the workers; fails as soon as one of them has died without reporting (instead of waiting out the limit)"""
+    import queue
+    import time
+    res, t0 = {}, time.time()
+    while len(res) < world:
+        try:
+            r, d = q.get(timeout=2.)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 >= limit:
+                for p in procs:          # peers of a dead rank wait in a collective for ever: end the processes we started
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError('worker exit codes %s' % dead if dead else 'workers did not report within %g s' % limit)
+            continue
+        if isinstance(d, str):
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(d)
+        res[r] = d
+    return res
+
+
 def build(case, golden_dir):
     import pylabfea_amd as FE
     mat = FE.Material()
@@ -101,11 +126,7 @@ def test_sharded_ranks_on_one_gpu(golden_dir, case, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, golden_dir, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in range(world):
-        r, d = q.get(timeout=600)
-        assert not isinstance(d, str), d
-        res[r] = d
+    res = collect(q, procs, world, 600.)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -183,14 +204,16 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
     if case.endswith('+python'):   # the statement-by-statement Python transcription of the load step over the C-ABI calls
         os.environ['PLFX_NATIVE_STEP'] = '0'
     # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on 64-column strips)
-    level = {'tension': {2: 3, 4: 2, 8: 1}[world], 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
+    level = {'tension': {2: 3, 4: 2, 8: 1}.get(world), 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
     if case.endswith('+default'):
         level = None
+    if case.endswith('+sweephalo'):  # the redundant variant: halo elements swept locally, no generator exchange
+        os.environ['PLFX_STRIP_SWEEP_HALO'] = '1'
     _worker(rank, world, port, case.split('+')[0], golden_dir, q, mode='strip', level=level)
 
 
 @pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('tension', 8), ('inclusion', 3), ('laminate_svc', 2),
-                                        ('tension+python', 2), ('tension+default', 2)])
+                                        ('tension+python', 2), ('tension+default', 2), ('inclusion+sweephalo', 3)])
 def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     """Strips + halo on 2..8 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
@@ -202,16 +225,13 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     procs = [ctx.Process(target=_strip_worker, args=(r, world, port, case, golden_dir, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in range(world):
-        r, d = q.get(timeout=900)
-        assert not isinstance(d, str), d
-        res[r] = d
+    res = collect(q, procs, world)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     python_driver = case.endswith('+python')
     default_level = case.endswith('+default')
+    sweep_halo = case.endswith('+sweephalo')
     case = case.split('+')[0]
     fe, ms = build_strip(case, golden_dir)
     with warnings.catch_warnings():
@@ -225,11 +245,12 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         d = res[r]
         st = d['strip']
         assert st is not None and d['native'] == (not python_driver)
-        active, halo, Ld, clev, nh, nc, npart = d['strip_info']
+        active, halo, Ld, clev, nh, nc, npart, ngen = d['strip_info']
         assert active and halo == st['W'] == 4 << Ld and clev >= 2
         if default_level:
             assert Ld == 1          # 64-column strips: the lean default (halo 8 columns = width / 8)
         assert nh > 0 and nc > 0 and npart > 0
+        assert (ngen == 0) if sweep_halo else (ngen > 0)   # halo generators: received from their owners / recomputed locally
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
         assert d['its'] == its1                                      # same PCG iterations in every solve
         lo, hi = 2 * st['c0'] * nyn, 2 * (st['c1'] + 1) * nyn        # nodes of the owned columns
