@@ -430,35 +430,71 @@ class Model(object):
         lx, ly = self._lxy[:, 0], self._lxy[:, 1]
         if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]) or np.max(np.abs(ly - ly[0])) > 1e-12 * abs(ly[0]):
             return None
-        def widths(Ld):
-            al = 1 << Ld
+        cost = self._column_cost()
+
+        def boundaries(Ld):
+            """strip boundaries (element columns, multiples of 2^Ld): equal cost per strip, every strip at least one halo wide"""
+            al, W = 1 << Ld, 4 << Ld
             units = NX // al
-            cols = [((units * r) // nranks) * al for r in range(nranks + 1)]
-            return min(b - a for a, b in zip(cols[:-1], cols[1:]))
-        # hand-over level: the deepest one whose halo (4 * 2^Ld columns, recomputed redundantly on every interior side) stays
-        # below an eighth of the strip width; failing that, the deepest one that fits at all
-        cands = (coarse_level,) if coarse_level else (4, 3, 2, 1)
-        if not coarse_level and nranks > 1:
-            ok = [Ld for Ld in cands if NX % (1 << Ld) == 0 and NY % (1 << Ld) == 0]
-            lean = [Ld for Ld in ok if (4 << Ld) * 8 <= widths(Ld)]
-            if lean:
-                cands = tuple(lean) + tuple(Ld for Ld in cands if Ld not in lean)
-        for Ld in cands:
+            need = max(1, (W if nranks > 1 else al) // al)      # units a strip must own: its neighbours' halos lie inside it
+            if units < need * nranks:
+                return None
+            cu = np.concatenate(([0.], np.cumsum(cost.reshape(units, al).sum(axis=1))))
+            cols = [0]
+            for r in range(1, nranks):
+                k = int(np.searchsorted(cu, cu[-1] * r / nranks, side='left'))
+                if k > 0 and abs(cu[k - 1] - cu[-1] * r / nranks) <= abs(cu[k] - cu[-1] * r / nranks):
+                    k -= 1
+                k = min(max(k, cols[-1] + need), units - need * (nranks - r))
+                cols.append(k)
+            cols.append(units)
+            return [k * al for k in cols]
+
+        # Hand-over level: the one with the cheapest slowest strip.  Model of a strip's load step in units of one analytic
+        # element: its owned columns by cost, its halo columns (operator, smoother and transfers pass over them, the sweep
+        # does not) and the replicated coarse hierarchy (levels >= Ld of the GLOBAL grid, 4/3 of the nodes of level Ld).
+        best = None
+        for Ld in ((coarse_level,) if coarse_level else (4, 3, 2, 1)):
             al, W = 1 << Ld, 4 << Ld
             if NX % al or NY % al:
                 continue
             gx, gy = NX >> Ld, NY >> Ld
             if gx % 2 or gy % 2 or gx * gy <= 4:      # the replicated coarse grid needs a hierarchy of its own
                 continue
-            units = NX // al
-            cols = [((units * r) // nranks) * al for r in range(nranks + 1)]
-            if nranks > 1 and min(b - a for a, b in zip(cols[:-1], cols[1:])) < W:
+            cols = boundaries(Ld)
+            if cols is None or (nranks > 1 and min(b - a for a, b in zip(cols[:-1], cols[1:])) < W):
                 continue
+            cu = np.concatenate(([0.], np.cumsum(cost)))
+            t = max(cu[cols[r + 1]] - cu[cols[r]] + NY * W * ((r > 0) + (r < nranks - 1)) for r in range(nranks))
+            t += (4. / 3.) * gx * gy if nranks > 1 else 0.
+            if best is None or t < best[0]:
+                best = (t, Ld, cols)
+        if best is not None:
+            _, Ld, cols = best
+            W = 4 << Ld
             c0, c1 = cols[rank], cols[rank + 1]
             g0 = c0 - (W if rank > 0 else 0)
             g1 = c1 + (W if rank < nranks - 1 else 0)
             return dict(c0=c0, c1=c1, g0=g0, g1=g1, Ld=Ld, W=W, rank=rank, nranks=nranks)
         return None
+
+    def _column_cost(self):
+        """Relative cost of one load step per element column, the weights of the strip boundaries: an element of an
+        analytic material counts 1 (streaming sweep + its share of the solve), an element with an SVC yield function
+        ``nsv * nfeat / 8`` (its plastic corrector evaluates the support-vector sums 50 x per sweep; measured on config 4:
+        2.2 us per 1585 x 6 element update against 1e-4 us for a Hill element in the streaming sweep -- whatever the exact
+        ratio, strips have to balance the SVC elements first).  ``Model.strip_weights`` (array of NX column weights)
+        overrides it."""
+        w = getattr(self, 'strip_weights', None)
+        if w is not None:
+            w = np.asarray(w, dtype=float)
+            if w.shape != (self._NX,) or not np.all(w > 0.):
+                raise ValueError('strip_weights: NX positive column weights expected')
+            return w
+        if getattr(self, 'mat', None) is None or getattr(self, '_mat_id', None) is None:
+            return np.full(self._NX, float(self._NY))
+        per_mat = np.array([(len(m.svc['dual']) * m.Ndof / 8.) if getattr(m, 'ML_yf', False) else 1. for m in self.mat])
+        return per_mat[self._mat_id].reshape(self._NX, self._NY).sum(axis=1)
 
     def strip_range(self, rank, nranks):
         """Owned element range of x-strip ``rank``: whole element columns, balanced."""

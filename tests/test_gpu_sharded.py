@@ -203,7 +203,7 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
     build = build_strip            # the worker above takes the model from build()
     if case.endswith('+python'):   # the statement-by-statement Python transcription of the load step over the C-ABI calls
         os.environ['PLFX_NATIVE_STEP'] = '0'
-    # hand-over levels as deep as the small test meshes allow (the default prefers lean halos: level 1 on 64-column strips)
+    # hand-over levels as deep as the small test meshes allow (the default follows the plan's cost model)
     level = {'tension': {2: 3, 4: 2, 8: 1}.get(world), 'inclusion': 3, 'laminate_svc': 2}[case.split('+')[0]]
     if case.endswith('+default'):
         level = None
@@ -213,7 +213,8 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
 
 
 @pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('tension', 8), ('inclusion', 3), ('laminate_svc', 2),
-                                        ('tension+python', 2), ('tension+default', 2), ('inclusion+sweephalo', 3)])
+                                        ('tension+python', 2), ('tension+default', 2), ('inclusion+sweephalo', 3),
+                                        ('laminate_svc+default', 4)])
 def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     """Strips + halo on 2..8 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
@@ -247,8 +248,12 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         assert st is not None and d['native'] == (not python_driver)
         active, halo, Ld, clev, nh, nc, npart, ngen = d['strip_info']
         assert active and halo == st['W'] == 4 << Ld and clev >= 2
-        if default_level:
-            assert Ld == 1          # 64-column strips: the lean default (halo 8 columns = width / 8)
+        if default_level and case == 'tension':
+            assert Ld == 2          # the cheapest slowest strip of the plan's cost model on 2 x 64 columns
+        if default_level and case == 'laminate_svc':
+            # boundaries follow the cost of the columns: every strip gets its share of the SVC columns, widths differ
+            widths = [res[q]['strip']['c1'] - res[q]['strip']['c0'] for q in range(world)]
+            assert len(set(widths)) > 1 and min(widths) >= st['W'], widths
         assert nh > 0 and nc > 0 and npart > 0
         assert (ngen == 0) if sweep_halo else (ngen > 0)   # halo generators: received from their owners / recomputed locally
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)

@@ -89,6 +89,43 @@ def test_strip_plan(NX, NY, nranks):
         assert Ld == 3 and W == 32                      # config 5: 256-column strips -> halo an eighth of the width
 
 
+def test_strip_plan_balances_svc_columns():
+    """config 5's laminate [2,1,2,1,2] (J2 | SVC | J2 | SVC | J2) on 8 strips: equal column counts would put every SVC element
+    on two of the eight ranks; the boundaries follow the cost of the columns instead"""
+    rng = np.random.default_rng(0)
+    a = FE.Material(name='J2')
+    a.elasticity(E=200.e3, nu=0.3)
+    a.plasticity(sy=150., khard=500., sdim=6)
+    b = FE.Material(name='ML', num=2)
+    b.elasticity(E=151220., nu=0.3)
+    b.plasticity(sy=46.76, sdim=6)
+    b.set_svc(rng.normal(size=(800, 6)), rng.normal(size=800), 0.1, 2.5, 50.)
+    fe = FE.Model(dim=2)
+    fe.geom([2, 1, 2, 1, 2], LY=1.)
+    fe.assign([a, b, a, b, a])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.001, 'disp')
+    fe.mesh(NX=512, NY=64)
+    plans = [fe.strip_plan(r, 8) for r in range(8)]
+    assert all(p is not None for p in plans)
+    W = plans[0]['W']
+    svc_col = np.zeros(512, dtype=bool)
+    svc_col[128:192] = svc_col[320:384] = True
+    n_svc = [int(svc_col[p['c0']:p['c1']].sum()) for p in plans]
+    assert sum(n_svc) == 128 and max(n_svc) <= 24 and min(n_svc) >= 8, n_svc      # 16 per rank were perfect
+    assert min(p['c1'] - p['c0'] for p in plans) >= W
+    for x, y in zip(plans[:-1], plans[1:]):
+        assert x['c1'] == y['c0']
+    # explicit weights win over the material model
+    fe.strip_weights = np.ones(512)
+    assert [fe.strip_plan(r, 8)['c0'] for r in range(8)] == [64 * r for r in range(8)]
+    fe.strip_weights = np.ones(5)
+    with pytest.raises(ValueError):
+        fe.strip_plan(0, 8)
+
+
 def test_strip_plan_refuses_what_cannot_work():
     fe = FE.Model(dim=2)
     fe._NX, fe._NY = 96, 24
