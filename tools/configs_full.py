@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Whole Model.solve() wall-clock of the BASELINE.json configs on one GPU (full load schedules)."""
+"""Whole Model.solve() wall-clock of the BASELINE.json configs on one GPU (full load schedules).
+
+Launched through ``python -m torch.distributed.run --nproc-per-node N tools/configs_full.py 5full`` the model is distributed
+over N ranks (strip-local engine): RCCL with one GPU per rank, or -- PLFX_TOOL_TRANSPORT=host -- the host-staged transport
+with all ranks on the GPUs that exist (functional full-size check on a single-GPU box; the wall-clock then says nothing)."""
 import os
 import sys
 import time
@@ -24,8 +28,35 @@ def tension(mat, n, eps):
     return fe
 
 
+RANK, WORLD = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+DIST = None
+if WORLD > 1:
+    import torch
+    import torch.distributed as DIST
+    HOST = os.environ.get('PLFX_TOOL_TRANSPORT') == 'host'
+    DEV = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(DEV)
+    DIST.init_process_group('gloo' if HOST else 'nccl')
+
+
+def distribute(fe):
+    if DIST is None:
+        return
+    fe.device = DEV
+    if HOST:
+        fe.distribute(RANK, WORLD, None, host_allreduce=FE.host_transport(DIST, RANK, WORLD))
+    else:
+        from pylabfea_amd import _lib
+        uid = [_lib.Context(DEV).comm_unique_id() if RANK == 0 else None]
+        DIST.broadcast_object_list(uid, src=0)
+        fe.distribute(RANK, WORLD, uid[0])
+
+
 def run(name, fe, ms):
+    distribute(fe)
     eng = fe._ensure_engine()
+    if DIST is not None:
+        DIST.barrier()
     eng.sync()
     t = time.perf_counter()
     with warnings.catch_warnings():
@@ -34,6 +65,18 @@ def run(name, fe, ms):
     eng.sync()
     dt = time.perf_counter() - t
     its = [s[0] for s in fe.solver_stats]
+    if DIST is not None:
+        st = fe._strip
+        svc = np.array([getattr(m, 'ML_yf', False) for m in fe.mat])[fe._mat_id[fe._e0:fe._e1]]
+        heavy = int(np.sum(fe._state('max_steps')[fe._e0:fe._e1] == 49))
+        rows = [None] * WORLD
+        DIST.all_gather_object(rows, (RANK, st and (st['c0'], st['c1'], st['W'], st['Ld']), int(svc.sum()), heavy, dt))
+        if RANK == 0:
+            for r in rows:
+                print('    rank %d: owned columns / halo / level %s, SVC elements owned %d, on the 50-sub-step corrector in the last sweep %d, %.1f s'
+                      % (r[0], r[1], r[2], r[3], r[4]))
+        if RANK != 0:
+            return
     print('%-34s %8.3f s  load steps %3d  K-iterations %4d  sweeps %4d  solves %4d  PCG its %5d  updates/s %.3g  sgl_yy %.6f'
           % (name, dt, fe.nsteps, sum(max(n, 0) + 1 for n in fe.niter), fe.n_sweeps, len(its), sum(its),
              fe.Nel * fe.n_sweeps / dt if fe.n_sweeps else 0., fe.sgl[-1][1]))
@@ -115,7 +158,11 @@ if '5' in which or '5full' in which:
     fe.mesh(NX=2048, NY=2048)
     if '5full' in which:
         run('config 5: 2048x2048 laminate J2 + Goss-Barlat SVC, all 20 load steps', fe, 20)
-        print('    SVC elements on the 50-sub-step corrector at least once: %d' % int(np.sum(fe._state('max_steps') == 49)))
+        if RANK == 0 and DIST is None:
+            print('    SVC elements on the 50-sub-step corrector at least once: %d' % int(np.sum(fe._state('max_steps') == 49)))
     else:
         fe._max_load_steps = 8
         run('config 5: 2048x2048 laminate J2 + Goss-Barlat SVC, first 8 of 20 steps', fe, 20)
+if DIST is not None:
+    DIST.barrier()
+    DIST.destroy_process_group()
