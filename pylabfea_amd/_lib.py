@@ -50,7 +50,7 @@ SYMBOLS = [
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
-    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample',
+    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks',
 ]
 
 _lib = None
@@ -313,6 +313,12 @@ class Context(object):
         lv = C.c_int()
         self._chk(self.lib.plfx_precond_info(self.h, C.byref(k), C.byref(lv)))
         return k.value, lv.value
+
+    def solve_fallbacks(self):
+        """solves completed by Jacobi-PCG after multigrid-PCG broke down or stalled"""
+        n = C.c_int64()
+        self._chk(self.lib.plfx_solve_fallbacks(self.h, C.byref(n)))
+        return n.value
 
     def set_operator(self, kind):
         self._chk(self.lib.plfx_set_operator(self.h, int(kind)))

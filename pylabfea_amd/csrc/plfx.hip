@@ -246,6 +246,7 @@ struct plfx_ctx {
     int fin_pin_n = 0;
     int fin_defer = -1;             // slot the next plfx_finish_step posts into instead of waiting
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
+    bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
     // geometric multigrid preconditioner (structured grids, plfx_set_grid)
@@ -1176,6 +1177,7 @@ void mg_graph_drop(plfx_ctx *c)
 // to the host is hidden behind the head instead of idling the GPU.
 int mg_vcycle_head(plfx_ctx *c)
 {
+    if (c->strip_jacobi) return 0;
     const int nl = (int)c->mg.size();
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
     if (lt >= 1) return mg_down_level(c, 0);
@@ -1184,6 +1186,12 @@ int mg_vcycle_head(plfx_ctx *c)
 
 int mg_vcycle_rest(plfx_ctx *c)
 {
+    if (c->strip_jacobi) {  // Jacobi fall-back of a strip: same PCG loop, same exchanges, z = D^-1 r on the local grid
+        hipLaunchKernelGGL(k_jacobi_z, dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, c->nnode, (const double2 *)c->dinv,
+                           (const double2 *)c->r, (double2 *)c->z, c->sc);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     const int nl = (int)c->mg.size();
     const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
     int rc;
@@ -2376,6 +2384,13 @@ int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
     return PLFX_OK;
 }
 
+int plfx_solve_fallbacks(plfx_ctx *c, int64_t *count)
+{
+    if (!c || !count) return PLFX_ERR_ARG;
+    *count = c->mg_fallbacks;
+    return PLFX_OK;
+}
+
 // ------------------------------------------------------------------------------ state
 int plfx_state_reset(plfx_ctx *c)
 {
@@ -3153,7 +3168,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 
     const int chunk = mg ? 1 : 50;  // multigrid: the flag is polled inside the iteration, before the V-cycle
     const int maxit_all = maxit;
-    if (mg) maxit = std::min(maxit, 300);  // multigrid-PCG converges in tens of iterations or not at all
+    if (mg && !c->strip_jacobi) maxit = std::min(maxit, 300);  // multigrid-PCG converges in tens of iterations or not at all
     int it = 0;
     while (it < maxit && !done) {
         const int stop = std::min(maxit, it + chunk);
@@ -3224,9 +3239,21 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         }
         done = hs.done;
     }
-    if (mg && done != 1 && c->strip.on)
-        return fail(c, PLFX_ERR_UNSUPPORTED, "multigrid-PCG did not converge in %d iterations on a strip (no Jacobi fall-back there)", it);
-    if (mg && done != 1) {
+    if (mg && done != 1 && c->strip.on && !c->strip_jacobi) {
+        // every rank sees the same all-reduced sums and takes this branch together: Jacobi-PCG through the same loop
+        // (owned-only sums, halo refresh of r per iteration), warm-started from the last iterate
+        if ((rc = halo_refresh(c, c->x))) return rc;
+        hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
+        HIPCHK(c, hipGetLastError());
+        c->strip_jacobi = true;
+        c->mg_fallbacks++;
+        int it2 = 0;
+        const int rc2 = plfx_solve(c, rtol, maxit_all, 1, &it2, relres);
+        c->strip_jacobi = false;
+        if (iters) *iters = it + it2;
+        return rc2;
+    }
+    if (mg && done != 1 && !c->strip.on) {
         // breakdown (indefinite tangent, preconditioner not SPD) or stagnation: fall back to Jacobi-PCG,
         // warm-started from the last iterate
         hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);

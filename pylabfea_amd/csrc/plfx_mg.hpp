@@ -213,6 +213,17 @@ k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ di
 }
 
 // Coarsest grid: Jacobi-PCG on (nnode <= MG_COARSE_MAX) nodes inside one workgroup, vectors in LDS.
+// z = D^-1 r (the preconditioner of a strip's Jacobi fall-back; the V-cycle's slot in the PCG loop)
+__global__ void __launch_bounds__(BLOCK)
+k_jacobi_z(int nn, const double2 *__restrict__ dinv, const double2 *__restrict__ r, double2 *__restrict__ z, const CgScalars *sc)
+{
+    if (sc->done) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const double2 d = dinv[i], ri = r[i];
+        z[i] = make_double2(d.x * ri.x, d.y * ri.y);
+    }
+}
+
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
 constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel

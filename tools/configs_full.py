@@ -77,8 +77,8 @@ def run(name, fe, ms):
                       % (r[0], r[1], r[2], r[3], r[4]))
         if RANK != 0:
             return
-    print('%-34s %8.3f s  load steps %3d  K-iterations %4d  sweeps %4d  solves %4d  PCG its %5d  updates/s %.3g  sgl_yy %.6f'
-          % (name, dt, fe.nsteps, sum(max(n, 0) + 1 for n in fe.niter), fe.n_sweeps, len(its), sum(its),
+    print('%-34s %8.3f s  load steps %3d  K-iterations %4d  sweeps %4d  solves %4d  PCG its %5d (max %d, Jacobi fall-backs %d)  updates/s %.3g  sgl_yy %.6f'
+          % (name, dt, fe.nsteps, sum(max(n, 0) + 1 for n in fe.niter), fe.n_sweeps, len(its), sum(its), max(its), eng.solve_fallbacks(),
              fe.Nel * fe.n_sweeps / dt if fe.n_sweeps else 0., fe.sgl[-1][1]))
     sys.stdout.flush()
 
@@ -155,9 +155,12 @@ if '5' in which or '5full' in which:
     fe.bcbot(0.)
     fe.bcright(0., 'force')
     fe.bctop(0.003 * fe.leny, 'disp')
-    fe.mesh(NX=2048, NY=2048)
+    n5x, n5y = int(os.environ.get('CFG5_NX', '2048')), int(os.environ.get('CFG5_NY', '2048'))   # experiments: smaller meshes
+    fe.mesh(NX=n5x, NY=n5y)
+    if os.environ.get('CFG5_EQUAL') == '1':
+        fe.strip_weights = np.ones(n5x)                     # strips of equal width instead of equal cost
     if '5full' in which:
-        run('config 5: 2048x2048 laminate J2 + Goss-Barlat SVC, all 20 load steps', fe, 20)
+        run('config 5: %dx%d laminate J2 + Goss-Barlat SVC, all 20 load steps' % (n5x, n5y), fe, 20)
         if RANK == 0 and DIST is None:
             print('    SVC elements on the 50-sub-step corrector at least once: %d' % int(np.sum(fe._state('max_steps') == 49)))
     else:
