@@ -146,8 +146,10 @@ int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
  * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.65, 2) */
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
-/* number of plfx_solve calls so far in which multigrid-PCG broke down (indefinite tangent) or did not converge within 300
- * iterations and the solve was completed by Jacobi-PCG, warm-started from the last iterate */
+/* number of plfx_solve calls so far that PCG could not finish: a direction of negative curvature was met (the tangents of
+ * Material.response are not always positive semi-definite, material.py:324-338) and preconditioned MINRES completed the
+ * solve from the last iterate -- the reference's LU does not need definiteness either -- or multigrid-PCG did not converge
+ * within 300 iterations and Jacobi-PCG took over */
 int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
  * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to

@@ -246,6 +246,8 @@ struct plfx_ctx {
     int fin_pin_n = 0;
     int fin_defer = -1;             // slot the next plfx_finish_step posts into instead of waiting
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
+    int n_minres = 0;     // solves completed by MINRES (indefinite tangent stiffness)
+    double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
     bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
@@ -670,6 +672,8 @@ void free_mesh(plfx_ctx *c)
     dfree(c->r);
     dfree(c->z);
     dfree(c->q);
+    dfree(c->mr_r1);
+    dfree(c->mr_w);
     dfree(c->p[0]);
     dfree(c->p[1]);
     for (auto &L : c->mg) {
@@ -2387,7 +2391,7 @@ int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
 int plfx_solve_fallbacks(plfx_ctx *c, int64_t *count)
 {
     if (!c || !count) return PLFX_ERR_ARG;
-    *count = c->mg_fallbacks;
+    *count = (int64_t)c->mg_fallbacks + c->n_minres;
     return PLFX_OK;
 }
 
@@ -3101,6 +3105,150 @@ int cg_check_wait(plfx_ctx *c, unsigned long long seq, CgScalars *hs)
     return 0;
 }
 
+// sum of per-block partials on the host (strip: all-reduced first): n slots of MAXPART doubles starting at `part`
+int host_sums(plfx_ctx *c, double *part, int nslots, int gn, double *out)
+{
+    int rc;
+    if ((rc = part_allreduce(c, part, (size_t)(nslots - 1) * MAXPART + gn))) return rc;
+    std::vector<double> h((size_t)(nslots - 1) * MAXPART + gn);
+    if ((rc = fetch_results(c, part, (int)h.size(), h.data()))) return rc;
+    for (int s = 0; s < nslots; s++) {
+        double t = 0.;
+        for (int i = 0; i < gn; i++) t += h[(size_t)s * MAXPART + i];
+        out[s] = t;
+    }
+    return 0;
+}
+
+// Preconditioned MINRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp).  Returns 0 = converged to
+// |r| <= rtol |b| (true residual, checked whenever the recurrence says so), 1 = iteration limit, < 0 = error.
+int minres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
+{
+    const size_t nd = c->ndof;
+    const int nn = c->nnode, gn = c->grid_nodes;
+    const int olo = own_lo(c), ohi = own_hi(c);
+    int rc;
+    if (!c->mr_r1 && (rc = dalloc(c, &c->mr_r1, nd))) return rc;
+    if (!c->mr_w && (rc = dalloc(c, &c->mr_w, nd))) return rc;
+    double *P0 = c->part, *P_rz = c->part + 3 * MAXPART, *P_rr = c->part + 4 * MAXPART, *P_bb = c->part + 5 * MAXPART;
+    bool use_mg = mg_active(c);
+    int itn = 0;
+    double bb = 0., rr = 0.;
+    auto precond = [&](double *rz_out) -> int {  // z = M^-1 r, r.z
+        int e;
+        if (c->strip.on && (e = halo_refresh(c, c->r))) return e;
+        if (use_mg) {
+            if ((e = mg_vcycle(c))) return e;
+        } else {
+            hipLaunchKernelGGL(k_jacobi_z, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->dinv,
+                               (const double2 *)c->r, (double2 *)c->z, c->sc);
+        }
+        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r, (const double2 *)c->z, P0);
+        HIPCHK(c, hipGetLastError());
+        return host_sums(c, P0, 1, gn, rz_out);
+    };
+    auto true_resid = [&](double *out) -> int {
+        LAUNCH_OP1(k_resid_norm, matfree(c), dim3(gn), c->op, nn, (const double2 *)c->x, (const double2 *)c->rhs,
+                   (const double2 *)c->dinv, P0, olo, ohi);
+        HIPCHK(c, hipGetLastError());
+        return host_sums(c, P0, 1, gn, out);
+    };
+restart:
+    // r2 = P (b - K x) in c->r
+    LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, 1, (const double2 *)c->x, (const double2 *)c->rhs,
+               (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz, P_rr, P_bb, olo, ohi);
+    HIPCHK(c, hipGetLastError());
+    {
+        double o[3];
+        if ((rc = host_sums(c, P_rz, 3, gn, o))) return rc;
+        rr = o[1];
+        bb = o[2];
+    }
+    hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);  // clears the sticky done flag
+    const double tol2 = rtol * rtol * bb;
+    double rl = bb > 0. ? std::sqrt(rr / bb) : 0.;
+    if (rr <= tol2) {
+        if (iters) *iters = itn;
+        if (relres) *relres = rl;
+        return 0;
+    }
+    double rz;
+    if ((rc = precond(&rz))) return rc;
+    if (!(rz > 0.)) {
+        if (!use_mg) return fail(c, PLFX_ERR_HIP, "MINRES: the Jacobi scaling is not positive");
+        use_mg = false;  // the V-cycle built on this operator is not positive definite: D^-1 is
+        if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e <= 0 at the start: Jacobi preconditioner\n", rz);
+        goto restart;
+    }
+    {
+        HIPCHK(c, hipMemsetAsync(c->mr_w, 0, 8 * nd, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->p[1], 0, 8 * nd, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->mr_r1, 0, 8 * nd, c->stream));
+        const double beta1 = std::sqrt(rz), rr0 = rr;
+        double beta = beta1, oldb = 0., dbar = 0., epsln = 0., phibar = beta1, cs = -1., sn = 0.;
+        double *v = c->p[0], *w1 = c->mr_w, *w2 = c->p[1];  // w1 = oldest direction
+        double check_at = 1.;  // true-residual check once the estimate (phibar / beta1) sqrt(rr0) falls below check_at * rtol |b|
+        int first = 1;
+        while (itn < maxit) {
+            itn++;
+            double o2[2];
+            LAUNCH_OP1(k_minres_apply, matfree(c), dim3(gn), c->op, nn, 1. / beta, (const double2 *)c->z, (const double2 *)c->dinv,
+                       (const double2 *)c->mr_r1, (double2 *)v, (double2 *)c->q, P0, P0 + MAXPART, olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = host_sums(c, P0, 2, gn, o2))) return rc;
+            const double c1 = first ? 0. : beta / oldb;
+            const double alfa = o2[0] - c1 * o2[1];
+            hipLaunchKernelGGL(k_minres_update1, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, alfa / beta, c1,
+                               (const double2 *)c->q, (double2 *)c->r, (double2 *)c->mr_r1);
+            first = 0;
+            if ((rc = precond(&rz))) return rc;
+            if (rz < 0. && rz < -1e-14 * beta * beta) {  // preconditioner not positive definite on this Krylov space
+                if (!use_mg) {
+                    if (iters) *iters = itn;
+                    if (relres) *relres = rl;
+                    return 1;
+                }
+                use_mg = false;
+                if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e < 0 in iteration %d: Jacobi preconditioner\n", rz, itn);
+                goto restart;  // from the current iterate, with D^-1
+            }
+            oldb = beta;
+            beta = std::sqrt(std::max(rz, 0.));
+            const double oldeps = epsln;
+            const double delta = cs * dbar + sn * alfa;
+            const double gbar = sn * dbar - cs * alfa;
+            epsln = sn * beta;
+            dbar = -cs * beta;
+            double gamma = std::sqrt(gbar * gbar + beta * beta);
+            if (!(gamma > 0.)) gamma = 1e-300;
+            cs = gbar / gamma;
+            sn = beta / gamma;
+            const double phi = cs * phibar;
+            phibar = sn * phibar;
+            hipLaunchKernelGGL(k_minres_update2, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, oldeps, delta, 1. / gamma, phi,
+                               (const double2 *)v, (double2 *)w1, (const double2 *)w2, (double2 *)c->x);
+            std::swap(w1, w2);  // the direction just written is the newest one: next w2
+            HIPCHK(c, hipGetLastError());
+            const double est2 = (phibar / beta1) * (phibar / beta1) * rr0;
+            if (est2 <= check_at * check_at * tol2 || beta == 0. || itn == maxit) {
+                if ((rc = true_resid(&rr))) return rc;
+                rl = bb > 0. ? std::sqrt(rr / bb) : 0.;
+                if (rr <= tol2) {
+                    if (iters) *iters = itn;
+                    if (relres) *relres = rl;
+                    return 0;
+                }
+                if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] iteration %d (%s): estimate %.3e, true relative residual %.3e\n", itn, use_mg ? "V-cycle" : "Jacobi", std::sqrt(est2 / (bb > 0. ? bb : 1.)), rl);
+                if (beta == 0.) goto restart;  // Krylov space exhausted short of the tolerance (rounding): again from here
+                check_at = 0.5 * std::sqrt(est2 / tol2);  // the norms differ: ask for half of the present estimate
+            }
+        }
+    }
+    if (iters) *iters = itn;
+    if (relres) *relres = rl;
+    return 1;
+}
+
 }  // namespace
 
 int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
@@ -3143,7 +3291,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     }
     hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);
     const bool mg = mg_active(c);
-    CgScalars hs;
+    CgScalars hs{};
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
         const unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
@@ -3239,6 +3387,81 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         }
         done = hs.done;
     }
+    static const bool solve_debug = getenv("PLFX_SOLVE_DEBUG") && atoi(getenv("PLFX_SOLVE_DEBUG")) != 0;
+    if (solve_debug && mg && done != 1) {  // what made multigrid-PCG give up: sums of the last iteration, NaN census
+        hipStreamSynchronize(c->stream);
+        std::vector<double> hp((size_t)6 * MAXPART), hv(nd);
+        hipMemcpy(hp.data(), c->part, hp.size() * 8, hipMemcpyDeviceToHost);
+        auto psum = [&](int slot) { double t = 0.; for (int i = 0; i < gn; i++) t += hp[(size_t)slot * MAXPART + i]; return t; };
+        auto census = [&](const double *dev, const char *name) {
+            hipMemcpy(hv.data(), dev, nd * 8, hipMemcpyDeviceToHost);
+            size_t nan = 0, neg = 0; double mx = 0., mn = 1e300;
+            for (size_t i = 0; i < nd; i++) { const double v = hv[i]; if (!(v == v)) nan++; else { if (v < 0.) neg++; mx = std::max(mx, std::fabs(v)); if (v != 0.) mn = std::min(mn, std::fabs(v)); } }
+            fprintf(stderr, "    %-5s nan %zu  negative %zu  max|.| %.3e  min nonzero|.| %.3e\n", name, nan, neg, mx, mn);
+        };
+        fprintf(stderr, "[plfx_solve] multigrid-PCG gave up after %d iterations: done %d rr_final %.3e thresh2 %.3e | p.q %.6e  r.z %.6e / %.6e  r.r %.6e / %.6e  b.b %.6e\n",
+                it, hs.done, hs.rr_final, hs.thresh2, psum(0), psum(1), psum(3), psum(2), psum(4), psum(5));
+        census(c->dinv, "dinv"); census(c->r, "r"); census(c->z, "z"); census(c->x, "x"); census(c->q, "q");
+        {
+            std::vector<double> hm((size_t)6 * c->nel_total);
+            hipMemcpy(hm.data(), matfree(c) ? c->Mop : c->Mel, hm.size() * 8, hipMemcpyDeviceToHost);
+            size_t nan = 0; double mx = 0.;
+            for (double v : hm) { if (!(v == v)) nan++; else mx = std::max(mx, std::fabs(v)); }
+            fprintf(stderr, "    generators nan %zu  max|.| %.3e\n", nan, mx);
+            // per element: smallest eigenvalue of the 3 x 3 generator matrix [XX XY XS; XY YY YS; XS YS SS] (PSD for a PSD tangent)
+            const size_t ne = c->nel_total;
+            size_t nneg = 0, worst = 0; double wv = 0.;
+            for (size_t e = 0; e < ne; e++) {
+                const double a = hm[e], b = hm[ne + e], cc = hm[2 * ne + e], d = hm[3 * ne + e], f = hm[4 * ne + e], g = hm[5 * ne + e];
+                // Sylvester: leading minors
+                const double m1 = a, m2 = a * d - b * b, m3 = a * (d * g - f * f) - b * (b * g - f * cc) + cc * (b * f - d * cc);
+                const double sc1 = std::fabs(a) + std::fabs(d) + std::fabs(g);
+                const double bad = std::min(m1 / sc1, std::min(m2 / (sc1 * sc1), m3 / (sc1 * sc1 * sc1)));
+                if (bad < -1e-9) { nneg++; if (bad < wv) { wv = bad; worst = e; } }
+            }
+            fprintf(stderr, "    elements with an indefinite generator matrix: %zu of %zu (worst scaled minor %.3e at element %zu)\n", nneg, ne, wv, worst);
+            if (nneg && worst >= (size_t)c->e0 && worst < (size_t)c->e0 + c->nel) {
+                const size_t e = worst - c->e0, n = c->nel;
+                double v[21]; int ms = 0; double fy = 0.;
+                fprintf(stderr, "      class %d material %d kind %d  M =", (int)c->hcls_id[worst], c->hcls[c->hcls_id[worst]].mat, (int)c->hmat[c->hcls[c->hcls_id[worst]].mat].kind);
+                for (int k = 0; k < 6; k++) fprintf(stderr, " %.6e", hm[k * ne + worst]);
+                for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->sig + k * n + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      sig = %.6e %.6e %.6e %.6e %.6e %.6e", v[0], v[1], v[2], v[3], v[4], v[5]);
+                for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->res_sig + k * n + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      res_sig = %.6e %.6e %.6e %.6e %.6e %.6e", v[0], v[1], v[2], v[3], v[4], v[5]);
+                for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->epl + k * n + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      epl = %.6e %.6e %.6e %.6e %.6e %.6e", v[0], v[1], v[2], v[3], v[4], v[5]);
+                for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->res_depl + k * n + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      res_depl = %.6e %.6e %.6e %.6e %.6e %.6e", v[0], v[1], v[2], v[3], v[4], v[5]);
+                for (int k = 0; k < 21; k++) hipMemcpy(&v[k], c->elstiff + k * n + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      elstiff(21) =");
+                for (int k = 0; k < 21; k++) fprintf(stderr, " %.5e", v[k]);
+                hipMemcpy(&ms, c->max_steps + e, 4, hipMemcpyDeviceToHost);
+                hipMemcpy(&fy, c->fyn + e, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "\n      max_steps %d  fyn %.6e\n", ms, fy);
+            }
+        }
+    }
+    if (done != 1 && hs.done == 2) {
+        // negative curvature met (p.K p <= 0) or a NaN residual: the tangent stiffness is not positive definite (lstsq
+        // correction of Material.response, material.py:324-338) -- the reference's LU solves such systems, so does MINRES
+        int itm = 0;
+        double rl = 0.;
+        const int rcm = minres_solve(c, rtol, maxit_all, &itm, &rl);
+        if (rcm < 0) return rcm;
+        c->n_minres++;
+        if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+        if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;
+        hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
+        HIPCHK(c, hipGetLastError());
+        c->x_is_du = true;
+        if (iters) *iters = it + itm;
+        if (relres) *relres = rl;
+        c->memo.valid = rcm == 0;
+        c->memo.rtol = rtol;
+        c->memo.relres = rl;
+        return rcm == 0 ? PLFX_OK : 1;
+    }
     if (mg && done != 1 && c->strip.on && !c->strip_jacobi) {
         // every rank sees the same all-reduced sums and takes this branch together: Jacobi-PCG through the same loop
         // (owned-only sums, halo refresh of r per iteration), warm-started from the last iterate
@@ -3264,6 +3487,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         int it2 = 0;
         const int rc2 = plfx_solve(c, rtol, maxit_all, 1, &it2, relres);
         c->precond = saved;
+        if (solve_debug) fprintf(stderr, "[plfx_solve] Jacobi fall-back: rc %d, %d iterations, relative residual %.3e\n", rc2, it2, relres ? *relres : -1.);
         if (iters) *iters = it + it2;
         return rc2;
     }

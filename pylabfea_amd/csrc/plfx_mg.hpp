@@ -224,6 +224,96 @@ k_jacobi_z(int nn, const double2 *__restrict__ dinv, const double2 *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------- MINRES
+// The tangents of the reference are not always positive semi-definite: the correction step of Material.response
+// (material.py:317-338) subtracts a least-squares fit of the excess stress from the tangent, and single elements end up with
+// negative diagonal entries.  The reference's dense LU does not care; PCG stops at the first direction of negative curvature.
+// Such systems are solved by preconditioned MINRES (Paige & Saunders) with the same SPD preconditioner (V-cycle or D^-1).
+// One iteration: k_minres_apply (v = s y, q = P K v, partials of v.q and v.r1), k_minres_update1 (three-term recurrence: new
+// residual vector), preconditioner, k_dot_rz, k_minres_update2 (search direction and iterate); scalars on the host.
+template <int GRID>
+__global__ void __launch_bounds__(BLOCK)
+k_minres_apply(KOp op, int nnode, double s, const double2 *__restrict__ y, const double2 *__restrict__ dinv,
+               const double2 *__restrict__ r1, double2 *__restrict__ v, double2 *__restrict__ q, double *__restrict__ part,
+               double *__restrict__ part_vr1, int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0., acc1 = 0.;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) {
+            const double2 yj = y[j];
+            return make_double2(s * yj.x, s * yj.y);
+        });
+        const double2 yi = y[i], di = dinv[i];
+        const double2 vi = make_double2(s * yi.x, s * yi.y);
+        const double2 qi = make_double2(di.x != 0. ? qv.x : 0., di.y != 0. ? qv.y : 0.);
+        v[i] = vi;
+        q[i] = qi;
+        if (i >= own_lo && i < own_hi) {
+            const double2 a = r1[i];
+            acc = fma(vi.x, qi.x, fma(vi.y, qi.y, acc));
+            acc1 = fma(vi.x, a.x, fma(vi.y, a.y, acc1));  // alfa = v.(K v - (beta / oldb) r1), as Paige & Saunders order it
+        }
+    }
+    const double t = block_sum(acc, sh);
+    const double t1 = block_sum(acc1, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = t;
+        part_vr1[blockIdx.x] = t1;
+    }
+}
+
+// y = q - c2 r2 - c1 r1;  r1 <- r2;  r2 <- y
+__global__ void __launch_bounds__(BLOCK)
+k_minres_update1(int nn, double c2, double c1, const double2 *__restrict__ q, double2 *__restrict__ r2, double2 *__restrict__ r1)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 qi = q[i], b = r2[i], a = r1[i];
+        r1[i] = b;
+        r2[i] = make_double2(qi.x - c2 * b.x - c1 * a.x, qi.y - c2 * b.y - c1 * a.y);
+    }
+}
+
+// w = (v - oldeps w1 - delta w2) / gamma (written over w1, the oldest direction);  x += phi w
+__global__ void __launch_bounds__(BLOCK)
+k_minres_update2(int nn, double oldeps, double delta, double inv_gamma, double phi, const double2 *__restrict__ v,
+                 double2 *__restrict__ w1, const double2 *__restrict__ w2, double2 *__restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 vi = v[i], a = w1[i], b = w2[i];
+        double2 xi = x[i];
+        const double2 w = make_double2((vi.x - oldeps * a.x - delta * b.x) * inv_gamma, (vi.y - oldeps * a.y - delta * b.y) * inv_gamma);
+        w1[i] = w;
+        xi.x = fma(phi, w.x, xi.x);
+        xi.y = fma(phi, w.y, xi.y);
+        x[i] = xi;
+    }
+}
+
+// partials of |P (b - K x)|^2 over [own_lo, own_hi) (true residual of an iterate; nothing stored)
+template <int GRID>
+__global__ void __launch_bounds__(BLOCK)
+k_resid_norm(KOp op, int nnode, const double2 *__restrict__ x, const double2 *__restrict__ b, const double2 *__restrict__ dinv,
+             double *__restrict__ part, int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
+    const int nb = gridDim.x;
+    for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
+        const int i = t * BLOCK + threadIdx.x;
+        if (i >= nnode || i < own_lo || i >= own_hi) continue;
+        const double2 qv = op_apply<GRID>(op, i, [&](int j) { return x[j]; });
+        const double2 bi = b[i], di = dinv[i];
+        const double rx = di.x != 0. ? bi.x - qv.x : 0., ry = di.y != 0. ? bi.y - qv.y : 0.;
+        acc = fma(rx, rx, fma(ry, ry, acc));
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
 constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel

@@ -212,3 +212,63 @@ def test_odd_coarse_grid_chebyshev_vs_oracle():
     assert np.max(np.abs(fe.u - ref.u)) < 1e-6 * np.max(np.abs(ref.u))
     assert np.max(np.abs(fe._state('sig') - ref.sig)) < 1e-6 * s
     assert np.max(np.abs(fe.sgl - ref.sgl)) < 1e-6 * s
+
+
+# tangent of an SVC element after the least-squares correction step of Material.response (material.py:324-338), as met in
+# BASELINE config 5 at full size (upper triangle by rows): the yy entry is NEGATIVE -- such tangents are what the reference
+# hands to its LU solver
+BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+02, -3.89722e+01, -5.30574e+05, -2.01886e+05,
+                  8.08981e+02, -9.29004e+02, 4.43106e+01, 2.03386e+05, -4.23220e+01, 4.86228e+01, -2.33304e+00, 5.81516e+04,
+                  1.14637e+01, -5.47451e-01, 5.81484e+04, 6.34734e-01, 5.81615e+04]
+
+
+@pytest.mark.parametrize('nx,ny,mg', [(64, 64, True), (48, 24, True), (13, 6, False)])
+def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg):
+    """A stiffness matrix with negative eigenvalues: PCG meets a direction of negative curvature and the solve is completed
+    by preconditioned MINRES; the solution must be the one a direct solver (the reference's numpy.linalg.solve) finds."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import pylabfea_amd as FE
+    from pylabfea_amd import _lib
+    mat = FE.Material()
+    mat.elasticity(E=151220., nu=0.3)
+    fe = FE.Model(dim=2, planestress=False)
+    fe.geom([4.], LY=4. * ny / nx)
+    fe.assign([mat])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.002 * fe.leny, 'disp')
+    fe.mesh(NX=nx, NY=ny)
+    eng = fe._ensure_engine()
+    assert (eng.precond_info()[0] == 1) == mg
+    CV = fe._element_CV(mat)
+    D = np.tile(CV, (fe.Nel, 1, 1))
+    bad = np.zeros((6, 6))
+    bad[np.triu_indices(6)] = BAD_TANGENT_21
+    bad = bad + bad.T - np.diag(np.diag(bad))
+    # isolated elements, as in config 5 (2 of 4.2 million): the diagonal of K stays positive, K itself does not stay definite
+    for cx, cy in ((nx // 3, ny // 2), (2 * nx // 3, ny // 4), (nx // 2, (3 * ny) // 4)):
+        D[cx * ny + cy] = bad
+    eng.state_set(_lib.ST_ELSTIFF, D.reshape(fe.Nel, 36))
+    eng.assemble()
+    z, d = np.zeros(2), np.array([0., 0.002 * fe.leny])
+    presc, first, w, fext = fe._bc_data(z, z, z, d, None)
+    eng.apply_bc(presc, first, w, fext)
+    n0 = eng.solve_fallbacks()
+    it, rr, ok = eng.solve(1e-10, 20000, False)
+    assert ok and rr <= 1e-10
+    assert eng.solve_fallbacks() == n0 + 1            # PCG gave up, MINRES finished the solve
+    du = eng.state_get(_lib.ST_DU)
+    K = eng.get_csr().tocsr()
+    free = np.setdiff1d(np.arange(fe.Ndof), presc)
+    wfull = np.zeros(fe.Ndof)
+    wfull[presc] = w
+    rhs = (-(K @ wfull) if fext is None else fext - K @ wfull)[free]
+    Kff = K[free][:, free].tocsc()
+    assert Kff.diagonal().min() > 0.
+    lam = spla.eigsh(Kff, k=1, which='SA', tol=1e-4, return_eigenvectors=False)
+    assert lam[0] < -1e-3 * Kff.diagonal().max()       # really indefinite
+    ref = spla.spsolve(Kff, rhs)
+    assert np.max(np.abs(du[free] - ref)) < 1e-6 * np.max(np.abs(ref))
+    assert np.array_equal(du[presc], first)

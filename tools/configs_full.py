@@ -77,6 +77,13 @@ def run(name, fe, ms):
                       % (r[0], r[1], r[2], r[3], r[4]))
         if RANK != 0:
             return
+    if os.environ.get('CFG_VERBOSE') == '1':
+        print('    K-iterations per load step: %s' % list(fe.niter))
+        print('    PCG iterations per solve: %s' % its)
+    rel = np.array([s[1] for s in fe.solver_stats])
+    print('    solves above rtol %g: %d (worst relative residual %.3g); load steps with unconverged K-iterations: %s; sgl_yy per load step: %s'
+          % (fe.cg_rtol, int(np.sum(rel > fe.cg_rtol)), rel.max() if len(rel) else 0., list(np.asarray(fe.co_nconv).ravel()),
+             np.round([s[1] for s in fe.sgl], 3).tolist()))
     print('%-34s %8.3f s  load steps %3d  K-iterations %4d  sweeps %4d  solves %4d  PCG its %5d (max %d, Jacobi fall-backs %d)  updates/s %.3g  sgl_yy %.6f'
           % (name, dt, fe.nsteps, sum(max(n, 0) + 1 for n in fe.niter), fe.n_sweeps, len(its), sum(its), max(its), eng.solve_fallbacks(),
              fe.Nel * fe.n_sweeps / dt if fe.n_sweeps else 0., fe.sgl[-1][1]))
@@ -164,7 +171,7 @@ if '5' in which or '5full' in which:
         if RANK == 0 and DIST is None:
             print('    SVC elements on the 50-sub-step corrector at least once: %d' % int(np.sum(fe._state('max_steps') == 49)))
     else:
-        fe._max_load_steps = 8
+        fe._max_load_steps = int(os.environ.get('CFG5_STEPS', '8'))
         run('config 5: 2048x2048 laminate J2 + Goss-Barlat SVC, first 8 of 20 steps', fe, 20)
 if DIST is not None:
     DIST.barrier()
