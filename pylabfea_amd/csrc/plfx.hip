@@ -248,6 +248,8 @@ struct plfx_ctx {
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int n_minres = 0;     // solves completed by MINRES (indefinite tangent stiffness)
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
+    double *gm_V = nullptr, *gm_part = nullptr;  // GMRES: Krylov basis (GMRES_M + 1 vectors) and partial sums, on first use
+    int n_gmres = 0;
     bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
@@ -674,6 +676,8 @@ void free_mesh(plfx_ctx *c)
     dfree(c->q);
     dfree(c->mr_r1);
     dfree(c->mr_w);
+    dfree(c->gm_V);
+    dfree(c->gm_part);
     dfree(c->p[0]);
     dfree(c->p[1]);
     for (auto &L : c->mg) {
@@ -3120,8 +3124,152 @@ int host_sums(plfx_ctx *c, double *part, int nslots, int gn, double *out)
     return 0;
 }
 
+// Right-preconditioned restarted GMRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp): x = x0 + B t with t in the
+// Krylov space of K B.  Returns 0 = |P(b - K x)| <= rtol |b|, 1 = iteration limit, < 0 = error.
+constexpr int GMRES_M = 60;
+int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
+{
+    const size_t nd = c->ndof;
+    const int nn = c->nnode, gn = c->grid_nodes;
+    const int olo = own_lo(c), ohi = own_hi(c);
+    const int M = GMRES_M;
+    int rc;
+    if (!c->gm_V && (rc = dalloc(c, &c->gm_V, (size_t)(M + 1) * nd))) return rc;
+    if (!c->gm_part && (rc = dalloc(c, &c->gm_part, (size_t)8 * MAXPART))) return rc;
+    auto Vj = [&](int j) { return c->gm_V + (size_t)j * nd; };
+    double *P_rz = c->part + 3 * MAXPART, *P_rr = c->part + 4 * MAXPART, *P_bb = c->part + 5 * MAXPART;
+    const bool use_mg = mg_active(c);
+    auto apply_B = [&]() -> int {  // c->z = B c->r
+        int e;
+        if (c->strip.on && (e = halo_refresh(c, c->r))) return e;
+        if (use_mg) return mg_vcycle(c);
+        hipLaunchKernelGGL(k_jacobi_z, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->dinv,
+                           (const double2 *)c->r, (double2 *)c->z, c->sc);
+        return 0;
+    };
+    int itn = 0;
+    double rl = 0.;
+    std::vector<double> H((size_t)(M + 1) * M), cs(M), sn(M), g(M + 1), hcol(M + 2);
+    while (true) {
+        // r0 = P (b - K x) -> c->r; beta = |r0|
+        LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, 1, (const double2 *)c->x, (const double2 *)c->rhs,
+                   (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz, P_rr, P_bb, olo, ohi);
+        HIPCHK(c, hipGetLastError());
+        double o[3];
+        if ((rc = host_sums(c, P_rz, 3, gn, o))) return rc;
+        const double rr = o[1], bb = o[2];
+        hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);  // clears the sticky done flag
+        const double tol = rtol * std::sqrt(bb);
+        rl = bb > 0. ? std::sqrt(rr / bb) : 0.;
+        if (std::sqrt(rr) <= tol || itn >= maxit) {
+            if (iters) *iters = itn;
+            if (relres) *relres = rl;
+            return std::sqrt(rr) <= tol ? 0 : 1;
+        }
+        const double beta = std::sqrt(rr);
+        hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1. / beta, (const double2 *)c->r,
+                           (double2 *)Vj(0), (double2 *)nullptr);
+        std::fill(g.begin(), g.end(), 0.);
+        g[0] = beta;
+        int k = 0;  // columns built in this cycle
+        for (int j = 0; j < M && itn < maxit; j++) {
+            itn++;
+            // w = P K B V_j  -> c->q
+            hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1., (const double2 *)Vj(j),
+                               (double2 *)c->r, (double2 *)nullptr);
+            if ((rc = apply_B())) return rc;
+            LAUNCH_OP1(k_minres_apply, matfree(c), dim3(gn), c->op, nn, 1., (const double2 *)c->z, (const double2 *)c->dinv,
+                       (const double2 *)c->z, (double2 *)c->p[0], (double2 *)c->q, c->gm_part, c->gm_part + MAXPART, olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            // classical Gram-Schmidt, twice: h = V^T w; w -= V h
+            std::fill(hcol.begin(), hcol.end(), 0.);
+            double wnorm2 = 0.;
+            for (int pass = 0; pass < 2; pass++) {
+                std::vector<double> hp(j + 1, 0.);
+                for (int b0 = 0; b0 <= j; b0 += 8) {
+                    const int n8 = std::min(8, j + 1 - b0);
+                    Ptr8 V8;
+                    for (int q = 0; q < 8; q++) V8.p[q] = (const double2 *)Vj(b0 + std::min(q, n8 - 1));
+                    hipLaunchKernelGGL(k_gmres_dots, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, n8, (const double2 *)c->q, V8,
+                                       c->gm_part);
+                    HIPCHK(c, hipGetLastError());
+                    double o8[8];
+                    if ((rc = host_sums(c, c->gm_part, n8, gn, o8))) return rc;
+                    for (int q = 0; q < n8; q++) hp[b0 + q] = o8[q];
+                }
+                for (int b0 = 0; b0 <= j; b0 += 8) {
+                    const int n8 = std::min(8, j + 1 - b0);
+                    Ptr8 V8;
+                    Coef8 C8;
+                    for (int q = 0; q < 8; q++) {
+                        V8.p[q] = (const double2 *)Vj(b0 + std::min(q, n8 - 1));
+                        C8.c[q] = q < n8 ? -hp[b0 + q] : 0.;
+                    }
+                    const bool last = b0 + 8 > j;
+                    hipLaunchKernelGGL(k_gmres_axpy, dim3(gn), dim3(BLOCK), 0, c->stream, nn, n8, (double2 *)c->q, V8, C8,
+                                       last ? c->gm_part : (double *)nullptr, olo, ohi);
+                    HIPCHK(c, hipGetLastError());
+                    if (last && (rc = host_sums(c, c->gm_part, 1, gn, &wnorm2))) return rc;
+                }
+                for (int q = 0; q <= j; q++) hcol[q] += hp[q];
+            }
+            const double hn = std::sqrt(std::max(wnorm2, 0.));
+            hcol[j + 1] = hn;
+            // Givens rotations: previous ones on the new column, then the new one
+            for (int q = 0; q < j; q++) {
+                const double t = cs[q] * hcol[q] + sn[q] * hcol[q + 1];
+                hcol[q + 1] = -sn[q] * hcol[q] + cs[q] * hcol[q + 1];
+                hcol[q] = t;
+            }
+            const double den = std::hypot(hcol[j], hcol[j + 1]);
+            cs[j] = den > 0. ? hcol[j] / den : 1.;
+            sn[j] = den > 0. ? hcol[j + 1] / den : 0.;
+            hcol[j] = den;
+            hcol[j + 1] = 0.;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            for (int q = 0; q <= j; q++) H[(size_t)q * M + j] = hcol[q];
+            k = j + 1;
+            if (std::fabs(g[j + 1]) <= tol || !(hn > 0.)) break;
+            hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1. / hn, (const double2 *)c->q,
+                               (double2 *)Vj(j + 1), (double2 *)nullptr);
+        }
+        // y = H^-1 g (upper triangular); t = V y -> c->r; x += B t
+        std::vector<double> y(k, 0.);
+        for (int q = k - 1; q >= 0; q--) {
+            double t = g[q];
+            for (int p2 = q + 1; p2 < k; p2++) t -= H[(size_t)q * M + p2] * y[p2];
+            y[q] = H[(size_t)q * M + q] != 0. ? t / H[(size_t)q * M + q] : 0.;
+        }
+        HIPCHK(c, hipMemsetAsync(c->r, 0, 8 * nd, c->stream));
+        for (int b0 = 0; b0 < k; b0 += 8) {
+            const int n8 = std::min(8, k - b0);
+            Ptr8 V8;
+            Coef8 C8;
+            for (int q = 0; q < 8; q++) {
+                V8.p[q] = (const double2 *)Vj(b0 + std::min(q, n8 - 1));
+                C8.c[q] = q < n8 ? y[b0 + q] : 0.;
+            }
+            hipLaunchKernelGGL(k_gmres_axpy, dim3(gn), dim3(BLOCK), 0, c->stream, nn, n8, (double2 *)c->r, V8, C8, (double *)nullptr, olo, ohi);
+        }
+        if ((rc = apply_B())) return rc;
+        {
+            Ptr8 V8;
+            Coef8 C8;
+            for (int q = 0; q < 8; q++) {
+                V8.p[q] = (const double2 *)c->z;
+                C8.c[q] = q == 0 ? 1. : 0.;
+            }
+            hipLaunchKernelGGL(k_gmres_axpy, dim3(gn), dim3(BLOCK), 0, c->stream, nn, 1, (double2 *)c->x, V8, C8, (double *)nullptr, olo, ohi);
+        }
+        HIPCHK(c, hipGetLastError());
+        // next cycle starts from the true residual of x (and ends the solve if it is small enough)
+    }
+}
+
 // Preconditioned MINRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp).  Returns 0 = converged to
-// |r| <= rtol |b| (true residual, checked whenever the recurrence says so), 1 = iteration limit, < 0 = error.
+// |r| <= rtol |b| (true residual, checked whenever the recurrence says so), 1 = iteration limit, 2 = the preconditioner is
+// not positive definite on this system or the recurrences stalled (the caller continues with GMRES), < 0 = error.
 int minres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
 {
     const size_t nd = c->ndof;
@@ -3174,11 +3322,11 @@ restart:
     }
     double rz;
     if ((rc = precond(&rz))) return rc;
-    if (!(rz > 0.)) {
-        if (!use_mg) return fail(c, PLFX_ERR_HIP, "MINRES: the Jacobi scaling is not positive");
-        use_mg = false;  // the V-cycle built on this operator is not positive definite: D^-1 is
-        if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e <= 0 at the start: Jacobi preconditioner\n", rz);
-        goto restart;
+    if (!(rz > 0.)) {  // the preconditioner built on this operator is not positive definite: GMRES does not need that
+        if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e <= 0 at the start\n", rz);
+        if (iters) *iters = itn;
+        if (relres) *relres = rl;
+        return 2;
     }
     {
         HIPCHK(c, hipMemsetAsync(c->mr_w, 0, 8 * nd, c->stream));
@@ -3187,6 +3335,8 @@ restart:
         const double beta1 = std::sqrt(rz), rr0 = rr;
         double beta = beta1, oldb = 0., dbar = 0., epsln = 0., phibar = beta1, cs = -1., sn = 0.;
         double *v = c->p[0], *w1 = c->mr_w, *w2 = c->p[1];  // w1 = oldest direction
+        double last_rl = 1e300;
+        int stalled = 0;
         double check_at = 1.;  // true-residual check once the estimate (phibar / beta1) sqrt(rr0) falls below check_at * rtol |b|
         int first = 1;
         while (itn < maxit) {
@@ -3203,14 +3353,10 @@ restart:
             first = 0;
             if ((rc = precond(&rz))) return rc;
             if (rz < 0. && rz < -1e-14 * beta * beta) {  // preconditioner not positive definite on this Krylov space
-                if (!use_mg) {
-                    if (iters) *iters = itn;
-                    if (relres) *relres = rl;
-                    return 1;
-                }
-                use_mg = false;
-                if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e < 0 in iteration %d: Jacobi preconditioner\n", rz, itn);
-                goto restart;  // from the current iterate, with D^-1
+                if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] r.Br = %.3e < 0 in iteration %d\n", rz, itn);
+                if (iters) *iters = itn;
+                if (relres) *relres = rl;
+                return 2;  // the iterate so far is kept: GMRES continues from it
             }
             oldb = beta;
             beta = std::sqrt(std::max(rz, 0.));
@@ -3240,6 +3386,12 @@ restart:
                 }
                 if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[minres] iteration %d (%s): estimate %.3e, true relative residual %.3e\n", itn, use_mg ? "V-cycle" : "Jacobi", std::sqrt(est2 / (bb > 0. ? bb : 1.)), rl);
                 if (beta == 0.) goto restart;  // Krylov space exhausted short of the tolerance (rounding): again from here
+                if (rl > 0.7 * last_rl && ++stalled >= 2) {  // the recurrences have lost their orthogonality: no further progress
+                    if (iters) *iters = itn;
+                    if (relres) *relres = rl;
+                    return 2;
+                }
+                last_rl = rl;
                 check_at = 0.5 * std::sqrt(est2 / tol2);  // the norms differ: ask for half of the present estimate
             }
         }
@@ -3447,10 +3599,19 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         // correction of Material.response, material.py:324-338) -- the reference's LU solves such systems, so does MINRES
         int itm = 0;
         double rl = 0.;
-        const int rcm = minres_solve(c, rtol, maxit_all, &itm, &rl);
+        const bool gmres_first = getenv("PLFX_INDEFINITE_SOLVER") && !strcmp(getenv("PLFX_INDEFINITE_SOLVER"), "gmres");  // (tests)
+        int rcm = gmres_first ? 2 : minres_solve(c, rtol, maxit_all, &itm, &rl);
         if (rcm < 0) return rcm;
         c->n_minres++;
         if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+        if (rcm == 2) {
+            int itg = 0;
+            rcm = gmres_solve(c, rtol, maxit_all, &itg, &rl);
+            if (rcm < 0) return rcm;
+            c->n_gmres++;
+            itm += itg;
+            if (solve_debug) fprintf(stderr, "[plfx_solve] GMRES(%d): rc %d, %d iterations, relative residual %.3e\n", GMRES_M, rcm, itg, rl);
+        }
         if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;
         hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
         HIPCHK(c, hipGetLastError());

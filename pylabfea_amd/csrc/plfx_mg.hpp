@@ -314,6 +314,77 @@ k_resid_norm(KOp op, int nnode, const double2 *__restrict__ x, const double2 *__
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// ---------------------------------------------------------------------------------------------- GMRES
+// Restarted GMRES with the V-cycle as RIGHT preconditioner: the solver of last resort for indefinite tangent stiffness when
+// the V-cycle built on such an operator is not positive definite either (MINRES needs an SPD preconditioner, GMRES needs
+// nothing).  Minimises the true residual |P(b - K x)|_2, the quantity PCG's stopping test uses.  Classical Gram-Schmidt
+// with re-orthogonalisation, eight basis vectors per pass (coefficients by value).
+struct Coef8 {
+    double c[8];
+};
+struct Ptr8 {
+    const double2 *p[8];
+};
+
+// partials of w . V_k, k < n (<= 8), over [own_lo, own_hi): part[k * MAXPART + block]
+__global__ void __launch_bounds__(BLOCK)
+k_gmres_dots(int own_lo, int own_hi, int n, const double2 *__restrict__ w, Ptr8 V, double *__restrict__ part)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    for (int i = own_lo + blockIdx.x * BLOCK + threadIdx.x; i < own_hi; i += gridDim.x * BLOCK) {
+        const double2 wi = w[i];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n) {
+                const double2 v = V.p[k][i];
+                acc[k] = fma(wi.x, v.x, fma(wi.y, v.y, acc[k]));
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= n) break;
+        const double t = block_sum(acc[k], sh);
+        if (threadIdx.x == 0) part[(size_t)k * MAXPART + blockIdx.x] = t;
+    }
+}
+
+// w += sum_k c_k V_k, k < n (<= 8); with norm_part: partials of |w|^2 over [own_lo, own_hi) after the update
+__global__ void __launch_bounds__(BLOCK)
+k_gmres_axpy(int nn, int n, double2 *__restrict__ w, Ptr8 V, Coef8 C, double *__restrict__ norm_part, int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        double2 wi = w[i];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n) {
+                const double2 v = V.p[k][i];
+                wi.x = fma(C.c[k], v.x, wi.x);
+                wi.y = fma(C.c[k], v.y, wi.y);
+            }
+        w[i] = wi;
+        if (norm_part && i >= own_lo && i < own_hi) acc = fma(wi.x, wi.x, fma(wi.y, wi.y, acc));
+    }
+    if (norm_part) {
+        const double t = block_sum(acc, sh);
+        if (threadIdx.x == 0) norm_part[blockIdx.x] = t;
+    }
+}
+
+// dst = s * src (and a second copy, if given)
+__global__ void __launch_bounds__(BLOCK)
+k_scale_copy(int nn, double s, const double2 *__restrict__ src, double2 *__restrict__ dst, double2 *__restrict__ dst2)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 a = src[i];
+        const double2 b = make_double2(s * a.x, s * a.y);
+        dst[i] = b;
+        if (dst2) dst2[i] = b;
+    }
+}
+
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
 constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel
