@@ -3126,7 +3126,7 @@ int host_sums(plfx_ctx *c, double *part, int nslots, int gn, double *out)
 
 // Right-preconditioned restarted GMRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp): x = x0 + B t with t in the
 // Krylov space of K B.  Returns 0 = |P(b - K x)| <= rtol |b|, 1 = iteration limit, < 0 = error.
-constexpr int GMRES_M = 60;
+constexpr int GMRES_M = 200;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on indefinite K)
 int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
 {
     const size_t nd = c->ndof;
@@ -3147,8 +3147,8 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
                            (const double2 *)c->r, (double2 *)c->z, c->sc);
         return 0;
     };
-    int itn = 0;
-    double rl = 0.;
+    int itn = 0, cycles = 0, poor = 0;
+    double rl = 0., rr_prev = -1.;
     std::vector<double> H((size_t)(M + 1) * M), cs(M), sn(M), g(M + 1), hcol(M + 2);
     while (true) {
         // r0 = P (b - K x) -> c->r; beta = |r0|
@@ -3161,11 +3161,16 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
         hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);  // clears the sticky done flag
         const double tol = rtol * std::sqrt(bb);
         rl = bb > 0. ? std::sqrt(rr / bb) : 0.;
-        if (std::sqrt(rr) <= tol || itn >= maxit) {
+        if (getenv("PLFX_SOLVE_DEBUG")) fprintf(stderr, "[gmres] cycle %d starts at iteration %d: true relative residual %.3e\n", cycles, itn, rl);
+        if (rr_prev >= 0. && rr > 0.25 * rr_prev) poor++;  // a whole cycle bought less than a factor of two
+        else poor = 0;
+        rr_prev = rr;
+        if (std::sqrt(rr) <= tol || itn >= maxit || poor >= 2 || cycles >= 20) {
             if (iters) *iters = itn;
             if (relres) *relres = rl;
             return std::sqrt(rr) <= tol ? 0 : 1;
         }
+        cycles++;
         const double beta = std::sqrt(rr);
         hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1. / beta, (const double2 *)c->r,
                            (double2 *)Vj(0), (double2 *)nullptr);
@@ -3599,11 +3604,14 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         // correction of Material.response, material.py:324-338) -- the reference's LU solves such systems, so does MINRES
         int itm = 0;
         double rl = 0.;
-        const bool gmres_first = getenv("PLFX_INDEFINITE_SOLVER") && !strcmp(getenv("PLFX_INDEFINITE_SOLVER"), "gmres");  // (tests)
+        // GMRES by default.  PLFX_INDEFINITE_SOLVER=minres tries MINRES first (short recurrences, half the cost per iteration):
+        // measured on config 5 at 2048^2, the V-cycle built on the indefinite operator is itself not positive definite in
+        // about half of these solves and MINRES has to hand over after a few (wasted) iterations
+        const bool gmres_first = !(getenv("PLFX_INDEFINITE_SOLVER") && !strcmp(getenv("PLFX_INDEFINITE_SOLVER"), "minres"));
         int rcm = gmres_first ? 2 : minres_solve(c, rtol, maxit_all, &itm, &rl);
         if (rcm < 0) return rcm;
         c->n_minres++;
-        if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+        if (solve_debug && !gmres_first) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
         if (rcm == 2) {
             int itg = 0;
             rcm = gmres_solve(c, rtol, maxit_all, &itg, &rl);
