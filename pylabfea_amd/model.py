@@ -857,6 +857,7 @@ class Model(object):
             raise AttributeError('Attributes for mesh not set, but required by solver.')
         eng = self._ensure_engine()
         self._cache = {}
+        n_stats0 = len(self.solver_stats)
         dim = 2
         if self.u is None:
             eng.state_reset()
@@ -1057,6 +1058,12 @@ class Model(object):
         self.nsteps = il
         self.niter = niter
         self.co_nconv = co_nconv
+        # the reference's LU always returns; an iterative solve can end above its tolerance (nearly singular tangents at a
+        # limit load): say so instead of continuing silently
+        bad = [r for (_, r) in self.solver_stats[n_stats0:] if not r <= 10. * self.cg_rtol]
+        if bad:
+            warnings.warn('{} of {} linear solves ended above the tolerance (worst relative residual {:.2e}, rtol {:g})'
+                          .format(len(bad), len(self.solver_stats) - n_stats0, max(bad), self.cg_rtol))
         self.u = self._nodal(eng.state_get(_lib.ST_U))
         self.f = self._nodal(eng.state_get(_lib.ST_F))
         self.du = self._nodal(eng.state_get(_lib.ST_DU))
