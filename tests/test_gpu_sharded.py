@@ -313,3 +313,86 @@ def test_bench_two_ranks_weak_scaling_path(tmp_path):
     fe.solve(min_step=ninc)
     its = [s[0] for s in fe.solver_stats[marks['q0']:marks['q1']]]
     assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# indefinite tangent stiffness on strips: the GMRES / MINRES fall-backs with owned-only sums and halo exchanges
+BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+02, -3.89722e+01, -5.30574e+05, -2.01886e+05,
+                  8.08981e+02, -9.29004e+02, 4.43106e+01, 2.03386e+05, -4.23220e+01, 4.86228e+01, -2.33304e+00, 5.81516e+04,
+                  1.14637e+01, -5.47451e-01, 5.81484e+04, 6.34734e-01, 5.81615e+04]
+
+
+def indefinite_solve(rank=None, world=None, dist=None):
+    """elastic 128 x 32 mesh with the tangent of tests/test_gpu_random.py planted into three elements -- one of them in the
+    column next to the strip boundary, so that the neighbour's operator needs it through the generator exchange"""
+    import pylabfea_amd as FE
+    from pylabfea_amd import _lib
+    mat = FE.Material()
+    mat.elasticity(E=151220., nu=0.3)
+    fe = FE.Model(dim=2, planestress=False)
+    fe.geom([16.], LY=4.)
+    fe.assign([mat])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.002 * fe.leny, 'disp')
+    fe.mesh(NX=128, NY=32)
+    if dist is not None:
+        fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world), mode='strip', coarse_level=2)
+    eng = fe._ensure_engine()
+    NY = fe._NY
+    bad = np.zeros((6, 6))
+    bad[np.triu_indices(6)] = BAD_TANGENT_21
+    bad = bad + bad.T - np.diag(np.diag(bad))
+    D = np.tile(fe._element_CV(mat), (fe.Nel, 1, 1))
+    for cx, cy in ((40, 16), (63, 8), (90, 24)):
+        D[cx * NY + cy] = bad
+    eng.state_set(_lib.ST_ELSTIFF, D[fe._e0:fe._e1].reshape(-1, 36))
+    eng.assemble()
+    z, d = np.zeros(2), np.array([0., 0.002 * fe.leny])
+    fe._bc_apply(eng, z, z, z, d, None)
+    n0 = eng.solve_fallbacks()
+    it, rr, ok = eng.solve(1e-10, 20000, False)
+    assert ok and rr <= 1e-10 and eng.solve_fallbacks() == n0 + 1
+    return fe, it, fe._nodal(eng.state_get(_lib.ST_DU))
+
+
+def _indef_worker(rank, world, port, solver, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['PLFX_INDEFINITE_SOLVER'] = solver
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        fe, it, du = indefinite_solve(rank, world, dist)
+        q.put((rank, dict(it=it, du=du, strip=fe._strip)))
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'ERROR: ' + traceback.format_exc()))
+        raise exc
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('solver', ['gmres', 'minres'])
+def test_strip_indefinite_tangent(solver, monkeypatch):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_indef_worker, args=(r, world, port, solver, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = collect(q, procs, world, 300.)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
+    fe, it1, du1 = indefinite_solve()
+    nyn = fe.NnodeY
+    for r in range(world):
+        st = res[r]['strip']
+        assert abs(res[r]['it'] - it1) <= 3, (res[r]['it'], it1)     # same Krylov method; sums in another order
+        lo, hi = 2 * st['c0'] * nyn, 2 * (st['c1'] + 1) * nyn
+        assert np.max(np.abs(res[r]['du'][lo:hi] - du1[lo:hi])) <= 1e-7 * np.max(np.abs(du1))
