@@ -82,7 +82,7 @@ def run(name, fe, ms):
         print('    PCG iterations per solve: %s' % its)
     rel = np.array([s[1] for s in fe.solver_stats])
     print('    solves above rtol %g: %d (worst relative residual %.3g); load steps with unconverged K-iterations: %s; sgl_yy per load step: %s'
-          % (fe.cg_rtol, int(np.sum(rel > fe.cg_rtol)), rel.max() if len(rel) else 0., list(np.asarray(fe.co_nconv).ravel()),
+          % (fe.cg_rtol, int(np.sum(rel > fe.cg_rtol)), rel.max() if len(rel) else 0., [int(v) for v in np.asarray(fe.co_nconv).ravel()],
              np.round([s[1] for s in fe.sgl], 3).tolist()))
     print('%-34s %8.3f s  load steps %3d  K-iterations %4d  sweeps %4d  solves %4d  PCG its %5d (max %d, Jacobi fall-backs %d)  updates/s %.3g  sgl_yy %.6f'
           % (name, dt, fe.nsteps, sum(max(n, 0) + 1 for n in fe.niter), fe.n_sweeps, len(its), sum(its), max(its), eng.solve_fallbacks(),
