@@ -249,7 +249,7 @@ struct plfx_ctx {
     int n_minres = 0;     // solves completed by MINRES (indefinite tangent stiffness)
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
     double *gm_V = nullptr, *gm_part = nullptr;  // GMRES: Krylov basis (GMRES_M + 1 vectors) and partial sums, on first use
-    int n_gmres = 0;
+    int n_gmres = 0, gm_m = 0;
     bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
@@ -3126,15 +3126,22 @@ int host_sums(plfx_ctx *c, double *part, int nslots, int gn, double *out)
 
 // Right-preconditioned restarted GMRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp): x = x0 + B t with t in the
 // Krylov space of K B.  Returns 0 = |P(b - K x)| <= rtol |b|, 1 = iteration limit, < 0 = error.
-constexpr int GMRES_M = 200;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on indefinite K)
+constexpr int GMRES_M = 400;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on
+                            // indefinite K); halved until the basis fits into a third of the free HBM
 int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
 {
     const size_t nd = c->ndof;
     const int nn = c->nnode, gn = c->grid_nodes;
     const int olo = own_lo(c), ohi = own_hi(c);
-    const int M = GMRES_M;
     int rc;
-    if (!c->gm_V && (rc = dalloc(c, &c->gm_V, (size_t)(M + 1) * nd))) return rc;
+    if (!c->gm_V) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(c, hipMemGetInfo(&fr, &tot));
+        c->gm_m = GMRES_M;
+        while (c->gm_m > 25 && (size_t)(c->gm_m + 1) * nd * 8 > fr / 3) c->gm_m /= 2;
+        if ((rc = dalloc(c, &c->gm_V, (size_t)(c->gm_m + 1) * nd))) return rc;
+    }
+    const int M = c->gm_m;
     if (!c->gm_part && (rc = dalloc(c, &c->gm_part, (size_t)8 * MAXPART))) return rc;
     auto Vj = [&](int j) { return c->gm_V + (size_t)j * nd; };
     double *P_rz = c->part + 3 * MAXPART, *P_rr = c->part + 4 * MAXPART, *P_bb = c->part + 5 * MAXPART;
@@ -3618,7 +3625,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             if (rcm < 0) return rcm;
             c->n_gmres++;
             itm += itg;
-            if (solve_debug) fprintf(stderr, "[plfx_solve] GMRES(%d): rc %d, %d iterations, relative residual %.3e\n", GMRES_M, rcm, itg, rl);
+            if (solve_debug) fprintf(stderr, "[plfx_solve] GMRES(%d): rc %d, %d iterations, relative residual %.3e\n", c->gm_m, rcm, itg, rl);
         }
         if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;
         hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);

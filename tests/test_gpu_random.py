@@ -226,7 +226,7 @@ BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+
 @pytest.mark.parametrize('nx,ny,mg', [(64, 64, True), (48, 24, True), (13, 6, False)])
 def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkeypatch):
     """A stiffness matrix with negative eigenvalues: PCG meets a direction of negative curvature and the solve is completed
-    by preconditioned MINRES -- or by right-preconditioned GMRES(200), which takes over when the V-cycle built on such an
+    by preconditioned MINRES -- or by right-preconditioned GMRES(400), which takes over when the V-cycle built on such an
     operator is not positive definite either (forced here); the solution must be the one a direct solver (the reference's
     numpy.linalg.solve) finds."""
     monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
