@@ -241,7 +241,9 @@ def inclusion_variant(FE, n, K, W, device=0):
             'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'ms_per_step': 1e3 * dt / K, 'sweeps': int(sweeps),
             'solves': len(its), 'pcg_iterations': int(np.sum(its)),
             'pcg_iterations_per_computed_solve': float(np.mean(computed)) if computed else 0.,
-            'elements_on_50_substep_corrector_last_sweep': int(np.sum(fe._state('max_steps') == 49))}
+            'elements_on_50_substep_corrector_last_sweep': int(np.sum(fe._state('max_steps') == 49)),
+            # solves (whole run) PCG could not finish: indefinite tangent -> GMRES, stalled multigrid -> Jacobi-PCG
+            'solves_completed_by_fallback_solver': int(fe._engine.solve_fallbacks())}
 
 
 def main():
@@ -455,6 +457,7 @@ def main():
         # were therefore not recomputed (plfx_reuse_info; PLFX_REUSE=0 recomputes them) -- included in 'solves' above
         'unchanged_inputs_reused': dict(zip(('assemblies', 'bc_applications', 'solves'),
                                             [int(b - a) for a, b in zip(marks['ru0'], marks['ru1'])])),
+        'solves_completed_by_fallback_solver': int(eng.solve_fallbacks()),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),
         'roofline_spmv': roof('spmv'),
