@@ -3139,6 +3139,13 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         c->gm_m = GMRES_M;
         while (c->gm_m > 25 && (size_t)(c->gm_m + 1) * nd * 8 > fr / 3) c->gm_m /= 2;
+        if (c->strip.on && strip_coll(c)) {  // every rank must run the same cycle length (the collectives are paired)
+            double mv = c->gm_m;
+            HIPCHK(c, hipMemcpyAsync(c->small, &mv, 8, hipMemcpyHostToDevice, c->stream));
+            if ((rc = allreduce(c, c->small, 1, NCCL_FLOAT64, NCCL_MIN, "GMRES basis length"))) return rc;
+            if ((rc = fetch_results(c, c->small, 1, &mv))) return rc;
+            c->gm_m = (int)mv;
+        }
         if ((rc = dalloc(c, &c->gm_V, (size_t)(c->gm_m + 1) * nd))) return rc;
     }
     const int M = c->gm_m;
