@@ -315,6 +315,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # RCCL writes its version banner through C stdio, which is block-buffered when stdout is a pipe: push it out now, so that
+    # the JSON line below is the LAST line this process prints
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+
     strip = fe._strip            # strip-local engine in use (None: single GPU, or the replicated-solve fall-back)
 
     # torch initialises its HIP context lazily on the first CUDA call (a few ms that would otherwise land inside the
@@ -476,8 +481,12 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args.cpu_mesh, max(1, min(K, 3)), 0)
     elif rank == 0:
         out['cpu_baseline'] = None
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()           # everything the other ranks had to say is out before the result line
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
