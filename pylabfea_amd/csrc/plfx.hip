@@ -3487,7 +3487,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 
     const int chunk = mg ? 1 : 50;  // multigrid: the flag is polled inside the iteration, before the V-cycle
     const int maxit_all = maxit;
-    if (mg && !c->strip_jacobi) maxit = std::min(maxit, 300);  // multigrid-PCG converges in tens of iterations or not at all
+    // multigrid-PCG converges in tens of iterations or not at all (PLFX_MG_MAXIT: the cap, for tests of the fall-back)
+    const int mg_cap = getenv("PLFX_MG_MAXIT") ? std::max(1, atoi(getenv("PLFX_MG_MAXIT"))) : 300;
+    if (mg && !c->strip_jacobi) maxit = std::min(maxit, mg_cap);
     int it = 0;
     while (it < maxit && !done) {
         const int stop = std::min(maxit, it + chunk);

@@ -107,7 +107,7 @@ def _worker(rank, world, port, case, golden_dir, q, mode='replicated', level=Non
         strip = fe._strip
         q.put((rank, dict(nsteps=fe.nsteps, niter=list(fe.niter), u=fe.u, f=fe.f, sgl=fe.sgl, e0=e0, e1=e1,
                           sig=fe._state('sig')[e0:e1], epl=fe._state('epl')[e0:e1], native=fe._native_step and fe._dev_coll,
-                          strip=strip, strip_info=eng.strip_info(), its=[s[0] for s in fe.solver_stats],
+                          strip=strip, strip_info=eng.strip_info(), its=[s[0] for s in fe.solver_stats], fallbacks=eng.solve_fallbacks(),
                           glob={k: v for k, v in fe.glob.items() if np.ndim(v) == 0 and v is not None})))
     except Exception as exc:  # noqa: BLE001
         import traceback
@@ -209,13 +209,15 @@ def _strip_worker(rank, world, port, case, golden_dir, q):
         level = None
     if case.endswith('+sweephalo'):  # the redundant variant: halo elements swept locally, no generator exchange
         os.environ['PLFX_STRIP_SWEEP_HALO'] = '1'
+    if case.endswith('+mgcap'):      # multigrid-PCG capped at 2 iterations: every solve ends in the Jacobi-PCG fall-back
+        os.environ['PLFX_MG_MAXIT'] = '2'
     _worker(rank, world, port, case.split('+')[0], golden_dir, q, mode='strip', level=level)
 
 
 @pytest.mark.parametrize('case,world', [('tension', 2), ('tension', 4), ('tension', 8), ('inclusion', 3), ('laminate_svc', 2),
                                         ('tension+python', 2), ('tension+default', 2), ('inclusion+sweephalo', 3),
-                                        ('laminate_svc+default', 4)])
-def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
+                                        ('laminate_svc+default', 4), ('tension+mgcap', 2)])
+def test_strip_local_engine_on_one_gpu(golden_dir, case, world, monkeypatch):
     """Strips + halo on 2..8 ranks (processes on cuda:0, host-staged transport over gloo: halo refresh of r / x, coarse
     right-hand side, partial sums, flags, statistics) against the single-rank run of the same model: identical load-step,
     K-iteration AND PCG-iteration counts (the V-cycle is arithmetically the single-GPU one), fields to 1e-9."""
@@ -230,6 +232,9 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    if case.endswith('+mgcap'):
+        monkeypatch.setenv('PLFX_MG_MAXIT', '2')
+    mgcap = case.endswith('+mgcap')
     python_driver = case.endswith('+python')
     default_level = case.endswith('+default')
     sweep_halo = case.endswith('+sweephalo')
@@ -257,19 +262,23 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world):
         assert nh > 0 and nc > 0 and npart > 0
         assert (ngen == 0) if sweep_halo else (ngen > 0)   # halo generators: received from their owners / recomputed locally
         assert d['nsteps'] == fe.nsteps and d['niter'] == list(fe.niter)
-        assert d['its'] == its1                                      # same PCG iterations in every solve
+        if not mgcap:
+            assert d['its'] == its1                                  # same PCG iterations in every solve
+        else:
+            assert d['fallbacks'] > 0 and fe._engine.solve_fallbacks() > 0
         lo, hi = 2 * st['c0'] * nyn, 2 * (st['c1'] + 1) * nyn        # nodes of the owned columns
         su = np.max(np.abs(fe.u))
-        assert np.max(np.abs(d['u'][lo:hi] - fe.u[lo:hi])) <= 1e-9 * su
+        slack = 300. if mgcap else 1.     # two different Jacobi-PCG loops, each converged to rtol = 1e-10 of the residual
+        assert np.max(np.abs(d['u'][lo:hi] - fe.u[lo:hi])) <= 1e-9 * slack * su
         flo, fhi = 2 * st['own_nodes'][0], 2 * st['own_nodes'][1]
-        assert np.max(np.abs(d['f'][flo:fhi] - fe.f[flo:fhi])) <= 1e-8 * np.max(np.abs(fe.f))
-        assert np.max(np.abs(d['sgl'] - fe.sgl)) <= 1e-9 * np.max(np.abs(fe.sgl))
+        assert np.max(np.abs(d['f'][flo:fhi] - fe.f[flo:fhi])) <= 1e-8 * slack * np.max(np.abs(fe.f))
+        assert np.max(np.abs(d['sgl'] - fe.sgl)) <= 1e-9 * slack * np.max(np.abs(fe.sgl))
         for k, v in d['glob'].items():
-            assert abs(v - fe.glob[k]) <= 1e-8 * max(1e-3, abs(fe.glob[k])), k
+            assert abs(v - fe.glob[k]) <= 1e-8 * slack * max(1e-3, abs(fe.glob[k])), k
         e0, e1 = d['e0'], d['e1']
         assert (e0, e1) == (st['c0'] * fe._NY, st['c1'] * fe._NY)
-        assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * np.max(np.abs(sig1))
-        assert np.max(np.abs(d['epl'] - epl1[e0:e1])) <= 1e-8 * max(np.max(np.abs(epl1)), 1e-30)
+        assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * slack * np.max(np.abs(sig1))
+        assert np.max(np.abs(d['epl'] - epl1[e0:e1])) <= 1e-8 * slack * max(np.max(np.abs(epl1)), 1e-30)
     assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
 
 
