@@ -208,8 +208,12 @@ int plfx_apply_bc(plfx_ctx *ctx, int n, const int32_t *presc_idx, const double *
  * inconsistent_entry: first entry whose value differs from the first one on its DOF (the reference's warning), -1 if none. */
 int plfx_set_bc_plan(plfx_ctx *ctx, int nseg, const int32_t *seg_len, const int32_t *idx);
 int plfx_apply_bc_plan(plfx_ctx *ctx, const double *seg_val, const double *fext, int *inconsistent_entry);
-/* Kred + np.linalg.solve (model.py:1028-1033, 1291, 1335) as Jacobi-PCG on the free DOFs.
- * warm != 0 starts from the previous du on the free DOFs.  Result in du (state 8). */
+/* Kred + np.linalg.solve (model.py:1028-1033, 1291, 1335) as an iterative solve on the free DOFs: PCG with the multigrid
+ * V-cycle (uniform structured grids) or the Jacobi scaling as preconditioner, stopped at |P(b - K du)| <= rtol |P b|.
+ * Systems PCG cannot finish are completed from its last iterate: tangent stiffness that is not positive definite (a
+ * direction with p.Kp <= 0 was met) by right-preconditioned GMRES(400), stalled multigrid (300 iterations) by Jacobi-PCG;
+ * plfx_solve_fallbacks counts them.  warm != 0 starts from the previous du on the free DOFs.  Result in du (state 8);
+ * returns 1 when maxit iterations did not reach rtol (iters / relres report what was reached). */
 int plfx_solve(plfx_ctx *ctx, double rtol, int maxit, int warm, int *iters, double *relres);
 
 /* ---------------------------------------------------------------- non-linear driver pieces */
