@@ -290,6 +290,9 @@ int plfx_finish_fetch(plfx_ctx *ctx, int slot, double *u_at, double *f_at, doubl
  * plfx_sweep flags, plfx_scf_all statistics and plfx_finish_step element sums then refer to the whole grid; u_at / f_at of
  * plfx_finish_step and the nodal arrays are local (owned + halo columns); element state arrays hold the owned element range. */
 int plfx_set_strip(plfx_ctx *ctx, int own_col0, int own_col1, int global_col0, int global_nx, int coarse_level);
+/* diagnostic: one ncclSend / ncclRecv pair of this rank with itself inside a group plus one all-reduce on scratch buffers,
+ * results checked on the host (the entry points the library binds by dlsym, on whatever hardware is at hand) */
+int plfx_comm_selftest(plfx_ctx *ctx);
 int plfx_strip_info(plfx_ctx *ctx, int *active, int *halo, int *coarse_level, int *coarse_levels, int64_t *halo_refreshes,
                     int64_t *coarse_gathers, int64_t *partial_allreduces, int64_t *generator_exchanges);
 /* in-place all-reduce of n <= 32 host doubles over the context's communicator (op 0 = sum, 3 = min): the boundary sums of

@@ -50,7 +50,7 @@ SYMBOLS = [
     'plfx_set_finish_set', 'plfx_finish_step', 'plfx_scf_all', 'plfx_comm_info', 'plfx_comm_init_callback',
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
-    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks',
+    'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
 ]
 
 _lib = None
@@ -516,6 +516,10 @@ class Context(object):
         self._chk(self.lib.plfx_strip_info(self.h, C.byref(a), C.byref(h), C.byref(l), C.byref(cl), C.byref(nh),
                                            C.byref(nc), C.byref(npart), C.byref(ng)))
         return bool(a.value), h.value, l.value, cl.value, nh.value, nc.value, npart.value, ng.value
+
+    def comm_selftest(self):
+        """send / receive to self + all-reduce on scratch buffers through the RCCL communicator (raises on a mismatch)"""
+        self._chk(self.lib.plfx_comm_selftest(self.h))
 
     def allreduce_host(self, values, op=0):
         """all-reduce <= 32 host doubles over the context's communicator (op 0 sum, 3 min)"""

@@ -3974,6 +3974,41 @@ int plfx_comm_init(plfx_ctx *c, const char id[128], int rank, int nranks)
     return PLFX_OK;
 }
 
+// ncclSend / ncclRecv of this rank to itself inside one group, and an all-reduce, on scratch buffers: checks the entry points
+// bound by dlsym (signatures, the data-type and reduction constants) on hardware where no second GPU is at hand
+int plfx_comm_selftest(plfx_ctx *c)
+{
+    if (!c || !c->stream) return PLFX_ERR_STATE;
+    if (!c->comm) return fail(c, PLFX_ERR_STATE, "no RCCL communicator (plfx_comm_init first)");
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
+    const int n = 4096;
+    double *buf = nullptr;
+    int rc = dalloc(c, &buf, (size_t)3 * n);
+    if (rc) return rc;
+    std::vector<double> h(n), back(n), red(n);
+    for (int i = 0; i < n; i++) h[i] = 1.5 * i - 7. + c->rank;
+    HIPCHK(c, hipMemcpyAsync(buf, h.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf + 2 * n, h.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(buf + n, 0, 8 * n, c->stream));
+    int r1 = g_rccl.GroupStart();
+    if (!r1) r1 = g_rccl.Send(buf, n, NCCL_FLOAT64, c->rank, c->comm, c->stream);
+    if (!r1) r1 = g_rccl.Recv(buf + n, n, NCCL_FLOAT64, c->rank, c->comm, c->stream);
+    const int r2 = g_rccl.GroupEnd();
+    const int r3 = g_rccl.AllReduce(buf + 2 * n, buf + 2 * n, n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
+    HIPCHK(c, hipMemcpyAsync(back.data(), buf + n, 8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(red.data(), buf + 2 * n, 8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(buf);
+    if (r1 || r2 || r3) return fail(c, PLFX_ERR_HIP, "RCCL self test: send/recv %d, group end %d, all-reduce %d", r1, r2, r3);
+    for (int i = 0; i < n; i++)
+        if (back[i] != h[i]) return fail(c, PLFX_ERR_HIP, "RCCL self test: received %g instead of %g at %d", back[i], h[i], i);
+    if (c->nranks == 1)
+        for (int i = 0; i < n; i++)
+            if (red[i] != h[i]) return fail(c, PLFX_ERR_HIP, "RCCL self test: all-reduce over one rank changed entry %d", i);
+    return PLFX_OK;
+}
+
 int plfx_comm_init_callback(plfx_ctx *c, int rank, int nranks, plfx_allreduce_fn fn, void *user)
 {
     if (!c || !c->stream) return PLFX_ERR_STATE;
