@@ -304,6 +304,8 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             fe.distribute(rank, world, uid[0])
     eng = fe._ensure_engine()
+    if dist is not None and not host_transport:
+        eng.comm_selftest()      # ncclSend / ncclRecv / ncclAllReduce as the library binds them: fail here, not inside a solve
     if os.environ.get('MG_NU'):  # experiment knob: smoothing sweeps / damping of the multigrid preconditioner
         eng.set_precond(1, float(os.environ.get('MG_OMEGA', '0.65')), int(os.environ['MG_NU']))
     devname, cus, hbm = eng.device_info()
