@@ -953,7 +953,8 @@ int assemble_fine_val(plfx_ctx *c)
 {
     hipLaunchKernelGGL(k_assemble, dim3(grid_for(c->nnode), c->nslot), dim3(BLOCK), 0, c->stream,
                        c->dcls, c->ncls, c->nnode, c->nslot, c->nq, c->nel_total, c->dcontrib, c->dcls_all,
-                       (matfree(c) && c->assembled) ? c->Mop : c->Mel, c->dcol, c->dval, c->diag);
+                       (matfree(c) && c->assembled) ? c->Mop : c->Mel, c->dcol, c->dval, c->diag,
+                       (matfree(c) && c->assembled) ? 1 : 0);  // the snapshot is in pair layout, the live array SoA
     HIPCHK(c, hipGetLastError());
     c->val_valid = true;
     return 0;
@@ -970,16 +971,16 @@ int mg_assemble(plfx_ctx *c)
         auto &L = c->mg[l];
         if (!(mf && (F.matfree || tail_mf(c))))  // otherwise the parent's setup kernel has already produced this level's generators
             hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
-                               F.nel, F.Mel, L.Mel);
+                               F.nel, F.Mel, L.Mel, mf ? 1 : 0, mf ? 1 : 0);  // matrix-free mode: pair layout on every level >= 1
         const bool setup_mf = mf && (L.matfree || (tail_mf(c) && l < nl - 1));  // coarsest: assembled for the dense inverse
         if (setup_mf)  // only the diagonal (Jacobi smoother) is needed
-            hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
                                (double *)nullptr, (l + 1 < nl) ? c->mg[l + 1].Mel : (double *)nullptr,
                                (const double2 *)c->dinv, c->mg[0].ny + 1, l,
                                c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr);
         else
             hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
-                               L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag);
+                               L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag, mf ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     c->mg_inv_valid = false;
@@ -1290,9 +1291,10 @@ int strip_child_assemble(plfx_ctx *c)
     plfx_ctx *k = S.child;
     auto &L = c->mg[S.Ld];
     const StripWin w = strip_window(c);
+    // pair layout on both sides: three arrays of (2 doubles per element); element columns are contiguous, so is the window
     const size_t tot = (size_t)6 * k->nel_total;
-    hipLaunchKernelGGL(k_strip_pack, dim3(grid_for(tot)), dim3(BLOCK), 0, c->stream, 6, (size_t)k->nel_total, (size_t)L.nel,
-                       (size_t)(w.g0 + w.ec0) * L.ny, (size_t)(w.ec1 - w.ec0) * L.ny, (size_t)w.ec0 * L.ny,
+    hipLaunchKernelGGL(k_strip_pack, dim3(grid_for(tot)), dim3(BLOCK), 0, c->stream, 3, (size_t)2 * k->nel_total, (size_t)2 * L.nel,
+                       (size_t)2 * (w.g0 + w.ec0) * L.ny, (size_t)2 * (w.ec1 - w.ec0) * L.ny, (size_t)2 * w.ec0 * L.ny,
                        (const double *)L.Mel, k->Mel);
     HIPCHK(c, hipGetLastError());
     if (strip_coll(c)) {
@@ -1301,7 +1303,7 @@ int strip_child_assemble(plfx_ctx *c)
     }
     KOp live = k->op;
     live.M = k->Mel;
-    hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(k->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)k->diag, k->Mop,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(k->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)k->diag, k->Mop,
                        k->mg[1].Mel, (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
     HIPCHK(c, hipGetLastError());
     k->bc_valid = false;  // its Jacobi scalings / Dirichlet masks follow in strip_child_dinv (after the parent's calc_BC)
@@ -2559,7 +2561,7 @@ int plfx_assemble(plfx_ctx *c)
     if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
         KOp live = c->op;
         live.M = c->Mel;  // diagonal + snapshot of the generators (+ generators of multigrid level 1) in one pass
-        hipLaunchKernelGGL(k_grid_setup, dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
                            c->Mop, mg_active(c) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
                            (double2 *)nullptr);
         c->val_valid = false;
@@ -3585,7 +3587,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             const size_t ne = c->nel_total;
             size_t nneg = 0, worst = 0; double wv = 0.;
             for (size_t e = 0; e < ne; e++) {
-                const double a = hm[e], b = hm[ne + e], cc = hm[2 * ne + e], d = hm[3 * ne + e], f = hm[4 * ne + e], g = hm[5 * ne + e];
+                const bool pr = matfree(c);  // layout of the array read above
+                const double a = hm[gen_index(pr, 0, ne, e)], b = hm[gen_index(pr, 1, ne, e)], cc = hm[gen_index(pr, 2, ne, e)],
+                             d = hm[gen_index(pr, 3, ne, e)], f = hm[gen_index(pr, 4, ne, e)], g = hm[gen_index(pr, 5, ne, e)];
                 // Sylvester: leading minors
                 const double m1 = a, m2 = a * d - b * b, m3 = a * (d * g - f * f) - b * (b * g - f * cc) + cc * (b * f - d * cc);
                 const double sc1 = std::fabs(a) + std::fabs(d) + std::fabs(g);
@@ -3597,7 +3601,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 const size_t e = worst - c->e0, n = c->nel;
                 double v[21]; int ms = 0; double fy = 0.;
                 fprintf(stderr, "      class %d material %d kind %d  M =", (int)c->hcls_id[worst], c->hcls[c->hcls_id[worst]].mat, (int)c->hmat[c->hcls[c->hcls_id[worst]].mat].kind);
-                for (int k = 0; k < 6; k++) fprintf(stderr, " %.6e", hm[k * ne + worst]);
+                for (int k = 0; k < 6; k++) fprintf(stderr, " %.6e", hm[gen_index(matfree(c), k, ne, worst)]);
                 for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->sig + k * n + e, 8, hipMemcpyDeviceToHost);
                 fprintf(stderr, "\n      sig = %.6e %.6e %.6e %.6e %.6e %.6e", v[0], v[1], v[2], v[3], v[4], v[5]);
                 for (int k = 0; k < 6; k++) hipMemcpy(&v[k], c->res_sig + k * n + e, 8, hipMemcpyDeviceToHost);

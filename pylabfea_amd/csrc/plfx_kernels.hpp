@@ -763,6 +763,18 @@ k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *els
 }
 
 // ---------------------------------------------------------------------------------------------
+// Layouts of the six stiffness generators (XX XY XS YY YS SS) of nel elements:
+//   live array (written by the material sweep, exchanged between strips): SoA [6][stride]
+//   operator side of the matrix-free path (the snapshot Mop, the generators of the multigrid levels >= 1, the replicated
+//   coarse problem of a strip): PAIR layout [3][nel] double2 = (XX,XY) (XS,YY) (YS,SS) -- a node reads the generators of its
+//   four elements with 12 sixteen-byte loads instead of 24 eight-byte ones; the operator kernels are bound by the loads a
+//   wave keeps in flight, not by bytes (tools/probes/pair_probe.hip: fine-level smoother 27.6 -> 23.2 us).
+__host__ __device__ __forceinline__ size_t gen_index(bool pair, int c, size_t nel, size_t e)
+{
+    return pair ? ((size_t)(c >> 1) * nel + e) * 2 + (c & 1) : (size_t)c * nel + e;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Assembly (model.py:954-977) as a gather: thread (node i, slot s) sums the <= nq element
 // contributions of block K[i, col(s)] in ascending element order.  contrib code = e*16 + a*4 + b
 // (e local owned-element index, a/b local node numbers), -1 = none.
@@ -770,7 +782,7 @@ k_refresh_M(const ClassDev *gcls, int nel, const int32_t *cls, const double *els
 __global__ void __launch_bounds__(BLOCK)
 k_assemble(const ClassDev *gcls, int ncls, int nnode, int nslot, int nq, int nel,
            const int32_t *contrib, const int32_t *cls, const double *Mel, const int32_t *col,
-           double *val, double *diag)
+           double *val, double *diag, int pair /* layout of Mel: 0 SoA, 1 pairs */)
 {
     __shared__ ClassDev scls[MAXCLS];
     {
@@ -788,9 +800,9 @@ k_assemble(const ClassDev *gcls, int ncls, int nnode, int nslot, int nq, int nel
             if (code < 0) continue;
             const int e = code >> 4, a = (code >> 2) & 3, b = code & 3;
             const ClassDev &c = scls[cls[e]];
-            const double Mxx = Mel[e], Mxy = Mel[(size_t)nel + e], Mxs = Mel[(size_t)2 * nel + e],
-                         Myy = Mel[(size_t)3 * nel + e], Mys = Mel[(size_t)4 * nel + e],
-                         Mss = Mel[(size_t)5 * nel + e];
+            const double Mxx = Mel[gen_index(pair, 0, nel, e)], Mxy = Mel[gen_index(pair, 1, nel, e)],
+                         Mxs = Mel[gen_index(pair, 2, nel, e)], Myy = Mel[gen_index(pair, 3, nel, e)],
+                         Mys = Mel[gen_index(pair, 4, nel, e)], Mss = Mel[gen_index(pair, 5, nel, e)];
             const double sxx = c.Sxx[a * 4 + b], sxy = c.Sxy[a * 4 + b], syx = c.Sxy[b * 4 + a],
                          syy = c.Syy[a * 4 + b];
             k00 += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
@@ -853,7 +865,7 @@ struct KOp {
     const int32_t *col;
     const double *val;
     int nxn, nyn, nel;   // nodes per row / column, elements
-    const double *M;     // SoA [6][nel]: XX XY XS YY YS SS
+    const double *M;     // generators XX XY XS YY YS SS: pair layout [3][nel] double2 (gen_index), k_grid_setup<0> reads SoA [6][nel]
     const double *tab;   // [4 positions][4 b][sxx_ab, syy_ab, sxy_ab, sxy_ba]; position p = pj*2+pk <-> element (j-1+pj, k-1+pk)
 };
 
@@ -921,11 +933,70 @@ __device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const
     return make_double2(qx, qy);
 }
 
+// the same with the generators in pair layout: mf2(q) = pair number q = c2 * nel + e
+template <class MF2, class XF>
+__device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf)
+{
+    const int nye = nyn - 1, nxe = nxn - 1;
+    const int j = i / nyn, k = i - j * nyn;
+    double2 u[3][3];
+#pragma unroll
+    for (int dj = 0; dj < 3; dj++) {
+        const int jj = min(max(j + dj - 1, 0), nxe);
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) {
+            const int kk = min(max(k + dk - 1, 0), nye);
+            u[dj][dk] = xf(jj * nyn + kk);
+        }
+    }
+    double m[4][6];
+#pragma unroll
+    for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            const int ej = j - 1 + pj, ek = k - 1 + pk;
+            const bool ok = ej >= 0 && ej < nxe && ek >= 0 && ek < nye;
+            const int e = min(max(ej, 0), nxe - 1) * nye + min(max(ek, 0), nye - 1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double2 v = mf2(c * nel + e);
+                m[pj * 2 + pk][2 * c] = ok ? v.x : 0.;
+                m[pj * 2 + pk][2 * c + 1] = ok ? v.y : 0.;
+            }
+        }
+    double qx = 0., qy = 0.;
+#pragma unroll
+    for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            const int p = pj * 2 + pk;
+            const double *T = tab + p * 16;  // wave-uniform -> scalar loads
+            double A1 = 0., A2 = 0., A3 = 0., A4 = 0., A5 = 0., A6 = 0., A7 = 0., A8 = 0.;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const double2 ub = u[pj + (b >> 1)][pk + (b & 1)];
+                const double sxx = T[b * 4 + 0], syy = T[b * 4 + 1], sxy = T[b * 4 + 2], syx = T[b * 4 + 3];
+                A1 = fma(sxx, ub.x, A1);
+                A2 = fma(sxx, ub.y, A2);
+                A3 = fma(syy, ub.x, A3);
+                A4 = fma(syy, ub.y, A4);
+                A5 = fma(sxy, ub.x, A5);
+                A6 = fma(sxy, ub.y, A6);
+                A7 = fma(syx, ub.x, A7);
+                A8 = fma(syx, ub.y, A8);
+            }
+            const double Mxx = m[p][0], Mxy = m[p][1], Mxs = m[p][2], Myy = m[p][3], Mys = m[p][4], Mss = m[p][5];
+            qx = fma(Mxx, A1, fma(Mxs, A5 + A7 + A2, fma(Mss, A3 + A8, fma(Mxy, A6, fma(Mys, A4, qx)))));
+            qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
+        }
+    return make_double2(qx, qy);
+}
+
 template <class XF>
 __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
 {
-    const double *M = g.M;
-    return grid_apply_g(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M[q]; }, xf);
+    const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
+    return grid_apply_pairs(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf);
 }
 
 template <int GRID, class XF>
@@ -944,6 +1015,9 @@ __device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
 //   Mc     generators of the next coarser level = mean of the four children (node (2J,2K) owns coarse element (J,K))
 //   dinv   (coarse levels, Dirichlet set known) free ? 1/|diag| : 0 with the mask of the coincident finest-grid node
 //          (node (j << shift, k << shift) of the grid with mask_nyn nodes per column)
+// SRC_PAIR: layout of g.M (0: the live SoA array of the finest level; 1: pair layout, every other level); Msnap and Mc are
+// written in pair layout.
+template <int SRC_PAIR>
 __global__ void __launch_bounds__(BLOCK)
 k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, double *__restrict__ Mc,
              const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv)
@@ -965,16 +1039,24 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                 const int a = (1 - pj) * 2 + (1 - pk);
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
                 const double sxx = T[0], syy = T[1], sxy = T[2], syx = T[3];
-                const double Mxx = g.M[e], Mxy = g.M[(size_t)g.nel + e], Mxs = g.M[(size_t)2 * g.nel + e],
-                             Myy = g.M[(size_t)3 * g.nel + e], Mys = g.M[(size_t)4 * g.nel + e],
-                             Mss = g.M[(size_t)5 * g.nel + e];
+                double Mxx, Mxy, Mxs, Myy, Mys, Mss;
+                if (SRC_PAIR) {
+                    const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
+                    const double2 a01 = M2[e], a23 = M2[(size_t)g.nel + e], a45 = M2[(size_t)2 * g.nel + e];
+                    Mxx = a01.x, Mxy = a01.y, Mxs = a23.x, Myy = a23.y, Mys = a45.x, Mss = a45.y;
+                } else {
+                    Mxx = g.M[e], Mxy = g.M[(size_t)g.nel + e], Mxs = g.M[(size_t)2 * g.nel + e];
+                    Myy = g.M[(size_t)3 * g.nel + e], Mys = g.M[(size_t)4 * g.nel + e], Mss = g.M[(size_t)5 * g.nel + e];
+                }
                 dx += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
                 dy += Myy * syy + Mys * (syx + sxy) + Mss * sxx;
                 if (pj == 1 && pk == 1) {  // node (j,k) "owns" element (j,k)
                     own[0] = Mxx; own[1] = Mxy; own[2] = Mxs; own[3] = Myy; own[4] = Mys; own[5] = Mss;
                     if (Msnap) {
-#pragma unroll
-                        for (int c = 0; c < 6; c++) Msnap[(size_t)c * g.nel + e] = own[c];
+                        double2 *S2 = reinterpret_cast<double2 *>(Msnap);
+                        S2[e] = make_double2(own[0], own[1]);
+                        S2[(size_t)g.nel + e] = make_double2(own[2], own[3]);
+                        S2[(size_t)2 * g.nel + e] = make_double2(own[4], own[5]);
                     }
                 }
             }
@@ -989,11 +1071,15 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
         if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {  // nxe, nye are even on levels that are coarsened
             const size_t e00 = (size_t)j * nye + k, e10 = e00 + nye;
             const size_t ec = (size_t)(j >> 1) * nyc + (k >> 1);
+            double mc[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const double *m = g.M + (size_t)c * g.nel;
-                Mc[(size_t)c * nel_c + ec] = 0.25 * (own[c] + m[e00 + 1] + m[e10] + m[e10 + 1]);
-            }
+            for (int c = 0; c < 6; c++)
+                mc[c] = 0.25 * (own[c] + g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] + g.M[gen_index(SRC_PAIR, c, g.nel, e10)] +
+                                g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)]);
+            double2 *C2 = reinterpret_cast<double2 *>(Mc);
+            C2[ec] = make_double2(mc[0], mc[1]);
+            C2[nel_c + ec] = make_double2(mc[2], mc[3]);
+            C2[2 * nel_c + ec] = make_double2(mc[4], mc[5]);
         }
     }
 }

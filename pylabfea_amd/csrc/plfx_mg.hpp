@@ -181,17 +181,18 @@ k_mg_prolong_add(int nxf_nodes, int nyf, int nyc, const double2 *__restrict__ x_
 
 // coarse stiffness generator: mean of the four children (element id = j*NY + k, model.py:935)
 __global__ void __launch_bounds__(BLOCK)
-k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ M_f, double *__restrict__ M_c)
+k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ M_f, double *__restrict__ M_c,
+               int pair_f, int pair_c /* layouts of the two arrays (gen_index) */)
 {
     const int nel_c = nxc * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nel_c; i += gridDim.x * BLOCK) {
         const int J = i / nyc, K = i - J * nyc;
         const size_t e00 = (size_t)(2 * J) * nyf + 2 * K, e10 = e00 + nyf;
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const double *m = M_f + (size_t)c * nel_f;
-            M_c[(size_t)c * nel_c + i] = 0.25 * (m[e00] + m[e00 + 1] + m[e10] + m[e10 + 1]);
-        }
+        for (int c = 0; c < 6; c++)
+            M_c[gen_index(pair_c, c, nel_c, i)] =
+                0.25 * (M_f[gen_index(pair_f, c, nel_f, e00)] + M_f[gen_index(pair_f, c, nel_f, e00 + 1)] +
+                        M_f[gen_index(pair_f, c, nel_f, e10)] + M_f[gen_index(pair_f, c, nel_f, e10 + 1)]);
     }
 }
 
@@ -950,7 +951,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return w[j]; });
                 const double2 bi = b[i], x1 = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
@@ -962,7 +963,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return x[j]; });
                 const double2 bi = b[i];
                 w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
@@ -1049,7 +1050,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return x[j]; });
                 const double2 bi = b[i], xi = x[i];
                 w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
@@ -1061,7 +1062,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_g(nxn, nyn, nel, tab, i, [&](int m) { return Ml[m]; },
+                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return w[j]; });
                 const double2 bi = b[i], wi = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));
