@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achieva
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
 # calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
 PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
-               'matfree': {'mg_smooth': 120.7e6, 'spmv': 128.4e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r02j_bench1024_rocprofv3_summary.txt'}
+               'matfree': {'mg_smooth': 120.5e6, 'spmv': 126.4e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r02m_bench1024_rocprofv3_summary.txt'}
 
 
 def hill_material(FE):
