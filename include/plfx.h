@@ -89,6 +89,8 @@ int plfx_create(int device, plfx_ctx **out);
 void plfx_destroy(plfx_ctx *ctx);
 const char *plfx_last_error(plfx_ctx *ctx);
 const char *plfx_version(void);
+/* number of GPUs visible to the process (0 when there is none or the HIP runtime cannot start); needs no context */
+int plfx_device_count(void);
 /* name[<=len], number of CUs, bytes of HBM */
 int plfx_device_info(plfx_ctx *ctx, char *name, int len, int *cus, int64_t *hbm_bytes);
 /* HIP stream the library launches on (for hipEvent timing by the caller) */

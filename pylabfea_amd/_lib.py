@@ -39,7 +39,7 @@ class CMaterial(C.Structure):
 
 # every symbol include/plfx.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
-    'plfx_create', 'plfx_destroy', 'plfx_last_error', 'plfx_version', 'plfx_device_info',
+    'plfx_create', 'plfx_destroy', 'plfx_last_error', 'plfx_version', 'plfx_device_count', 'plfx_device_info',
     'plfx_stream', 'plfx_sync', 'plfx_set_materials', 'plfx_seq_batch', 'plfx_fgrad_batch',
     'plfx_yf_batch', 'plfx_full_yf_batch', 'plfx_response_batch', 'plfx_set_mesh', 'plfx_get_bmat',
     'plfx_get_kel', 'plfx_state_get', 'plfx_state_set', 'plfx_state_reset', 'plfx_gather',
@@ -87,6 +87,11 @@ class CStep(C.Structure):
                 ('nit', C.c_int32), ('nconv', C.c_int32), ('nsweeps', C.c_int32), ('nsolves', C.c_int32),
                 ('soft_fail', C.c_int32), ('inconsistent_entry', C.c_int32),
                 ('its', C.c_int32 * 40), ('relres', C.c_double * 40)]
+
+
+def device_count():
+    """GPUs visible to this process (plfx_device_count; 0 without a GPU)"""
+    return int(load().plfx_device_count())
 
 
 def _dp(a):

@@ -1458,6 +1458,16 @@ void plfx_destroy(plfx_ctx *c)
 
 const char *plfx_last_error(plfx_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+int plfx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 int plfx_device_info(plfx_ctx *c, char *name, int len, int *cus, int64_t *hbm)
 {
     if (!c || !c->stream) return PLFX_ERR_STATE;
@@ -3860,7 +3870,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                        c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
                        c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                       c->small + 32, c->scf_hh, c->scf_mult);
+                       c->small + 32, c->scf_hh, c->scf_mult, (const double *)c->kh_el);
     const int elo = c->strip.on ? c->strip.eown_lo : 0, ehi = c->strip.on ? c->strip.eown_hi : 0x7fffffff;
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr, elo, ehi);

@@ -13,6 +13,7 @@ sdim=3 flow rules use the reference's axis-tracking principal stresses (exact fo
 Tresca and Barlat Yld2004-18p are equivalent stresses only (the reference has no normal for them).
 ML materials: 6 stress features (sdim=6) or the 2 features (seq, polar angle) of ``setup_yf_SVM_3D`` (sdim=3).
 """
+import hashlib
 import os
 import warnings
 
@@ -21,16 +22,18 @@ import numpy as np
 from . import _lib
 from .basic import eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, yf_tolerance
 
-_point_ctx = {}        # shared contexts for point evaluations, one per GPU
-_point_key = None
+_point_ctx = {}        # shared contexts for point evaluations, one per GPU (each remembers the record it holds)
 
 
 def point_device():
-    """GPU of the point-evaluation context: PLFX_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else 0"""
+    """GPU of the point-evaluation context: PLFX_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else 0.
+    Taken modulo the number of visible GPUs, so that several ranks sharing one GPU (host transport, tests) all find a
+    device; negative or non-numeric values are ignored."""
     for var in ('PLFX_DEVICE', 'LOCAL_RANK'):
         v = os.environ.get(var)
-        if v is not None and v.strip().lstrip('-').isdigit():
-            return int(v)
+        if v is not None and v.strip().isdigit():
+            n = _lib.device_count()
+            return int(v) % n if n > 0 else 0
     return 0
 
 
@@ -43,11 +46,9 @@ def _ctx():
 
 def close_point_contexts():
     """release the shared point-evaluation contexts (HBM of the support-vector tables, streams)"""
-    global _point_key
     for c in _point_ctx.values():
         c.close()
     _point_ctx.clear()
-    _point_key = None
 
 
 class Material(object):
@@ -434,17 +435,42 @@ class Material(object):
         if self.tresca:
             raise ValueError('calc_fgrad: analytical gradient for Tresca not implemented')
 
+    def _content_key(self, CV=None, ana=False, rec=None, parameters_only=False):
+        """Digest of everything the device evaluates for this material: the packed ``plfx_material`` record (kind, elastic
+        and plastic parameters, Hill / Barlat coefficients, SVC scalars) and the support-vector / dual-coefficient tables.
+        Two materials share a key only if the GPU would compute the same numbers for them -- never because one was
+        garbage-collected and the next landed at the same address, and an attribute edited in place (``m.hill[0] = ...``,
+        which the reference honours on the next call, material.py:139-205) changes the key.  ``parameters_only`` leaves
+        out what is STATE rather than a parameter: the hardening modulus of a work-hardening SVC material, which every
+        gradient evaluation overwrites (material.py:808-814)."""
+        if rec is None:
+            rec = self._record(np.asarray(self.CV if CV is None else CV, dtype=float), ana=ana)
+        m, keep = rec
+        h = hashlib.blake2b(digest_size=16)
+        sv_ptr, dual_ptr = m.sv, m.dual
+        kh = m.khard
+        m.sv = m.dual = None             # host addresses of the tables are not content
+        if parameters_only and m.kind == _lib.SVC_WH:
+            m.khard = 0.
+        h.update(bytes(m))
+        m.sv, m.dual, m.khard = sv_ptr, dual_ptr, kh
+        for a in keep:
+            h.update(np.ascontiguousarray(a).data)
+        return h.digest()
+
     def _load(self, CV=None, ana=False):
-        """Make this material (with element matrix CV) material 0 of the shared point context."""
-        global _point_key
+        """Make this material (with element matrix CV) material 0 of the shared point context.  The context keeps the last
+        record it was given; it is re-sent whenever its CONTENT differs (see ``_content_key``)."""
         cv = np.asarray(self.CV if CV is None else CV, dtype=float)
         if cv.shape != (6, 6):
             raise ValueError('CV must be a (6,6) array')
         ctx = _ctx()
-        key = (id(ctx), id(self), self._version, bool(ana), cv.tobytes(), self.khard, self.sy)
-        if key != _point_key:
-            ctx.set_materials([self._record(cv, ana=ana)])
-            _point_key = key
+        rec = self._record(cv, ana=ana)
+        key = self._content_key(rec=rec)
+        if getattr(ctx, '_point_key', None) != key:
+            ctx._point_key = None          # a failing set_materials must not leave a stale key behind
+            ctx.set_materials([rec])
+            ctx._point_key = key
         return ctx
 
     @staticmethod

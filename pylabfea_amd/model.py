@@ -504,7 +504,9 @@ class Model(object):
         return c0 * NY, c1 * NY
 
     def _ensure_engine(self):
-        vers = tuple(m._version for m in self.mat)
+        # content digests, not object identities or setter counters: an attribute edited in place (m.hill[0] = ...) is
+        # honoured like in the reference, and a new Material at a recycled address is never mistaken for the old one
+        vers = tuple(m._content_key(self._element_CV(m), parameters_only=True) for m in self.mat)
         if self._engine is not None and self._mat_versions == vers:
             return self._engine
         if self._engine is not None and self.u is not None:
