@@ -14,11 +14,17 @@ are run untimed as set-up so that warm-up and timed steps lie in the plastic reg
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1 (one rank per GPU over RCCL): WEAK scaling -- every GPU holds a 1024-column strip of a (N*1024) x 1024 mesh of the
-same square elements (the domain grows in x: LX = 4 N) and runs the strip-local engine (plfx_set_strip, DESIGN.md
-section 6): state, sweep, operator, multigrid levels and solve are all distributed; per PCG iteration the ranks exchange
-one halo slab of the residual (ncclSend/ncclRecv), one all-reduce of the coarse right-hand side and three all-reduces of
-8 KB of partial sums.  `value` = elements of the whole mesh x sweeps / wall-clock.  Rank 0 prints ONE JSON line.
+N>1 (one rank per GPU over RCCL), default: STRONG scaling of the SAME workload -- the 1024 x 1024 mesh of config 3 cut into
+N cost-balanced x-strips of whole element columns (Model.strip_plan; element and node numbering are x-major in the
+reference, model.py:893, 935, so a strip is a contiguous element / node range), every rank running the strip-local engine
+(plfx_set_strip): state, sweep, operator, multigrid levels and solve are all distributed; per PCG
+iteration the ranks exchange one halo slab of the residual (ncclSend/ncclRecv), one all-reduce of the coarse right-hand
+side and three all-reduces of 8 KB of partial sums.  `config.workload` is identical to N=1, `scaling` = "strong",
+`value` = elements of the mesh x sweeps / wall-clock (max over ranks).  Rank 0 prints ONE JSON line.
+  --weak       weak scaling instead: every GPU holds a 1024-column strip of a (N*1024) x 1024 mesh (LX = 4 N).
+  --config 5   BASELINE config 5: 2048 x 2048 laminate [2,1,2,1,2] of J2 and the SVC trained on Barlat Yld2004-18p / Goss
+               texture (fixture tests/golden/svc_goss_barlat.npz), eps = 0.003, min_step = 20; the timed steps start at the
+               onset of yielding of the SVC phase (a plastic step of this configuration takes seconds: use --steps 1..3).
 PLFX_BENCH_TRANSPORT=host runs the same path over gloo with the host-staged transport (several ranks on ONE GPU: a
 functional check, not a measurement).
 """
@@ -75,6 +81,30 @@ def tension_model(FE, mat, n, eps, device=0, strips=1):
     fe.bctop(eps * fe.leny, 'disp')
     fe.mesh(NX=n * strips, NY=n)
     return fe
+
+
+def laminate_model(FE, n, device=0):
+    """BASELINE config 5: laminate [2,1,2,1,2] (notebooks/pyLabFEA_Composites cell 1) with LY = 8 so that the
+    elements stay square, phase A = J2 (sy=150, khard=500), phase B = the SVC trained with the reference on Barlat
+    Yld2004-18p with the Goss coefficients of examples/train_goss_barlat.py:36-41 (1418 support vectors), n x n elements
+    -> element columns [n/4, n/8, n/4, n/8, n/4] by model.py:826-830; uniaxial tension eps = 0.003"""
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'svc_gossbarlat.npz'))
+    ma = FE.Material(name='J2', num=1)
+    ma.elasticity(E=200.e3, nu=0.3)
+    ma.plasticity(sy=150., khard=500., sdim=6)
+    mb = FE.Material(name='ML-Goss-Barlat', num=2)
+    mb.elasticity(CV=z['par_CV'])
+    mb.plasticity(sy=float(z['par_sy']), sdim=6)
+    mb.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']))
+    fe = FE.Model(dim=2, planestress=False, device=device)
+    fe.geom([2, 1, 2, 1, 2], LY=8.)
+    fe.assign([ma, mb, ma, mb, ma])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.003 * fe.leny, 'disp')
+    fe.mesh(NX=n, NY=n)
+    return fe, len(z['par_dual'])
 
 
 def cpu_run(n, steps, warmup, nthreads, linear, pcg_threads=None):
@@ -215,6 +245,8 @@ def inclusion_variant(FE, n, K, W, device=0):
     el[n // 3:2 * (n // 3), n // 3:2 * (n // 3)] = 2
     fe.mesh(elmts=el, NX=n, NY=n)
     eng = fe._ensure_engine()
+    if os.environ.get('MG_NU'):  # experiment knob: smoothing sweeps / damping of the multigrid preconditioner
+        eng.set_precond(1, float(os.environ.get('MG_OMEGA', '0.65')), int(os.environ['MG_NU']))
     marks = {}
     ninc, pre = schedule(K, W)
 
@@ -251,7 +283,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mesh', type=int, default=1024)
+    ap.add_argument('--mesh', type=int, default=None, help='elements per side (default: 1024 for config 3, 2048 for config 5)')
+    ap.add_argument('--config', type=int, default=3, choices=(3, 5),
+                    help='BASELINE.json configs[2] (default, the configuration the metric is quoted on) or configs[4]')
+    ap.add_argument('--weak', action='store_true',
+                    help='N>1: weak scaling (N strips of mesh x mesh elements side by side) instead of strong scaling of the same mesh')
     ap.add_argument('--cpu-mesh', type=int, default=224)
     ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -291,9 +327,16 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
-    K, W, n = args.steps, args.warmup, args.mesh
-    mat = hill_material(FE)
-    fe = tension_model(FE, mat, n, 0.005, device=local, strips=world)
+    K, W = args.steps, args.warmup
+    n = args.mesh or (1024 if args.config == 3 else 2048)
+    weak = bool(args.weak and world > 1)
+    if args.config == 5:
+        if weak:
+            raise SystemExit('--weak applies to config 3 only')
+        fe, nsv5 = laminate_model(FE, n, device=local)
+    else:
+        mat = hill_material(FE)
+        fe = tension_model(FE, mat, n, 0.005, device=local, strips=world if weak else 1)
     if dist is not None:
         if host_transport:
             fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world))
@@ -330,7 +373,14 @@ def main():
     barrier()
 
     marks = {}
-    ninc, pre = schedule(K, W)
+    if args.config == 5:
+        # 20 increments; the SVC phase starts to yield in load step 5 (sgl_yy 134.7 -> 135.0, profiles/r02j_config5_full_solve.txt):
+        # steps 0..4 are the untimed elastic pre-roll
+        ninc, pre = 20, 5
+        if pre + W + K > ninc:
+            raise SystemExit('config 5 has 20 load steps: --warmup + --steps <= 15')
+    else:
+        ninc, pre = schedule(K, W)
 
     dbg = [] if os.environ.get('BENCH_DEBUG') else None
 
@@ -340,7 +390,7 @@ def main():
         if il == pre + W:
             eng.timing_reset()
             # two hipEventRecord calls per timed launch: by default only the kernels of the two roofline objects
-            eng.timing_select(None if args.all_families else (_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV))
+            eng.timing_select(None if args.all_families else ((_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV) + ((_lib.T_COMM,) if world > 1 else ())))
             eng.timing_sample(args.sample)
             eng.timing_enable(True)
             gc.collect()
@@ -363,7 +413,11 @@ def main():
 
     fe._step_hook = hook
     fe._max_load_steps = pre + W + K
-    fe.solve(min_step=ninc)
+    import warnings
+    with warnings.catch_warnings():
+        if args.config == 5:
+            warnings.simplefilter('ignore')   # set_svc / non-converged-iteration notices of the SVC phase
+        fe.solve(min_step=ninc)
 
     if dbg:
         print('hook times (ms since t0):', [(i, round(1e3 * (t - marks['t0']), 3)) for i, t in dbg if i >= pre + W],
@@ -441,19 +495,24 @@ def main():
     out = {
         'metric': 'integration-point updates/sec (wall-clock per load step in ms_per_step)',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak' if (strip or world == 1) else 'strong',
+        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak' if (weak or world == 1) else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
-                               'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
-                               'of %d (after %d untimed elastic pre-roll steps)'
-                               % ('%dx%d' % (fe._NX, fe._NY), ninc, pre + W, pre + W + K, ninc, pre),
+        'config': {'workload': ('%s Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
+                                'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
+                                'of %d (after %d untimed elastic pre-roll steps)'
+                                % ('%dx%d' % (fe._NX, fe._NY), ninc, pre + W, pre + W + K, ninc, pre)) if args.config == 3 else
+                               ('%s Q4 two-phase laminate [2,1,2,1,2] (BASELINE config 5): J2 (sy=150, khard=500) + SVC yield function '
+                                'trained on Barlat Yld2004-18p / Goss (%d support vectors), plane strain, uniaxial tension eps=0.003, '
+                                'min_step=20; timed load steps %d..%d of 20 (after %d untimed elastic pre-roll steps)'
+                                % ('%dx%d' % (fe._NX, fe._NY), nsv5, pre + W, pre + W + K, pre)),
                    'elements': fe.Nel, 'dofs': fe.Ndof,
                    'parallelism': ('single GPU' if world == 1 else
                                    ('strip-local engine x%d: %d owned + %d halo element columns per GPU, halo refresh of the residual '
                                     '(ncclSend/ncclRecv) + coarse right-hand-side all-reduce (level %d, replicated %d-level coarse '
                                     'hierarchy) + 3 all-reduces of 8 KB partial sums per PCG iteration, stiffness generators of the '
-                                    'halo columns from their owners after a sweep that changed a tangent; weak scaling, %d x %d mesh'
-                                    % (world, strip['c1'] - strip['c0'], strip['W'], strip['Ld'], eng.strip_info()[3], fe._NX, fe._NY))
+                                    'halo columns from their owners after a sweep that changed a tangent; %s scaling, %d x %d mesh'
+                                    % (world, strip['c1'] - strip['c0'], strip['W'], strip['Ld'], eng.strip_info()[3],
+                                       'weak' if weak else 'strong', fe._NX, fe._NY))
                                    if strip else
                                    ('x-strip element shard x%d: material state and sweep sharded, operator + multigrid solve '
                                     'replicated, one all-reduce of the stiffness generators per changed sweep' % world)),
@@ -470,6 +529,17 @@ def main():
         'roofline_spmv': roof('spmv'),
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items() if v[1] > 0},
     }
+    if dist is not None:
+        # per-rank view: roofline of the dominant kernel on every rank's own strip, and the time its stream spent in
+        # collectives (HIP events around every RCCL call: includes the wait for the slowest peer)
+        cms, cn = eng.timing_get(_lib.T_COMM)
+        mine = {'rank': rank, 'owned_columns': [strip['c0'], strip['c1']] if strip else None,
+                'halo_columns': strip['W'] if strip else None, 'roofline': roof(dominant), 'roofline_sweep': roof('sweep'),
+                'collective_ms_per_step': cms / K, 'collectives_per_step': cn / K}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        out['per_rank'] = rows
+        out['collective_ms_per_step'] = max(r['collective_ms_per_step'] for r in rows)
     if strip:
         si = eng.strip_info()
         out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'generator_exchanges': si[7], 'note': 'since the start of the run (rank 0)'}

@@ -149,9 +149,10 @@ int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
 /* number of plfx_solve calls so far that PCG could not finish: a direction of negative curvature was met (the tangents of
- * Material.response are not always positive semi-definite, material.py:324-338) and preconditioned MINRES completed the
- * solve from the last iterate -- the reference's LU does not need definiteness either -- or multigrid-PCG did not converge
- * within 300 iterations and Jacobi-PCG took over */
+ * Material.response are not always positive semi-definite, material.py:324-338) and the indefinite-system solver completed
+ * the solve from the last iterate (right-preconditioned GMRES by default, preconditioned MINRES with
+ * PLFX_INDEFINITE_SOLVER=minres) -- the reference's LU does not need definiteness either -- or multigrid-PCG did not
+ * converge within 300 iterations and Jacobi-PCG took over */
 int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
  * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to
@@ -321,7 +322,9 @@ int plfx_comm_init(plfx_ctx *ctx, const char id[128], int rank, int nranks);
 /* accumulated HIP-event time (ms) and launch count of a named kernel family since the last reset:
  * which: 0 streaming phase of the material sweep (k_sweep_light / k_sweep_svc_wave<0>), 1 spmv(+dot), 2 cg vector
  *        update, 3 assemble, 4 multigrid V-cycle (whole cycle), 5 fine-level multigrid smoother launches,
- *        6 sub-stepping phase of the material sweep (k_sweep_heavy / k_sweep_svc_wave<1>) */
+ *        6 sub-stepping phase of the material sweep (k_sweep_heavy / k_sweep_svc_wave<1>),
+ *        7 collectives on the library's stream (RCCL all-reduces, halo and generator exchanges; every call is timed, the time
+ *          includes the wait for the slowest peer) */
 int plfx_timing_get(plfx_ctx *ctx, int which, double *ms, int64_t *launches);
 int plfx_timing_reset(plfx_ctx *ctx);
 int plfx_timing_enable(plfx_ctx *ctx, int on);

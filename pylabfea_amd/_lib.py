@@ -19,7 +19,7 @@ ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3, SVC_WH = 0, 1, 2, 3, 4, 5, 6
 ST_SIG, ST_EPS, ST_EPL, ST_RES_SIG, ST_RES_DEPL, ST_ELSTIFF, ST_U, ST_F, ST_DU, ST_FYN, ST_MAXSTEPS, ST_KHARD = range(12)
 
 # timing families
-T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE, T_VCYCLE, T_SMOOTH, T_SWEEP_HEAVY = range(7)
+T_SWEEP, T_SPMV, T_CGUPD, T_ASSEMBLE, T_VCYCLE, T_SMOOTH, T_SWEEP_HEAVY, T_COMM = range(8)
 
 
 class PlfxError(RuntimeError):

@@ -389,7 +389,7 @@ void tim_begin(plfx_ctx *c, int which, EvPair **out)
     *out = nullptr;
     Timing &t = c->tim;
     if (!t.on || !((t.mask >> which) & 1u)) return;
-    if (t.every > 1 && (t.seen[which]++ % t.every) != 0) return;  // sampled: two event records per timed launch cost host time
+    if (t.every > 1 && which != 7 && (t.seen[which]++ % t.every) != 0) return;  // family 7 (collectives): every call  // sampled: two event records per timed launch cost host time
     if (t.ring.empty()) {
         t.ring.resize(2048);
         for (auto &e : t.ring) {
@@ -781,8 +781,11 @@ bool comm_active(const plfx_ctx *c) { return c->comm != nullptr || c->host_ar !=
 int allreduce(plfx_ctx *c, void *dev, size_t count, int nccl_dtype, int nccl_op, const char *what)
 {
     if (c->comm) {
-        if (g_rccl.AllReduce(dev, dev, count, nccl_dtype, nccl_op, c->comm, c->stream) != 0)
-            return fail(c, PLFX_ERR_HIP, "ncclAllReduce(%s) failed", what);
+        EvPair *ev;
+        tim_begin(c, 7, &ev);  // family 7: collectives (time on the stream incl. the wait for the slowest peer)
+        const int rcn = g_rccl.AllReduce(dev, dev, count, nccl_dtype, nccl_op, c->comm, c->stream);
+        tim_end(c, ev);
+        if (rcn != 0) return fail(c, PLFX_ERR_HIP, "ncclAllReduce(%s) failed", what);
         return 0;
     }
     if (c->host_ar) {
@@ -852,6 +855,8 @@ int halo_refresh(plfx_ctx *c, double *v)
     if (c->comm) {
         if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
             return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
+        EvPair *ev;
+        tim_begin(c, 7, &ev);
         int rc = g_rccl.GroupStart();
         if (!rc && S.has_left) {
             rc = g_rccl.Send(sendL, n, NCCL_FLOAT64, c->rank - 1, c->comm, c->stream);
@@ -862,6 +867,7 @@ int halo_refresh(plfx_ctx *c, double *v)
             if (!rc) rc = g_rccl.Recv(recvR, n, NCCL_FLOAT64, c->rank + 1, c->comm, c->stream);
         }
         const int rc2 = g_rccl.GroupEnd();
+        tim_end(c, ev);
         if (rc || rc2) return fail(c, PLFX_ERR_HIP, "halo refresh (ncclSend/ncclRecv) failed: %d / %d", rc, rc2);
         return 0;
     }
@@ -897,6 +903,8 @@ int strip_sync_M(plfx_ctx *c)
     if (c->comm) {
         if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
             return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
+        EvPair *ev;
+        tim_begin(c, 7, &ev);
         int rc = g_rccl.GroupStart();
         for (int k = 0; k < 6 && !rc; k++) {
             if (S.has_left) {
@@ -909,6 +917,7 @@ int strip_sync_M(plfx_ctx *c)
             }
         }
         const int rc2 = g_rccl.GroupEnd();
+        tim_end(c, ev);
         if (rc || rc2) return fail(c, PLFX_ERR_HIP, "generator halo exchange (ncclSend/ncclRecv) failed: %d / %d", rc, rc2);
         return 0;
     }
@@ -2107,6 +2116,8 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (nx < 1 || ny < 1 || (long long)nx * ny != c->nel_total || (long long)(nx + 1) * (ny + 1) != c->nnode)
         return fail(c, PLFX_ERR_ARG, "grid %dx%d does not match the mesh", nx, ny);
+    if (c->strip.on)  // the hierarchy, halo analysis and coarse child context of a strip belong to the grid they were set up for
+        return fail(c, PLFX_ERR_STATE, "plfx_set_grid after plfx_set_strip: call plfx_set_mesh again");
     const int nrow = ny + 1;
     for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
         const int n1 = (e / ny) * nrow + e % ny;
@@ -2322,6 +2333,7 @@ int plfx_set_operator(plfx_ctx *c, int kind)
 {
     if (!c) return PLFX_ERR_ARG;
     if (kind != 0 && kind != 1) return fail(c, PLFX_ERR_ARG, "operator kind must be 0 (assembled) or 1 (matrix-free)");
+    if (c->strip.on && kind != 1) return fail(c, PLFX_ERR_UNSUPPORTED, "a strip (plfx_set_strip) runs the matrix-free operator only");
     if (kind != c->want_matfree) {
         mg_graph_drop(c);
         c->want_matfree = kind;
@@ -2388,6 +2400,14 @@ int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
 {
     if (!c) return PLFX_ERR_STATE;
     if (kind != 0 && kind != 1) return fail(c, PLFX_ERR_ARG, "precond kind must be 0 (Jacobi) or 1 (multigrid)");
+    if (c->strip.on) {
+        // the halo validity widths were worked out for V(2,2) and the replicated coarse context copied omega / nu at
+        // plfx_set_strip: only a call that changes nothing is accepted afterwards
+        if (kind != 1 || (nu > 0 && nu != c->mg_nu) || (omega > 0. && omega != c->mg_omega))
+            return fail(c, PLFX_ERR_UNSUPPORTED, "plfx_set_precond after plfx_set_strip: a strip runs multigrid V(2,2) with the "
+                        "smoother chosen before plfx_set_strip");
+        return PLFX_OK;
+    }
     c->precond = kind;
     if (omega > 0.) c->mg_omega = omega;
     if (nu > 0) c->mg_nu = nu;
@@ -3151,7 +3171,7 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         c->gm_m = GMRES_M;
         while (c->gm_m > 25 && (size_t)(c->gm_m + 1) * nd * 8 > fr / 3) c->gm_m /= 2;
-        if (c->strip.on && strip_coll(c)) {  // every rank must run the same cycle length (the collectives are paired)
+        if (comm_active(c)) {  // every rank must run the same cycle length (paired collectives of a strip; identical iterates of a replicated solve)
             double mv = c->gm_m;
             HIPCHK(c, hipMemcpyAsync(c->small, &mv, 8, hipMemcpyHostToDevice, c->stream));
             if ((rc = allreduce(c, c->small, 1, NCCL_FLOAT64, NCCL_MIN, "GMRES basis length"))) return rc;

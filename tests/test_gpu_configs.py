@@ -230,3 +230,46 @@ def test_config5_sgl_does_not_depend_on_the_mesh(golden_dir):
     sa, sb = np.array(a.sgl), np.array(b.sgl)
     assert np.max(np.abs(sa - sb)) < 2e-4 * np.max(np.abs(sa))
     assert abs(sa[-1][1] - 144.133) < 0.02          # the value every mesh from 512 x 64 to 2048 x 2048 gives
+
+
+def test_config5_full_size_2048_real_materials(golden_dir):
+    """BASELINE config 5 at its stated size with its real materials: 2048 x 2048 laminate [2,1,2,1,2] of J2 and the SVC
+    trained on Barlat Yld2004-18p / Goss (examples/train_goss_barlat.py:36-41, 70-83; laminate sections by
+    model.py:826-830 -> element columns [512, 256, 512, 256, 512]), eps = 0.003, min_step = 20 -- the first 12 load steps
+    (5 elastic ones, then the SVC phase yields: its 1 M elements run the 50-sub-step corrector on the wave-per-element
+    kernels; the whole schedule takes minutes on one GPU and is what tools/configs_full.py 5full runs).  Pinned through
+    the size-independent property of the laminate (uniform along y, piecewise constant per section): the global stress /
+    strain history equals the one of the 512 x 64 mesh, whose materials are pinned against the reference's trace (8 x 4)
+    and the oracle (64 x 32) above."""
+    big = laminate_cfg5(golden_dir, 2048, 2048)
+    small = laminate_cfg5(golden_dir, 512, 64)
+    for fe in (small, big):
+        fe._max_load_steps = 12
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=20)
+    assert big.Nel == 2048 * 2048 and big.Ndof == 8396802
+    assert np.array_equal(np.bincount(big._mat_id.reshape(2048, 2048)[:, 0]), [512, 256, 512, 256, 512])   # sections A B A B A
+    svc_el = np.isin(big._mat_id, (1, 3))
+    eng = big._engine
+    assert eng.precond_info()[0] == 1 and eng.operator_info()[0] == 1          # multigrid + matrix-free operator
+    assert big.nsteps == small.nsteps == 12
+    # (the K-iteration counts are NOT size independent: a load step ends when no element's tangent moved by more than 1e-3,
+    # model.py:1346-1355, and the maximum over 4 M elements of a round-off-perturbed uniform field stays above that threshold
+    # longer than the maximum over 32 k -- 15 instead of 5 iterations in load step 6; the converged fields agree)
+    assert list(big.niter[:6]) == list(small.niter[:6])                         # elastic steps + first yield: identical
+    sb, ss = np.array(big.sgl), np.array(small.sgl)
+    assert np.max(np.abs(sb - ss)) < 2e-4 * np.max(np.abs(ss))
+    assert np.max(np.abs(np.array(big.egl) - np.array(small.egl))) < 2e-4 * np.max(np.abs(small.egl))
+    assert np.max(np.abs(np.array(big.epgl) - np.array(small.epgl))) < 2e-4 * np.max(np.abs(small.egl))
+    assert sb[5][1] > 134. and sb[-1][1] > sb[5][1]                             # the SVC phase has yielded (134.67 at step 5)
+    ms = big._state('max_steps')
+    assert np.sum(ms[svc_el] == 49) > 1000000                                   # ... on the 50-sub-step corrector (load steps 11, 12)
+    # every linear solve reached the tolerance; the ones PCG could not finish (indefinite tangents, material.py:317-338)
+    # were completed by the fall-back solver and are reported
+    rel = np.array([s[1] for s in big.solver_stats])
+    assert np.all(rel <= 1.0000001 * big.cg_rtol), rel.max()
+    nfb = eng.solve_fallbacks()
+    print('config 5 at 2048^2, 12 load steps: %d sweeps, %d solves (%d completed by the fall-back solver), %d PCG iterations, '
+          'sgl_yy %s' % (big.n_sweeps, len(rel), nfb, sum(s[0] for s in big.solver_stats), np.round(sb[:, 1], 3).tolist()))
+    assert 0 <= nfb <= len(rel)
