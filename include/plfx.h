@@ -118,8 +118,14 @@ int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const doubl
  * the Material object: every calc_fgrad call overwrites it (khard = max(0, -sum dK/dx[wh] scale_seq/scale_wh),
  * material.py:808-814), every get_sflow / epl_dot / C_tan reads it, and it is carried from call to call.  Here it is an
  * explicit input and output per point: khard_in[n] (NULL: the material's khard) is what Material.khard holds when
- * response() is entered, khard_out[n] what it holds on return.  Inside the load-step loop the library carries it per
- * material point (state 11). */
+ * response() is entered, khard_out[n] what it holds on return.
+ * CONTRACT inside the load-step loop (plfx_sweep / plfx_load_step; a documented deviation from the reference): the library
+ * carries the modulus PER MATERIAL POINT (state 11: entry value of a point's call = exit value of the same point's previous
+ * call; plfx_scf_all / plfx_scf_stats and the yield-function ratio of the sweep read the point's own value).  The reference
+ * hands ONE value from element to element in index order (model.py:1340-1359), a sequential chain through all elements that
+ * a data-parallel sweep cannot follow.  Both semantics are restated by the oracle (oracle/solve_ref.py: wh_per_point): the
+ * GPU path equals the per-point form to 1e-6 with identical load-step and iteration counts, and the per-point form moves the
+ * reference's own 4 x 4 trace by < 1e-4 with the same load-step count (tests/test_workhard_svc.py). */
 int plfx_response_batch_kh(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig, const double *epl,
                            const double *deps, const double *khard_in, double *fy, double *sig_out, double *depl,
                            double *ct, int32_t *nsteps, double *khard_out);
@@ -154,6 +160,13 @@ int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
  * PLFX_INDEFINITE_SOLVER=minres) -- the reference's LU does not need definiteness either -- or multigrid-PCG did not
  * converge within 300 iterations and Jacobi-PCG took over */
 int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
+/* The solves with an indefinite tangent stiffness among them (p.Kp <= 0 met by PCG): how many there were, how many were
+ * completed by MINRES with the V-cycle of the SPD surrogate operator (every indefinite element matrix -- Kel is PSD iff the
+ * 3 x 3 matrix of its stiffness generators is -- shifted by its most negative eigenvalue; uniform structured grids, one GPU
+ * or a replicated solve), how many needed GMRES (strips; MINRES stalled; PLFX_INDEFINITE_SOLVER=gmres), the number of surrogate
+ * hierarchies built (one per operator that needed it) and the elements shifted in the last one.  Any pointer may be NULL. */
+int plfx_indefinite_info(plfx_ctx *ctx, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres,
+                         int64_t *surrogates_built, int64_t *elements_replaced);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
  * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to
  * the diagonal) wherever plfx_set_grid found a structured grid with one element shape; kind 0 always assembles the

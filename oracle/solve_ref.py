@@ -31,8 +31,13 @@ YF_TOL = 5.e-3
 
 
 class RefSolver(object):
-    def __init__(self, model, nthreads=0, linear='lu', pcg_rtol=1.e-10, pcg_threads=None):
+    def __init__(self, model, nthreads=0, linear='lu', pcg_rtol=1.e-10, pcg_threads=None, wh_per_point=False):
         m = self.m = model
+        # work-hardening-aware SVC materials (material.py:808-814): the reference keeps the hardening modulus in ONE mutable
+        # attribute of the Material object and carries it through its element loop in index order (default here).
+        # wh_per_point=True restates the data-parallel contract of include/plfx.h instead: every material point carries its
+        # OWN modulus from sweep to sweep (entry value of a call = exit value of the point's previous call)
+        self.wh_per_point = bool(wh_per_point)
         self.nthreads = nthreads
         self.linear = linear
         self.pcg_rtol = pcg_rtol
@@ -205,7 +210,9 @@ class RefSolver(object):
 
     def sflow(self, epl, sel=None, kh=None):
         sy = np.array([0. if mm.sy is None else mm.sy for mm in self.m.mat])[self.mat_id]
-        if kh is None:   # per material: the value the material object holds now
+        if kh is None and self.has_wh and self.wh_per_point:
+            kh = self.khard_pt
+        elif kh is None:   # per material: the value the material object holds now
             kh = (self.khard_mat if self.has_wh else
                   np.array([0. if mm.khard is None else mm.khard for mm in self.m.mat]))[self.mat_id]
         if sel is not None:
@@ -234,7 +241,12 @@ class RefSolver(object):
             low = yf0 < -0.15
             if om.c.kind in (O.SVC6, O.SVC_WH) and np.any(low):  # model.py:1049-1053: full yield function along the loading direction
                 yf0 = np.array(yf0)
-                yf0[low] = O.ML_full_yf_ld(om, self.sig[sel][low], self.epl[sel][low], sld)
+                if om.c.kind == O.SVC_WH and self.wh_per_point:   # get_sflow inside ML_full_yf reads the point's own modulus
+                    for q in np.nonzero(low)[0]:
+                        om.c.khard = float(self.khard_pt[sel[q]])
+                        yf0[q] = O.ML_full_yf_ld(om, self.sig[sel[q]][None], self.epl[sel[q]][None], sld)[0]
+                else:
+                    yf0[low] = O.ML_full_yf_ld(om, self.sig[sel][low], self.epl[sel][low], sld)
             hh = np.where(low, np.minimum(1., -yf0 / sref),
                           np.minimum(1., np.sqrt(1.5) * self.sflow(self.epl[sel], sel) / sref))
             sc.extend(hh.tolist())
@@ -255,6 +267,7 @@ class RefSolver(object):
         self.epl = np.zeros((self.nel, 6))
         self.elstiff = np.array(self.CVs[self.mat_id])
         self.khard_mat = np.array([0. if mm.khard is None else float(mm.khard) for mm in self.m.mat])
+        self.khard_pt = self.khard_mat[self.mat_id].copy()
         sgl, egl, epgl = [np.zeros(6)], [np.zeros(6)], [np.zeros(6)]
         bcr0 = np.zeros(2)
         bct0 = np.zeros(2)
@@ -313,7 +326,11 @@ class RefSolver(object):
                     du = self.lin_solve(K, m.bcl, m.bcb, dbcr, dbct, dbcn)
                     t = time.perf_counter()
                     deps = self.strain(du)
-                    if self.has_wh:
+                    if self.has_wh and self.wh_per_point:
+                        fy, res_sig, res_depl, ct, ns, self.khard_pt = O.response_wh(
+                            self.mats, self.CVs, self.sig, self.epl, deps, khard_in=self.khard_pt, mat_id=self.mat_id)
+                        kh_pt = self.khard_pt
+                    elif self.has_wh:
                         # the reference's loop over the elements mutates ONE khard per Material object, call after call
                         # (material.py:808-814): run the points in index order and carry the value from sweep to sweep
                         fy, res_sig, res_depl, ct, ns, self.khard_mat, kh_pt = O.response_wh(

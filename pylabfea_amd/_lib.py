@@ -51,6 +51,7 @@ SYMBOLS = [
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
+    'plfx_indefinite_info',
 ]
 
 _lib = None
@@ -324,6 +325,14 @@ class Context(object):
         n = C.c_int64()
         self._chk(self.lib.plfx_solve_fallbacks(self.h, C.byref(n)))
         return n.value
+
+    def indefinite_info(self):
+        """dict: solves with an indefinite tangent stiffness, how they were completed (MINRES with the surrogate V-cycle /
+        GMRES), surrogate hierarchies built, elements replaced in the last one (plfx_indefinite_info)"""
+        v = [C.c_int64() for _ in range(5)]
+        self._chk(self.lib.plfx_indefinite_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(('solves', 'by_minres_surrogate', 'by_gmres', 'surrogates_built', 'elements_replaced'),
+                        [x.value for x in v]))
 
     def set_operator(self, kind):
         self._chk(self.lib.plfx_set_operator(self.h, int(kind)))

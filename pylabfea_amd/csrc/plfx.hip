@@ -250,6 +250,15 @@ struct plfx_ctx {
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
     double *gm_V = nullptr, *gm_part = nullptr;  // GMRES: Krylov basis (GMRES_M + 1 vectors) and partial sums, on first use
     int n_gmres = 0, gm_m = 0;
+    // SPD surrogate of an indefinite operator (k_make_surrogate): generators with every indefinite element's 3 x 3 generator
+    // matrix shifted by its most negative eigenvalue, the diagonal / Jacobi scaling of that operator; while sur_active the V-cycle (level 0 and every level
+    // below it) is built on the surrogate, the Krylov method applies the true operator
+    double *Msur = nullptr, *diag_sur = nullptr, *dinv_sur = nullptr;
+    int *sur_cnt = nullptr;
+    bool sur_active = false;
+    int n_sur = 0;             // surrogate hierarchies built
+    long long sur_replaced = 0; // elements replaced in the last one
+    int n_sur_minres = 0;      // solves MINRES completed with the surrogate V-cycle
     bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
@@ -635,6 +644,7 @@ bool build_pattern(int nnode, const int32_t *conn, int el_begin, int el_end, std
 void mg_graph_drop(plfx_ctx *c);
 int strip_coarse(plfx_ctx *c);
 void strip_free(plfx_ctx *c);
+void surrogate_drop(plfx_ctx *c);
 
 void free_mesh(plfx_ctx *c)
 {
@@ -678,6 +688,11 @@ void free_mesh(plfx_ctx *c)
     dfree(c->mr_w);
     dfree(c->gm_V);
     dfree(c->gm_part);
+    dfree(c->Msur);
+    dfree(c->diag_sur);
+    dfree(c->dinv_sur);
+    dfree(c->sur_cnt);
+    c->sur_active = false;
     dfree(c->p[0]);
     dfree(c->p[1]);
     for (auto &L : c->mg) {
@@ -2424,6 +2439,18 @@ int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
     return PLFX_OK;
 }
 
+int plfx_indefinite_info(plfx_ctx *c, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres, int64_t *surrogates_built,
+                         int64_t *elements_replaced)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (solves) *solves = c->n_minres;
+    if (by_minres_surrogate) *by_minres_surrogate = c->n_sur_minres;
+    if (by_gmres) *by_gmres = c->n_gmres;
+    if (surrogates_built) *surrogates_built = c->n_sur;
+    if (elements_replaced) *elements_replaced = c->sur_replaced;
+    return PLFX_OK;
+}
+
 int plfx_solve_fallbacks(plfx_ctx *c, int64_t *count)
 {
     if (!c || !count) return PLFX_ERR_ARG;
@@ -2586,6 +2613,7 @@ int plfx_assemble(plfx_ctx *c)
         c->n_reuse_assemble++;
         return PLFX_OK;
     }
+    surrogate_drop(c);  // the hierarchy is rebuilt from the new generators below
     EvPair *ev;
     tim_begin(c, 3, &ev);
     if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
@@ -2761,8 +2789,10 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
                        fext ? c->fext : nullptr, c->kw, c->diag, c->is_presc, c->rhs, c->dinv);
     HIPCHK(c, hipGetLastError());
     if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->sur_active)  // level 0 of the V-cycle runs on the surrogate operator: its Jacobi scaling with the new mask
+        hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
     if (mg_active(c)) {
-        rc = mg_update_dinv(c, same_set);
+        rc = mg_update_dinv(c, same_set && !c->sur_active);
         if (rc) return rc;
     }
     if (c->strip.on && (rc = strip_child_dinv(c))) return rc;
@@ -3158,6 +3188,59 @@ int host_sums(plfx_ctx *c, double *part, int nslots, int gn, double *out)
 
 // Right-preconditioned restarted GMRES on P K P x = P b from the iterate in c->x (see plfx_mg.hpp): x = x0 + B t with t in the
 // Krylov space of K B.  Returns 0 = |P(b - K x)| <= rtol |b|, 1 = iteration limit, < 0 = error.
+// Level 0 of the V-cycle back on the true operator (called before the hierarchy is rebuilt from new generators)
+void surrogate_drop(plfx_ctx *c)
+{
+    if (!c->sur_active) return;
+    auto &L0 = c->mg[0];
+    L0.op.M = c->Mop;
+    L0.diag = c->diag;
+    L0.dinv = c->dinv;
+    c->sur_active = false;
+}
+
+// Rebuild the multigrid hierarchy on the SPD surrogate of the current operator (see k_make_surrogate).  *replaced = number
+// of elements whose generators were shifted (0: the operator's element matrices are all PSD -- nothing was changed).
+int surrogate_build(plfx_ctx *c, long long *replaced)
+{
+    *replaced = 0;
+    if (!matfree(c) || !mg_active(c) || c->strip.on || !c->assembled) return 0;
+    int rc;
+    const size_t ne = c->nel_total, nd = c->ndof;
+    const int g = grid_for(ne);
+    if (!c->Msur && (rc = dalloc(c, &c->Msur, 6 * ne))) return rc;
+    if (!c->diag_sur && (rc = dalloc(c, &c->diag_sur, nd))) return rc;
+    if (!c->dinv_sur && (rc = dalloc(c, &c->dinv_sur, nd))) return rc;
+    if (!c->sur_cnt && (rc = dalloc(c, &c->sur_cnt, (size_t)1024))) return rc;
+    hipLaunchKernelGGL(k_make_surrogate, dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, (int)ne, c->dcls_all, c->Mop,
+                       c->Msur, c->sur_cnt);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int> h(g);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->sur_cnt, (size_t)4 * g, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long long nb = 0;
+    for (int v : h) nb += v;
+    *replaced = nb;
+    if (nb == 0) return 0;
+    auto &L0 = c->mg[0];
+    KOp sop = c->op;
+    sop.M = c->Msur;
+    // diagonal of the surrogate + generators of level 1, then the coarser levels, Jacobi scalings and the coarse inverse
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, sop,
+                       (double2 *)c->diag_sur, (double *)nullptr, c->mg[1].Mel, (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
+    hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
+    HIPCHK(c, hipGetLastError());
+    L0.op.M = c->Msur;
+    L0.diag = c->diag_sur;
+    L0.dinv = c->dinv_sur;
+    c->sur_active = true;
+    if ((rc = mg_assemble(c))) return rc;
+    if ((rc = mg_update_dinv(c, false))) return rc;
+    c->n_sur++;
+    c->sur_replaced = nb;
+    return 0;
+}
+
 constexpr int GMRES_M = 400;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on
                             // indefinite K); halved until the basis fits into a third of the free HBM
 int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
@@ -3654,14 +3737,34 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         // correction of Material.response, material.py:324-338) -- the reference's LU solves such systems, so does MINRES
         int itm = 0;
         double rl = 0.;
-        // GMRES by default.  PLFX_INDEFINITE_SOLVER=minres tries MINRES first (short recurrences, half the cost per iteration):
-        // measured on config 5 at 2048^2, the V-cycle built on the indefinite operator is itself not positive definite in
-        // about half of these solves and MINRES has to hand over after a few (wasted) iterations
-        const bool gmres_first = !(getenv("PLFX_INDEFINITE_SOLVER") && !strcmp(getenv("PLFX_INDEFINITE_SOLVER"), "minres"));
-        int rcm = gmres_first ? 2 : minres_solve(c, rtol, maxit_all, &itm, &rl);
-        if (rcm < 0) return rcm;
+        // Default: rebuild the V-cycle on the SPD surrogate of the operator (every indefinite element matrix shifted by
+        // its most negative eigenvalue, k_make_surrogate) and finish with preconditioned MINRES on the TRUE operator --
+        // short recurrences, no Krylov basis.  GMRES remains the safety net (MINRES reports a non-positive r.Br or a stall),
+        // the solver of strips, and PLFX_INDEFINITE_SOLVER=gmres; =minres is MINRES with the V-cycle of the indefinite
+        // operator itself (measured on config 5 at 2048^2: not positive definite in about half of these solves).
+        const char *isv = getenv("PLFX_INDEFINITE_SOLVER");
+        const int imode = !isv ? 0 : (!strcmp(isv, "gmres") ? 1 : (!strcmp(isv, "minres") ? 2 : 0));
+        int rcm = 2;
+        if (imode == 0) {
+            long long nrep = c->sur_replaced;
+            if (!c->sur_active && (rc = surrogate_build(c, &nrep))) return rc;
+            if (solve_debug) fprintf(stderr, "[plfx_solve] surrogate preconditioner %s: %lld indefinite element matrices shifted\n",
+                                    c->sur_active ? "active" : "not built", nrep);
+            if (c->sur_active) {
+                // capped: GMRES takes over from MINRES's iterate when the short recurrences do not get there
+                static const int sur_cap = getenv("PLFX_SURROGATE_MAXIT") ? std::max(1, atoi(getenv("PLFX_SURROGATE_MAXIT"))) : 600;
+                rcm = minres_solve(c, rtol, std::min(maxit_all, sur_cap), &itm, &rl);
+                if (rcm < 0) return rcm;
+                if (rcm == 0) c->n_sur_minres++;
+                else rcm = 2;
+                if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES (surrogate V-cycle): rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+            }
+        } else if (imode == 2) {
+            rcm = minres_solve(c, rtol, maxit_all, &itm, &rl);
+            if (rcm < 0) return rcm;
+            if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+        }
         c->n_minres++;
-        if (solve_debug && !gmres_first) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
         if (rcm == 2) {
             int itg = 0;
             rcm = gmres_solve(c, rtol, maxit_all, &itg, &rl);

@@ -721,6 +721,69 @@ k_init_tangent(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t 
     for (int k = 0; k < 6; k++) Mel[(size_t)k * mel_stride + e] = M[k];
 }
 
+// SPD surrogate of the operator (DESIGN "Indefinite tangents"): the correction step of Material.response (material.py:317-338)
+// can leave a tangent that is not positive semi-definite; the element stiffness matrix Kel = Jac sum_gp B^T D B is linear in
+// the 3 x 3 generator matrix G = [XX XY XS; XY YY YS; XS YS SS] and PSD iff G is.  Msur = M (pair layout) with every
+// indefinite G shifted by its most negative eigenvalue, G + |lambda_min| I (closed-form eigenvalues of the symmetric 3 x 3
+// matrix): K_sur is positive semi-definite by construction, keeps the soft directions of the elastic-plastic tangents (the
+// V-cycle built on it is as good a preconditioner as the one of K itself) and differs from K by sum_e |lambda_min,e| Kel(I) --
+// a handful of elements early in config 5 (2 of 4.2 M), ~1e5 mildly indefinite ones late in its schedule (measured: replacing
+// those by their ELASTIC matrices instead costs the preconditioner its quality: MINRES 600+, GMRES thousands of iterations).
+// MINRES on the true, symmetric indefinite K needs exactly that: an SPD preconditioner.  nbad[block] = shifted elements.
+__global__ void __launch_bounds__(BLOCK)
+k_make_surrogate(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcls, int nel, const int32_t *__restrict__ cls,
+                 const double *__restrict__ Mop, double *__restrict__ Msur, int *__restrict__ nbad)
+{
+    (void)gmat; (void)gcls; (void)cls;
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const double2 *S = reinterpret_cast<const double2 *>(Mop);
+    double2 *T = reinterpret_cast<double2 *>(Msur);
+    int mine = 0;
+    for (size_t e = blockIdx.x * (size_t)BLOCK + threadIdx.x; e < (size_t)nel; e += (size_t)gridDim.x * BLOCK) {
+        double2 a01 = S[e], a23 = S[(size_t)nel + e], a45 = S[(size_t)2 * nel + e];
+        const double a = a01.x, b = a01.y, cc = a23.x, d = a23.y, f = a45.x, g = a45.y;   // XX XY XS YY YS SS
+        // smallest eigenvalue of [a b cc; b d f; cc f g] (trigonometric form)
+        const double q = (a + d + g) / 3.;
+        const double p1 = b * b + cc * cc + f * f;
+        const double p2 = (a - q) * (a - q) + (d - q) * (d - q) + (g - q) * (g - q) + 2. * p1;
+        const double sc1 = fabs(a) + fabs(d) + fabs(g);
+        double lmin = fmin(a, fmin(d, g));
+        if (p2 > 1e-30 * sc1 * sc1) {
+            const double p = sqrt(p2 / 6.);
+            const double ba = (a - q) / p, bd = (d - q) / p, bg = (g - q) / p, bb = b / p, bc = cc / p, bf = f / p;
+            double r = 0.5 * (ba * (bd * bg - bf * bf) - bb * (bb * bg - bf * bc) + bc * (bb * bf - bd * bc));
+            r = fmin(1., fmax(-1., r));
+            const double phi = acos(r) / 3.;
+            lmin = q + 2. * p * cos(phi + 2.0943951023931953);   // + 2 pi / 3: the smallest of the three
+        }
+        if (!(lmin >= -1e-10 * sc1)) {   // really indefinite (round-off of a singular PSD tangent stays far above this)
+            const double sh = (lmin == lmin) ? -lmin * (1. + 1e-6) + 1e-14 * sc1 : sc1;   // NaN entries: a plain positive shift
+            a01.x = a + sh;
+            a23.y = d + sh;
+            a45.y = g + sh;
+            mine++;
+        }
+        T[e] = a01;
+        T[(size_t)nel + e] = a23;
+        T[(size_t)2 * nel + e] = a45;
+    }
+    if (mine) atomicAdd(&cnt, mine);  // integer count: order does not matter
+    __syncthreads();
+    if (threadIdx.x == 0) nbad[blockIdx.x] = cnt;
+}
+
+// Jacobi scaling of another diagonal with the Dirichlet mask of `mask_dinv` (zero = prescribed DOF)
+__global__ void __launch_bounds__(BLOCK)
+k_dinv_masked(size_t ndof, const double *__restrict__ diag, const double *__restrict__ mask_dinv, double *__restrict__ dinv)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        const double d = fabs(diag[i]);
+        dinv[i] = (mask_dinv[i] != 0.) ? (d > 1e-300 ? 1. / d : 1.) : 0.;
+    }
+}
+
 // M from CV for ALL elements of the mesh (sharded runs keep the stiffness generators of the whole
 // mesh on every rank: the matrix hierarchy is replicated, only the sweep is sharded)
 __global__ void __launch_bounds__(BLOCK)

@@ -222,14 +222,18 @@ BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+
                   1.14637e+01, -5.47451e-01, 5.81484e+04, 6.34734e-01, 5.81615e+04]
 
 
-@pytest.mark.parametrize('solver', ['minres', 'gmres'])
+@pytest.mark.parametrize('solver', ['surrogate', 'minres', 'gmres'])
 @pytest.mark.parametrize('nx,ny,mg', [(64, 64, True), (48, 24, True), (13, 6, False)])
 def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkeypatch):
     """A stiffness matrix with negative eigenvalues: PCG meets a direction of negative curvature and the solve is completed
-    by preconditioned MINRES -- or by right-preconditioned GMRES(400), which takes over when the V-cycle built on such an
-    operator is not positive definite either (forced here); the solution must be the one a direct solver (the reference's
-    numpy.linalg.solve) finds."""
-    monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
+    by preconditioned MINRES -- default: with the V-cycle rebuilt on the SPD surrogate operator (the indefinite element
+    matrices replaced by their elastic ones), which must then need no GMRES at all -- or by right-preconditioned
+    GMRES(400), which takes over when the V-cycle built on the indefinite operator itself is not positive definite either
+    (forced here); the solution must be the one a direct solver (the reference's numpy.linalg.solve) finds."""
+    if solver == 'surrogate':
+        monkeypatch.delenv('PLFX_INDEFINITE_SOLVER', raising=False)     # the default
+    else:
+        monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     import pylabfea_amd as FE
@@ -263,6 +267,30 @@ def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkey
     it, rr, ok = eng.solve(1e-10, 20000, False)
     assert ok and rr <= 1e-10
     assert eng.solve_fallbacks() == n0 + 1            # PCG gave up, MINRES finished the solve
+    info = eng.indefinite_info()
+    assert info['solves'] == 1
+    if solver == 'surrogate' and mg:
+        # the three planted element matrices were found and replaced, MINRES with the SPD V-cycle finished: no GMRES
+        assert info == dict(solves=1, by_minres_surrogate=1, by_gmres=0, surrogates_built=1, elements_replaced=3)
+        # a second system on the same operator (other boundary values) reuses the surrogate hierarchy
+        presc2, first2, w2, fext2 = fe._bc_data(z, z, z, 0.5 * d, None)
+        eng.apply_bc(presc2, first2, w2, fext2)
+        it2, rr2, ok2 = eng.solve(1e-10, 20000, False)
+        assert ok2 and rr2 <= 1e-10
+        du2 = eng.state_get(_lib.ST_DU)
+        assert eng.indefinite_info()['surrogates_built'] == 1 and eng.indefinite_info()['by_gmres'] == 0
+        eng.apply_bc(presc, first, w, fext)
+        it, rr, ok = eng.solve(1e-10, 20000, False)
+        assert ok and rr <= 1e-10
+        assert np.max(np.abs(du2 - 0.5 * eng.state_get(_lib.ST_DU))) < 1e-7 * np.max(np.abs(du2))   # linear system: half the load
+        # a new assembly (tangents unchanged in content, but rewritten) goes back to the true operator first
+        eng.state_set(_lib.ST_ELSTIFF, D.reshape(fe.Nel, 36))
+        eng.assemble()
+        eng.apply_bc(presc, first, w, fext)
+        it, rr, ok = eng.solve(1e-10, 20000, False)
+        assert ok and eng.indefinite_info()['surrogates_built'] == 2
+    elif solver == 'gmres':
+        assert info['by_gmres'] == 1 and info['surrogates_built'] == 0
     du = eng.state_get(_lib.ST_DU)
     K = eng.get_csr().tocsr()
     free = np.setdiff1d(np.arange(fe.Ndof), presc)

@@ -282,11 +282,14 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world, monkeypatch):
     assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
 
 
-def test_bench_two_ranks_weak_scaling_path(tmp_path):
+@pytest.mark.parametrize('mode', ['strong', 'weak'])
+def test_bench_two_ranks(tmp_path, mode):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
-    ONE GPU over the host-staged transport (PLFX_BENCH_TRANSPORT=host; RCCL refuses two ranks on a device): the weak-scaling
-    strip path end to end -- JSON contract, honest labels, and the same sweeps / solves / PCG iterations as the single-GPU
-    run of the same (2 x 128) x 128 mesh."""
+    ONE GPU over the host-staged transport (PLFX_BENCH_TRANSPORT=host; RCCL refuses two ranks on a device).  Default =
+    STRONG scaling (north star: the SAME mesh cut into x-strips, contiguous in the reference's x-major numbering,
+    model.py:893, 935): `config.workload` identical to the single-GPU line, `scaling: "strong"`; `--weak`: 2 strips of
+    128 x 128 elements side by side.  Either way: JSON contract, honest labels, per-rank rooflines, and the same sweeps /
+    solves / PCG iterations as the single-GPU run of the same mesh."""
     import json
     import subprocess
     import sys
@@ -295,33 +298,47 @@ def test_bench_two_ranks_weak_scaling_path(tmp_path):
     env = dict(os.environ, PLFX_BENCH_TRANSPORT='host')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--mesh', '128']
+           '--mesh', '128'] + (['--weak'] if mode == 'weak' else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    assert out.stdout.strip().splitlines()[-1] == line          # the JSON line is the last thing printed
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 3 and d['dtype'] == 'f64'
-    assert d['config']['elements'] == 256 * 128 and 'strip-local engine x2' in d['config']['parallelism']
+    strips = 2 if mode == 'weak' else 1
+    assert d['n_gpus'] == 2 and d['scaling'] == mode and d['steps'] == 3 and d['dtype'] == 'f64'
+    assert d['config']['elements'] == strips * 128 * 128 and 'strip-local engine x2' in d['config']['parallelism']
+    assert ('%dx128 Q4' % (strips * 128)) in d['config']['workload'] and (mode + ' scaling') in d['config']['parallelism']
     assert d['strip_collectives']['halo_refreshes'] > 0 and d['strip_collectives']['coarse_gathers'] > 0
     assert d['roofline'] is not None and d['cpu_baseline'] is None
-    # the same workload on one rank: identical counts
-    import pylabfea_amd as FE
+    assert [r['rank'] for r in d['per_rank']] == [0, 1] and all(r['roofline'] is not None for r in d['per_rank'])
+    cols = [r['owned_columns'] for r in d['per_rank']]
+    assert cols[0][0] == 0 and cols[0][1] == cols[1][0] and cols[1][1] == strips * 128       # the strips tile the mesh
+    # the same workload on one rank: identical counts (and, for strong scaling, the identical workload string)
     sys.path.insert(0, root)
-    import bench
-    fe = bench.tension_model(FE, bench.hill_material(FE), 128, 0.005, strips=2)
-    ninc, pre = bench.schedule(3, 1)
-    marks = {}
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--mesh', '128',
+                          '--no-cpu', '--no-svc', '--no-inclusion', '--no-2048'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    if mode == 'strong':
+        assert d1['config']['workload'] == d['config']['workload'] and d1['config']['elements'] == d['config']['elements']
+        assert (d['sweeps'], d['solves'], d['pcg_iterations']) == (d1['sweeps'], d1['solves'], d1['pcg_iterations'])
+    else:
+        import pylabfea_amd as FE
+        import bench
+        fe = bench.tension_model(FE, bench.hill_material(FE), 128, 0.005, strips=2)
+        ninc, pre = bench.schedule(3, 1)
+        marks = {}
 
-    def hook(il):
-        if il == pre + 1:
-            marks['s0'], marks['q0'] = fe.n_sweeps, len(fe.solver_stats)
-        if il == pre + 4:
-            marks['s1'], marks['q1'] = fe.n_sweeps, len(fe.solver_stats)
-    fe._step_hook = hook
-    fe._max_load_steps = pre + 4
-    fe.solve(min_step=ninc)
-    its = [s[0] for s in fe.solver_stats[marks['q0']:marks['q1']]]
-    assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
+        def hook(il):
+            if il == pre + 1:
+                marks['s0'], marks['q0'] = fe.n_sweeps, len(fe.solver_stats)
+            if il == pre + 4:
+                marks['s1'], marks['q1'] = fe.n_sweeps, len(fe.solver_stats)
+        fe._step_hook = hook
+        fe._max_load_steps = pre + 4
+        fe.solve(min_step=ninc)
+        its = [s[0] for s in fe.solver_stats[marks['q0']:marks['q1']]]
+        assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

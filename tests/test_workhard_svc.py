@@ -167,3 +167,78 @@ def test_gpu_model_with_workhardening_svc(z):
     assert np.max(np.abs(fe._state('epl') - z['wh4_epl'])) < 1e-4 * np.max(np.abs(z['wh4_eps']))
     kh = fe._engine.state_get(_lib.ST_KHARD)
     assert kh.shape == (16,) and np.all(kh >= 0.)
+
+
+def wh_model(z, n=4):
+    import pylabfea_amd as FE
+    m = facade_material(z)
+    fe = FE.Model(dim=2)
+    fe.geom([4.], LY=4.)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.004 * fe.leny, 'disp')
+    fe.mesh(NX=n, NY=n)
+    return fe
+
+
+def test_oracle_per_point_variant_is_close_to_the_sequential_reference(z):
+    """The contract of include/plfx.h for work-hardening SVC materials inside Model.solve: every material point carries its
+    own hardening modulus (the reference: one mutable Material.khard handed from element to element in index order,
+    material.py:808-814 + model.py:1340-1359 -- a sequential chain a data-parallel sweep cannot follow).  The oracle
+    restates BOTH; this pins how far the documented deviation moves the reference's 4x4 trace: same load steps, 1e-4."""
+    from oracle.solve_ref import RefSolver
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r = RefSolver(wh_model(z), wh_per_point=True).solve(min_step=8)
+    assert r.nsteps == int(z['wh4_nsteps'])
+    assert np.max(np.abs(r.sgl - z['wh4_sgl'])) < 1e-4 * np.max(np.abs(z['wh4_sgl']))
+    assert np.max(np.abs(r.u - z['wh4_u'])) < 1e-4 * np.max(np.abs(z['wh4_u']))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [4, 12])
+def test_gpu_model_equals_the_per_point_oracle(z, n):
+    """GPU Model.solve with the work-hardening SVC against the oracle variant with the SAME semantics (per-point moduli,
+    see the test above): north-star tolerance 1e-6, identical load-step AND stiffness-iteration counts, per-point moduli
+    (state 11) included."""
+    from oracle.solve_ref import RefSolver
+    from pylabfea_amd import _lib
+    fe = wh_model(z, n)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=8)
+        r = RefSolver(wh_model(z, n), wh_per_point=True).solve(min_step=8)
+    assert fe.nsteps == r.nsteps and list(fe.niter) == list(r.niter) and list(fe.co_nconv) == list(r.co_nconv)
+    s = np.max(np.abs(r.sig))
+    assert np.max(np.abs(fe.sgl - r.sgl)) < 1e-6 * s
+    assert np.max(np.abs(fe.u - r.u)) < 1e-6 * np.max(np.abs(r.u))
+    assert np.max(np.abs(fe._state('sig') - r.sig)) < 1e-6 * s
+    assert np.max(np.abs(fe._state('epl') - r.epl)) < 1e-6 * np.max(np.abs(r.eps))
+    kh = fe._engine.state_get(_lib.ST_KHARD)
+    assert np.max(np.abs(kh - r.khard_pt)) < 1e-5 * max(1., np.max(np.abs(r.khard_pt)))
+
+
+@pytest.mark.gpu
+def test_gpu_scf_entry_points_agree_for_workhardening_svc(z):
+    """calc_scf (model.py:1036-1067) reads the hardening modulus the material holds NOW; both C-ABI entry points of its
+    statistics (plfx_scf_all: one call, used by the load-step driver; plfx_scf_stats: two passes) must use the per-point
+    moduli of the sweeps, not the static record value."""
+    from pylabfea_amd import _lib
+    fe = wh_model(z, 6)
+    fe._max_load_steps = 5
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=8)
+    eng = fe._engine
+    assert np.max(np.abs(fe._state('epl'))) > 0.                         # plastic strain present
+    kh = eng.state_get(_lib.ST_KHARD)
+    assert np.ptp(kh) > 0. or np.any(kh != fe.mat[0].khard)              # per-point moduli differ from the record's value
+    sld = np.array([0., 1., 0., 0., 0., 0.])
+    cnt, mn, sm, s2 = eng.scf_all(sld)
+    cnt2, mn2, sm2 = eng.scf_stats(sld)
+    assert cnt == cnt2 and cnt > 0
+    assert abs(mn - mn2) <= 1e-14 * abs(mn2) and abs(sm - sm2) <= 1e-12 * abs(sm2)
+    s2b = eng.scf_sumsq(sm2 / cnt2)
+    assert abs(s2 - s2b) <= 1e-9 * max(abs(s2b), 1e-30)

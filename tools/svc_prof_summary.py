@@ -22,28 +22,40 @@ for r in rows[:14]:
     L.append('%-28s %8s %12.2f %12.3f %8.3f' % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3,
                                                 float(r['TotalDurationNs']) / 1e6, float(r['Percentage'])))
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob('%s/pmc*/*counter_collection.csv' % d):
+for f in sorted(glob.glob('%s/pmc*/*counter_collection.csv' % d)):
+    # every pass carries SQ_INSTS_VALU: the productive dispatches (> 1e6 VALU instructions) are selected pass by pass
+    one = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = short(r['Kernel_Name'])
         if k.startswith('k_sweep_svc_wave'):
-            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+            one[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, c in one.items():
+        keep = [i for i, v in enumerate(c.get('SQ_INSTS_VALU', [])) if v > 1e6]
+        for name, v in c.items():
+            if name in acc[k]:
+                continue            # SQ_INSTS_VALU of a later pass
+            acc[k][name] = [v[i] for i in keep] if (keep and len(v) == len(c['SQ_INSTS_VALU'])) else v
 L.append('')
 L.append('== rocprofv3 --pmc (SQ counters, average per dispatch; productive dispatches = those with > 1e6 VALU instructions) ==')
 for k in sorted(acc):
     c = acc[k]
-    keep = None
-    if 'SQ_INSTS_VALU' in c:
-        keep = [i for i, v in enumerate(c['SQ_INSTS_VALU']) if v > 1e6]
     L.append(k)
     for name in sorted(c):
         v = c[name]
-        if keep is not None and len(v) == len(c['SQ_INSTS_VALU']):
-            v = [v[i] for i in keep]
         if v:
             L.append('   %-24s n=%4d  avg %16.1f' % (name, len(v), sum(v) / len(v)))
+    keep = list(range(len(c.get('SQ_INSTS_VALU', []))))
     if keep and k.endswith('<1>'):
         iv = [c['SQ_INSTS_VALU'][i] for i in keep]
         L.append('   -> VALU wave-instructions per element update: %.1f (%g elements per launch)' % (sum(iv) / len(iv) / nel, nel))
+        if all(n in c for n in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64')):
+            # productive dispatches of THAT pass (its own SQ_INSTS_VALU column has the same length)
+            kp = list(range(len(c['SQ_INSTS_VALU_FMA_F64'])))
+            fma = sum(c['SQ_INSTS_VALU_FMA_F64'][i] for i in kp) / len(kp)
+            add = sum(c['SQ_INSTS_VALU_ADD_F64'][i] for i in kp) / len(kp)
+            mul = sum(c['SQ_INSTS_VALU_MUL_F64'][i] for i in kp) / len(kp)
+            L.append('   -> FP64 wave-instructions per element update: FMA %.1f  ADD %.1f  MUL %.1f  => %.4e FP64 flop per element update '
+                     '((2 FMA + ADD + MUL) x 64 lanes)' % (fma / nel, add / nel, mul / nel, (2 * fma + add + mul) * 64. / nel))
         if 'SQ_ACTIVE_INST_VALU' in c and 'SQ_WAVE_CYCLES' in c:
             a = [c['SQ_ACTIVE_INST_VALU'][i] for i in keep]
             w = [c['SQ_WAVE_CYCLES'][i] for i in keep]
