@@ -173,9 +173,12 @@ def cpu_baseline(n, steps, warmup, n1=128):
 # FP64 VALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 FP64 instruction per SIMD every 4 cycles (16 FP64 lanes per
 # SIMD) = 614 G wave-instructions/s = 78.6 TFLOP/s when every one is an FMA (MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s)
 VALU_FP64_PEAK_TFLOPS = 78.6
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.   # wave64 FP64 instructions per second of the whole GPU
 # VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
 # same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
 SVC_VALU_PER_ELEMENT = {'corrector': 910606., 'streaming': 804363926.5 / 16384.}
+# FP64 flop per element update, (2 FMA + ADD + MUL) x 64 lanes (same profile; None until measured)
+SVC_FP64_FLOP_PER_ELEMENT = {'corrector': None}
 SVC_PROFILE = 'profiles/r02c_svc_rocprofv3_summary.txt'
 
 
@@ -216,12 +219,20 @@ def svc_sample(FE, _lib, n=128, device=0):
     out['launches']['corrector_productive'] = n_prod
     if n_h > 0 and vc:
         per_launch_s = ms_h * 1e-3 / n_prod   # (the empty launches of the ten elastic steps take ~5 us each)
-        ach = vc * heavy_el * 128. / per_launch_s / 1e12     # wave-instructions x 64 lanes x 2 flop (FMA-equivalent issue slots)
+        # two figures: the TRUE FP64 flop rate -- (2 FMA + ADD + MUL) x 64 lanes per element update from the
+        # committed rocprofv3 pass over SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 -- against the 78.6 TFLOP/s FP64 vector peak, and the
+        # share of the VALU issue slots the kernel fills (every VALU wave-instruction, FP64 or not, against 614 G/s)
+        issue = vc * heavy_el / per_launch_s / VALU_ISSUE_PEAK
+        fl = SVC_FP64_FLOP_PER_ELEMENT['corrector']
+        ach = (fl * heavy_el / per_launch_s / 1e12) if fl else None
         out['roofline'] = {'kernel': 'k_sweep_svc_wave<1> (one wave per element: 50 sub-steps of the plastic corrector, support-'
                                      'vector sums split over the lanes, tables in LDS)',
-                           'bound': 'valu_fp64', 'achieved': ach, 'peak': VALU_FP64_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s (FP64 VALU issue slots x 128 flop)', 'frac': ach / VALU_FP64_PEAK_TFLOPS,
-                           'valu_wave_instructions_per_element': vc, 'valu_source': 'rocprofv3 --pmc SQ_INSTS_VALU, ' + SVC_PROFILE,
+                           'bound': 'valu_fp64', 'achieved': ach, 'peak': VALU_FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': (ach / VALU_FP64_PEAK_TFLOPS) if ach else None,
+                           'fp64_flop_per_element_update': fl,
+                           'valu_issue_slot_utilisation': issue,
+                           'valu_wave_instructions_per_element': vc,
+                           'counter_source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, ' + SVC_PROFILE,
                            'avg_launch_ms': per_launch_s * 1e3, 'elements_per_launch': heavy_el, 'traffic': None,
                            'us_per_element_update': per_launch_s * 1e6 / heavy_el * 1.0}
     return out

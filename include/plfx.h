@@ -156,15 +156,16 @@ int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
 /* number of plfx_solve calls so far that PCG could not finish: a direction of negative curvature was met (the tangents of
  * Material.response are not always positive semi-definite, material.py:324-338) and the indefinite-system solver completed
- * the solve from the last iterate (right-preconditioned GMRES by default, preconditioned MINRES with
- * PLFX_INDEFINITE_SOLVER=minres) -- the reference's LU does not need definiteness either -- or multigrid-PCG did not
+ * the solve from the last iterate (right-preconditioned GMRES by default; PLFX_INDEFINITE_SOLVER=surrogate / minres:
+ * preconditioned MINRES, see plfx_indefinite_info) -- the reference's LU does not need definiteness either -- or multigrid-PCG did not
  * converge within 300 iterations and Jacobi-PCG took over */
 int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
 /* The solves with an indefinite tangent stiffness among them (p.Kp <= 0 met by PCG): how many there were, how many were
- * completed by MINRES with the V-cycle of the SPD surrogate operator (every indefinite element matrix -- Kel is PSD iff the
- * 3 x 3 matrix of its stiffness generators is -- shifted by its most negative eigenvalue; uniform structured grids, one GPU
- * or a replicated solve), how many needed GMRES (strips; MINRES stalled; PLFX_INDEFINITE_SOLVER=gmres), the number of surrogate
- * hierarchies built (one per operator that needed it) and the elements shifted in the last one.  Any pointer may be NULL. */
+ * completed by MINRES with the V-cycle of the SPD surrogate operator (PLFX_INDEFINITE_SOLVER=surrogate: every indefinite
+ * element matrix -- Kel is PSD iff the 3 x 3 matrix of its stiffness generators is -- shifted by its most negative
+ * eigenvalue; uniform structured grids, one GPU or a replicated solve), how many by GMRES (the default; strips; MINRES not
+ * converged), the number of surrogate hierarchies built (one per operator that needed it) and the elements shifted in the
+ * last one.  Any pointer may be NULL. */
 int plfx_indefinite_info(plfx_ctx *ctx, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres,
                          int64_t *surrogates_built, int64_t *elements_replaced);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies

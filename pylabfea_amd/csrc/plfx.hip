@@ -3737,13 +3737,19 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         // correction of Material.response, material.py:324-338) -- the reference's LU solves such systems, so does MINRES
         int itm = 0;
         double rl = 0.;
-        // Default: rebuild the V-cycle on the SPD surrogate of the operator (every indefinite element matrix shifted by
-        // its most negative eigenvalue, k_make_surrogate) and finish with preconditioned MINRES on the TRUE operator --
-        // short recurrences, no Krylov basis.  GMRES remains the safety net (MINRES reports a non-positive r.Br or a stall),
-        // the solver of strips, and PLFX_INDEFINITE_SOLVER=gmres; =minres is MINRES with the V-cycle of the indefinite
-        // operator itself (measured on config 5 at 2048^2: not positive definite in about half of these solves).
+        // PLFX_INDEFINITE_SOLVER selects what completes such a solve from PCG's last iterate:
+        //   gmres (default)  right-preconditioned GMRES(400) with the V-cycle of the operator as it is (need not be SPD)
+        //   surrogate        the V-cycle rebuilt on the SPD surrogate of the operator (every indefinite element matrix shifted
+        //                    by its most negative eigenvalue, k_make_surrogate) + preconditioned MINRES on the TRUE operator:
+        //                    short recurrences, no Krylov basis; GMRES takes over if MINRES has not converged after 600
+        //                    iterations.  Measured on config 5 at 2048^2: same wall-clock (203 vs 198 s),
+        //                    GMRES still needed in 8 of 63 such solves (48 of 48 with gmres), 22.5 k instead of 16.6 k
+        //                    iterations in total -- an SPD preconditioner leaves the negative eigenvalues of K on the other
+        //                    side of zero, which costs MINRES about a factor of two -- hence not the default
+        //   minres           MINRES with the V-cycle of the indefinite operator itself (not positive definite in about half
+        //                    of config 5's solves: hands over to GMRES after a few wasted iterations)
         const char *isv = getenv("PLFX_INDEFINITE_SOLVER");
-        const int imode = !isv ? 0 : (!strcmp(isv, "gmres") ? 1 : (!strcmp(isv, "minres") ? 2 : 0));
+        const int imode = !isv ? 1 : (!strcmp(isv, "surrogate") ? 0 : (!strcmp(isv, "minres") ? 2 : 1));
         int rcm = 2;
         if (imode == 0) {
             long long nrep = c->sur_replaced;

@@ -226,14 +226,11 @@ BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+
 @pytest.mark.parametrize('nx,ny,mg', [(64, 64, True), (48, 24, True), (13, 6, False)])
 def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkeypatch):
     """A stiffness matrix with negative eigenvalues: PCG meets a direction of negative curvature and the solve is completed
-    by preconditioned MINRES -- default: with the V-cycle rebuilt on the SPD surrogate operator (the indefinite element
-    matrices replaced by their elastic ones), which must then need no GMRES at all -- or by right-preconditioned
-    GMRES(400), which takes over when the V-cycle built on the indefinite operator itself is not positive definite either
-    (forced here); the solution must be the one a direct solver (the reference's numpy.linalg.solve) finds."""
-    if solver == 'surrogate':
-        monkeypatch.delenv('PLFX_INDEFINITE_SOLVER', raising=False)     # the default
-    else:
-        monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
+    by right-preconditioned GMRES(400) (default), by preconditioned MINRES with the V-cycle rebuilt on the SPD surrogate
+    operator (every indefinite element matrix shifted by its most negative eigenvalue; needs no GMRES here), or by MINRES
+    with the V-cycle of the indefinite operator itself (GMRES takes over when that is not positive definite); the solution
+    must be the one a direct solver (the reference's numpy.linalg.solve) finds."""
+    monkeypatch.setenv('PLFX_INDEFINITE_SOLVER', solver)
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     import pylabfea_amd as FE

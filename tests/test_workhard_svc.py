@@ -226,8 +226,7 @@ def test_gpu_scf_entry_points_agree_for_workhardening_svc(z):
     statistics (plfx_scf_all: one call, used by the load-step driver; plfx_scf_stats: two passes) must use the per-point
     moduli of the sweeps, not the static record value."""
     from pylabfea_amd import _lib
-    fe = wh_model(z, 6)
-    fe._max_load_steps = 5
+    fe = wh_model(z, 4)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         fe.solve(min_step=8)

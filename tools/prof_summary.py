@@ -52,7 +52,8 @@ def main(d, out):
             thr = 15000
             v = [x[0] for x in acc.get(k, []) if x[1] > thr]
             if v:
-                lines.append('%-28s n=%6d  avg %14.1f KiB = %10.2f MB' % (k, len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6))
+                lines.append('%-28s n=%6d  avg %14.1f KiB = %10.2f MB   (min %.2f MB, max %.2f MB)'
+                             % (k, len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6, min(v) * 1024 / 1e6, max(v) * 1024 / 1e6))
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
