@@ -177,9 +177,9 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.   # wave64 FP64 instructions per second o
 # VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
 # same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
 SVC_VALU_PER_ELEMENT = {'corrector': 910606., 'streaming': 804363926.5 / 16384.}
-# FP64 flop per element update, (2 FMA + ADD + MUL) x 64 lanes (same profile; None until measured)
-SVC_FP64_FLOP_PER_ELEMENT = {'corrector': None}
-SVC_PROFILE = 'profiles/r02c_svc_rocprofv3_summary.txt'
+# FP64 flop per element update, (2 FMA + ADD + MUL) x 64 lanes (same profile)
+SVC_FP64_FLOP_PER_ELEMENT = {'corrector': 3.5910e7}
+SVC_PROFILE = 'profiles/r03_svc_rocprofv3_summary.txt'
 
 
 def svc_sample(FE, _lib, n=128, device=0):

@@ -758,6 +758,20 @@ int ensure_tmp(plfx_ctx *c, size_t n)
 }
 
 bool matfree(const plfx_ctx *c) { return c->grid_ok && c->want_matfree; }
+// Marching form of the finest-grid operator kernels (grid_march): PLFX_MARCH=0 never, =1 always; default: the PCG operator
+// kernel always (faster at every size measured), the three V-cycle kernels when one operator pass (112 B per node) does not
+// fit the 256 MiB Infinity Cache -- below that the gather form is as fast or faster (tools/probes/march_probe.hip)
+int march_env()
+{
+    static const int v = getenv("PLFX_MARCH") ? atoi(getenv("PLFX_MARCH")) : -1;
+    return v;
+}
+bool march_pcg(const plfx_ctx *c) { return matfree(c) && march_env() != 0; }
+bool march_mg(const plfx_ctx *c)
+{
+    if (!matfree(c) || march_env() == 0) return false;
+    return march_env() == 1 || (size_t)c->nnode * 112 > ((size_t)192 << 20);
+}
 // the single-workgroup tail of the V-cycle applies its levels from the generators too (needs the dense coarse inverse)
 bool tail_mf(const plfx_ctx *c)
 {
@@ -1046,8 +1060,12 @@ int mg_down_level(plfx_ctx *c, int l)
     EvPair *ev = nullptr;
     (void)ev;  // the head of the cycle is enqueued speculatively (may return at once): family 5 times the post-smoothing
                // launches of k_mg_smooth<1, .> only
+    const bool march = l == 0 && mf && march_mg(c);
     if (nu == 2) {  // both sweeps in one pass over the operator
-        if (l == 0)
+        if (march)
+            hipLaunchKernelGGL(k_mg_smooth2_zero_march, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.op, (const double2 *)L.dinv,
+                               (const double2 *)L.b, (double2 *)L.x, om, c->sc);
+        else if (l == 0)
             LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (double2 *)L.x, om, c->sc);
         else
@@ -1066,7 +1084,10 @@ int mg_down_level(plfx_ctx *c, int l)
             dst = (dst == L.x) ? L.t : L.x;
         }
     }
-    if (l == 0)
+    if (march)
+        hipLaunchKernelGGL(k_mg_residual_march, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.op, (const double2 *)L.dinv,
+                           (const double2 *)L.b, (const double2 *)L.x, (double2 *)L.res, c->sc);
+    else if (l == 0)
         LAUNCH_OP2(k_mg_residual, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                    (const double2 *)L.x, (double2 *)L.res, c->sc);
     else
@@ -1091,7 +1112,10 @@ int mg_up_level(plfx_ctx *c, int l)
     for (int k = 0; k < nu; k++) {
         EvPair *ev = nullptr;
         if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
-        if (l == 0)
+        if (l == 0 && mf && march_mg(c))
+            hipLaunchKernelGGL(k_mg_smooth_march, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.op, (const double2 *)L.dinv,
+                               (const double2 *)L.b, (const double2 *)src, (double2 *)dst, om, c->sc);
+        else if (l == 0)
             LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (const double2 *)src, (double2 *)dst, om, 0, c->sc);
         else
@@ -3614,7 +3638,16 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             double *pold = c->p[prev], *pnew = c->p[cur];
             EvPair *ev;
             tim_begin(c, 1, &ev);
-            if (it == 0 && !multi)  // first iteration: p = z, p_old untouched
+            if (!multi && march_pcg(c)) {  // marching form of the matrix-free operator (bit-identical q, p)
+                if (it == 0)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_march<2>), dim3(gn), dim3(BLOCK), 0, c->stream, c->op, (const double2 *)pold,
+                                       (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn,
+                                       P_pq, c->sc, it, olo, ohi);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_march<1>), dim3(gn), dim3(BLOCK), 0, c->stream, c->op, (const double2 *)pold,
+                                       (const double2 *)c->z, (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn,
+                                       P_pq, c->sc, it, olo, ohi);
+            } else if (it == 0 && !multi)  // first iteration: p = z, p_old untouched
                 LAUNCH_OP2(k_spmv, 2, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)pold, (const double2 *)c->z,
                            (double2 *)pnew, (double2 *)c->q, P_rz[prev], P_rz[cur], P_rr[prev], gn, P_pq, c->sc, it, olo, ohi);
             else
@@ -3743,7 +3776,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         //                    by its most negative eigenvalue, k_make_surrogate) + preconditioned MINRES on the TRUE operator:
         //                    short recurrences, no Krylov basis; GMRES takes over if MINRES has not converged after 600
         //                    iterations.  Measured on config 5 at 2048^2: same wall-clock (203 vs 198 s),
-        //                    GMRES still needed in 8 of 63 such solves (48 of 48 with gmres), 22.5 k instead of 16.6 k
+        //                    GMRES still needed in 6 of 63 such solves (48 of 48 with gmres), 22.5 k instead of 16.6 k
         //                    iterations in total -- an SPD preconditioner leaves the negative eigenvalues of K on the other
         //                    side of zero, which costs MINRES about a factor of two -- hence not the default
         //   minres           MINRES with the V-cycle of the indefinite operator itself (not positive definite in about half

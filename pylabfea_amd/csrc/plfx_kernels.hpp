@@ -1069,6 +1069,123 @@ __device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
     return bell_apply(o.nnode, o.nslot, o.col, o.val, i, xf);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same operator, MARCHING along x with the 3 x 3 stencil window in registers (round 3).  Measured with rocprofv3 at
+// 2048^2 -- one pass = 470 MB, beyond the 256 MiB Infinity Cache -- the gather form above moves 1.15x (smoother) and 1.38x
+// (PCG operator with its two gathered vectors) the algorithmic bytes: what the 9-node / 4-element gathers re-read has left
+// the L2.  Here a WAVE owns 64 consecutive rows k and LC columns j; stepping j -> j + 1 it loads only the new vector column
+// (3 entries per lane: rows k - 1, k, k + 1) and the new element column (2 elements x 3 generator pairs), the other six
+// vector entries and two elements stay in registers: 3 (1 + 2/LC) + 6 (1 + 1/LC) loads per node instead of 9 + 12, all
+// coalesced.  Same arithmetic in the same order as grid_apply_pairs: bit-identical results (tools/probes/march_probe.hip:
+// 2048^2 smoother 122 -> 98 us, PCG operator 148 -> 103 us; 1024^2, Infinity-Cache resident: 23.1 -> 24.0 and 28.4 -> 26.7 us).
+// Tasks (row chunk rk fastest, column range rj): XCD x = blockIdx % 8 takes the contiguous range [x ntask/8, (x+1) ntask/8).
+//   xf(node) -> double2 vector entry;  emit(node, K-row result, centre entry) for every node of the task
+struct Gen3 {
+    double2 a, b, c;   // (XX,XY) (XS,YY) (YS,SS) of one element
+};
+
+__device__ __forceinline__ double2 stencil_window(const double2 (&u)[3][3], const Gen3 (&m)[2][2], const double *tab)
+{
+    double qx = 0., qy = 0.;
+#pragma unroll
+    for (int pj = 0; pj < 2; pj++)
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            const int p = pj * 2 + pk;
+            const double *T = tab + p * 16;  // wave-uniform -> scalar loads
+            double A1 = 0., A2 = 0., A3 = 0., A4 = 0., A5 = 0., A6 = 0., A7 = 0., A8 = 0.;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const double2 ub = u[pj + (b >> 1)][pk + (b & 1)];
+                const double sxx = T[b * 4 + 0], syy = T[b * 4 + 1], sxy = T[b * 4 + 2], syx = T[b * 4 + 3];
+                A1 = fma(sxx, ub.x, A1);
+                A2 = fma(sxx, ub.y, A2);
+                A3 = fma(syy, ub.x, A3);
+                A4 = fma(syy, ub.y, A4);
+                A5 = fma(sxy, ub.x, A5);
+                A6 = fma(sxy, ub.y, A6);
+                A7 = fma(syx, ub.x, A7);
+                A8 = fma(syx, ub.y, A8);
+            }
+            const double Mxx = m[pj][pk].a.x, Mxy = m[pj][pk].a.y, Mxs = m[pj][pk].b.x, Myy = m[pj][pk].b.y, Mys = m[pj][pk].c.x,
+                         Mss = m[pj][pk].c.y;
+            qx = fma(Mxx, A1, fma(Mxs, A5 + A7 + A2, fma(Mss, A3 + A8, fma(Mxy, A6, fma(Mys, A4, qx)))));
+            qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
+        }
+    return make_double2(qx, qy);
+}
+
+constexpr int MARCH_LC = 8;   // columns per wave task
+
+template <int LC, class XF, class EM>
+__device__ __forceinline__ void grid_march(const KOp &g, XF xf, EM emit)
+{
+    const int nxn = g.nxn, nyn = g.nyn, nel = g.nel;
+    const double2 *__restrict__ M2 = reinterpret_cast<const double2 *>(g.M);
+    const double *tab = g.tab;
+    const int nye = nyn - 1, nxe = nxn - 1;
+    const int nrk = (nyn + 63) >> 6, nrj = (nxn + LC - 1) / LC, ntask = nrk * nrj;
+    const int lane = threadIdx.x & 63;
+    constexpr int wpb = BLOCK >> 6;
+    int t0, t1, stride, first;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+        t0 = (int)((long long)ntask * xcd / 8);
+        t1 = (int)((long long)ntask * (xcd + 1) / 8);
+        first = t0 + lb * wpb + (threadIdx.x >> 6);
+        stride = nbx * wpb;
+    } else {
+        t0 = 0;
+        t1 = ntask;
+        first = blockIdx.x * wpb + (threadIdx.x >> 6);
+        stride = gridDim.x * wpb;
+    }
+    for (int task = first; task < t1; task += stride) {
+        const int rj = task / nrk, rk = task - rj * nrk;
+        const int k = (rk << 6) + lane;
+        const bool act = k < nyn;
+        const int kc = min(k, nye), km = max(kc - 1, 0), kp = min(kc + 1, nye);
+        const int j0 = rj * LC, j1 = min(j0 + LC, nxn);
+        const int ek0 = min(max(kc - 1, 0), nye - 1), ek1 = min(kc, nye - 1);  // element rows k - 1, k (clamped: every load in range)
+        const bool ok0 = kc - 1 >= 0, ok1 = kc < nye;
+        double2 u[3][3];
+        Gen3 m[2][2];
+        auto load_col = [&](int jj, double2(&col)[3]) {
+            const int jc = min(max(jj, 0), nxe);
+            col[0] = xf(jc * nyn + km);
+            col[1] = xf(jc * nyn + kc);
+            col[2] = xf(jc * nyn + kp);
+        };
+        auto load_el = [&](int ej, Gen3(&gg)[2]) {
+            const bool okj = ej >= 0 && ej < nxe;
+            const int ec = min(max(ej, 0), nxe - 1);
+            const size_t e0 = (size_t)ec * nye + ek0, e1 = (size_t)ec * nye + ek1;
+            Gen3 g0 = {M2[e0], M2[(size_t)nel + e0], M2[(size_t)2 * nel + e0]};
+            Gen3 g1 = {M2[e1], M2[(size_t)nel + e1], M2[(size_t)2 * nel + e1]};
+            const double2 z = make_double2(0., 0.);
+            if (!(okj && ok0)) g0 = {z, z, z};   // elements outside the grid enter with M = 0
+            if (!(okj && ok1)) g1 = {z, z, z};
+            gg[0] = g0;
+            gg[1] = g1;
+        };
+        load_col(j0 - 1, u[0]);
+        load_col(j0, u[1]);
+        load_el(j0 - 1, m[0]);
+        for (int j = j0; j < j1; j++) {
+            load_col(j + 1, u[2]);
+            load_el(j, m[1]);
+            if (act) emit(j * nyn + k, stencil_window(u, m, tab), u[1][1]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                u[0][r] = u[1][r];
+                u[1][r] = u[2][r];
+            }
+            m[0][0] = m[1][0];
+            m[0][1] = m[1][1];
+        }
+    }
+}
+
 // Everything the matrix-free operator of one grid level needs after the generators changed, in ONE pass over them
 // (node (j,k) reads its <= 4 elements):
 //   diag   diagonal of K (what k_assemble writes for the block-ELL matrix) -> Jacobi smoother / preconditioner
@@ -1230,6 +1347,56 @@ k_spmv(KOp op, int n_begin, int n_end,
         const double t = block_sum(acc_pq, sh);
         if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
     }
+}
+
+// k_spmv<MODE, 1> (MODE 1 / 2) of the finest grid in marching form (grid_march): same scalars, same partial-sum slots --
+// one partial per block, summed over the nodes its waves emit
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_march(KOp op, const double2 *__restrict__ p, const double2 *__restrict__ z, double2 *__restrict__ pnew,
+             double2 *__restrict__ q, const double *__restrict__ part_rz_new, const double *__restrict__ part_rz_old,
+             const double *__restrict__ part_rr, int npart_prev, double *__restrict__ part_pq, CgScalars *__restrict__ sc, int it,
+             int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double beta = 0.;
+    if (sc->done) return;
+    double rr, rzn = 0., rzo = 1.;
+    if (MODE == 1) {
+        const double *const arr[3] = {part_rr, part_rz_new, part_rz_old};
+        double o[3];
+        sum_partials_n<3>(arr, npart_prev, o);
+        rr = o[0];
+        rzn = o[1];
+        rzo = o[2];
+    } else {
+        rr = sum_partials(part_rr, npart_prev, sh);
+    }
+    if (rr <= sc->thresh2 || !(rr == rr)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            sc->done = (rr == rr) ? 1 : 2;
+            sc->iters = it;
+            sc->rr_final = rr;
+        }
+        return;
+    }
+    if (MODE == 1) beta = rzn / rzo;
+    double acc_pq = 0.;
+    grid_march<MARCH_LC>(
+        op,
+        [&](int n) {
+            const double2 zj = z[n];
+            if (MODE == 2) return zj;
+            const double2 po = p[n];
+            return make_double2(fma(beta, po.x, zj.x), fma(beta, po.y, zj.y));
+        },
+        [&](int i, double2 qv, double2 pn) {
+            q[i] = qv;
+            pnew[i] = pn;
+            if (i >= own_lo && i < own_hi) acc_pq = fma(pn.x, qv.x, fma(pn.y, qv.y, acc_pq));
+        });
+    const double t = block_sum(acc_pq, sh);
+    if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
 }
 
 // partial sums of p.q over all nodes (multi-GPU: after the all-reduce of q), and the p update for

@@ -86,6 +86,51 @@ k_mg_residual(KOp op,
     }
 }
 
+// The three fine-level kernels of the V-cycle in marching form (grid_march, plfx_kernels.hpp): bit-identical results, fewer
+// and fully coalesced loads; used on the finest grid when one operator pass exceeds the Infinity Cache (plfx.hip: use_march)
+__global__ void __launch_bounds__(BLOCK)
+k_mg_smooth_march(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__ b, const double2 *__restrict__ xin,
+                  double2 *__restrict__ xout, double omega, const CgScalars *sc)
+{
+    if (sc->done) return;
+    grid_march<MARCH_LC>(
+        op, [&](int n) { return xin[n]; },
+        [&](int i, double2 qv, double2 xi) {
+            const double2 di = dinv[i], bi = b[i];
+            xout[i] = make_double2(fma(omega * di.x, bi.x - qv.x, xi.x), fma(omega * di.y, bi.y - qv.y, xi.y));
+        });
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_mg_smooth2_zero_march(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__ b, double2 *__restrict__ xout,
+                        double omega, const CgScalars *sc)
+{
+    if (sc->done) return;
+    grid_march<MARCH_LC>(
+        op,
+        [&](int n) {
+            const double2 dj = dinv[n], bj = b[n];
+            return make_double2(omega * dj.x * bj.x, omega * dj.y * bj.y);
+        },
+        [&](int i, double2 qv, double2 x1) {
+            const double2 di = dinv[i], bi = b[i];
+            xout[i] = make_double2(fma(omega * di.x, bi.x - qv.x, x1.x), fma(omega * di.y, bi.y - qv.y, x1.y));
+        });
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_mg_residual_march(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__ b, const double2 *__restrict__ x,
+                    double2 *__restrict__ res, const CgScalars *sc)
+{
+    if (sc->done) return;
+    grid_march<MARCH_LC>(
+        op, [&](int n) { return x[n]; },
+        [&](int i, double2 qv, double2) {
+            const double2 di = dinv[i], bi = b[i];
+            res[i] = make_double2(di.x != 0. ? bi.x - qv.x : 0., di.y != 0. ? bi.y - qv.y : 0.);
+        });
+}
+
 // One step of the Jacobi-preconditioned Chebyshev iteration for K x = b (coarsest level too large for a dense inverse):
 //   d <- c1 d + c2 D^-1 (b - K x),  x <- x + d        (first != 0: x = 0, d = c2 D^-1 b)
 // A fixed number of steps with fixed coefficients is a fixed polynomial in D^-1 K: a symmetric positive definite
