@@ -273,8 +273,12 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world, monkeypatch):
         flo, fhi = 2 * st['own_nodes'][0], 2 * st['own_nodes'][1]
         assert np.max(np.abs(d['f'][flo:fhi] - fe.f[flo:fhi])) <= 1e-8 * slack * np.max(np.abs(fe.f))
         assert np.max(np.abs(d['sgl'] - fe.sgl)) <= 1e-9 * slack * np.max(np.abs(fe.sgl))
+        smax = np.max(np.abs(fe.sgl))
         for k, v in d['glob'].items():
-            assert abs(v - fe.glob[k]) <= 1e-8 * slack * max(1e-3, abs(fe.glob[k])), k
+            # entries that vanish in exact arithmetic (stress on the force-free boundary) are compared on the scale of the
+            # stresses of the run, not on an absolute floor below the solver tolerance
+            floor = 1e-3 * smax if k.startswith('s') else 1e-3
+            assert np.max(np.abs(v - fe.glob[k])) <= 1e-8 * slack * max(floor, np.max(np.abs(fe.glob[k]))), k
         e0, e1 = d['e0'], d['e1']
         assert (e0, e1) == (st['c0'] * fe._NY, st['c1'] * fe._NY)
         assert np.max(np.abs(d['sig'] - sig1[e0:e1])) <= 1e-8 * slack * np.max(np.abs(sig1))

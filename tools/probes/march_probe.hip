@@ -11,7 +11,7 @@
 #include <vector>
 using namespace plfx;
 
-struct Gen3 { double2 a, b, c; };   // (XX,XY) (XS,YY) (YS,SS) of one element
+// (Gen3 = the generator pairs of one element: plfx_kernels.hpp)
 
 __device__ __forceinline__ double2 stencil(const double2 (&u)[3][3], const Gen3 (&m)[2][2], const double *tab)
 {
@@ -88,6 +88,67 @@ __device__ __forceinline__ void march(int nxn, int nyn, int nel, const double2 *
             m[0][0] = m[1][0]; m[0][1] = m[1][1];
         }
     }
+}
+
+// the same with the loads of step j + 1 issued BEFORE the arithmetic of step j (one column / element column in flight)
+template <int LC, class XF, class EM>
+__device__ __forceinline__ void marchp(int nxn, int nyn, int nel, const double2 *__restrict__ M2, const double *tab, XF xf, EM emit)
+{
+    const int nye = nyn - 1, nxe = nxn - 1;
+    const int nrk = (nyn + 63) >> 6, nrj = (nxn + LC - 1) / LC, ntask = nrk * nrj;
+    const int lane = threadIdx.x & 63;
+    const int wpb = BLOCK >> 6;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = max(1, (int)gridDim.x >> 3);
+    const int t0 = (int)((long long)ntask * xcd / 8), t1 = (int)((long long)ntask * (xcd + 1) / 8);
+    for (int task = t0 + lb * wpb + (threadIdx.x >> 6); task < t1; task += nbx * wpb) {
+        const int rj = task / nrk, rk = task - rj * nrk;
+        const int k = (rk << 6) + lane;
+        const bool act = k < nyn;
+        const int kc = min(k, nye), km = max(kc - 1, 0), kp = min(kc + 1, nye);
+        const int j0 = rj * LC, j1 = min(j0 + LC, nxn);
+        const int ek0 = min(max(kc - 1, 0), nye - 1), ek1 = min(kc, nye - 1);
+        const bool ok0 = kc - 1 >= 0, ok1 = kc < nye;
+        double2 u[3][3], un[3];
+        Gen3 m[2][2], mn[2];
+        auto load_col = [&](int jj, double2 (&col)[3]) {
+            const int jc = min(max(jj, 0), nxe);
+            col[0] = xf(jc * nyn + km); col[1] = xf(jc * nyn + kc); col[2] = xf(jc * nyn + kp);
+        };
+        auto load_el = [&](int ej, Gen3 (&g)[2]) {
+            const bool okj = ej >= 0 && ej < nxe;
+            const int ec = min(max(ej, 0), nxe - 1);
+            const size_t e0 = (size_t)ec * nye + ek0, e1 = (size_t)ec * nye + ek1;
+            Gen3 g0 = {M2[e0], M2[(size_t)nel + e0], M2[(size_t)2 * nel + e0]};
+            Gen3 g1 = {M2[e1], M2[(size_t)nel + e1], M2[(size_t)2 * nel + e1]};
+            const double2 z = make_double2(0., 0.);
+            if (!(okj && ok0)) g0 = {z, z, z};
+            if (!(okj && ok1)) g1 = {z, z, z};
+            g[0] = g0; g[1] = g1;
+        };
+        load_col(j0 - 1, u[0]);
+        load_col(j0, u[1]);
+        load_el(j0 - 1, m[0]);
+        load_col(j0 + 1, u[2]);
+        load_el(j0, m[1]);
+        for (int j = j0; j < j1; j++) {
+            if (j + 1 < j1) { load_col(j + 2, un); load_el(j + 1, mn); }
+            if (act) emit(j * nyn + k, stencil(u, m, tab), u[1][1]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) { u[0][r] = u[1][r]; u[1][r] = u[2][r]; u[2][r] = un[r]; }
+            m[0][0] = m[1][0]; m[0][1] = m[1][1]; m[1][0] = mn[0]; m[1][1] = mn[1];
+        }
+    }
+}
+
+template <int LC>
+__global__ void __launch_bounds__(BLOCK)
+k_smooth_marchp(int nxn, int nyn, int nel, const double2 *__restrict__ M2, const double *__restrict__ tab, const double2 *__restrict__ dinv,
+                const double2 *__restrict__ b, const double2 *__restrict__ xin, double2 *__restrict__ xout, double omega)
+{
+    marchp<LC>(nxn, nyn, nel, M2, tab, [&](int n) { return xin[n]; }, [&](int i, double2 qv, double2 xi) {
+        const double2 di = dinv[i], bi = b[i];
+        xout[i] = make_double2(fma(omega * di.x, bi.x - qv.x, xi.x), fma(omega * di.y, bi.y - qv.y, xi.y));
+    });
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -215,6 +276,10 @@ int main(int argc, char **argv)
             const float t16 = best_of([&] { k_smooth_march<16><<<grid, BLOCK>>>(ARGS_S x2, 0.65); });
             const double d16 = diff(x1, x2);
             const float t32 = best_of([&] { k_smooth_march<4><<<grid, BLOCK>>>(ARGS_S x2, 0.65); });
+            const float p8 = best_of([&] { k_smooth_marchp<8><<<grid, BLOCK>>>(ARGS_S x2, 0.65); });
+            const double dp8 = diff(x1, x2);
+            const float p16 = best_of([&] { k_smooth_marchp<16><<<grid, BLOCK>>>(ARGS_S x2, 0.65); });
+            printf("   grid %5d smoother march + prefetch LC=8 %.2f us (diff %.1e) | LC=16 %.2f\n", grid, p8, dp8, p16);
             printf("   grid %5d smoother march LC=2 %.2f us (diff %.1e) | LC=8 %.2f (%.1e) | LC=16 %.2f (%.1e) | LC=4 %.2f\n", grid, t4, d4, t8, d8, t16, d16, t32);
             k_spmv_base<<<1024, BLOCK>>>(ARGS_P x1, (double2 *)q1, 0.37, part);
             const float s4 = best_of([&] { k_spmv_march<2><<<grid, BLOCK>>>(ARGS_P x2, (double2 *)q2, 0.37, part); });
