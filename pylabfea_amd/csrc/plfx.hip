@@ -250,6 +250,7 @@ struct plfx_ctx {
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
     double *gm_V = nullptr, *gm_part = nullptr;  // GMRES: Krylov basis (GMRES_M + 1 vectors) and partial sums, on first use
     int n_gmres = 0, gm_m = 0;
+    double *fuse_rz = nullptr;  // != null during a V-cycle of the PCG loop: the last fine-level post-smoothing launch writes the r.z partials here
     // SPD surrogate of an indefinite operator (k_make_surrogate): generators with every indefinite element's 3 x 3 generator
     // matrix shifted by its most negative eigenvalue, the diagonal / Jacobi scaling of that operator; while sur_active the V-cycle (level 0 and every level
     // below it) is built on the surrogate, the Krylov method applies the true operator
@@ -1112,12 +1113,20 @@ int mg_up_level(plfx_ctx *c, int l)
     for (int k = 0; k < nu; k++) {
         EvPair *ev = nullptr;
         if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
+        DotOut dot{};
+        if (l == 0 && k == nu - 1 && c->fuse_rz && !(nu & 1) && L.grid <= c->grid_nodes) {  // (even nu: the last launch writes L.x = z)
+            dot.part = c->fuse_rz;
+            dot.nslots = c->grid_nodes;
+            dot.own_lo = own_lo(c);
+            dot.own_hi = own_hi(c);
+            c->fuse_rz = nullptr;  // consumed: the caller launches k_dot_rz itself if this is still set
+        }
         if (l == 0 && mf && march_mg(c))
             hipLaunchKernelGGL(k_mg_smooth_march, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.op, (const double2 *)L.dinv,
-                               (const double2 *)L.b, (const double2 *)src, (double2 *)dst, om, c->sc);
+                               (const double2 *)L.b, (const double2 *)src, (double2 *)dst, om, c->sc, dot);
         else if (l == 0)
             LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                       (const double2 *)src, (double2 *)dst, om, 0, c->sc);
+                       (const double2 *)src, (double2 *)dst, om, 0, c->sc, dot);
         else
             LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (const double2 *)src, (double2 *)dst, om, 0, c->sc);
@@ -3609,11 +3618,16 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         if ((rc = cg_check_wait(c, seq, &hs))) return rc;
         done = hs.done;
     }
+    static const bool fuse_dot = !(getenv("PLFX_FUSE_DOT") && atoi(getenv("PLFX_FUSE_DOT")) == 0);
     if (mg && !done) {
+        c->fuse_rz = fuse_dot ? P_rz[1] : nullptr;  // r.z partials from the last post-smoothing launch of the cycle
         rc = mg_vcycle_rest(c);
+        const bool fused = fuse_dot && c->fuse_rz == nullptr;
+        c->fuse_rz = nullptr;
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
-                           (const double2 *)c->z, P_rz[1]);
+        if (!fused)
+            hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
+                               (const double2 *)c->z, P_rz[1]);
         if ((rc = part_allreduce(c, P_rz[1], gn))) return rc;
     }
     // beta of the first iteration is 0 (k_spmv<1> takes p = z for it == 0 without touching p_old); only the sharded
@@ -3686,11 +3700,15 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                     it++;
                     break;
                 }
+                c->fuse_rz = fuse_dot ? P_rz[cur] : nullptr;
                 rc = mg_vcycle_rest(c);
+                const bool fused = fuse_dot && c->fuse_rz == nullptr;
+                c->fuse_rz = nullptr;
                 tim_end(c, evv);
                 if (rc) return rc;
-                hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
-                                   (const double2 *)c->z, P_rz[cur]);
+                if (!fused)
+                    hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r,
+                                       (const double2 *)c->z, P_rz[cur]);
                 if ((rc = part_allreduce(c, P_rz[cur], gn))) return rc;
             } else {
                 tim_begin(c, 2, &ev);

@@ -16,6 +16,23 @@
 
 namespace plfx {
 
+// The last post-smoothing launch of the finest level writes z = M^-1 r (x aliases z, b aliases r there): it can deliver the
+// per-block partial sums of r.z that PCG needs next -- b[i] and the new x[i] are in registers -- and saves the separate
+// k_dot_rz pass over both vectors (one launch and 32 B per node per PCG iteration).  part == nullptr: no sums.
+struct DotOut {
+    double *part = nullptr;   // [nslots] partial sums, one per block; slots >= gridDim.x are zeroed by block 0
+    int nslots = 0;
+    int own_lo = 0, own_hi = 0;   // nodes summed (all; the owned columns of a strip)
+};
+
+__device__ __forceinline__ void dot_finish(const DotOut &dot, double acc, double *sh)
+{
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) dot.part[blockIdx.x] = t;
+    if (blockIdx.x == 0)
+        for (int k = gridDim.x + threadIdx.x; k < dot.nslots; k += BLOCK) dot.part[k] = 0.;
+}
+
 // xout = xin + omega * dinv * (b - K xin)      (first != 0: xin == 0 -> xout = omega * dinv * b)
 // FINE = 1 instantiations run the finest grid only, so that profilers list the HBM-bound fine-level
 // launches (the dominant kernels of a load step) separately from the latency-bound coarse ones.
@@ -24,9 +41,11 @@ __global__ void __launch_bounds__(BLOCK)
 k_mg_smooth(KOp op,
             const double2 *__restrict__ dinv, const double2 *__restrict__ b,
             const double2 *__restrict__ xin, double2 *__restrict__ xout, double omega, int first,
-            const CgScalars *sc)
+            const CgScalars *sc, DotOut dot = DotOut{})
 {
     if (sc->done) return;  // PCG already converged: the remaining launches of the chunk are no-ops
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
     const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
@@ -39,8 +58,11 @@ k_mg_smooth(KOp op,
         const double2 qv = op_apply<GRID>(op, i, [&](int j) { return xin[j]; });
         const double qx = qv.x, qy = qv.y;
         const double2 xi = xin[i];
-        xout[i] = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
+        const double2 xo = make_double2(fma(omega * di.x, bi.x - qx, xi.x), fma(omega * di.y, bi.y - qy, xi.y));
+        xout[i] = xo;
+        if (dot.part && i >= dot.own_lo && i < dot.own_hi) acc = fma(bi.x, xo.x, fma(bi.y, xo.y, acc));
     }
+    if (dot.part) dot_finish(dot, acc, sh);
 }
 
 // two damped-Jacobi sweeps from a zero guess in one pass:
@@ -90,15 +112,20 @@ k_mg_residual(KOp op,
 // and fully coalesced loads; used on the finest grid when one operator pass exceeds the Infinity Cache (plfx.hip: use_march)
 __global__ void __launch_bounds__(BLOCK)
 k_mg_smooth_march(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__ b, const double2 *__restrict__ xin,
-                  double2 *__restrict__ xout, double omega, const CgScalars *sc)
+                  double2 *__restrict__ xout, double omega, const CgScalars *sc, DotOut dot)
 {
     if (sc->done) return;
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
     grid_march<MARCH_LC>(
         op, [&](int n) { return xin[n]; },
         [&](int i, double2 qv, double2 xi) {
             const double2 di = dinv[i], bi = b[i];
-            xout[i] = make_double2(fma(omega * di.x, bi.x - qv.x, xi.x), fma(omega * di.y, bi.y - qv.y, xi.y));
+            const double2 xo = make_double2(fma(omega * di.x, bi.x - qv.x, xi.x), fma(omega * di.y, bi.y - qv.y, xi.y));
+            xout[i] = xo;
+            if (dot.part && i >= dot.own_lo && i < dot.own_hi) acc = fma(bi.x, xo.x, fma(bi.y, xo.y, acc));
         });
+    if (dot.part) dot_finish(dot, acc, sh);
 }
 
 __global__ void __launch_bounds__(BLOCK)

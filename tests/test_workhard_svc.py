@@ -232,12 +232,20 @@ def test_gpu_scf_entry_points_agree_for_workhardening_svc(z):
         fe.solve(min_step=8)
     eng = fe._engine
     assert np.max(np.abs(fe._state('epl'))) > 0.                         # plastic strain present
-    kh = eng.state_get(_lib.ST_KHARD)
-    assert np.ptp(kh) > 0. or np.any(kh != fe.mat[0].khard)              # per-point moduli differ from the record's value
+    # a displacement increment large enough that calc_scf's ratios sqrt(1.5) sflow / seq(dsig) fall below 1 (:1056), and
+    # per-point moduli that differ from the record's value and from each other
+    eng.state_set(_lib.ST_DU, 300. * eng.state_get(_lib.ST_DU))
+    rng = np.random.default_rng(4)
     sld = np.array([0., 1., 0., 0., 0., 0.])
-    cnt, mn, sm, s2 = eng.scf_all(sld)
-    cnt2, mn2, sm2 = eng.scf_stats(sld)
-    assert cnt == cnt2 and cnt > 0
-    assert abs(mn - mn2) <= 1e-14 * abs(mn2) and abs(sm - sm2) <= 1e-12 * abs(sm2)
-    s2b = eng.scf_sumsq(sm2 / cnt2)
-    assert abs(s2 - s2b) <= 1e-9 * max(abs(s2b), 1e-30)
+    res = {}
+    for tag, kh in (('zero', np.zeros(fe.Nel)), ('varied', 2.e4 * rng.uniform(0.5, 1.5, size=fe.Nel))):
+        eng.state_set(_lib.ST_KHARD, kh)
+        assert np.array_equal(eng.state_get(_lib.ST_KHARD), kh)
+        cnt, mn, sm, s2 = eng.scf_all(sld)
+        cnt2, mn2, sm2 = eng.scf_stats(sld)
+        assert cnt == cnt2 and cnt > 0
+        assert abs(mn - mn2) <= 1e-14 * abs(mn2) and abs(sm - sm2) <= 1e-12 * abs(sm2)
+        s2b = eng.scf_sumsq(sm2 / cnt2)
+        assert abs(s2 - s2b) <= 1e-9 * max(abs(s2b), 1e-30)
+        res[tag] = (mn, sm)
+    assert res['zero'] != res['varied']                                  # the statistics do read the per-point moduli

@@ -26,7 +26,8 @@ def main(d, out):
         dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     lines.append('')
     lines.append('== fine-level / productive launches only (coarse-level and post-convergence no-op launches filtered by duration) ==')
-    FINE = ('k_mg_smooth<1,1>', 'k_mg_smooth2_zero<1,1>', 'k_mg_residual<1,1>', 'k_spmv<1,1>', 'k_spmv<2,1>',
+    FINE = ('k_mg_smooth_march', 'k_mg_smooth2_zero_march', 'k_mg_residual_march', 'k_spmv_march<1>', 'k_spmv_march<2>', 'k_dot_rz',
+            'k_mg_smooth<1,1>', 'k_mg_smooth2_zero<1,1>', 'k_mg_residual<1,1>', 'k_spmv<1,1>', 'k_spmv<2,1>',
             'k_spmv<0,1>', 'k_cg_start<1>', 'k_mg_smooth<1,0>', 'k_mg_smooth2_zero<1,0>', 'k_mg_residual<1,0>',
             'k_spmv<1,0>', 'k_spmv<0,0>', 'k_cg_update', 'k_cg_update_mg', 'k_sweep_light<1>', 'k_sweep_light<0>',
             'k_sweep_heavy<1>', 'k_grid_setup', 'k_grid_diag', 'k_assemble', 'k_mg_tail_mf', 'k_mg_tail_lds',
