@@ -450,7 +450,7 @@ def main():
         if il == pre + W:
             eng.timing_reset()
             # two hipEventRecord calls per timed launch: by default only the kernels of the two roofline objects
-            eng.timing_select(None if args.all_families else ((_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV) + ((_lib.T_COMM,) if world > 1 else ())))
+            eng.timing_select(None if args.all_families else ((_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV) + ((_lib.T_COMM,) if dist is not None else ())))
             eng.timing_sample(args.sample)
             eng.timing_enable(True)
             gc.collect()

@@ -43,7 +43,10 @@ k_mg_smooth(KOp op,
             const double2 *__restrict__ xin, double2 *__restrict__ xout, double omega, int first,
             const CgScalars *sc, DotOut dot = DotOut{})
 {
-    if (sc->done) return;  // PCG already converged: the remaining launches of the chunk are no-ops
+    // PCG already converged: the launches of a speculatively enqueued cycle head are no-ops.  Only the finest level is ever
+    // enqueued speculatively (mg_vcycle_head); the coarser levels run after the host has seen "not converged", and there
+    // the flag would be one more dependent scalar load in front of a launch-latency-bound kernel
+    if (FINE && sc->done) return;
     __shared__ double sh[BLOCK / 64];
     double acc = 0.;
     const int nb = gridDim.x, nnode = op.nnode;
@@ -73,7 +76,7 @@ k_mg_smooth2_zero(KOp op,
                   const double2 *__restrict__ dinv, const double2 *__restrict__ b,
                   double2 *__restrict__ xout, double omega, const CgScalars *sc)
 {
-    if (sc->done) return;
+    if (FINE && sc->done) return;
     const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;
@@ -96,7 +99,7 @@ k_mg_residual(KOp op,
               const double2 *__restrict__ dinv, const double2 *__restrict__ b,
               const double2 *__restrict__ x, double2 *__restrict__ res, const CgScalars *sc)
 {
-    if (sc->done) return;
+    if (FINE && sc->done) return;
     const int nb = gridDim.x, nnode = op.nnode;
     for (int t = xcd_tile(blockIdx.x, nb); t * BLOCK < nnode; t += nb) {
         const int i = t * BLOCK + threadIdx.x;

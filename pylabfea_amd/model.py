@@ -410,6 +410,8 @@ class Model(object):
         results are filled on this rank's columns only (zeros elsewhere)."""
         if mode not in (None, 'strip', 'replicated'):
             raise ValueError("distribute: mode must be None, 'strip' or 'replicated'")
+        if int(nranks) > 1 and uid is None and host_allreduce is None:
+            raise ValueError('distribute: pass the RCCL unique id (uid) or a host_allreduce callback')
         self._shard = (int(rank), int(nranks), uid)
         self._host_allreduce = host_allreduce
         self._dist_mode = mode
@@ -798,39 +800,24 @@ class Model(object):
             scf = 1.e-3
         return float(scf)
 
-    # collectives of the host-side scalars (only in sharded runs; torch.distributed is the plumbing)
-    def _allgather(self, x):
-        """(nranks, len(x)) array of every rank's vector: ONE collective per host-side reduction; the reduction itself
-        (sum / min over the rank axis, in rank order) is then done locally and is identical on every rank"""
-        import torch
-        import torch.distributed as dist
-        v = np.atleast_1d(np.asarray(x, dtype=np.float64))
-        dev = torch.device('cuda', self.device) if dist.get_backend() == 'nccl' else torch.device('cpu')
-        key = (len(v), str(dev))
-        buf = self._gather_buf.get(key) if hasattr(self, '_gather_buf') else None
-        if buf is None:
-            if not hasattr(self, '_gather_buf'):
-                self._gather_buf = {}
-            n = dist.get_world_size()
-            buf = (torch.empty(len(v), dtype=torch.float64, device=dev),
-                   [torch.empty(len(v), dtype=torch.float64, device=dev) for _ in range(n)])
-            self._gather_buf[key] = buf
-        t, outs = buf
-        t.copy_(torch.from_numpy(v))
-        dist.all_gather(outs, t)
-        return torch.stack(outs).cpu().numpy()
-
+    # collectives of the host-side scalars of the Python load-step driver (sharded runs whose library communicator is the
+    # host-staged transport): through the library's own communicator (plfx_allreduce_host) -- the package itself needs no
+    # process-group library; sums / minima are identical on every rank
     def _allreduce_sum(self, x):
-        r = self._allgather(x).sum(axis=0)
-        return r if np.ndim(x) else float(r[0])
+        v = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        out = np.empty_like(v)
+        for i in range(0, len(v), 32):           # plfx_allreduce_host takes <= 32 doubles per call
+            out[i:i + 32] = self._engine.allreduce_host(v[i:i + 32], op=0)
+        return out if np.ndim(x) else float(out[0])
 
     def _allreduce_scf(self, cnt, mn, s):
-        g = self._allgather(np.array([cnt, s, mn], dtype=np.float64))
-        return int(round(g[:, 0].sum())), float(g[:, 2].min()), float(g[:, 1].sum())
+        g = self._engine.allreduce_host(np.array([cnt, s], dtype=np.float64), op=0)
+        m = self._engine.allreduce_host(np.array([mn], dtype=np.float64), op=3)
+        return int(round(g[0])), float(m[0]), float(g[1])
 
     def _allreduce_flags(self, change, conv):
-        g = self._allgather(np.array([float(change), float(not conv)]))
-        return bool(g[:, 0].sum() > 0.), not bool(g[:, 1].sum() > 0.)
+        g = self._engine.allreduce_host(np.array([float(change), float(not conv)]), op=0)
+        return bool(g[0] > 0.), not bool(g[1] > 0.)
 
     # ------------------------------------------------------------------ solution
     def solve(self, min_step=None, verb=False):
