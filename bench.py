@@ -450,7 +450,7 @@ def main():
         if il == pre + W:
             eng.timing_reset()
             # two hipEventRecord calls per timed launch: by default only the kernels of the two roofline objects
-            eng.timing_select(None if args.all_families else ((_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV) + ((_lib.T_COMM,) if dist is not None else ())))
+            eng.timing_select(None if args.all_families else ((_lib.T_SMOOTH, _lib.T_SWEEP, _lib.T_SPMV, _lib.T_VCYCLE) + ((_lib.T_COMM,) if dist is not None else ())))
             eng.timing_sample(args.sample)
             eng.timing_enable(True)
             gc.collect()
@@ -589,6 +589,16 @@ def main():
         'roofline_spmv': roof('spmv'),
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items() if v[1] > 0},
     }
+    if tim['vcycle'][1] > 0 and tim['mg_smooth'][1] > 0:
+        # the part of a load step that has NO roofline: levels >= 1 of the V-cycle are launch-latency bound (24 kernels of 4-7 us
+        # + the single-workgroup tail) -- reported as time, not as a fraction of anything
+        vc_us = 1e3 * tim['vcycle'][0] / tim['vcycle'][1]
+        sm_us = 1e3 * tim['mg_smooth'][0] / tim['mg_smooth'][1]
+        out['vcycle'] = {'avg_us': vc_us, 'cycles_timed': tim['vcycle'][1],
+                         'fine_level_us': 4. * sm_us, 'coarse_levels_us': vc_us - 4. * sm_us,
+                         'note': 'whole V(2,2) cycle (HIP events, every %d-th cycle); fine level = 4 operator passes at the rate of the '
+                                 'roofline kernel; the rest (levels >= 1: transfers, 24 launch-latency-bound kernels replayed from a hipGraph, '
+                                 'single-workgroup tail) is latency-bound and has no roofline' % args.sample}
     if dist is not None:
         # per-rank view: roofline of the dominant kernel on every rank's own strip, and the time its stream spent in
         # collectives (HIP events around every RCCL call: includes the wait for the slowest peer)
