@@ -59,8 +59,11 @@ HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achieva
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
 # calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
 PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
-               'matfree': {'mg_smooth': 120.5e6, 'spmv': 126.4e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r02m_bench1024_rocprofv3_summary.txt'}
+               'matfree': {'mg_smooth': 120.45e6, 'spmv': 132.8e6, 'cg_update': 117.9e6,
+                           # the sweep per launch: 160.45 MB x 2 fetched + 109.05 MB written when no tangent is rewritten (430.0 MB
+                           # against 432.0 MB algorithmic), + 226.5 MB written when all are (counter min / max of the profile)
+                           'sweep': (429.95e6, 226.53e6)}}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r03n_bench1024_rocprofv3_summary.txt'}
 
 
 def hill_material(FE):
@@ -538,9 +541,11 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled and
         # WRITE_SIZE as calibrated there, MI355X_MICROARCH.md 'HBM'); measured on this workload (1 GPU, 1024^2)
         pmc = PMC_TRAFFIC['matfree' if mf else 'assembled']
-        traffic = pmc.get(k) if (world == 1 and n == 1024) else None   # from the committed profile of this workload, not this run
+        traffic = pmc.get(k) if (world == 1 and n == 1024 and args.config == 3) else None   # from the committed profile of this workload, not this run
+        if isinstance(traffic, tuple):   # sweep: base + extra bytes per rewritten tangent, with THIS run's share of rewritten tangents
+            traffic = traffic[0] + traffic[1] * rewritten / max(n_sw * nel_rank, 1)
         opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
-        return {'kernel': {'spmv': 'k_spmv<1> (PCG: fused p-update + %s + p.q)' % opname,
+        return {'kernel': {'spmv': ('k_spmv_march<1>' if mf else 'k_spmv<1>') + ' (PCG: fused p-update + %s + p.q%s)' % (opname, ', marching along x with the 3 x 3 stencil window in registers' if mf else ''),
                            'sweep': 'k_sweep_light<1> (strain gather + return mapping + tangent test / refresh; 412 B per element + 216 B per '
                                     'rewritten tangent, %.0f %% of the elements per sweep here; the compacted 50-sub-step list of '
                                     'k_sweep_heavy is empty on this workload and timed separately)' % (100. * rewritten / max(n_sw * nel_rank, 1)),

@@ -1049,6 +1049,15 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
     return 0;
 }
 
+// smoothing sweeps of level l: mg_nu everywhere; experiment knob PLFX_MG_NU_COARSE=n: n sweeps on the launch-latency-bound
+// levels >= 2 that are launched kernel by kernel (fewer launches per cycle, weaker smoothing there; not with strips, whose
+// halo validity analysis assumes V(2,2))
+inline int level_nu(const plfx_ctx *c, int l)
+{
+    static const int nc = getenv("PLFX_MG_NU_COARSE") ? atoi(getenv("PLFX_MG_NU_COARSE")) : 0;
+    return (nc > 0 && l >= 2 && !c->strip.on) ? nc : c->mg_nu;
+}
+
 // z = V(nu,nu)-cycle applied to r  (level-0 x aliases z, b aliases r)
 // one level of the down leg: nu pre-smoothing sweeps from a zero guess, residual, restriction to level l+1
 int mg_down_level(plfx_ctx *c, int l)
@@ -1057,7 +1066,7 @@ int mg_down_level(plfx_ctx *c, int l)
     auto &L = c->mg[l];
     auto &C = c->mg[l + 1];
     const bool mf = L.matfree && matfree(c);
-    const int nu = c->mg_nu;
+    const int nu = level_nu(c, l);
     EvPair *ev = nullptr;
     (void)ev;  // the head of the cycle is enqueued speculatively (may return at once): family 5 times the post-smoothing
                // launches of k_mg_smooth<1, .> only
@@ -1106,7 +1115,7 @@ int mg_up_level(plfx_ctx *c, int l)
     auto &L = c->mg[l];
     auto &C = c->mg[l + 1];
     const bool mf = L.matfree && matfree(c);
-    const int nu = c->mg_nu;
+    const int nu = level_nu(c, l);
     hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
                        C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
     double *src = L.x, *dst = L.t;
