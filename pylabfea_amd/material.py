@@ -20,7 +20,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from .basic import eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, yf_tolerance
+from .basic import eps_eq, sig_dev, sig_eq_j2, sig_polar_ang, sig_princ, yf_tolerance
 
 _point_ctx = {}        # shared contexts for point evaluations, one per GPU (each remembers the record it holds)
 
@@ -487,6 +487,24 @@ class Material(object):
             s = np.concatenate((s, np.zeros((len(s), 3))), axis=1)
         return np.ascontiguousarray(s), single
 
+    def _princ_rows(self, s):
+        """Principal-stress materials (sdim = 3: 3-parameter Hill) see a Voigt stress through ``basic.sig_princ`` -- the
+        general eigen-solver ``np.linalg.eig`` plus the axis-tracking re-ordering (basic.py:153-175) -- and the ORDER of the
+        principal stresses enters the Hill form (material.py:667-670).  For plane states (every state of a 2-d model) the
+        device reproduces that order in closed form; for states with out-of-plane shear it depends on LAPACK's eigenvalue
+        order, so those rows are reduced HERE with the very same LAPACK call and handed to the device as diagonal states
+        (whose order the device keeps): the point functions then equal the reference for every stress state."""
+        if self.sdim != 3 or self.ML_yf or self.tresca or self.barlat:
+            return s
+        gen = (s[:, 3] != 0.) | (s[:, 4] != 0.)
+        if not np.any(gen):
+            return s
+        s = s.copy()
+        sp, _ = sig_princ(s[gen])
+        s[gen, 0:3] = sp.reshape(-1, 3)
+        s[gen, 3:6] = 0.
+        return s
+
     # ------------------------------------------------------------------ constitutive functions
     def calc_seq(self, sig):
         """Generalised (Hill/Drucker) equivalent stress (material.py:576-676)."""
@@ -494,7 +512,7 @@ class Material(object):
         if self.sy is None:
             seq = sig_eq_j2(s)  # elastic material: J2 (material.py:637-640)
         else:
-            seq = self._load(ana=True).seq(0, s)
+            seq = self._load(ana=True).seq(0, self._princ_rows(s))
             self.msg['equiv'] = ('6-parameter Hill, full Voigt stress'
                                  if self.sdim == 6 and not (self.tresca or self.barlat) else '3-parameter Hill')
         return seq[0] if single else seq
@@ -559,7 +577,7 @@ class Material(object):
             else:
                 self.msg['yield_fct'] = 'ML_yf-decision-fct'
         else:
-            f = self._load(ana=True).yf(0, s, e)
+            f = self._load(ana=True).yf(0, self._princ_rows(s), e)
             self.msg['yield_fct'] = 'analytical'
         return f[0] if single else f
 

@@ -35,3 +35,48 @@ def test_polar_angle_stress_strain(g):
     assert abs(s.seq_j2() - float(g['seq7'])) < 1e-12
     e = FE.Strain(g['eps'])
     assert abs(e.eeq() - float(g['eeq'])) < 1e-18 and np.array_equal(e.inv(), g['einv'])
+
+
+# ---------------------------------------------------------------------------------------------------- general 3-d states
+@pytest.fixture(scope='module')
+def pg(golden_dir):
+    return np.load(os.path.join(golden_dir, 'princ_general.npz'))
+
+
+def test_sig_princ_general_states_bit_identical(pg):
+    """400 stresses incl. out-of-plane shear, nearly diagonal and equal-normal-stress states (oracle/gen_princ_general.py)"""
+    import pylabfea_amd as FE
+    sp, ev = FE.sig_princ(pg['sig'])
+    assert np.array_equal(sp, pg['princ']) and np.array_equal(ev, pg['evec'])
+
+
+def hill3_material(pg):
+    import pylabfea_amd as FE
+    E, nu, sy, khard, dr = pg['par']
+    m = FE.Material()
+    m.elasticity(E=float(E), nu=float(nu))
+    m.plasticity(sy=float(sy), hill=list(pg['hill']), khard=float(khard), drucker=float(dr), sdim=3)
+    return m
+
+
+@pytest.mark.gpu
+def test_gpu_principal_stress_material_on_general_states(pg):
+    """3-parameter Hill on principal stresses (sdim = 3) for stress states WITH out-of-plane shear, where the order of the
+    principal stresses -- which the Hill form depends on -- follows LAPACK (basic.py:153-175, material.py:667-670): equal to
+    the reference for every state, batch and single calls"""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = hill3_material(pg)
+    sig = pg['sig']
+    sc = np.max(np.abs(pg['seq']))
+    assert np.max(np.abs(m.calc_seq(sig) - pg['seq'])) < 1e-11 * sc
+    one = np.array([m.calc_seq(sig[i]) for i in range(0, len(sig), 7)])
+    assert np.max(np.abs(one - pg['seq_single'])) < 1e-11 * sc
+    assert np.max(np.abs(m.calc_yf(sig, epl=pg['epl']) - pg['yf'])) < 1e-11 * sc
+    # had the device ordered these states by its own (plane-state) rule, a third of them would differ by per cent
+    import pylabfea_amd as FE
+    mt = FE.Material()
+    mt.elasticity(E=200.e3, nu=0.3)
+    mt.plasticity(sy=100., tresca=True, sdim=3)
+    assert np.max(np.abs(mt.calc_seq(sig) - pg['tresca_seq'])) < 1e-10 * np.max(pg['tresca_seq'])   # order-independent form
