@@ -238,7 +238,9 @@ static float best_of(L launch)
 
 int main(int argc, char **argv)
 {
-    for (int nx : {1024, 2048}) {
+    std::vector<int> sizes = {1024, 2048};
+    if (argc > 1) sizes = {atoi(argv[1])};
+    for (int nx : sizes) {
         const int ny = nx, nxn = nx + 1, nyn = ny + 1, nel = nx * ny, nn = nxn * nyn;
         std::vector<double> hM2(6 * (size_t)nel), htab(64), hv(2 * (size_t)nn), hw(2 * (size_t)nn);
         for (size_t e = 0; e < (size_t)nel; e++)
