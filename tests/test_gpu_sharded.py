@@ -345,6 +345,32 @@ def test_bench_two_ranks(tmp_path, mode):
         assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
 
 
+def test_bench_config5_option(tmp_path):
+    """bench.py --config 5 (BASELINE config 5: laminate of J2 + the Goss-Barlat-trained SVC) on a reduced mesh: one rank, and
+    two ranks on one GPU over the host transport with cost-balanced strips -- same sweeps / solves / iterations, one JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(root, 'bench.py'), '--config', '5', '--mesh', '256', '--steps', '1', '--warmup', '0', '--no-cpu']
+    one = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'two-phase laminate' in d1['config']['workload'] and d1['config']['elements'] == 256 * 256
+    assert d1['n_gpus'] == 1 and d1['sweeps'] > 0 and d1['value'] > 0. and 'roofline_2048' not in d1
+    port = free_port()
+    env = dict(os.environ, PLFX_BENCH_TRANSPORT='host')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port)] + base + ['--gpus', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['scaling'] == 'strong' and d['config']['workload'] == d1['config']['workload']
+    assert (d['sweeps'], d['solves']) == (d1['sweeps'], d1['solves'])
+    cols = [r['owned_columns'] for r in d['per_rank']]
+    assert cols[0][0] == 0 and cols[0][1] == cols[1][0] and cols[1][1] == 256
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # indefinite tangent stiffness on strips: the GMRES / MINRES fall-backs with owned-only sums and halo exchanges
 BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+02, -3.89722e+01, -5.30574e+05, -2.01886e+05,
