@@ -2175,6 +2175,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         return fail(c, PLFX_ERR_ARG, "grid %dx%d does not match the mesh", nx, ny);
     if (c->strip.on)  // the hierarchy, halo analysis and coarse child context of a strip belong to the grid they were set up for
         return fail(c, PLFX_ERR_STATE, "plfx_set_grid after plfx_set_strip: call plfx_set_mesh again");
+    c->sur_active = false;  // the levels are rebuilt below: level 0 points at the true operator again
     const int nrow = ny + 1;
     for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
         const int n1 = (e / ny) * nrow + e % ny;
