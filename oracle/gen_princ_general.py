@@ -44,6 +44,19 @@ def main():
         mt.elasticity(E=200.e3, nu=0.3)
         mt.plasticity(sy=100., tresca=True, sdim=3)
         rec['tresca_seq'] = mt.calc_seq(sig)
+        # 2-feature SVC of sdim = 3 (fixture svc_hill3d.npz: test_ml_plasticity's training): the features (J2 stress, polar angle
+        # on the deviatoric plane) come from the reference's create_scaled_input -> sig_princ, the decision function from the
+        # fixture's support vectors by its formula (pinned against scikit-learn by tests/test_oracle_golden.py)
+        zs = np.load(os.path.join(ROOT, 'tests', 'golden', 'svc_hill3d.npz'))
+        ml = FE.Material()
+        ml.elasticity(E=float(zs['par_E']), nu=float(zs['par_nu']))
+        ml.plasticity(sy=float(zs['par_sy']), hill=list(zs['par_hill']), sdim=3)
+        ml.scale_seq = float(zs['par_scale_seq'])
+        ml.Ndof = 2
+        x = ml.create_scaled_input(sig)
+        rec['ml3_x'] = x
+        d2 = np.sum((x[:, None, :] - zs['par_sv'][None, :, :]) ** 2, axis=2)
+        rec['ml3_yf'] = np.exp(-float(zs['par_gamma']) * d2) @ zs['par_dual'] + float(zs['par_intercept'])
     out = os.path.join(ROOT, 'tests', 'golden', 'princ_general.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, {k: v.shape for k, v in rec.items()})

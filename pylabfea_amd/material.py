@@ -488,13 +488,14 @@ class Material(object):
         return np.ascontiguousarray(s), single
 
     def _princ_rows(self, s):
-        """Principal-stress materials (sdim = 3: 3-parameter Hill) see a Voigt stress through ``basic.sig_princ`` -- the
+        """Principal-stress materials (sdim = 3: 3-parameter Hill; the 2-feature SVC, whose polar-angle feature is taken from
+        the principal stresses, basic.py:68-104) see a Voigt stress through ``basic.sig_princ`` -- the
         general eigen-solver ``np.linalg.eig`` plus the axis-tracking re-ordering (basic.py:153-175) -- and the ORDER of the
         principal stresses enters the Hill form (material.py:667-670).  For plane states (every state of a 2-d model) the
         device reproduces that order in closed form; for states with out-of-plane shear it depends on LAPACK's eigenvalue
         order, so those rows are reduced HERE with the very same LAPACK call and handed to the device as diagonal states
         (whose order the device keeps): the point functions then equal the reference for every stress state."""
-        if self.sdim != 3 or self.ML_yf or self.tresca or self.barlat:
+        if self.sdim != 3 or self.tresca or self.barlat:   # (Tresca, Barlat: symmetric in the principal values)
             return s
         gen = (s[:, 3] != 0.) | (s[:, 4] != 0.)
         if not np.any(gen):
@@ -570,7 +571,7 @@ class Material(object):
             if e.ndim == 1:
                 e = np.tile(e, (len(s), 1))
         if self.ML_yf and not ana:
-            f = self._load().yf(0, s, e)
+            f = self._load().yf(0, self._princ_rows(s), e)
             if pred:
                 f = np.where(f > 0., 1., -1.)
                 self.msg['yield_fct'] = 'ML_yf-predict'
