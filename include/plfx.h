@@ -167,7 +167,7 @@ int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
  * converged), the number of surrogate hierarchies built (one per operator that needed it) and the elements shifted in the
  * last one.  Any pointer may be NULL. */
 int plfx_indefinite_info(plfx_ctx *ctx, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres,
-                         int64_t *surrogates_built, int64_t *elements_replaced);
+                         int64_t *surrogates_built, int64_t *elements_shifted);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
  * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to
  * the diagonal) wherever plfx_set_grid found a structured grid with one element shape; kind 0 always assembles the

@@ -331,7 +331,7 @@ class Context(object):
         GMRES), surrogate hierarchies built, elements replaced in the last one (plfx_indefinite_info)"""
         v = [C.c_int64() for _ in range(5)]
         self._chk(self.lib.plfx_indefinite_info(self.h, *[C.byref(x) for x in v]))
-        return dict(zip(('solves', 'by_minres_surrogate', 'by_gmres', 'surrogates_built', 'elements_replaced'),
+        return dict(zip(('solves', 'by_minres_surrogate', 'by_gmres', 'surrogates_built', 'elements_shifted'),
                         [x.value for x in v]))
 
     def set_operator(self, kind):

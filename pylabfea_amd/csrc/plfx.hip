@@ -2483,14 +2483,14 @@ int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
 }
 
 int plfx_indefinite_info(plfx_ctx *c, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres, int64_t *surrogates_built,
-                         int64_t *elements_replaced)
+                         int64_t *elements_shifted)
 {
     if (!c) return PLFX_ERR_ARG;
     if (solves) *solves = c->n_minres;
     if (by_minres_surrogate) *by_minres_surrogate = c->n_sur_minres;
     if (by_gmres) *by_gmres = c->n_gmres;
     if (surrogates_built) *surrogates_built = c->n_sur;
-    if (elements_replaced) *elements_replaced = c->sur_replaced;
+    if (elements_shifted) *elements_shifted = c->sur_replaced;
     return PLFX_OK;
 }
 
