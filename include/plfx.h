@@ -146,6 +146,10 @@ int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t 
  * pass 0, nel for a single GPU. */
 int plfx_set_mesh(plfx_ctx *ctx, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
                   const double *lxy, double thick, int planestress, int el_begin, int el_end);
+/* Host-only self-test (no GPU needed): the closed-form block-ELL pattern that plfx_set_mesh / plfx_set_grid write for the
+ * reference's structured numbering equals the one derived generically from the connectivity (slots, gather codes, order).
+ * 0 = identical. */
+int plfx_pattern_selftest(int nx, int ny);
 /* Declare that the mesh is the reference's structured NX x NY grid (node j*(NY+1)+k, element j*NY+k,
  * model.py:893, 935); verified against conn.  Enables the geometric-multigrid preconditioner of
  * plfx_solve when all elements have one shape and NX, NY halve down to a small grid. */

@@ -51,7 +51,7 @@ SYMBOLS = [
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
-    'plfx_indefinite_info',
+    'plfx_indefinite_info', 'plfx_pattern_selftest',
 ]
 
 _lib = None

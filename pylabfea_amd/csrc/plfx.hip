@@ -163,7 +163,8 @@ struct plfx_ctx {
     int own_n0 = 0, own_n1 = 0;                    // disjoint node ownership for the sharded SpMV rows
     int nslot = 0, nq = 0;
     int32_t *dcol = nullptr, *dcontrib = nullptr;
-    std::vector<int32_t> hcol;
+    std::vector<int32_t> hcol;   // host copy of the neighbour slots (empty when the pattern is the closed-form structured one)
+    int pat_nx = 0, pat_ny = 0;  // > 0: structured nx x ny grid, pattern in closed form (structured_slot), hcol not kept
     double *dval = nullptr;
     int n_begin = 0, n_end = 0;  // node range touched by owned elements
     bool nonlin = false;
@@ -582,6 +583,37 @@ ClassDev make_class(const plfx_ctx *c, int mat, double lx, double ly)
 
 // Block-ELL pattern of the elements [e0, e1): per node the sorted neighbour list (slots) and, per
 // (node, slot), the element contributions (e_local*16 + a*4 + b) in ascending element order.
+// Is conn the reference's structured numbering of an nx x ny grid (model.py:893, 935-948), nx, ny >= 2?
+bool structured_dims(int nel, int nnode, const int32_t *conn, int *nx_out, int *ny_out)
+{
+    if (nel < 4) return false;
+    const int nyn = conn[2] - conn[0];   // first element: [0, 1, nyn, nyn + 1]
+    if (conn[0] != 0 || conn[1] != 1 || nyn < 3 || conn[3] != nyn + 1) return false;
+    const int ny = nyn - 1;
+    if (nel % ny) return false;
+    const int nx = nel / ny;
+    if (nx < 2 || (long long)(nx + 1) * nyn != nnode) return false;
+    for (int e = 0; e < nel; e++) {
+        const int n1 = (e / ny) * nyn + e % ny;
+        const int32_t *q = conn + 4 * (size_t)e;
+        if (q[0] != n1 || q[1] != n1 + 1 || q[2] != n1 + nyn || q[3] != n1 + nyn + 1) return false;
+    }
+    *nx_out = nx;
+    *ny_out = ny;
+    return true;
+}
+
+// neighbour node in slot s of node i on the host: closed form on structured grids, the stored pattern otherwise
+inline int host_col(const plfx_ctx *c, int s, int i)
+{
+    if (c->pat_nx > 0) {
+        int32_t cj, codes[4];
+        structured_slot(c->pat_nx, c->pat_ny, i, s, &cj, codes);
+        return cj;
+    }
+    return c->hcol[(size_t)s * c->nnode + i];
+}
+
 bool build_pattern(int nnode, const int32_t *conn, int el_begin, int el_end, std::vector<int32_t> &hcol,
                    std::vector<int32_t> &hcontrib, int &nslot, int &nq, int &nb, int &ne)
 {
@@ -1906,8 +1938,23 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     // The matrix (and its multigrid hierarchy) is assembled for the WHOLE mesh on every rank; a sharded
     // rank owns the material state of its x-strip only and the rows [own_n0, own_n1) of the CG SpMV.
     c->sharded = (nown != nel);
-    if (!build_pattern(nnode, conn, 0, nel, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
-        return fail(c, PLFX_ERR_ARG, "empty mesh");
+    // structured grids (every mesh of the reference's Model.mesh): slots and gather codes in closed form, written by a kernel
+    // below -- the generic derivation sorts the neighbourhood of every node on the host and uploads 180 B per node (0.4 of
+    // the 0.6 s of plfx_set_mesh at 2048^2)
+    static const bool closed_form = !(getenv("PLFX_PATTERN_CLOSED_FORM") && atoi(getenv("PLFX_PATTERN_CLOSED_FORM")) == 0);
+    c->pat_nx = c->pat_ny = 0;
+    c->hcol.clear();
+    c->hcol.shrink_to_fit();
+    if (closed_form && structured_dims(nel, nnode, conn, &c->pat_nx, &c->pat_ny)) {
+        nslot = 9;
+        nq = 4;
+        c->n_begin = 0;
+        c->n_end = nnode;
+    } else {
+        c->pat_nx = c->pat_ny = 0;
+        if (!build_pattern(nnode, conn, 0, nel, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
+            return fail(c, PLFX_ERR_ARG, "empty mesh");
+    }
     {
         int lo = nnode, nxt = nnode;
         for (int e = el_begin; e < el_end; e++)
@@ -1965,8 +2012,14 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     HIPCHK(c, hipMemcpyAsync(c->dconn, conn, (size_t)16 * nel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dcls_id, c->hcls_id.data() + el_begin, (size_t)4 * nown, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dcls_all, c->hcls_id.data(), (size_t)4 * nel, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dcol, c->hcol.data(), c->hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dcontrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->pat_nx > 0) {
+        hipLaunchKernelGGL(k_structured_pattern, dim3(grid_for(nnode)), dim3(256), 0, c->stream, c->pat_nx, c->pat_ny, c->dcol,
+                           c->dcontrib);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->dcol, c->hcol.data(), c->hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dcontrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->grid_nodes = grid_xcd(nnode);
     c->grid_el = grid_xcd(nown);
@@ -2060,20 +2113,27 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             continue;
         }
         L.owned = true;
-        std::vector<int32_t> conn((size_t)4 * L.nel), hcol, hcontrib;
-        const int nr = L.ny + 1;
-        for (int e = 0; e < L.nel; e++) {
-            const int n1 = (e / L.ny) * nr + e % L.ny;
-            conn[4 * (size_t)e] = n1;
-            conn[4 * (size_t)e + 1] = n1 + 1;
-            conn[4 * (size_t)e + 2] = n1 + nr;
-            conn[4 * (size_t)e + 3] = n1 + nr + 1;
+        std::vector<int32_t> conn, hcol, hcontrib;
+        const bool closed = L.nx >= 2 && L.ny >= 2 && !(getenv("PLFX_PATTERN_CLOSED_FORM") && atoi(getenv("PLFX_PATTERN_CLOSED_FORM")) == 0);
+        if (closed) {   // the levels are structured grids by construction: pattern in closed form, written on the device
+            L.nslot = 9;
+            L.nq = 4;
+        } else {
+            conn.resize((size_t)4 * L.nel);
+            const int nr = L.ny + 1;
+            for (int e = 0; e < L.nel; e++) {
+                const int n1 = (e / L.ny) * nr + e % L.ny;
+                conn[4 * (size_t)e] = n1;
+                conn[4 * (size_t)e + 1] = n1 + 1;
+                conn[4 * (size_t)e + 2] = n1 + nr;
+                conn[4 * (size_t)e + 3] = n1 + nr + 1;
+            }
+            int nb, ne;
+            if (!build_pattern(L.nnode, conn.data(), 0, L.nel, hcol, hcontrib, L.nslot, L.nq, nb, ne))
+                return fail(c, PLFX_ERR_ARG, "empty multigrid level");
         }
-        int nb, ne;
-        if (!build_pattern(L.nnode, conn.data(), 0, L.nel, hcol, hcontrib, L.nslot, L.nq, nb, ne))
-            return fail(c, PLFX_ERR_ARG, "empty multigrid level");
-        if ((rc = dalloc(c, &L.col, hcol.size()))) return rc;
-        if ((rc = dalloc(c, &L.contrib, hcontrib.size()))) return rc;
+        if ((rc = dalloc(c, &L.col, (size_t)L.nslot * L.nnode))) return rc;
+        if ((rc = dalloc(c, &L.contrib, (size_t)L.nslot * L.nq * L.nnode))) return rc;
         if ((rc = dalloc(c, &L.cls0, (size_t)L.nel))) return rc;
         if ((rc = dalloc(c, &L.val, (size_t)L.nslot * 4 * L.nnode))) return rc;
         if ((rc = dalloc(c, &L.diag, (size_t)2 * L.nnode))) return rc;
@@ -2081,8 +2141,13 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
         if ((rc = dalloc(c, &L.Mel, (size_t)6 * L.nel))) return rc;
         if ((rc = dalloc(c, &L.x, (size_t)2 * L.nnode))) return rc;
         if ((rc = dalloc(c, &L.b, (size_t)2 * L.nnode))) return rc;
-        HIPCHK(c, hipMemcpyAsync(L.col, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(L.contrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+        if (closed) {
+            hipLaunchKernelGGL(k_structured_pattern, dim3(grid_for(L.nnode)), dim3(256), 0, c->stream, L.nx, L.ny, L.col, L.contrib);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            HIPCHK(c, hipMemcpyAsync(L.col, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L.contrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     {
@@ -2454,6 +2519,37 @@ int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t 
     return PLFX_OK;
 }
 
+int plfx_pattern_selftest(int nx, int ny)
+{
+    // closed-form pattern of a structured grid (structured_slot) against the generic derivation from the connectivity
+    if (nx < 2 || ny < 2 || (int64_t)(nx + 1) * (ny + 1) > (1 << 24)) return PLFX_ERR_ARG;
+    const int nel = nx * ny, nnode = (nx + 1) * (ny + 1), nyn = ny + 1;
+    std::vector<int32_t> conn((size_t)4 * nel), hcol, hcontrib;
+    for (int e = 0; e < nel; e++) {
+        const int n1 = (e / ny) * nyn + e % ny;
+        conn[4 * (size_t)e] = n1;
+        conn[4 * (size_t)e + 1] = n1 + 1;
+        conn[4 * (size_t)e + 2] = n1 + nyn;
+        conn[4 * (size_t)e + 3] = n1 + nyn + 1;
+    }
+    int gx = 0, gy = 0;
+    if (!structured_dims(nel, nnode, conn.data(), &gx, &gy) || gx != nx || gy != ny) return 1;
+    int nslot = 0, nq = 0, nb = 0, ne = 0;
+    if (!build_pattern(nnode, conn.data(), 0, nel, hcol, hcontrib, nslot, nq, nb, ne)) return 2;
+    if (nslot != 9 || nq != 4 || nb != 0 || ne != nnode) return 3;
+    for (int i = 0; i < nnode; i++)
+        for (int s = 0; s < 9; s++) {
+            int32_t cj, codes[4];
+            structured_slot(nx, ny, i, s, &cj, codes);
+            if (cj != hcol[(size_t)s * nnode + i]) return 4;
+            for (int q = 0; q < 4; q++)
+                if (codes[q] != hcontrib[((size_t)s * 4 + q) * nnode + i]) return 5;
+        }
+    std::swap(conn[4], conn[5]);  // any other numbering is not "structured"
+    if (structured_dims(nel, nnode, conn.data(), &gx, &gy)) return 6;
+    return PLFX_OK;
+}
+
 int plfx_set_precond(plfx_ctx *c, int kind, double omega, int nu)
 {
     if (!c) return PLFX_ERR_STATE;
@@ -2695,7 +2791,7 @@ int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, do
     for (int i = 0; i < nn; i++) {
         int k = 0;
         for (int s = 0; s < ns; s++)
-            if (c->hcol[(size_t)s * nn + i] >= 0) k++;
+            if (host_col(c, s, i) >= 0) k++;
         cnt += 4 * (int64_t)k;
     }
     if (nnz) *nnz = cnt;
@@ -2712,7 +2808,7 @@ int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, do
         for (int rr = 0; rr < 2; rr++) {
             rowptr[2 * i + rr] = (int32_t)pos;
             for (int s = 0; s < ns; s++) {
-                const int j = c->hcol[(size_t)s * nn + i];
+                const int j = host_col(c, s, i);
                 if (j < 0) continue;
                 for (int cc = 0; cc < 2; cc++) {
                     colidx[pos] = 2 * j + cc;
@@ -2760,7 +2856,7 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
             for (int k = 0; k < n; k++) {
                 const int i = idx[k] >> 1;
                 for (int s2 = 0; s2 < c->nslot; s2++) {
-                    const int j = c->hcol[(size_t)s2 * nn + i];
+                    const int j = host_col(c, s2, i);
                     if (j >= 0) mark[j] = 1;  // the pattern is symmetric: j has i as a neighbour
                 }
             }

@@ -838,6 +838,56 @@ __host__ __device__ __forceinline__ size_t gen_index(bool pair, int c, size_t ne
 }
 
 // ---------------------------------------------------------------------------------------------
+// Block-ELL pattern of the reference's STRUCTURED grid in closed form (what build_pattern() derives from the connectivity
+// by sorting: same slots, same gather codes, same order).  Node i = j * (ny + 1) + k, element e = ej * ny + ek with the
+// local nodes 0:(ej,ek) 1:(ej,ek+1) 2:(ej+1,ek) 3:(ej+1,ek+1) (model.py:893, 935-948).  Slot s of node i = the s-th of its
+// neighbour nodes (itself included) in ascending node order; its <= 4 gather codes e*16 + a*4 + b (a / b: local numbers of
+// node i / the neighbour in element e) in ascending element order -- the reference's addition order.  Needs nx, ny >= 2
+// (then nslot = 9, nq = 4).
+__host__ __device__ inline void structured_slot(int nx, int ny, int i, int s, int32_t *col, int32_t *codes /* [4] */)
+{
+    const int nyn = ny + 1;
+    const int j = i / nyn, k = i - j * nyn;
+    const int jlo = j > 0 ? j - 1 : 0, jhi = j < nx ? j + 1 : nx;
+    const int klo = k > 0 ? k - 1 : 0, khi = k < ny ? k + 1 : ny;
+    const int nkk = khi - klo + 1, cnt = (jhi - jlo + 1) * nkk;
+    codes[0] = codes[1] = codes[2] = codes[3] = -1;
+    if (s >= cnt) {
+        *col = -1;
+        return;
+    }
+    const int jj = jlo + s / nkk, kk = klo + s % nkk;
+    *col = jj * nyn + kk;
+    int qn = 0;
+    for (int ej = j - 1; ej <= j; ej++) {
+        if (ej < 0 || ej >= nx || jj < ej || jj > ej + 1) continue;
+        for (int ek = k - 1; ek <= k; ek++) {
+            if (ek < 0 || ek >= ny || kk < ek || kk > ek + 1) continue;
+            const int e = ej * ny + ek, a = (j - ej) * 2 + (k - ek), b = (jj - ej) * 2 + (kk - ek);
+            codes[qn++] = e * 16 + a * 4 + b;
+        }
+    }
+}
+
+// col[s * nnode + i], contrib[(s * 4 + q) * nnode + i] of a structured nx x ny grid, filled on the device (no host pattern,
+// no upload: 180 B per node)
+__global__ void __launch_bounds__(256)
+k_structured_pattern(int nx, int ny, int32_t *__restrict__ col, int32_t *__restrict__ contrib)
+{
+    const int nnode = (nx + 1) * (ny + 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nnode; i += gridDim.x * 256) {
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            int32_t cj, codes[4];
+            structured_slot(nx, ny, i, s, &cj, codes);
+            col[(size_t)s * nnode + i] = cj;
+#pragma unroll
+            for (int q = 0; q < 4; q++) contrib[((size_t)s * 4 + q) * nnode + i] = codes[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Assembly (model.py:954-977) as a gather: thread (node i, slot s) sums the <= nq element
 // contributions of block K[i, col(s)] in ascending element order.  contrib code = e*16 + a*4 + b
 // (e local owned-element index, a/b local node numbers), -1 = none.

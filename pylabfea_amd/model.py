@@ -320,11 +320,11 @@ class Model(object):
         self.Ndof = self.Nnode * 2
         self.Nel = NX * NY
         nrow = self.NnodeY
-        npos = np.zeros(self.Ndof)
-        jj, kk = np.meshgrid(np.arange(self.NnodeX), np.arange(nrow), indexing='ij')
-        inode = (jj * nrow + kk)
+        # node (j, k) has number j * nrow + k (model.py:893): in that order the node numbers are 0 .. Nnode-1, so the
+        # interleaved position array is filled by slices (no index arrays of the size of the mesh)
+        npos = np.empty(self.Ndof)
         dy = self.leny / NY
-        npos[2 * inode.ravel() + 1] = (kk * dy).ravel()
+        npos[1::2] = np.tile(np.arange(nrow) * dy, self.NnodeX)
         if elmts is None:
             # elements per section: proportional, the largest section absorbs the remainder (:826-830)
             hh = self.LS / self.lenx
@@ -345,26 +345,36 @@ class Model(object):
                 mat_col[c0:c0 + nes[i]] = i
                 dx_col[c0:c0 + nes[i]] = dx
                 c0 += nes[i]
-            npos[2 * inode.ravel()] = np.repeat(xcol, nrow)
+            npos[0::2] = np.repeat(xcol, nrow)
             mat_id = np.repeat(mat_col, NY)
-            lxy = np.stack((np.repeat(dx_col, NY), np.full(self.Nel, dy)), axis=1)
+            lxy = np.empty((self.Nel, 2))
+            lxy[:, 0] = np.repeat(dx_col, NY)
+            lxy[:, 1] = dy
         else:
             dx = self.lenx / NX
-            npos[2 * inode.ravel()] = (jj * dx).ravel()
+            npos[0::2] = np.repeat(np.arange(self.NnodeX) * dx, nrow)
             mat_id = (el - 1).ravel().astype(np.int64)
             if mat_id.min() < 0 or mat_id.max() >= len(self.mat):
                 raise IndexError('mesh: material number in elmts out of range')
-            lxy = np.stack((np.full(self.Nel, dx), np.full(self.Nel, dy)), axis=1)
+            lxy = np.empty((self.Nel, 2))
+            lxy[:, 0] = dx
+            lxy[:, 1] = dy
         self.npos = npos
         # boundary node lists in the reference's append order (:897-911): j outer, k inner
-        self.noleft = [int(n) for n in inode[0, :]]
-        self.noright = [int(n) for n in inode[-1, :]]
-        self.nobot = [int(n) for n in inode[:, 0]]
-        self.notop = [int(n) for n in inode[:, -1]]
-        self.noinner = [int(n) for n in inode[1:-1, 1:-1].ravel()]
-        ih = np.arange(self.Nel)
+        self.noleft = list(range(nrow))
+        self.noright = list(range(NX * nrow, NX * nrow + nrow))
+        self.nobot = list(range(0, self.NnodeX * nrow, nrow))
+        self.notop = list(range(NY, self.NnodeX * nrow, nrow))
+        self._noinner = None          # (NX-1)(NY-1) entries: materialised on first access (property noinner)
+        # connectivity [n1, n1+1, n1+nrow, n1+nrow+1], n1 = (ih // NY) * nrow + ih % NY (:936-948); int32 like the library
+        ih = np.arange(self.Nel, dtype=np.int32)
         n1 = (ih // NY) * nrow + ih % NY
-        self._conn = np.stack((n1, n1 + 1, n1 + nrow, n1 + nrow + 1), axis=1).astype(np.int64)
+        conn = np.empty((self.Nel, 4), dtype=np.int32)
+        conn[:, 0] = n1
+        conn[:, 1] = n1 + 1
+        conn[:, 2] = n1 + nrow
+        conn[:, 3] = n1 + nrow + 1
+        self._conn = conn
         self._mat_id = mat_id
         self._lxy = lxy
         self._NX, self._NY = NX, NY
@@ -374,6 +384,19 @@ class Model(object):
         self._bc_struct = None
         self._bc_registered = None
         self._drop_engine()
+
+    @property
+    def noinner(self):
+        """nodes that are on no edge, in the reference's append order (model.py:897-911: j outer, k inner)"""
+        if self._noinner is None:
+            nrow = self.NnodeY
+            j, k = np.meshgrid(np.arange(1, self.NnodeX - 1), np.arange(1, nrow - 1), indexing='ij')
+            self._noinner = (j * nrow + k).ravel().tolist()
+        return self._noinner
+
+    @noinner.setter
+    def noinner(self, v):
+        self._noinner = v
 
     # ------------------------------------------------------------------ engine plumbing
     def _drop_engine(self):

@@ -136,3 +136,14 @@ def test_free_dofs_match_reference_ind(golden_dir):
     assert list(noc) == [0]
     fe.bcnode(noc, 0., 'disp', 'x')
     assert np.array_equal(fe.free_dofs(), z['bcnode18_ind'])
+
+
+def test_structured_pattern_closed_form_equals_generic():
+    """plfx_set_mesh / plfx_set_grid write the block-ELL pattern of the reference's structured numbering (model.py:893,
+    935-948) in closed form; it must equal the pattern derived generically from the connectivity -- neighbour slots in
+    ascending node order, gather codes in ascending element order (the reference's addition order, model.py:954-977)"""
+    from pylabfea_amd import _lib
+    lib = _lib.load()
+    for nx, ny in ((2, 2), (2, 7), (9, 2), (5, 3), (16, 16), (31, 18), (64, 33)):
+        assert lib.plfx_pattern_selftest(nx, ny) == 0, (nx, ny)
+    assert lib.plfx_pattern_selftest(1, 4) < 0       # needs nx, ny >= 2 (narrower grids use the generic derivation)
