@@ -826,20 +826,33 @@ class Model(object):
     # collectives of the host-side scalars of the Python load-step driver (sharded runs whose library communicator is the
     # host-staged transport): through the library's own communicator (plfx_allreduce_host) -- the package itself needs no
     # process-group library; sums / minima are identical on every rank
+    def _host_reduce(self, values, op):
+        """all-reduce <= 32 host doubles (op 0 sum, 3 min): through the engine's communicator, or -- before an engine
+        exists -- through the host-transport callback given to ``distribute``"""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if self._engine is not None:
+            return self._engine.allreduce_host(v, op=op)
+        fn = getattr(self, '_host_allreduce', None)
+        if fn is None:
+            raise RuntimeError('sharded model without a communicator: call distribute(rank, nranks, uid | host_allreduce=...)')
+        out = v.copy()
+        fn(out, op)
+        return out
+
     def _allreduce_sum(self, x):
         v = np.atleast_1d(np.asarray(x, dtype=np.float64))
         out = np.empty_like(v)
         for i in range(0, len(v), 32):           # plfx_allreduce_host takes <= 32 doubles per call
-            out[i:i + 32] = self._engine.allreduce_host(v[i:i + 32], op=0)
+            out[i:i + 32] = self._host_reduce(v[i:i + 32], 0)
         return out if np.ndim(x) else float(out[0])
 
     def _allreduce_scf(self, cnt, mn, s):
-        g = self._engine.allreduce_host(np.array([cnt, s], dtype=np.float64), op=0)
-        m = self._engine.allreduce_host(np.array([mn], dtype=np.float64), op=3)
+        g = self._host_reduce(np.array([cnt, s], dtype=np.float64), 0)
+        m = self._host_reduce(np.array([mn], dtype=np.float64), 3)
         return int(round(g[0])), float(m[0]), float(g[1])
 
     def _allreduce_flags(self, change, conv):
-        g = self._engine.allreduce_host(np.array([float(change), float(not conv)]), op=0)
+        g = self._host_reduce(np.array([float(change), float(not conv)]), 0)
         return bool(g[0] > 0.), not bool(g[1] > 0.)
 
     # ------------------------------------------------------------------ solution

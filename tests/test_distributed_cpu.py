@@ -63,7 +63,8 @@ def _worker(rank, world, port, q):
         from oracle import oracle as O
         from oracle.solve_ref import RefSolver
         fe = make_model(12)
-        fe._shard = (rank, world, b'\0' * 128)      # host-side collectives only; no engine is created
+        fe._shard = (rank, world, None)             # host-side collectives only; no engine is created
+        fe._host_allreduce = FE.host_transport(dist, rank, world)
         # --- scalar collectives of the façade
         ch, cv = fe._allreduce_flags(rank == 1, rank == 0)
         assert bool(ch) is True and bool(cv) is False
