@@ -350,7 +350,7 @@ def main():
                     help='BASELINE.json configs[2] (default, the configuration the metric is quoted on) or configs[4]')
     ap.add_argument('--weak', action='store_true',
                     help='N>1: weak scaling (N strips of mesh x mesh elements side by side) instead of strong scaling of the same mesh')
-    ap.add_argument('--cpu-mesh', type=int, default=224)
+    ap.add_argument('--cpu-mesh', type=int, default=448)
     ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-inclusion', action='store_true', help='skip the heterogeneous (soft inclusion) variant of the workload')
