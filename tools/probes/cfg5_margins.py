@@ -1,8 +1,10 @@
+"""Margins of the size-independent property tests of BASELINE config 5 (tests/test_gpu_configs.py): measured differences
+against their tolerances.  python tools/probes/cfg5_margins.py"""
 import sys, os, warnings, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-os.chdir('/root/repo')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_gpu_configs as T
-g = os.path.join('/root/repo', 'tests', 'golden')
+g = os.path.join(ROOT, 'tests', 'golden')
 def run(nx, ny, steps=None):
     fe = T.laminate_cfg5(g, nx, ny)
     if steps: fe._max_load_steps = steps
