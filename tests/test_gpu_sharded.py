@@ -286,7 +286,7 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world, monkeypatch):
     assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
 
 
-@pytest.mark.parametrize('mode', ['strong', 'weak'])
+@pytest.mark.parametrize('mode', ['strong', 'weak', 'strong4'])
 def test_bench_two_ranks(tmp_path, mode):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
     ONE GPU over the host-staged transport (PLFX_BENCH_TRANSPORT=host; RCCL refuses two ranks on a device).  Default =
@@ -300,26 +300,32 @@ def test_bench_two_ranks(tmp_path, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = free_port()
     env = dict(os.environ, PLFX_BENCH_TRANSPORT='host')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--mesh', '128'] + (['--weak'] if mode == 'weak' else [])
+    # 'strong4': four strips of 128 owned + 2 x 32 halo columns, hand-over level 3 -- the geometry of the driver's 8-GPU run of
+    # the 1024 x 1024 mesh (profiles/r03u_*: that run itself, 4 and 8 ranks on one GPU)
+    nr, mesh = (4, 512) if mode == 'strong4' else (2, 128)
+    mode = 'strong' if mode == 'strong4' else mode
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nr), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nr), '--steps', '3', '--warmup', '1',
+           '--mesh', str(mesh)] + (['--weak'] if mode == 'weak' else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     assert out.stdout.strip().splitlines()[-1] == line          # the JSON line is the last thing printed
     d = json.loads(line)
     strips = 2 if mode == 'weak' else 1
-    assert d['n_gpus'] == 2 and d['scaling'] == mode and d['steps'] == 3 and d['dtype'] == 'f64'
-    assert d['config']['elements'] == strips * 128 * 128 and 'strip-local engine x2' in d['config']['parallelism']
-    assert ('%dx128 Q4' % (strips * 128)) in d['config']['workload'] and (mode + ' scaling') in d['config']['parallelism']
+    assert d['n_gpus'] == nr and d['scaling'] == mode and d['steps'] == 3 and d['dtype'] == 'f64'
+    assert d['config']['elements'] == strips * mesh * mesh and ('strip-local engine x%d' % nr) in d['config']['parallelism']
+    assert ('%dx%d Q4' % (strips * mesh, mesh)) in d['config']['workload'] and (mode + ' scaling') in d['config']['parallelism']
     assert d['strip_collectives']['halo_refreshes'] > 0 and d['strip_collectives']['coarse_gathers'] > 0
     assert d['roofline'] is not None and d['cpu_baseline'] is None
-    assert [r['rank'] for r in d['per_rank']] == [0, 1] and all(r['roofline'] is not None for r in d['per_rank'])
+    assert [r['rank'] for r in d['per_rank']] == list(range(nr)) and all(r['roofline'] is not None for r in d['per_rank'])
     cols = [r['owned_columns'] for r in d['per_rank']]
-    assert cols[0][0] == 0 and cols[0][1] == cols[1][0] and cols[1][1] == strips * 128       # the strips tile the mesh
+    assert cols[0][0] == 0 and cols[-1][1] == strips * mesh and all(a[1] == b[0] for a, b in zip(cols[:-1], cols[1:]))   # the strips tile the mesh
+    if nr == 4:
+        assert all(r['halo_columns'] == 32 for r in d['per_rank']) and [c[1] - c[0] for c in cols] == [128] * 4
     # the same workload on one rank: identical counts (and, for strong scaling, the identical workload string)
     sys.path.insert(0, root)
-    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--mesh', '128',
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--mesh', str(mesh),
                           '--no-cpu', '--no-svc', '--no-inclusion', '--no-2048'], capture_output=True, text=True, timeout=900, cwd=root)
     assert one.returncode == 0, one.stderr[-3000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
