@@ -560,7 +560,7 @@ def main():
     out = {
         'metric': 'integration-point updates/sec (wall-clock per load step in ms_per_step)',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak' if (weak or world == 1) else 'strong',
+        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'none' if world == 1 else ('weak' if weak else 'strong'),
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': ('%s Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
                                 'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
@@ -604,6 +604,13 @@ def main():
                          'note': 'whole V(2,2) cycle (HIP events, every %d-th cycle); fine level = 4 operator passes at the rate of the '
                                  'roofline kernel; the rest (levels >= 1: transfers, 24 launch-latency-bound kernels replayed from a hipGraph, '
                                  'single-workgroup tail) is latency-bound and has no roofline' % args.sample}
+        if world == 1 and eng.precond_info()[0] == 1:
+            # the same cycle measured WITHOUT the solver around it: 200 applications back to back between one pair of HIP events
+            # (plfx_precond_bench), and the part below the fine level alone -- reproducible to 1 %, where the in-run figure above
+            # carries the sampling events and whatever the stream did before each sampled cycle
+            tl = min(eng.precond_bench(200) for _ in range(3))
+            out['vcycle']['tight_loop_us'] = tl[0]
+            out['vcycle']['tight_loop_coarse_levels_us'] = tl[1]
     if dist is not None:
         # per-rank view: roofline of the dominant kernel on every rank's own strip, and the time its stream spent in
         # collectives (HIP events around every RCCL call: includes the wait for the slowest peer)

@@ -158,6 +158,11 @@ int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
  * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.65, 2) */
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
+/* measurement hook (bench.py: `vcycle`): `reps` applications of the multigrid preconditioner back to back on the current
+ * residual vector, one pair of HIP events around them -> microseconds per V-cycle; us_coarse (may be NULL): the part of a cycle
+ * below the fine level (transfers to / from level 1, the launch-latency-bound levels, the single-workgroup tail).  Only scratch
+ * vectors are written.  Single-GPU hierarchies (no strip). */
+int plfx_precond_bench(plfx_ctx *ctx, int reps, double *us_per_cycle, double *us_coarse);
 /* number of plfx_solve calls so far that PCG could not finish: a direction of negative curvature was met (the tangents of
  * Material.response are not always positive semi-definite, material.py:324-338) and the indefinite-system solver completed
  * the solve from the last iterate (right-preconditioned GMRES by default; PLFX_INDEFINITE_SOLVER=surrogate / minres:

@@ -51,7 +51,7 @@ SYMBOLS = [
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
-    'plfx_indefinite_info', 'plfx_pattern_selftest',
+    'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench',
 ]
 
 _lib = None
@@ -319,6 +319,12 @@ class Context(object):
         lv = C.c_int()
         self._chk(self.lib.plfx_precond_info(self.h, C.byref(k), C.byref(lv)))
         return k.value, lv.value
+
+    def precond_bench(self, reps=100):
+        """(microseconds per V-cycle, microseconds of it below the fine level) from `reps` back-to-back applications"""
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.lib.plfx_precond_bench(self.h, int(reps), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def solve_fallbacks(self):
         """solves completed by Jacobi-PCG after multigrid-PCG broke down or stalled"""

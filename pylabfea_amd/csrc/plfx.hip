@@ -2079,8 +2079,11 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     int rc;
     std::vector<std::pair<int, int>> dims;
     dims.push_back({nx, ny});
-    while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 &&
-           (long long)dims.back().first * dims.back().second > 4)
+    // coarsening stops at <= 16 elements (4 x 4: 25 nodes, 50 DOFs -- solved with the dense inverse, MG_DENSE_MAX); round 3
+    // went on to 2 x 2, one more level of six workgroup-barrier phases in every cycle (PLFX_MG_COARSEST_ELEMS=4 restores it)
+    static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 16;
+    while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 && (long long)dims.back().first * dims.back().second > 4 &&
+           ((long long)dims.back().first * dims.back().second > coarsest || dims.size() < 2))  // (at least two levels)
         dims.push_back({dims.back().first / 2, dims.back().second / 2});
     if (dims.size() < 2) return PLFX_OK;
     if (!c->mg_cls) {
@@ -2588,6 +2591,55 @@ int plfx_indefinite_info(plfx_ctx *c, int64_t *solves, int64_t *by_minres_surrog
     if (surrogates_built) *surrogates_built = c->n_sur;
     if (elements_shifted) *elements_shifted = c->sur_replaced;
     return PLFX_OK;
+}
+
+// measurement hook: `reps` applications of the preconditioner (z = M^-1 r on whatever r holds) back to back, timed with one
+// pair of HIP events; *us_coarse = the same with the fine level's launches left out (levels >= 1 only: the restriction to
+// level 1, the launch-latency-bound levels, the single-workgroup tail, the prolongation to level 0).
+int plfx_precond_bench(plfx_ctx *c, int reps, double *us_per_cycle, double *us_coarse)
+{
+    if (!c || !mg_active(c) || c->strip.on) return c ? fail(c, PLFX_ERR_STATE, "needs the multigrid hierarchy of a single-GPU solve") : PLFX_ERR_STATE;
+    if (reps < 1) reps = 1;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipMemsetAsync(&c->sc->done, 0, sizeof(int), c->stream));  // the fine-level kernels are no-ops while it is set
+    int rc = 0;
+    float ms = 0.f;
+    for (int w = 0; w < 3 && !rc; w++) rc = mg_vcycle(c);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int k = 0; k < reps && !rc; k++) rc = mg_vcycle(c);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    if (us_per_cycle) *us_per_cycle = 1e3 * ms / reps;
+    if (us_coarse && !rc) {
+        const int nl = (int)c->mg.size();
+        const int lt = (c->mg_tail > 0) ? c->mg_tail : nl - 1;
+        auto coarse_only = [&]() -> int {
+            if (lt < 2 || !c->want_mg_graph) return mg_coarse_part(c);
+            if (!c->mg_graph_exec) return mg_vcycle_rest(c);  // (captures the graph; not reached after the cycles above)
+            return hipGraphLaunch(c->mg_graph_exec, c->stream) == hipSuccess ? 0 : PLFX_ERR_HIP;
+        };
+        auto &L = c->mg[0];
+        auto &C1 = c->mg[1];
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int k = 0; k < reps && !rc; k++) {
+            hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C1.nnode)), dim3(BLOCK), 0, c->stream, C1.nx + 1, C1.ny + 1, L.nx + 1, L.ny + 1,
+                               (const double2 *)L.res, (const double2 *)C1.dinv, (double2 *)C1.b);
+            rc = coarse_only();
+            hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1, C1.ny + 1,
+                               (const double2 *)C1.x, (const double2 *)L.dinv, (double2 *)L.x);
+        }
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        *us_coarse = 1e3 * ms / reps;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    c->x_is_du = c->x_is_du && true;  // (c->x untouched: z and the level vectors are scratch outside a solve)
+    return rc;
 }
 
 int plfx_solve_fallbacks(plfx_ctx *c, int64_t *count)

@@ -1046,12 +1046,12 @@ __device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const
     return make_double2(qx, qy);
 }
 
-// the same with the generators in pair layout: mf2(q) = pair number q = c2 * nel + e
-template <class MF2, class XF>
-__device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf)
+// the same with the generators in pair layout: mf2(q) = pair number q = c2 * nel + e; the vector comes as xjk(jj, kk) = entry
+// of node (column jj, row kk) (callers that interpolate the entry on the fly need the grid position, not the node number)
+template <class MF2, class XJK>
+__device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel, const double *tab, int j, int k, MF2 mf2, XJK xjk)
 {
     const int nye = nyn - 1, nxe = nxn - 1;
-    const int j = i / nyn, k = i - j * nyn;
     double2 u[3][3];
 #pragma unroll
     for (int dj = 0; dj < 3; dj++) {
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, c
 #pragma unroll
         for (int dk = 0; dk < 3; dk++) {
             const int kk = min(max(k + dk - 1, 0), nye);
-            u[dj][dk] = xf(jj * nyn + kk);
+            u[dj][dk] = xjk(jj, kk);
         }
     }
     double m[4][6];
@@ -1103,6 +1103,13 @@ __device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, c
             qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
         }
     return make_double2(qx, qy);
+}
+
+template <class MF2, class XF>
+__device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf)
+{
+    const int j = i / nyn, k = i - j * nyn;
+    return grid_apply_pairs_jk(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); });
 }
 
 template <class XF>
