@@ -79,7 +79,10 @@ typedef struct plfx_material {
                             * (calc_fgrad raises, material.py:822-825) -- plfx_fgrad_batch / plfx_response_batch / plfx_sweep
                             * refuse it.  1 (EXTENSION, north star "Barlat ... with their normals"): the analytic normal
                             * d seq / d sigma of Yld2004-18p through the eigen-decompositions of the two transformed deviators,
-                            * associated flow rule like the Hill materials. */
+                            * associated flow rule like the Hill materials.  NO REFERENCE VALUE EXISTS for this branch: the
+                            * reference raises for Barlat normals (material.py:822-825), so its parity is "unpinned" in the sense
+                            * of DESIGN.md 4 -- it is held by central finite differences of the pinned calc_seqB, Euler's theorem
+                            * (a . sigma = seq) and the identity "unit coefficients, a = 2" == J2 (tests/test_barlat_normal.py). */
     int32_t _pad2;
     double scale_wh;    /* PLFX_SVC_WH: scaling of the plastic-strain features (Material.scale_wh, material.py:1165-1172) */
 } plfx_material;

@@ -792,8 +792,10 @@ int ensure_tmp(plfx_ctx *c, size_t n)
 
 bool matfree(const plfx_ctx *c) { return c->grid_ok && c->want_matfree; }
 // Marching form of the finest-grid operator kernels (grid_march): PLFX_MARCH=0 never, =1 always; default: the PCG operator
-// kernel always (faster at every size measured), the three V-cycle kernels when one operator pass (112 B per node) does not
-// fit the 256 MiB Infinity Cache -- below that the gather form is as fast or faster (tools/probes/march_probe.hip)
+// kernel always (faster at every size measured), the three V-cycle kernels when one operator pass (112 B per node) exceeds
+// 192 MiB -- three quarters of the 256 MiB Infinity Cache: a pass shares the cache with the other vectors of the cycle, and the
+// gather form starts to re-fetch before the pass alone fills it (1448^2 nodes; measured cross-over between 1024^2, where the
+// gather form is as fast or faster, and 2048^2, where marching wins by 20 %, tools/probes/march_probe.hip)
 int march_env()
 {
     static const int v = getenv("PLFX_MARCH") ? atoi(getenv("PLFX_MARCH")) : -1;
@@ -1291,6 +1293,9 @@ int mg_vcycle_head(plfx_ctx *c)
     return 0;
 }
 
+// INVARIANT: only the finest level's kernels test sc->done.  The levels >= 1, the hipGraph replay and a strip's
+// child context (which shares c->sc) must therefore never be enqueued speculatively or while the flag is sticky: every caller
+// of mg_vcycle_rest has either seen done == 0 from cg_check_wait or has just cleared it (k_cg_setup, plfx_precond_bench).
 int mg_vcycle_rest(plfx_ctx *c)
 {
     if (c->strip_jacobi) {  // Jacobi fall-back of a strip: same PCG loop, same exchanges, z = D^-1 r on the local grid

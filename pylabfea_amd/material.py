@@ -26,15 +26,32 @@ _point_ctx = {}        # shared contexts for point evaluations, one per GPU (eac
 
 
 def point_device():
-    """GPU of the point-evaluation context: PLFX_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else 0.
-    Taken modulo the number of visible GPUs, so that several ranks sharing one GPU (host transport, tests) all find a
-    device; negative or non-numeric values are ignored."""
-    for var in ('PLFX_DEVICE', 'LOCAL_RANK'):
-        v = os.environ.get(var)
-        if v is not None and v.strip().isdigit():
-            n = _lib.device_count()
-            return int(v) % n if n > 0 else 0
+    """GPU of the point-evaluation context: PLFX_DEVICE (an explicit choice: must name a visible GPU, like
+    ``Model(device=...)``), else LOCAL_RANK (one process per GPU under torchrun; taken modulo the number of visible GPUs so
+    that several ranks sharing one GPU -- host transport, tests -- all find a device), else 0."""
+    n = _lib.device_count()
+    v = os.environ.get('PLFX_DEVICE')
+    if v is not None and v.strip().isdigit():
+        if n > 0 and int(v) >= n:
+            raise ValueError('PLFX_DEVICE=%s, but only %d GPU(s) are visible' % (v.strip(), n))
+        return int(v)
+    v = os.environ.get('LOCAL_RANK')
+    if v is not None and v.strip().isdigit():
+        return int(v) % n if n > 0 else 0
     return 0
+
+
+try:    # the support-vector tables (~90 KB) are digested on every point call (in-place edits must be seen): xxh3 does it in
+    import xxhash as _xxhash   # ~8 us where blake2b needs ~100 us (ADVICE r3); blake2b when the module is absent
+except ImportError:  # pragma: no cover
+    _xxhash = None
+
+
+def _table_digest(a):
+    """16-byte digest of the CONTENT of a contiguous array"""
+    if _xxhash is not None:
+        return _xxhash.xxh3_128_digest(a.data)
+    return hashlib.blake2b(a.data, digest_size=16).digest()
 
 
 def _ctx():
@@ -455,7 +472,7 @@ class Material(object):
         h.update(bytes(m))
         m.sv, m.dual, m.khard = sv_ptr, dual_ptr, kh
         for a in keep:
-            h.update(np.ascontiguousarray(a).data)
+            h.update(_table_digest(np.ascontiguousarray(a)))
         return h.digest()
 
     def _load(self, CV=None, ana=False):
@@ -494,7 +511,11 @@ class Material(object):
         principal stresses enters the Hill form (material.py:667-670).  For plane states (every state of a 2-d model) the
         device reproduces that order in closed form; for states with out-of-plane shear it depends on LAPACK's eigenvalue
         order, so those rows are reduced HERE with the very same LAPACK call and handed to the device as diagonal states
-        (whose order the device keeps): the point functions then equal the reference for every stress state."""
+        (whose order the device keeps): ``calc_seq`` and ``calc_yf`` then equal the reference for every stress state
+        (fixture ``tests/golden/princ_general.npz``).  SCOPE: the guarantee covers these two; ``ML_full_yf``, ``calc_fgrad``
+        with a (6,) stress and ``response`` hand the Voigt state to the device as it is, where a general 3-d state follows the
+        device's closed-form rule -- identical to the reference for plane states (all a 2-d ``Model`` ever produces), and for
+        states with out-of-plane shear only up to the order in which LAPACK happens to return the eigenvalues."""
         if self.sdim != 3 or self.tresca or self.barlat:   # (Tresca, Barlat: symmetric in the principal values)
             return s
         gen = (s[:, 3] != 0.) | (s[:, 4] != 0.)
