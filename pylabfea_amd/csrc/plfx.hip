@@ -249,7 +249,8 @@ struct plfx_ctx {
     int mg_fallbacks = 0; // solves that fell back from multigrid- to Jacobi-PCG
     int n_minres = 0;     // solves completed by MINRES (indefinite tangent stiffness)
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
-    double *gm_V = nullptr, *gm_part = nullptr;  // GMRES: Krylov basis (GMRES_M + 1 vectors) and partial sums, on first use
+    std::vector<double *> gm_blk;                // GMRES: Krylov basis in blocks of GMRES_BLK vectors, allocated as a cycle grows into them
+    double *gm_part = nullptr;                   //        partial sums, on first use
     int n_gmres = 0, gm_m = 0;
     double *fuse_rz = nullptr;  // != null during a V-cycle of the PCG loop: the last fine-level post-smoothing launch writes the r.z partials here
     // SPD surrogate of an indefinite operator (k_make_surrogate): generators with every indefinite element's 3 x 3 generator
@@ -719,7 +720,9 @@ void free_mesh(plfx_ctx *c)
     dfree(c->q);
     dfree(c->mr_r1);
     dfree(c->mr_w);
-    dfree(c->gm_V);
+    for (auto &b : c->gm_blk) dfree(b);
+    c->gm_blk.clear();
+    c->gm_m = 0;
     dfree(c->gm_part);
     dfree(c->Msur);
     dfree(c->diag_sur);
@@ -2084,9 +2087,11 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     int rc;
     std::vector<std::pair<int, int>> dims;
     dims.push_back({nx, ny});
-    // coarsening stops at <= 16 elements (4 x 4: 25 nodes, 50 DOFs -- solved with the dense inverse, MG_DENSE_MAX); round 3
-    // went on to 2 x 2, one more level of six workgroup-barrier phases in every cycle (PLFX_MG_COARSEST_ELEMS=4 restores it)
-    static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 16;
+    // coarsening goes on to 2 x 2 elements (9 nodes, 18 DOFs, dense inverse).  Stopping at 4 x 4 (PLFX_MG_COARSEST_ELEMS=16:
+    // 50 DOFs, one level of six workgroup-barrier phases less) saves 4.5 us of the 259 us of a cycle at 1024^2 -- and made four
+    // GMRES solves of config 5 at 2048^2 stall at 1e-6 in load step 16 (130 000 mildly indefinite elements: the 50 x 50
+    // Gauss-Jordan inverse has no pivoting; profiles/r04d_config5_coarsest_level.txt).  Measured, not adopted.
+    static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 4;
     while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 && (long long)dims.back().first * dims.back().second > 4 &&
            ((long long)dims.back().first * dims.back().second > coarsest || dims.size() < 2))  // (at least two levels)
         dims.push_back({dims.back().first / 2, dims.back().second / 2});
@@ -3437,6 +3442,7 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
     return 0;
 }
 
+constexpr int GMRES_BLK = 32;  // basis vectors per allocation
 constexpr int GMRES_M = 400;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on
                             // indefinite K); halved until the basis fits into a third of the free HBM
 int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
@@ -3445,7 +3451,7 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
     const int nn = c->nnode, gn = c->grid_nodes;
     const int olo = own_lo(c), ohi = own_hi(c);
     int rc;
-    if (!c->gm_V) {
+    if (c->gm_m == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         c->gm_m = GMRES_M;
@@ -3457,11 +3463,23 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
             if ((rc = fetch_results(c, c->small, 1, &mv))) return rc;
             c->gm_m = (int)mv;
         }
-        if ((rc = dalloc(c, &c->gm_V, (size_t)(c->gm_m + 1) * nd))) return rc;
     }
     const int M = c->gm_m;
     if (!c->gm_part && (rc = dalloc(c, &c->gm_part, (size_t)8 * MAXPART))) return rc;
-    auto Vj = [&](int j) { return c->gm_V + (size_t)j * nd; };
+    // The basis grows with the cycle (round 4): most of these solves end after 40-100 iterations, a few need the whole cycle --
+    // the 401 vectors of a full cycle are 27 GB at 2048^2, the first block 2.2 GB.  Every rank of a communicator walks the same
+    // j, so the blocks appear in lock-step; the cycle LENGTH was agreed above from the memory that is free.
+    auto need = [&](int j) -> int {
+        while ((int)c->gm_blk.size() * GMRES_BLK <= j) {
+            double *b = nullptr;
+            const int e = dalloc(c, &b, (size_t)GMRES_BLK * nd);
+            if (e) return e;
+            c->gm_blk.push_back(b);
+        }
+        return 0;
+    };
+    auto Vj = [&](int j) { return c->gm_blk[j / GMRES_BLK] + (size_t)(j % GMRES_BLK) * nd; };
+    if ((rc = need(0))) return rc;
     double *P_rz = c->part + 3 * MAXPART, *P_rr = c->part + 4 * MAXPART, *P_bb = c->part + 5 * MAXPART;
     const bool use_mg = mg_active(c);
     auto apply_B = [&]() -> int {  // c->z = B c->r
@@ -3561,6 +3579,7 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
             for (int q = 0; q <= j; q++) H[(size_t)q * M + j] = hcol[q];
             k = j + 1;
             if (std::fabs(g[j + 1]) <= tol || !(hn > 0.)) break;
+            if ((rc = need(j + 1))) return rc;
             hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1. / hn, (const double2 *)c->q,
                                (double2 *)Vj(j + 1), (double2 *)nullptr);
         }

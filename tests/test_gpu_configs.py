@@ -228,23 +228,25 @@ def test_config5_sgl_does_not_depend_on_the_mesh(golden_dir):
     a, b = run(256, 32), run(512, 128)
     assert a.nsteps == b.nsteps == 20
     sa, sb = np.array(a.sgl), np.array(b.sgl)
-    assert np.max(np.abs(sa - sb)) < 2e-4 * np.max(np.abs(sa))
-    assert abs(sa[-1][1] - 144.133) < 0.02          # the value every mesh from 512 x 64 to 2048 x 2048 gives
+    assert np.max(np.abs(sa - sb)) < 5e-5 * np.max(np.abs(sa))     # (measured 2e-5, tools/probes/cfg5_margins.py)
+    # the value every mesh from 512 x 64 to 2048 x 2048 gives is the REFERENCE's: its own trace of this schedule on 8 x 4 elements
+    # (fixture cfg5_lam_8x4_sgl: 144.1353) -- the laminate solution does not depend on the mesh
+    rs = np.load(os.path.join(golden_dir, 'solve_configs.npz'))['cfg5_lam_8x4_sgl']
+    assert abs(sa[-1][1] - rs[-1][1]) < 1e-4 * rs[-1][1] and np.max(np.abs(sa - rs)) < 2e-4 * np.max(np.abs(rs))
 
 
 def test_config5_full_size_2048_real_materials(golden_dir):
-    """BASELINE config 5 at its stated size with its real materials: 2048 x 2048 laminate [2,1,2,1,2] of J2 and the SVC
-    trained on Barlat Yld2004-18p / Goss (examples/train_goss_barlat.py:36-41, 70-83; laminate sections by
-    model.py:826-830 -> element columns [512, 256, 512, 256, 512]), eps = 0.003, min_step = 20 -- the first 12 load steps
-    (5 elastic ones, then the SVC phase yields: its 1 M elements run the 50-sub-step corrector on the wave-per-element
-    kernels; the whole schedule takes minutes on one GPU and is what tools/configs_full.py 5full runs).  Pinned through
-    the size-independent property of the laminate (uniform along y, piecewise constant per section): the global stress /
-    strain history equals the one of the 512 x 64 mesh, whose materials are pinned against the reference's trace (8 x 4)
-    and the oracle (64 x 32) above."""
+    """BASELINE config 5 at its stated size with its real materials, THE WHOLE SCHEDULE: 2048 x 2048 laminate [2,1,2,1,2] of
+    J2 and the SVC trained on Barlat Yld2004-18p / Goss (examples/train_goss_barlat.py:36-41, 70-83; laminate sections by
+    model.py:826-830 -> element columns [512, 256, 512, 256, 512]), eps = 0.003, min_step = 20 -- all 20 load steps (5 elastic
+    ones, then the SVC phase yields: its 1 M elements run the 50-sub-step corrector on the wave-per-element kernels).  Pinned
+    through the size-independent property of the laminate (uniform along y, piecewise constant per section): the global
+    stress / strain history equals the one of the 512 x 64 mesh, whose materials are pinned against the reference's trace
+    (8 x 4) and the oracle (64 x 32) above -- and it is held directly to the REFERENCE's own 8 x 4 trace of this schedule
+    (fixture cfg5_lam_8x4_*, written by oracle/gen_golden.py with the unmodified reference)."""
     big = laminate_cfg5(golden_dir, 2048, 2048)
     small = laminate_cfg5(golden_dir, 512, 64)
     for fe in (small, big):
-        fe._max_load_steps = 12
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             fe.solve(min_step=20)
@@ -253,23 +255,40 @@ def test_config5_full_size_2048_real_materials(golden_dir):
     svc_el = np.isin(big._mat_id, (1, 3))
     eng = big._engine
     assert eng.precond_info()[0] == 1 and eng.operator_info()[0] == 1          # multigrid + matrix-free operator
-    assert big.nsteps == small.nsteps == 12
-    # (the K-iteration counts are NOT size independent: a load step ends when no element's tangent moved by more than 1e-3,
-    # model.py:1346-1355, and the maximum over 4 M elements of a round-off-perturbed uniform field stays above that threshold
-    # longer than the maximum over 32 k -- 15 instead of 5 iterations in load step 6; the converged fields agree)
-    assert list(big.niter[:6]) == list(small.niter[:6])                         # elastic steps + first yield: identical
+    assert big.nsteps == small.nsteps == 20
     sb, ss = np.array(big.sgl), np.array(small.sgl)
-    assert np.max(np.abs(sb - ss)) < 2e-4 * np.max(np.abs(ss))
-    assert np.max(np.abs(np.array(big.egl) - np.array(small.egl))) < 2e-4 * np.max(np.abs(small.egl))
-    assert np.max(np.abs(np.array(big.epgl) - np.array(small.epgl))) < 2e-4 * np.max(np.abs(small.egl))
+    eb, es = np.array(big.egl), np.array(small.egl)
+    pb, ps = np.array(big.epgl), np.array(small.epgl)
+    rel = np.array([s[1] for s in big.solver_stats])
+    nfb = eng.solve_fallbacks()
+    info = eng.indefinite_info()
+    d_sgl = np.max(np.abs(sb - ss), axis=1) / np.max(np.abs(ss))
+    print('config 5 at 2048^2, 20 load steps: %d sweeps, %d solves (%d completed by the fall-back solver, %s), %d PCG iterations\n'
+          '  sgl_yy %s\n  niter 2048^2 %s\n  niter 512x64 %s\n  rel. difference of sgl per load step %s'
+          % (big.n_sweeps, len(rel), nfb, info, sum(s[0] for s in big.solver_stats), np.round(sb[:, 1], 3).tolist(),
+             list(big.niter), list(small.niter), ['%.1e' % v for v in d_sgl]))
+    # K-iteration counts: a load step ends when no element's tangent moved by more than 1e-3 (model.py:1346-1355); where the
+    # field is round-off-uniform the maximum over 4 M elements stays above that threshold longer than the maximum over 32 k
+    # (profiles/r03b_config5_niter_vs_mesh.txt), so the counts are size independent only in the elastic steps and at first yield
+    assert list(big.niter[:6]) == list(small.niter[:6])
+    assert not np.any(big.co_nconv) and not np.any(small.co_nconv)   # (none in the reference's trace either)
+    # the whole history against the 512 x 64 mesh (measured margin 2e-5 over 12 steps, tools/probes/cfg5_margins.py)
+    assert np.max(np.abs(sb[:13] - ss[:13])) < 5e-5 * np.max(np.abs(ss))
+    assert np.max(np.abs(sb - ss)) < 1e-4 * np.max(np.abs(ss))
+    assert np.max(np.abs(eb - es)) < 1e-4 * np.max(np.abs(es))
+    assert np.max(np.abs(pb - ps)) < 1e-4 * np.max(np.abs(es))
+    # ... and against the reference's own trace of this schedule on 8 x 4 elements (the laminate solution is mesh independent to
+    # ~1e-4: the trained SVC couples tension to small shear components, which the free edge sees)
+    g = np.load(os.path.join(golden_dir, 'solve_configs.npz'))
+    rs = g['cfg5_lam_8x4_sgl']
+    assert int(g['cfg5_lam_8x4_nsteps']) == 20
+    assert np.max(np.abs(sb - rs)) < 2e-4 * np.max(np.abs(rs))
+    assert abs(sb[-1][1] - rs[-1][1]) < 1e-4 * rs[-1][1]                       # 144.13 (the reference: 144.1353)
     assert sb[5][1] > 134. and sb[-1][1] > sb[5][1]                             # the SVC phase has yielded (134.67 at step 5)
     ms = big._state('max_steps')
-    assert np.sum(ms[svc_el] == 49) > 1000000                                   # ... on the 50-sub-step corrector (load steps 11, 12)
+    assert np.sum(ms[svc_el] == 49) > 1000000                                   # ... on the 50-sub-step corrector
     # every linear solve reached the tolerance; the ones PCG could not finish (indefinite tangents, material.py:317-338)
     # were completed by the fall-back solver and are reported
-    rel = np.array([s[1] for s in big.solver_stats])
     assert np.all(rel <= 1.0000001 * big.cg_rtol), rel.max()
-    nfb = eng.solve_fallbacks()
-    print('config 5 at 2048^2, 12 load steps: %d sweeps, %d solves (%d completed by the fall-back solver), %d PCG iterations, '
-          'sgl_yy %s' % (big.n_sweeps, len(rel), nfb, sum(s[0] for s in big.solver_stats), np.round(sb[:, 1], 3).tolist()))
-    assert 0 <= nfb <= len(rel)
+    assert 0 < nfb <= 0.4 * len(rel)                                            # (48 of 254 in profiles/r02j_config5_full_solve.txt)
+    assert 0 < info['solves'] <= nfb and info['by_gmres'] == info['solves'] and info['by_minres_surrogate'] == 0
