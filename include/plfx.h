@@ -250,6 +250,21 @@ int plfx_solve(plfx_ctx *ctx, double rtol, int maxit, int warm, int *iters, doub
  * response + |elstiff - Ct|_F > 1e-3 test + tangent refresh (averaging when nit >= 15).
  * changed: any tangent updated; conv: all fy/sflow <= yf_tolerance*1.0001 */
 int plfx_sweep(plfx_ctx *ctx, int nit, int *changed, int *conv);
+/* Work-hardening SVC materials (PLFX_SVC_WH) inside the load-step loop.  The reference keeps the hardening modulus in ONE
+ * mutable attribute of the Material object: every calc_fgrad overwrites it (material.py:808-814), get_sflow / epl_dot / C_tan
+ * read it, and the element loop of Model.solve (model.py:1340-1359) hands it from element to element in index order.
+ *   sequential = 1 (default; one GPU, no shard): exactly that.  plfx_sweep resolves the chain as a fixed point -- sweep with
+ *       guessed entry moduli, derive the entry moduli that sweep implies (exit modulus of the last element before e, same
+ *       material, whose call evaluated a gradient; else the value the material held when the sweep began), repeat while any
+ *       entry changed; tangents / generators are restored before every repetition.  plfx_wh_info counts sweeps and passes.
+ *       State 11 then returns the EXIT modulus of every element's last call; plfx_wh_carry reads / sets the value a material
+ *       object holds now (what Material.khard is after / before Model.solve in the reference).
+ *   sequential = 0: one modulus per material point, carried from sweep to sweep (state 11) -- the data-parallel contract of
+ *       rounds 2-3, the only form on several GPUs (the chain would cross every shard); deviates from the reference by ~1e-4
+ *       on its 4 x 4 trace (tests/test_workhard_svc.py). */
+int plfx_set_wh_mode(plfx_ctx *ctx, int sequential);
+int plfx_wh_info(plfx_ctx *ctx, int *sequential_in_use, int64_t *sweeps, int64_t *passes);
+int plfx_wh_carry(plfx_ctx *ctx, int mat, const double *set, double *get);
 /* calc_scf statistics (model.py:1036-1067): sum of entries, sum of squares about the mean, min, count.
  * sld[6] loading direction for SVC materials. */
 int plfx_scf_stats(plfx_ctx *ctx, const double *sld, double *sum, double *sumsq_c, double *minv,

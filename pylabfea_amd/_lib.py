@@ -51,7 +51,7 @@ SYMBOLS = [
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
-    'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench',
+    'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry',
 ]
 
 _lib = None
@@ -325,6 +325,23 @@ class Context(object):
         a, b = C.c_double(), C.c_double()
         self._chk(self.lib.plfx_precond_bench(self.h, int(reps), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_wh_mode(self, sequential):
+        """work-hardening SVC: hardening modulus handed from element to element like the reference (True) or per point"""
+        self._chk(self.lib.plfx_set_wh_mode(self.h, 1 if sequential else 0))
+
+    def wh_info(self):
+        """(sequential carry in use, sweeps run in that mode, passes they took)"""
+        a, b, c_ = C.c_int(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_wh_info(self.h, C.byref(a), C.byref(b), C.byref(c_)))
+        return bool(a.value), b.value, c_.value
+
+    def wh_carry(self, mat, value=None):
+        """the hardening modulus material `mat` holds now (sequential carry); value != None sets it first"""
+        g = C.c_double()
+        sv = None if value is None else C.byref(C.c_double(float(value)))
+        self._chk(self.lib.plfx_wh_carry(self.h, int(mat), sv, C.byref(g)))
+        return g.value
 
     def solve_fallbacks(self):
         """solves completed by Jacobi-PCG after multigrid-PCG broke down or stalled"""

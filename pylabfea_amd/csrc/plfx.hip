@@ -173,6 +173,14 @@ struct plfx_ctx {
     double *sig = nullptr, *epl = nullptr, *eps = nullptr, *res_sig = nullptr, *res_depl = nullptr;
     double *elstiff = nullptr, *Mel = nullptr, *fyn = nullptr, *scf_hh = nullptr;
     double *kh_el = nullptr;   // hardening modulus per material point (work-hardening SVC: mutable, carried from sweep to sweep)
+    // work-hardening SVC, sequential carry (the reference's semantics, plfx_kernels.hpp: k_wh_entry): kh_el holds the ENTRY
+    // modulus of every element, kh_out / kh_touch what its response() left, wh_carry the value each material object holds now
+    int wh_mode = 1;           // 1 = sequential carry (default on one GPU), 0 = one modulus per material point
+    double wh_carry[16] = {0};
+    double *kh_out = nullptr, *kh_new = nullptr, *wh_snap_el = nullptr, *wh_snap_M = nullptr;
+    int32_t *kh_touch = nullptr, *wh_bmax = nullptr, *wh_cnt = nullptr;
+    bool kh_out_valid = false;
+    int64_t n_wh_passes = 0, n_wh_sweeps = 0;
     int32_t *max_steps = nullptr, *scf_mult = nullptr, *heavy_list = nullptr;
     // dof vectors
     double *u = nullptr, *f = nullptr, *du = nullptr, *rhs = nullptr, *dinv = nullptr, *diag = nullptr,
@@ -701,6 +709,9 @@ void free_mesh(plfx_ctx *c)
     dfree(c->fyn);
     dfree(c->scf_hh);
     dfree(c->kh_el);
+    dfree(c->kh_out); dfree(c->kh_new); dfree(c->wh_snap_el); dfree(c->wh_snap_M);
+    dfree(c->kh_touch); dfree(c->wh_bmax); dfree(c->wh_cnt);
+    c->kh_out_valid = false;
     dfree(c->max_steps);
     dfree(c->scf_mult);
     dfree(c->heavy_list);
@@ -794,6 +805,9 @@ int ensure_tmp(plfx_ctx *c, size_t n)
 }
 
 bool matfree(const plfx_ctx *c) { return c->grid_ok && c->want_matfree; }
+bool comm_active(const plfx_ctx *c);
+// work-hardening SVC in the reference's sequential-carry semantics: single rank only (the chain crosses every shard)
+bool wh_sequential(const plfx_ctx *c) { return c->has_svcwh && c->wh_mode == 1 && !comm_active(c) && !c->sharded && !c->strip.on; }
 // Marching form of the finest-grid operator kernels (grid_march): PLFX_MARCH=0 never, =1 always; default: the PCG operator
 // kernel always (faster at every size measured), the three V-cycle kernels when one operator pass (112 B per node) exceeds
 // 192 MiB -- three quarters of the 256 MiB Infinity Cache: a pass shares the cache with the other vectors of the cycle, and the
@@ -2681,6 +2695,8 @@ int plfx_state_reset(plfx_ctx *c)
         for (int e = 0; e < c->nel; e++) kh[e] = c->hmat[c->hcls[c->hcls_id[c->e0 + e]].mat].khard;
         HIPCHK(c, hipMemcpyAsync(c->kh_el, kh.data(), (size_t)8 * c->nel, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int m = 0; m < c->nmat && m < 16; m++) c->wh_carry[m] = c->hmat[m].khard;
+        c->kh_out_valid = false;
     }
     hipLaunchKernelGGL(k_init_tangent, dim3((c->nel + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream,
                        c->dmat, c->dcls, c->nel, c->dcls_id, c->elstiff, c->Mel + c->e0, c->nel_total);
@@ -2708,7 +2724,7 @@ static int state_ptr(plfx_ctx *c, int which, double **p, size_t *comps, size_t *
     case 7: *p = c->f; *comps = 1; *n = c->ndof; *soa = false; break;
     case 8: *p = c->du; *comps = 1; *n = c->ndof; *soa = false; break;
     case 9: *p = c->fyn; *comps = 1; *soa = false; break;
-    case 11: *p = c->kh_el; *comps = 1; *soa = false; break;
+    case 11: *p = (wh_sequential(c) && c->kh_out_valid) ? c->kh_out : c->kh_el; *comps = 1; *soa = false; break;  // exit moduli of the last sweep
     default: return fail(c, PLFX_ERR_ARG, "unknown state id %d", which);
     }
     return 0;
@@ -4081,10 +4097,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 }
 
 // ------------------------------------------------------------------------------ non-linear driver pieces
-int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
+static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq)
 {
-    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
-    if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
     // (flags / bflags are left zeroed by the k_sweep_flags of the previous sweep)
     EvPair *ev;
     tim_begin(c, 0, &ev);
@@ -4132,7 +4146,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     }
     if (c->has_svcwh) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1, c->kh_el);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
+                           wh_seq ? c->kh_touch : (int32_t *)nullptr);
         first = 0;
     }
     tim_end(c, ev);  // family 0: the streaming phase (one launch per material kind present)
@@ -4158,7 +4173,8 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
                            c->stream, SWEEP_ARGS(c->svc_lds_need), -1);
     if (c->has_svcwh)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1, c->kh_el);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
+                           wh_seq ? c->kh_touch : (int32_t *)nullptr);
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
     tim_end(c, ev);
@@ -4187,6 +4203,136 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
     return PLFX_OK;
 }
 
+// Sweep of a model with a work-hardening SVC material in the reference's semantics: ONE hardening modulus per Material object,
+// handed from element to element in index order (material.py:808-814, model.py:1340-1359).  The entry modulus of an element is
+// the exit modulus of the last element before it whose call evaluated a gradient (else what the material held when the sweep
+// began) -- a chain the data-parallel sweep resolves as a fixed point: sweep with guessed entry values (those of the previous
+// sweep), derive the entry values that sweep implies (k_wh_entry), repeat while any element's entry value changed.  What a
+// sweep rewrites besides its outputs -- tangents and stiffness generators -- is restored from a snapshot before every
+// repetition, so the last pass IS the sequential loop's sweep, bit for bit in its inputs.  A handful of passes in practice
+// (an entry value only enters the yield check of its call, material.py:259-265 via get_sflow).
+static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
+{
+    int rc;
+    const size_t ne = c->nel;
+    const int nblk = (int)((ne + BLOCK - 1) / BLOCK);
+    if (!c->kh_out) {
+        if ((rc = dalloc(c, &c->kh_out, ne)) || (rc = dalloc(c, &c->kh_new, ne)) || (rc = dalloc(c, &c->kh_touch, ne)) ||
+            (rc = dalloc(c, &c->wh_bmax, (size_t)nblk)) || (rc = dalloc(c, &c->wh_cnt, 4)) ||
+            (rc = dalloc(c, &c->wh_snap_el, 21 * ne)) || (rc = dalloc(c, &c->wh_snap_M, (size_t)6 * c->nel_total)))
+            return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->wh_snap_el, c->elstiff, 21 * ne * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->wh_snap_M, c->Mel, (size_t)6 * c->nel_total * 8, hipMemcpyDeviceToDevice, c->stream));
+    const int64_t sw0 = c->n_sweeps, tr0 = c->n_tangents_rewritten;
+    int64_t tr_before = tr0;
+    bool any_changed = false;
+    int32_t last[16];
+    const int max_pass = (int)std::min<size_t>(ne + 2, 64);
+    int pass = 0;
+    for (;; pass++) {
+        if (pass > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->elstiff, c->wh_snap_el, 21 * ne * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->Mel, c->wh_snap_M, (size_t)6 * c->nel_total * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        int ch = 0, cv = 0;
+        tr_before = c->n_tangents_rewritten;
+        if ((rc = sweep_once(c, nit, &ch, &cv, true))) return rc;
+        any_changed = any_changed || ch;
+        if (changed) *changed = ch;
+        if (conv) *conv = cv;
+        // entry values this pass implies
+        HIPCHK(c, hipMemcpyAsync(c->kh_new, c->kh_el, ne * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->wh_cnt, 0, 16, c->stream));
+        for (int m = 0; m < c->nmat && m < 16; m++) {
+            last[m] = -1;
+            if (c->hmat[m].kind != 7) continue;
+            hipLaunchKernelGGL(k_wh_blockmax, dim3(nblk), dim3(BLOCK), 0, c->stream, c->nel, m, c->dcls, c->dcls_id, c->kh_touch, c->wh_bmax);
+            hipLaunchKernelGGL(k_wh_scan, dim3(1), dim3(BLOCK), 0, c->stream, nblk, c->wh_bmax, c->wh_cnt + 1);
+            hipLaunchKernelGGL(k_wh_entry, dim3(nblk), dim3(BLOCK), 0, c->stream, c->nel, m, c->dcls, c->dcls_id, c->kh_touch, c->wh_bmax,
+                               (const double *)c->kh_out, c->wh_carry[m], (const double *)c->kh_el, c->kh_new, c->wh_cnt);
+            HIPCHK(c, hipGetLastError());
+            int32_t h2[2];
+            HIPCHK(c, hipMemcpyAsync(h2, c->wh_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            last[m] = h2[1];   // (h2[0] accumulates over the materials)
+        }
+        int32_t nch = 0;
+        HIPCHK(c, hipMemcpyAsync(&nch, c->wh_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n_wh_passes++;
+        if (getenv("PLFX_WH_DEBUG")) {
+            std::vector<double> ko(ne), ki(ne);
+            std::vector<int32_t> tc(ne);
+            hipMemcpy(ko.data(), c->kh_out, ne * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(ki.data(), c->kh_el, ne * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(tc.data(), c->kh_touch, ne * 4, hipMemcpyDeviceToHost);
+            int nt = 0;
+            double kmax = 0., imax = 0.;
+            for (size_t e = 0; e < ne; e++) nt += tc[e], kmax = std::max(kmax, ko[e]), imax = std::max(imax, ki[e]);
+            fprintf(stderr, "[wh] sweep %lld pass %d: %d entries changed, %d touched, max entry %.6g, max exit %.6g, last touched %d, carry %.6g\n",
+                    (long long)c->n_wh_sweeps, pass, nch, nt, imax, kmax, last[0], c->wh_carry[0]);
+        }
+        if (nch == 0 || pass + 1 >= max_pass) break;
+        std::swap(c->kh_el, c->kh_new);
+    }
+    // the material objects now hold what their last gradient evaluation of this sweep left
+    for (int m = 0; m < c->nmat && m < 16; m++)
+        if (c->hmat[m].kind == 7 && last[m] >= 0)
+            HIPCHK(c, hipMemcpy(&c->wh_carry[m], c->kh_out + last[m], 8, hipMemcpyDeviceToHost));
+    c->kh_out_valid = true;
+    c->n_wh_sweeps++;
+    c->n_sweeps = sw0 + 1;   // one sweep of the load-step loop, however many passes it took
+    c->n_tangents_rewritten = tr0 + (c->n_tangents_rewritten - tr_before);   // ... and the rewrites of its last pass
+    if (any_changed) c->M_dirty = true;
+    return PLFX_OK;
+}
+
+int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
+{
+    if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
+    if (wh_sequential(c)) return sweep_wh_sequential(c, nit, changed, conv);
+    return sweep_once(c, nit, changed, conv, false);
+}
+
+// moduli calc_scf reads (model.py:1036-1067: calc_yf / ML_full_yf -> get_sflow with the value the material holds NOW): per
+// point, or -- sequential carry -- the material object's current value for every element of that material
+static const double *scf_moduli(plfx_ctx *c)
+{
+    if (!wh_sequential(c)) return c->kh_el;
+    if (!c->kh_new && dalloc(c, &c->kh_new, (size_t)c->nel)) return c->kh_el;
+    WhCarry w;
+    for (int m = 0; m < 16; m++) w.v[m] = c->wh_carry[m];
+    hipLaunchKernelGGL(k_wh_fill, dim3(grid_for(c->nel)), dim3(BLOCK), 0, c->stream, c->nel, c->dcls, c->dcls_id, w, c->kh_new);
+    return c->kh_new;
+}
+
+int plfx_set_wh_mode(plfx_ctx *c, int sequential)
+{
+    if (!c) return PLFX_ERR_STATE;
+    c->wh_mode = sequential ? 1 : 0;
+    c->kh_out_valid = false;
+    return PLFX_OK;
+}
+
+int plfx_wh_info(plfx_ctx *c, int *sequential_in_use, int64_t *sweeps, int64_t *passes)
+{
+    if (!c) return PLFX_ERR_STATE;
+    if (sequential_in_use) *sequential_in_use = wh_sequential(c) ? 1 : 0;
+    if (sweeps) *sweeps = c->n_wh_sweeps;
+    if (passes) *passes = c->n_wh_passes;
+    return PLFX_OK;
+}
+
+int plfx_wh_carry(plfx_ctx *c, int mat, const double *set, double *get)
+{
+    if (!c || mat < 0 || mat >= c->nmat || mat >= 16) return c ? fail(c, PLFX_ERR_ARG, "material %d out of range", mat) : PLFX_ERR_STATE;
+    if (set) c->wh_carry[mat] = *set;
+    if (get) *get = c->wh_carry[mat];
+    return PLFX_OK;
+}
+
 int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c, double *minv,
                    int64_t *count, double mean_in, int pass)
 {
@@ -4198,7 +4344,7 @@ int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c,
         hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                            c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
                            c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                           c->small + 32, c->scf_hh, c->scf_mult, (const double *)c->kh_el);
+                           c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c));
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult,
@@ -4232,7 +4378,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                        c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
                        c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                       c->small + 32, c->scf_hh, c->scf_mult, (const double *)c->kh_el);
+                       c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c));
     const int elo = c->strip.on ? c->strip.eown_lo : 0, ehi = c->strip.on ? c->strip.eown_hi : 0x7fffffff;
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr, elo, ehi);

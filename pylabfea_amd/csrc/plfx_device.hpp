@@ -459,6 +459,7 @@ struct YfHill {
     // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
     __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
     __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ int touched() const { return 0; }
     __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
     __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
@@ -478,6 +479,7 @@ struct YfBarlat {
     // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
     __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
     __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ int touched() const { return 0; }
     __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
     __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
@@ -497,6 +499,7 @@ struct YfPrinc3 {
     // hardening modulus / flow stress as the response loop sees them (a work-hardening-aware SVC carries a mutable khard)
     __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
     __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ int touched() const { return 0; }
     __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
     __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
@@ -1052,6 +1055,7 @@ struct YfSvcT {
     }
     __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
     __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ int touched() const { return 0; }
     __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
     __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
 };
@@ -1072,7 +1076,9 @@ struct YfSvcWh {
     const double *dual;
     const double K_in;   // hardening modulus at the entry of the call
     mutable double K;    // ... as of the last gradient evaluation
+    mutable int touch = 0;   // a gradient evaluation has overwritten the modulus (else the call hands its entry value on)
     __device__ YfSvcWh(const MatDev &mm, const double *s, const double *d, double k0) : m(mm), sv(s), dual(d), K_in(k0), K(k0) {}
+    __device__ __forceinline__ int touched() const { return touch; }
     __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
     __device__ __forceinline__ void features(const double *s, const double *epl, double *x) const
     {
@@ -1142,6 +1148,7 @@ struct YfSvcWh {
     {
         const double hk = fgrad_raw(s, epl, a);
         K = hk < 0. ? 0. : hk;  // strain softening not supported (:813-814)
+        touch = 1;
     }
     // ML_full_yf (material.py:414-516) with the plastic strain in the features
     __device__ inline double full_ld(const double *s, const double *epl, const double *ld, int *status) const

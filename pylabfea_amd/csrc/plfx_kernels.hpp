@@ -515,7 +515,9 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
               int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int skip_mat,
-              double *kh_el = nullptr /* KIND 7: hardening modulus of every material point, carried from sweep to sweep */)
+              double *kh_el = nullptr /* KIND 7: hardening modulus of every material point, carried from sweep to sweep */,
+              double *kh_out = nullptr, int32_t *kh_touch = nullptr /* sequential-carry mode: kh_el is read only; the exit
+              modulus and "a gradient evaluation overwrote it" go here */)
 {
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
@@ -554,7 +556,10 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
                 else {
                     sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, mel_stride, res_sig,
                                    res_depl, fyn, max_steps, nit, changed, nconv, KIND == 7 ? yf.kh() : -1.);
-                    if (KIND == 7 && kh_el) kh_el[e] = yf.kh();
+                    if (KIND == 7 && kh_el) {
+                        (kh_out ? kh_out : kh_el)[e] = yf.kh();
+                        if (kh_touch) kh_touch[e] = yf.touched();
+                    }
                 }
             }
         }
@@ -581,7 +586,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
               int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, int skip_mat,
-              double *kh_el = nullptr)
+              double *kh_el = nullptr, double *kh_out = nullptr, int32_t *kh_touch = nullptr)
 {
     const int count = flags[2];
     if (count == 0) return;
@@ -615,7 +620,10 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
         sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
                        res_depl, fyn, max_steps, nit, changed, nconv, KIND == 7 ? yf.kh() : -1.);
-        if (KIND == 7 && kh_el) kh_el[e] = yf.kh();
+        if (KIND == 7 && kh_el) {
+            (kh_out ? kh_out : kh_el)[e] = yf.kh();
+            if (kh_touch) kh_touch[e] = yf.touched();
+        }
     }
     post_block_flags(changed, nconv, bflags);
 }
@@ -2040,6 +2048,80 @@ __global__ void __launch_bounds__(BLOCK) k_scf_finish(const double *part, int g,
 __global__ void k_scf_mean(double *out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[3] = out[1] > 0. ? out[0] / (double)(long long)(out[1] + 0.5) : 0.;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Work-hardening SVC, SEQUENTIAL CARRY (the reference's semantics): Material.khard is ONE mutable attribute that every
+// calc_fgrad overwrites (material.py:808-814) and that the element loop of Model.solve hands from element to element in index
+// order (model.py:1340-1359).  Element e therefore ENTERS its response() with the exit modulus of the last element before it
+// (same material) whose call evaluated a gradient -- calls that stay elastic pass their entry value on -- or, if there is
+// none, with the value the material object held when the sweep began.  Given the exit moduli and "touched" flags of a
+// data-parallel sweep, these three kernels compute that entry value for every element (an exclusive prefix maximum of the
+// touched element indices) and count the elements whose entry value differs from the one the sweep was run with; the host
+// repeats the sweep until the count is zero (fixed point = the sequential loop's result, plfx.hip: sweep_wh_sequential).
+struct WhCarry {
+    double v[16];
+};
+__global__ void __launch_bounds__(BLOCK)
+k_wh_fill(int nel, const ClassDev *__restrict__ gcls, const int32_t *__restrict__ cls, WhCarry w, double *__restrict__ kh)
+{
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) kh[e] = w.v[gcls[cls[e]].mat & 15];
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_wh_blockmax(int nel, int mat, const ClassDev *__restrict__ gcls, const int32_t *__restrict__ cls, const int32_t *__restrict__ touch,
+              int32_t *__restrict__ bmax)
+{
+    __shared__ int sh[BLOCK / 64];
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    int key = -1;
+    if (e < nel && gcls[cls[e]].mat == mat && touch[e]) key = e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = sh[0];
+        for (int w = 1; w < BLOCK / 64; w++) m = max(m, sh[w]);
+        bmax[blockIdx.x] = m;
+    }
+}
+
+// exclusive prefix maximum over the block maxima (in place), total maximum -> last[0]; one workgroup
+__global__ void __launch_bounds__(BLOCK)
+k_wh_scan(int nblk, int32_t *__restrict__ bmax, int32_t *__restrict__ last)
+{
+    if (threadIdx.x != 0) return;
+    int run = -1;
+    for (int b = 0; b < nblk; b++) {
+        const int v = bmax[b];
+        bmax[b] = run;
+        run = max(run, v);
+    }
+    last[0] = run;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_wh_entry(int nel, int mat, const ClassDev *__restrict__ gcls, const int32_t *__restrict__ cls, const int32_t *__restrict__ touch,
+           const int32_t *__restrict__ bpre, const double *__restrict__ kh_out, double carry, const double *__restrict__ kh_in,
+           double *__restrict__ kh_new, int32_t *__restrict__ nchanged)
+{
+    __shared__ int key[BLOCK];
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    const bool mine = e < nel && gcls[cls[e]].mat == mat;
+    key[threadIdx.x] = (mine && touch[e]) ? e : -1;
+    __syncthreads();
+    int lm = bpre[blockIdx.x];
+    for (int t = 0; t < (int)threadIdx.x; t++) lm = max(lm, key[t]);   // (256 LDS reads per thread: the scan is not the cost of a sweep)
+    int diff = 0;
+    if (mine) {
+        const double v = lm >= 0 ? kh_out[lm] : carry;
+        kh_new[e] = v;
+        diff = __double_as_longlong(v) != __double_as_longlong(kh_in[e]);
+    }
+    const unsigned long long m = __ballot(diff);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(nchanged, __popcll(m));
 }
 
 }  // namespace plfx

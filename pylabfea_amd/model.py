@@ -193,6 +193,10 @@ class Model(object):
         self._strip = None  # strip-local engine: column window and numbering offsets of this rank (strip_plan)
         self._max_load_steps = None  # benchmarking aid: stop after this many load steps
         self._step_hook = None       # benchmarking aid: called as hook(il) after every load step
+        # work-hardening SVC materials: 'sequential' = the reference's semantics (ONE hardening modulus per Material object,
+        # handed from element to element in index order, material.py:808-814 + model.py:1340-1359; one GPU), 'per_point' = one
+        # modulus per material point (faster: no repeated sweeps; the only form on several GPUs; ~1e-4 off the reference)
+        self.wh_carry = 'sequential'
 
     # ------------------------------------------------------------------ pre-processing
     def geom(self, sect=1, LX=None, LY=1., LZ=1.):
@@ -551,6 +555,8 @@ class Model(object):
                 j = len(uniq) - 1
             remap.append(j)
         eng.set_materials([m._record(self._element_CV(m)) for m in uniq])
+        self._eng_uniq = uniq
+        eng.set_wh_mode(self.wh_carry != 'per_point')
         self._eng_mat_id = np.asarray(remap, dtype=np.int64)[self._mat_id]
         e0, e1 = 0, self.Nel
         self._strip = None
@@ -881,6 +887,7 @@ class Model(object):
         if self.Nnode is None:
             raise AttributeError('Attributes for mesh not set, but required by solver.')
         eng = self._ensure_engine()
+        eng.set_wh_mode(self.wh_carry != 'per_point')
         self._cache = {}
         n_stats0 = len(self.solver_stats)
         dim = 2
@@ -906,6 +913,9 @@ class Model(object):
         bcl0 = self.bcl
         bcb0 = self.bcb
         sgl, egl, epgl = list(self.sgl), list(self.egl), list(self.epgl)
+        wh = [(k, m) for k, m in enumerate(getattr(self, '_eng_uniq', [])) if getattr(m, 'whdat', False) and m.ML_yf]
+        for k, m in wh:   # the value the Material object holds NOW enters the first response() call (material.py:808-814)
+            eng.wh_carry(k, m.khard)
         self._bc_registered = None
         self._finish_register(eng)
         eng.assemble()
@@ -1083,6 +1093,9 @@ class Model(object):
         self.nsteps = il
         self.niter = niter
         self.co_nconv = co_nconv
+        if wh and eng.wh_info()[0]:   # ... and the objects keep what the last gradient evaluation of the run left
+            for k, m in wh:
+                m.khard = eng.wh_carry(k)
         # the reference's LU always returns; an iterative solve can end above its tolerance (nearly singular tangents at a
         # limit load): say so instead of continuing silently
         bad = [r for (_, r) in self.solver_stats[n_stats0:] if not r <= 10. * self.cg_rtol]
