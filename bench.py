@@ -424,6 +424,71 @@ def inclusion_variant(FE, n, K, W, device=0):
             'solves_completed_by_fallback_solver': int(fe._engine.solve_fallbacks())}
 
 
+def config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, n, K=2, W=1):
+    """Two load steps of BASELINE config 5 (2048 x 2048 laminate J2 + the Goss-Barlat SVC; load steps 6..8 of 20: the SVC phase has
+    begun to yield, every stiffness iteration sweeps ~1 M SVC elements) on the same ranks: the workload whose time is the material
+    sweep, which shards by elements without any collective -- next to the homogeneous config 3, whose load step is 1.6 ms of
+    launch-latency-bound kernels and cannot gain from strips.  Same timing contract as the main line."""
+    import warnings
+    fe, nsv = laminate_model(FE, n, device=local)
+    if dist is not None:
+        if host_transport:
+            fe.distribute(rank, world, None, host_allreduce=FE.host_transport(dist, rank, world))
+        else:
+            uid = [None]
+            if rank == 0:
+                uid[0] = _lib.Context(local).comm_unique_id()
+            dist.broadcast_object_list(uid, src=0)
+            fe.distribute(rank, world, uid[0])
+    eng = fe._ensure_engine()
+    pre = 5
+    marks = {}
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def hook(il):
+        if il == pre + W:
+            eng.timing_reset()
+            eng.timing_select((_lib.T_SWEEP, _lib.T_SWEEP_HEAVY) + ((_lib.T_COMM,) if dist is not None else ()))
+            eng.timing_sample(1)
+            eng.timing_enable(True)
+            barrier()
+            marks['t0'], marks['sw0'] = time.perf_counter(), fe.n_sweeps
+        if il == pre + W + K:
+            barrier()
+            marks['t1'], marks['sw1'] = time.perf_counter(), fe.n_sweeps
+            eng.timing_enable(False)
+
+    fe._step_hook = hook
+    fe._max_load_steps = pre + W + K
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=20)
+    dt = marks['t1'] - marks['t0']
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if host_transport else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sweeps = marks['sw1'] - marks['sw0']
+    ms_l, _ = eng.timing_get(_lib.T_SWEEP)
+    ms_h, _ = eng.timing_get(_lib.T_SWEEP_HEAVY)
+    cms, cn = eng.timing_get(_lib.T_COMM) if dist is not None else (0., 0)
+    out = {'workload': '%dx%d laminate [2,1,2,1,2], J2 + Goss-Barlat SVC (%d support vectors), eps=0.003, min_step=20; timed load steps '
+                       '%d..%d of 20' % (n, n, nsv, pre + W, pre + W + K),
+           'value': fe.Nel * sweeps / dt, 'unit': 'element-updates/s', 'ms_per_step': 1e3 * dt / K, 'steps': K, 'warmup': W,
+           'sweeps': int(sweeps), 'seconds': dt,
+           'rank0_sweep_kernel_ms_per_step': (ms_l + ms_h) / K, 'rank0_collective_ms_per_step': cms / K,
+           'rank0_owned_columns': [fe._strip['c0'], fe._strip['c1']] if fe._strip else None,
+           'sgl_yy': float(fe.sgl[-1][1])}
+    fe._drop_engine()
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
         return cpu_worker(sys.argv[2:8])
@@ -436,6 +501,9 @@ def main():
                     help='BASELINE.json configs[2] (default, the configuration the metric is quoted on) or configs[4]')
     ap.add_argument('--weak', action='store_true',
                     help='N>1: weak scaling (N strips of mesh x mesh elements side by side) instead of strong scaling of the same mesh')
+    ap.add_argument('--config5-leg-mesh', type=int, default=2048,
+                    help='N>1, config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
+                         'strips pay) on this mesh, reported as `config5_leg` of the same JSON line; 0 = skip')
     ap.add_argument('--cpu-mesh', type=int, default=448)
     ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -704,13 +772,43 @@ def main():
         mine = {'rank': rank, 'owned_columns': [strip['c0'], strip['c1']] if strip else None,
                 'halo_columns': strip['W'] if strip else None, 'roofline': roof(dominant), 'roofline_sweep': roof('sweep'),
                 'collective_ms_per_step': cms / K, 'collectives_per_step': cn / K}
+        # where this rank's load step goes (HIP events on its stream, ms per load step): what strips divide (the fine-level
+        # operator passes over its own columns, its share of the sweep) and what they do not (levels >= 1 of the V-cycle --
+        # launch-latency bound on the local levels, replicated below the hand-over level --, the collectives)
+        vc_ms, vc_n = tim['vcycle']
+        sm_ms, sm_n = tim['mg_smooth']
+        samp = max(1, args.sample)
+        fine_ms = 4. * (sm_ms / max(sm_n, 1)) * vc_n * samp / K if sm_n else 0.       # 4 fine-level operator passes per cycle
+        cyc_ms = vc_ms * samp / K
+        sw_ms = tim['sweep'][0] * samp / K
+        sp_ms = tim['spmv'][0] * samp / K
+        step_ms = 1e3 * (marks['t1'] - marks['t0']) / K
+        mine['time_budget_ms_per_step'] = {
+            'load_step': step_ms, 'vcycles': cyc_ms, 'vcycle_fine_level': fine_ms, 'vcycle_levels_below_incl_collectives': cyc_ms - fine_ms,
+            'sweep': sw_ms, 'pcg_operator': sp_ms, 'collectives': cms / K,
+            'divisible_by_strips': fine_ms + sw_ms + sp_ms, 'not_divisible': step_ms - (fine_ms + sw_ms + sp_ms),
+            'note': 'sampled HIP-event families scaled by the sampling stride; divisible = passes over the rank\'s own columns'}
         rows = [None] * world
         dist.all_gather_object(rows, mine)
         out['per_rank'] = rows
         out['collective_ms_per_step'] = max(r['collective_ms_per_step'] for r in rows)
+        # Amdahl arithmetic for this workload from rank 0's budget: T(N) = divisible(N) + not_divisible, where divisible(N) already
+        # is 1/N-th of the mesh.  Speed-up over one GPU that N -> infinity could reach with this engine: (N * divisible + fixed) / fixed
+        b0 = rows[0]['time_budget_ms_per_step']
+        if b0['not_divisible'] > 0.:
+            t1_est = world * b0['divisible_by_strips'] + (b0['not_divisible'] - b0['collectives'])
+            out['amdahl'] = {'estimated_one_gpu_ms_per_step': t1_est, 'measured_ms_per_step': b0['load_step'],
+                             'speedup_vs_estimate': t1_est / b0['load_step'],
+                             'ceiling_with_free_collectives': t1_est / max(b0['not_divisible'] - b0['collectives'], 1e-9),
+                             'note': 'one-GPU time estimated from this run: N x (divisible part of rank 0) + its fixed part without the '
+                                     'collectives; the driver computes the measured scaling from its own N = 1 run'}
     if strip:
         si = eng.strip_info()
         out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'generator_exchanges': si[7], 'note': 'since the start of the run (rank 0)'}
+    if world > 1 and args.config == 3 and not weak and args.config5_leg_mesh > 0:
+        fe._drop_engine()
+        leg = config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, args.config5_leg_mesh)
+        out['config5_leg'] = leg
     if rank == 0 and world == 1:
         fe._drop_engine()        # release the homogeneous model's HBM and stream before the other samples
     if rank == 0 and world == 1 and not args.no_2048 and args.config == 3 and n < 2048:

@@ -306,7 +306,7 @@ def test_bench_two_ranks(tmp_path, mode):
     mode = 'strong' if mode == 'strong4' else mode
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nr), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nr), '--steps', '3', '--warmup', '1',
-           '--mesh', str(mesh)] + (['--weak'] if mode == 'weak' else [])
+           '--mesh', str(mesh), '--config5-leg-mesh', '256' if nr == 2 else '0'] + (['--weak'] if mode == 'weak' else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
@@ -323,6 +323,14 @@ def test_bench_two_ranks(tmp_path, mode):
     assert cols[0][0] == 0 and cols[-1][1] == strips * mesh and all(a[1] == b[0] for a, b in zip(cols[:-1], cols[1:]))   # the strips tile the mesh
     if nr == 4:
         assert all(r['halo_columns'] == 32 for r in d['per_rank']) and [c[1] - c[0] for c in cols] == [128] * 4
+    # where every rank's load step goes, and the Amdahl arithmetic that follows from it
+    for r in d['per_rank']:
+        b = r['time_budget_ms_per_step']
+        assert b['load_step'] > 0. and b['vcycles'] > 0. and 0. < b['divisible_by_strips'] < b['load_step']
+    assert d['amdahl']['estimated_one_gpu_ms_per_step'] > 0.
+    if mode == 'strong' and nr == 2:   # the sweep-dominated leg (BASELINE config 5, here on 256 x 256 elements) in the same line
+        leg = d['config5_leg']
+        assert leg['sweeps'] > 0 and leg['value'] > 0. and '256x256 laminate' in leg['workload'] and leg['sgl_yy'] > 100.
     # the same workload on one rank: identical counts (and, for strong scaling, the identical workload string)
     sys.path.insert(0, root)
     one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--mesh', str(mesh),
