@@ -122,13 +122,9 @@ int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const doubl
  * material.py:808-814), every get_sflow / epl_dot / C_tan reads it, and it is carried from call to call.  Here it is an
  * explicit input and output per point: khard_in[n] (NULL: the material's khard) is what Material.khard holds when
  * response() is entered, khard_out[n] what it holds on return.
- * CONTRACT inside the load-step loop (plfx_sweep / plfx_load_step; a documented deviation from the reference): the library
- * carries the modulus PER MATERIAL POINT (state 11: entry value of a point's call = exit value of the same point's previous
- * call; plfx_scf_all / plfx_scf_stats and the yield-function ratio of the sweep read the point's own value).  The reference
- * hands ONE value from element to element in index order (model.py:1340-1359), a sequential chain through all elements that
- * a data-parallel sweep cannot follow.  Both semantics are restated by the oracle (oracle/solve_ref.py: wh_per_point): the
- * GPU path equals the per-point form to 1e-6 with identical load-step and iteration counts, and the per-point form moves the
- * reference's own 4 x 4 trace by < 1e-4 with the same load-step count (tests/test_workhard_svc.py). */
+ * Inside the load-step loop (plfx_sweep / plfx_load_step) the reference hands ONE value from element to element in index order
+ * (model.py:1340-1359): reproduced exactly by default, see plfx_set_wh_mode below (round 4; rounds 2-3 carried one modulus
+ * per material point, which remains available and is the only form on several GPUs). */
 int plfx_response_batch_kh(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig, const double *epl,
                            const double *deps, const double *khard_in, double *fy, double *sig_out, double *depl,
                            double *ct, int32_t *nsteps, double *khard_out);
@@ -149,6 +145,12 @@ int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t 
  * pass 0, nel for a single GPU. */
 int plfx_set_mesh(plfx_ctx *ctx, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
                   const double *lxy, double thick, int planestress, int el_begin, int el_end);
+/* The same for the structured grids Model.mesh produces (model.py:758-952): node j * (NY + 1) + k, element j * NY + k,
+ * connectivity [n1, n1 + 1, n1 + NY + 1, n1 + NY + 2] (:893, :935-948) written by the library; dx_col[NX] = element width of every
+ * column (laminate sections, :847), dy the element height; material numbers per column (mat_col[NX]) or per element
+ * (mat_el[NX * NY], the `elmts` form of Model.mesh); exactly one of the two non-NULL. */
+int plfx_set_mesh_structured(plfx_ctx *ctx, int NX, int NY, const int32_t *mat_col, const int32_t *mat_el, const double *dx_col,
+                             double dy, double thick, int planestress, int el_begin, int el_end);
 /* Host-only self-test (no GPU needed): the closed-form block-ELL pattern that plfx_set_mesh / plfx_set_grid write for the
  * reference's structured numbering equals the one derived generically from the connectivity (slots, gather codes, order).
  * 0 = identical. */

@@ -51,7 +51,7 @@ SYMBOLS = [
     'plfx_set_bc_sources',
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
-    'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry',
+    'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
 ]
 
 _lib = None
@@ -295,6 +295,20 @@ class Context(object):
         self.nel = nel
         self.nel_owned = el_end - el_begin
         self.ndof = 2 * int(nnode)
+
+    def set_mesh_structured(self, NX, NY, dx_col, dy, thick, planestress, mat_col=None, mat_el=None, el_begin=0, el_end=None):
+        """Model.mesh's structured grid by description (plfx_set_mesh_structured): the library writes the index arrays"""
+        nel = int(NX) * int(NY)
+        dx = _f64(dx_col).reshape(int(NX))
+        mc = None if mat_col is None else _i32(mat_col).reshape(int(NX))
+        me = None if mat_el is None else _i32(mat_el).reshape(nel)
+        if el_end is None:
+            el_end = nel
+        self._chk(self.lib.plfx_set_mesh_structured(self.h, int(NX), int(NY), _dp(mc), _dp(me), _dp(dx), C.c_double(dy),
+                                                    C.c_double(thick), int(bool(planestress)), int(el_begin), int(el_end)))
+        self.nel = nel
+        self.nel_owned = el_end - el_begin
+        self.ndof = 2 * (int(NX) + 1) * (int(NY) + 1)
 
     def set_grid(self, nx, ny):
         self._chk(self.lib.plfx_set_grid(self.h, int(nx), int(ny)))

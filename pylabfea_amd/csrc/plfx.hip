@@ -175,6 +175,8 @@ struct plfx_ctx {
     double *kh_el = nullptr;   // hardening modulus per material point (work-hardening SVC: mutable, carried from sweep to sweep)
     // work-hardening SVC, sequential carry (the reference's semantics, plfx_kernels.hpp: k_wh_entry): kh_el holds the ENTRY
     // modulus of every element, kh_out / kh_touch what its response() left, wh_carry the value each material object holds now
+    int hint_nx = 0, hint_ny = 0;   // the mesh came from plfx_set_mesh_structured (numbering known, no verification scans)
+    bool hint_uniform = false;
     int wh_mode = 1;           // 1 = sequential carry (default on one GPU), 0 = one modulus per material point
     double wh_carry[16] = {0};
     double *kh_out = nullptr, *kh_new = nullptr, *wh_snap_el = nullptr, *wh_snap_M = nullptr;
@@ -1903,8 +1905,14 @@ int plfx_fgrad_batch_wh(plfx_ctx *c, int mat, int n, const double *sig, const do
 }
 
 // ------------------------------------------------------------------------------ mesh
-int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
-                  const double *lxy, double thick, int planestress, int el_begin, int el_end)
+// hint: the caller (plfx_set_mesh_structured) wrote the arrays itself from an NX x NY grid description -- the scans that verify
+// what it already knows (index ranges, the structured numbering, uniform element sizes) are skipped
+struct StructHint {
+    int nx, ny;
+    bool uniform;
+};
+static int set_mesh_impl(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
+                         const double *lxy, double thick, int planestress, int el_begin, int el_end, const StructHint *hint)
 {
     if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
     if (nel < 1 || nnode < 4 || !conn || !mat_id || !lxy) return fail(c, PLFX_ERR_ARG, "bad mesh arguments");
@@ -1917,7 +1925,10 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     c->nel = el_end - el_begin;
     c->thick = thick;
     c->planestress = planestress ? 1 : 0;
-    for (int e = 0; e < nel; e++) {
+    c->hint_nx = hint ? hint->nx : 0;
+    c->hint_ny = hint ? hint->ny : 0;
+    c->hint_uniform = hint && hint->uniform;
+    for (int e = 0; e < nel && !hint; e++) {
         if (mat_id[e] < 0 || mat_id[e] >= c->nmat) return fail(c, PLFX_ERR_ARG, "mat_id[%d] out of range", e);
         for (int a = 0; a < 4; a++)
             if (conn[4 * e + a] < 0 || conn[4 * e + a] >= nnode)
@@ -1967,7 +1978,14 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     c->pat_nx = c->pat_ny = 0;
     c->hcol.clear();
     c->hcol.shrink_to_fit();
-    if (closed_form && structured_dims(nel, nnode, conn, &c->pat_nx, &c->pat_ny)) {
+    if (closed_form && hint && hint->nx >= 2 && hint->ny >= 2 && nel >= 4) {
+        c->pat_nx = hint->nx;
+        c->pat_ny = hint->ny;
+        nslot = 9;
+        nq = 4;
+        c->n_begin = 0;
+        c->n_end = nnode;
+    } else if (closed_form && structured_dims(nel, nnode, conn, &c->pat_nx, &c->pat_ny)) {
         nslot = 9;
         nq = 4;
         c->n_begin = 0;
@@ -1977,7 +1995,11 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
         if (!build_pattern(nnode, conn, 0, nel, c->hcol, hcontrib, nslot, nq, c->n_begin, c->n_end))
             return fail(c, PLFX_ERR_ARG, "empty mesh");
     }
-    {
+    if (hint) {   // first node of an element = (e / ny) * (ny + 1) + e % ny, increasing with e
+        const int ny = hint->ny, nyn = hint->ny + 1;
+        c->own_n0 = (el_begin == 0) ? 0 : (el_begin / ny) * nyn + el_begin % ny;
+        c->own_n1 = (el_end == nel) ? nnode : (el_end / ny) * nyn + el_end % ny;
+    } else {
         int lo = nnode, nxt = nnode;
         for (int e = el_begin; e < el_end; e++)
             for (int a = 0; a < 4; a++) lo = std::min(lo, (int)conn[4 * (size_t)e + a]);
@@ -2049,6 +2071,53 @@ int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const in
     c->val_valid = false;
     c->op = make_op(c, nnode, nslot, c->dcol, c->dval, 0, 0, nel, c->Mel);
     return plfx_state_reset(c);
+}
+
+int plfx_set_mesh(plfx_ctx *c, int nel, int nnode, const int32_t *conn, const int32_t *mat_id,
+                  const double *lxy, double thick, int planestress, int el_begin, int el_end)
+{
+    return set_mesh_impl(c, nel, nnode, conn, mat_id, lxy, thick, planestress, el_begin, el_end, nullptr);
+}
+
+// Model.mesh of the reference (model.py:758-952) produces nothing but structured grids: node j * (NY + 1) + k, element j * NY + k,
+// connectivity [n1, n1 + 1, n1 + NY + 1, n1 + NY + 2] (:893, :935-948), one element width per column (laminate sections, :847) and
+// one height.  This entry point takes that description -- NX column widths, material numbers per column or per element -- and
+// writes the index arrays itself (round 3 built them with NumPy in the facade: 155 ms of the 0.35 s between mesh() and the first
+// load step at 1024^2); everything else is plfx_set_mesh.
+int plfx_set_mesh_structured(plfx_ctx *c, int NX, int NY, const int32_t *mat_col, const int32_t *mat_el, const double *dx_col, double dy,
+                             double thick, int planestress, int el_begin, int el_end)
+{
+    if (!c) return PLFX_ERR_STATE;
+    if (NX < 1 || NY < 1 || (!mat_col && !mat_el) || !dx_col || (int64_t)(NX + 1) * (NY + 1) > INT32_MAX)
+        return fail(c, PLFX_ERR_ARG, "bad structured mesh description");
+    const int nel = NX * NY, nyn = NY + 1;
+    std::vector<int32_t> conn((size_t)4 * nel), mid((size_t)nel);
+    std::vector<double> lxy((size_t)2 * nel);
+    bool uniform = true;
+    for (int j = 0; j < NX; j++) {
+        const double dx = dx_col[j];
+        if (std::fabs(dx - dx_col[0]) > 1e-12 * std::fabs(dx_col[0])) uniform = false;   // (one element height by construction)
+        const int32_t mc = mat_col ? mat_col[j] : 0;
+        if (mat_col && (mc < 0 || mc >= c->nmat)) return fail(c, PLFX_ERR_ARG, "mat_col[%d] out of range", j);
+        int32_t *q = conn.data() + (size_t)4 * j * NY;
+        double *l = lxy.data() + (size_t)2 * j * NY;
+        int32_t *m = mid.data() + (size_t)j * NY;
+        const int32_t *me = mat_el ? mat_el + (size_t)j * NY : nullptr;
+        const int n0 = j * nyn;
+        for (int k = 0; k < NY; k++) {
+            const int n1 = n0 + k;
+            q[4 * k] = n1;
+            q[4 * k + 1] = n1 + 1;
+            q[4 * k + 2] = n1 + nyn;
+            q[4 * k + 3] = n1 + nyn + 1;
+            l[2 * k] = dx;
+            l[2 * k + 1] = dy;
+            m[k] = me ? me[k] : mc;
+            if (me && (me[k] < 0 || me[k] >= c->nmat)) return fail(c, PLFX_ERR_ARG, "mat_el[%d] out of range", j * NY + k);
+        }
+    }
+    const StructHint hint{NX, NY, uniform};
+    return set_mesh_impl(c, nel, (NX + 1) * nyn, conn.data(), mid.data(), lxy.data(), thick, planestress, el_begin, el_end, &hint);
 }
 
 int plfx_get_bmat(plfx_ctx *c, int e, double *B)
@@ -2269,7 +2338,8 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         return fail(c, PLFX_ERR_STATE, "plfx_set_grid after plfx_set_strip: call plfx_set_mesh again");
     c->sur_active = false;  // the levels are rebuilt below: level 0 points at the true operator again
     const int nrow = ny + 1;
-    for (int e = 0; e < c->nel_total; e++) {  // model.py:935-948
+    const bool known = c->hint_nx == nx && c->hint_ny == ny;   // written by plfx_set_mesh_structured: nothing to verify
+    for (int e = 0; e < c->nel_total && !known; e++) {  // model.py:935-948
         const int n1 = (e / ny) * nrow + e % ny;
         const int32_t *q = &c->hconn[4 * (size_t)e];
         if (q[0] != n1 || q[1] != n1 + 1 || q[2] != n1 + nrow || q[3] != n1 + nrow + 1)
@@ -2291,7 +2361,8 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     // coarse re-assembly and the matrix-free operator need one element shape.  Laminate meshes compute dx = LS[i]/nes[i]
     // per section (model.py:847), so nominally uniform sections can differ by an ulp: compare with a relative tolerance and
     // use element 0's shape for the operator tables (the strain operator keeps each class's own lx, ly).
-    for (int e = 1; e < c->nel_total; e++)
+    if (known && !c->hint_uniform) return PLFX_OK;
+    for (int e = 1; e < c->nel_total && !known; e++)
         if (std::fabs(c->hlxy[2 * (size_t)e] - c->hlxy[0]) > 1e-12 * std::fabs(c->hlxy[0]) ||
             std::fabs(c->hlxy[2 * (size_t)e + 1] - c->hlxy[1]) > 1e-12 * std::fabs(c->hlxy[1]))
             return PLFX_OK;

@@ -324,11 +324,12 @@ class Model(object):
         self.Ndof = self.Nnode * 2
         self.Nel = NX * NY
         nrow = self.NnodeY
-        # node (j, k) has number j * nrow + k (model.py:893): in that order the node numbers are 0 .. Nnode-1, so the
-        # interleaved position array is filled by slices (no index arrays of the size of the mesh)
-        npos = np.empty(self.Ndof)
+        # The grid is kept as a DESCRIPTION (round 4): node x-positions per column, element width / material per column (or the
+        # `elmts` array), one element height.  The mesh-sized products of the reference -- `npos`, the connectivity, per-element
+        # sizes and material numbers -- are materialised on first access (properties below, same numbers as before, bit for
+        # bit), and the library writes its own index arrays from the description (plfx_set_mesh_structured): mesh() no longer
+        # costs 155 ms of NumPy index work at 1024^2 before the first load step can start.
         dy = self.leny / NY
-        npos[1::2] = np.tile(np.arange(nrow) * dy, self.NnodeX)
         if elmts is None:
             # elements per section: proportional, the largest section absorbs the remainder (:826-830)
             hh = self.LS / self.lenx
@@ -349,38 +350,23 @@ class Model(object):
                 mat_col[c0:c0 + nes[i]] = i
                 dx_col[c0:c0 + nes[i]] = dx
                 c0 += nes[i]
-            npos[0::2] = np.repeat(xcol, nrow)
-            mat_id = np.repeat(mat_col, NY)
-            lxy = np.empty((self.Nel, 2))
-            lxy[:, 0] = np.repeat(dx_col, NY)
-            lxy[:, 1] = dy
+            mat_el = None
         else:
             dx = self.lenx / NX
-            npos[0::2] = np.repeat(np.arange(self.NnodeX) * dx, nrow)
-            mat_id = (el - 1).ravel().astype(np.int64)
-            if mat_id.min() < 0 or mat_id.max() >= len(self.mat):
+            xcol = np.arange(self.NnodeX) * dx
+            dx_col = np.full(NX, dx)
+            mat_col = None
+            mat_el = (el - 1).ravel().astype(np.int64)
+            if mat_el.min() < 0 or mat_el.max() >= len(self.mat):
                 raise IndexError('mesh: material number in elmts out of range')
-            lxy = np.empty((self.Nel, 2))
-            lxy[:, 0] = dx
-            lxy[:, 1] = dy
-        self.npos = npos
+        self._grid = {'xcol': xcol, 'dx_col': dx_col, 'dy': dy, 'mat_col': mat_col, 'mat_el': mat_el}
+        self._npos_arr = self._conn_arr = self._lxy_arr = self._mat_id_arr = None
         # boundary node lists in the reference's append order (:897-911): j outer, k inner
         self.noleft = list(range(nrow))
         self.noright = list(range(NX * nrow, NX * nrow + nrow))
         self.nobot = list(range(0, self.NnodeX * nrow, nrow))
         self.notop = list(range(NY, self.NnodeX * nrow, nrow))
         self._noinner = None          # (NX-1)(NY-1) entries: materialised on first access (property noinner)
-        # connectivity [n1, n1+1, n1+nrow, n1+nrow+1], n1 = (ih // NY) * nrow + ih % NY (:936-948); int32 like the library
-        ih = np.arange(self.Nel, dtype=np.int32)
-        n1 = (ih // NY) * nrow + ih % NY
-        conn = np.empty((self.Nel, 4), dtype=np.int32)
-        conn[:, 0] = n1
-        conn[:, 1] = n1 + 1
-        conn[:, 2] = n1 + nrow
-        conn[:, 3] = n1 + nrow + 1
-        self._conn = conn
-        self._mat_id = mat_id
-        self._lxy = lxy
         self._NX, self._NY = NX, NY
         self.element = _ElementList(self, self.Nel)
         self._bnd_idx = None
@@ -388,6 +374,62 @@ class Model(object):
         self._bc_struct = None
         self._bc_registered = None
         self._drop_engine()
+
+    # -- mesh-sized products of Model.mesh, materialised on first access
+    _grid = None
+    _npos_arr = _conn_arr = _lxy_arr = _mat_id_arr = None
+
+    @property
+    def npos(self):
+        """nodal positions, interleaved (x, y) in node order j * NnodeY + k (model.py:893, :847)"""
+        if self._npos_arr is None and getattr(self, '_grid', None) is not None:
+            g, nrow = self._grid, self.NnodeY
+            npos = np.empty(self.Ndof)
+            npos[1::2] = np.tile(np.arange(nrow) * g['dy'], self.NnodeX)
+            npos[0::2] = np.repeat(g['xcol'], nrow)
+            self._npos_arr = npos
+        return self._npos_arr
+
+    @npos.setter
+    def npos(self, v):
+        self._npos_arr = v
+
+    def _node_coord(self, nodes, pos):
+        """coordinate `pos` (0 = x, 1 = y) of the given nodes without materialising `npos`"""
+        g = self._grid
+        nodes = np.asarray(nodes, dtype=np.int64)
+        return g['xcol'][nodes // self.NnodeY] if pos == 0 else (nodes % self.NnodeY) * g['dy']
+
+    @property
+    def _conn(self):
+        """connectivity [n1, n1+1, n1+nrow, n1+nrow+1], n1 = (ih // NY) * nrow + ih % NY (:936-948); int32 like the library"""
+        if self._conn_arr is None and self._grid is not None:
+            NY, nrow = self._NY, self.NnodeY
+            ih = np.arange(self.Nel, dtype=np.int32)
+            n1 = (ih // NY) * nrow + ih % NY
+            conn = np.empty((self.Nel, 4), dtype=np.int32)
+            conn[:, 0] = n1
+            conn[:, 1] = n1 + 1
+            conn[:, 2] = n1 + nrow
+            conn[:, 3] = n1 + nrow + 1
+            self._conn_arr = conn
+        return self._conn_arr
+
+    @property
+    def _lxy(self):
+        if self._lxy_arr is None and self._grid is not None:
+            lxy = np.empty((self.Nel, 2))
+            lxy[:, 0] = np.repeat(self._grid['dx_col'], self._NY)
+            lxy[:, 1] = self._grid['dy']
+            self._lxy_arr = lxy
+        return self._lxy_arr
+
+    @property
+    def _mat_id(self):
+        if self._mat_id_arr is None and self._grid is not None:
+            g = self._grid
+            self._mat_id_arr = g['mat_el'] if g['mat_el'] is not None else np.repeat(g['mat_col'], self._NY)
+        return self._mat_id_arr
 
     @property
     def noinner(self):
@@ -456,8 +498,8 @@ class Model(object):
         -- or None when the mesh does not allow it (non-uniform elements, strips narrower than the halo, sizes that are
         not multiples of 2^Ld).  Strip boundaries are multiples of 2^Ld so that every level coarsens exactly as on one GPU."""
         NX, NY = self._NX, self._NY
-        lx, ly = self._lxy[:, 0], self._lxy[:, 1]
-        if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]) or np.max(np.abs(ly - ly[0])) > 1e-12 * abs(ly[0]):
+        lx = self._grid['dx_col']   # (one element height by construction)
+        if np.max(np.abs(lx - lx[0])) > 1e-12 * abs(lx[0]):
             return None
         cost = self._column_cost()
 
@@ -523,6 +565,8 @@ class Model(object):
         if getattr(self, 'mat', None) is None or getattr(self, '_mat_id', None) is None:
             return np.full(self._NX, float(self._NY))
         per_mat = np.array([(len(m.svc['dual']) * m.Ndof / 8.) if getattr(m, 'ML_yf', False) else 1. for m in self.mat])
+        if self._grid.get('mat_col') is not None:
+            return per_mat[self._grid['mat_col']] * float(self._NY)
         return per_mat[self._mat_id].reshape(self._NX, self._NY).sum(axis=1)
 
     def strip_range(self, rank, nranks):
@@ -557,7 +601,10 @@ class Model(object):
         eng.set_materials([m._record(self._element_CV(m)) for m in uniq])
         self._eng_uniq = uniq
         eng.set_wh_mode(self.wh_carry != 'per_point')
-        self._eng_mat_id = np.asarray(remap, dtype=np.int64)[self._mat_id]
+        remap = np.asarray(remap, dtype=np.int64)
+        g = self._grid
+        eng_mat_col = None if g['mat_col'] is None else remap[g['mat_col']]
+        eng_mat_el = None if g['mat_el'] is None else remap[g['mat_el']]
         e0, e1 = 0, self.Nel
         self._strip = None
         plan = None
@@ -579,16 +626,14 @@ class Model(object):
             NY, nyn = self._NY, self._NY + 1
             g0, g1 = plan['g0'], plan['g1']
             nxl = g1 - g0
-            ih = np.arange(nxl * NY)
-            n1 = (ih // NY) * nyn + ih % NY
-            conn = np.stack((n1, n1 + 1, n1 + nyn, n1 + nyn + 1), axis=1)
             nnode_l = (nxl + 1) * nyn
             # material state and sweep on the owned columns only; the stiffness generators of the halo columns come from
             # the neighbours that own them (PLFX_STRIP_SWEEP_HALO=1: sweep the halo elements redundantly instead)
             lean = os.environ.get('PLFX_STRIP_SWEEP_HALO', '0') != '1'
             eo0, eo1 = ((plan['c0'] - g0) * NY, (plan['c1'] - g0) * NY) if lean else (0, nxl * NY)
-            eng.set_mesh(conn, self._eng_mat_id[g0 * NY:g1 * NY], self._lxy[g0 * NY:g1 * NY], nnode_l, self.thick,
-                         self.planestress, eo0, eo1)
+            eng.set_mesh_structured(nxl, NY, g['dx_col'][g0:g1], g['dy'], self.thick, self.planestress,
+                                    mat_col=None if eng_mat_col is None else eng_mat_col[g0:g1],
+                                    mat_el=None if eng_mat_el is None else eng_mat_el[g0 * NY:g1 * NY], el_begin=eo0, el_end=eo1)
             eng.set_grid(nxl, NY)
             eng.set_strip(plan['c0'] - g0, plan['c1'] - g0, g0, self._NX, plan['Ld'])
             last = plan['rank'] == plan['nranks'] - 1
@@ -597,7 +642,8 @@ class Model(object):
             self._strip = plan
             e0, e1 = plan['c0'] * NY, plan['c1'] * NY
         else:
-            eng.set_mesh(self._conn, self._eng_mat_id, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+            eng.set_mesh_structured(self._NX, self._NY, g['dx_col'], g['dy'], self.thick, self.planestress, mat_col=eng_mat_col,
+                                    mat_el=eng_mat_el, el_begin=e0, el_end=e1)
             eng.set_grid(self._NX, self._NY)  # structured numbering -> multigrid preconditioner where possible
         if self.precond is not None:
             eng.set_precond(self.precond)
@@ -659,7 +705,7 @@ class Model(object):
 
         def share(nodes, npart, pos, length):
             hh = np.full(len(nodes), 1. / (npart - 1))   # share of the edge force per node
-            hp = self.npos[2 * nodes + pos]
+            hp = self._node_coord(nodes, pos)
             hh[(hp < 1.e-3) | (hp > length - 1.e-3)] *= 0.5  # half on corner nodes
             return hh
 

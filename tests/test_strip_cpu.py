@@ -69,7 +69,7 @@ def test_validity_widths():
 def test_strip_plan(NX, NY, nranks):
     fe = FE.Model(dim=2)
     fe._NX, fe._NY = NX, NY
-    fe._lxy = np.full((4, 2), 0.125)
+    fe._grid = {'dx_col': np.full(NX, 0.125), 'dy': 0.125, 'mat_col': None, 'mat_el': None}   # (what Model.mesh keeps of the grid)
     plans = [fe.strip_plan(r, nranks) for r in range(nranks)]
     assert all(p is not None for p in plans)
     Ld, W = plans[0]['Ld'], plans[0]['W']
@@ -129,9 +129,9 @@ def test_strip_plan_balances_svc_columns():
 def test_strip_plan_refuses_what_cannot_work():
     fe = FE.Model(dim=2)
     fe._NX, fe._NY = 96, 24
-    fe._lxy = np.full((4, 2), 0.125)
+    fe._grid = {'dx_col': np.full(96, 0.125), 'dy': 0.125, 'mat_col': None, 'mat_el': None}
     assert fe.strip_plan(0, 16) is None                  # 6 columns per strip: narrower than any halo
-    fe._lxy = np.array([[0.125, 0.125], [0.25, 0.125]])
+    fe._grid['dx_col'] = np.concatenate((np.full(48, 0.125), np.full(48, 0.25)))
     assert fe.strip_plan(0, 2) is None                   # non-uniform elements: no matrix-free grid operator
 
 

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Where does Model.mesh() -> first solve() set-up time go?  (host NumPy index work vs plfx_set_mesh / plfx_set_grid)"""
+"""Set-up latency: Model.mesh() -> first load step, per stage.  The first model of a process also pays the
+HIP context; the second one shows the steady state."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import pylabfea_amd as FE
 from pylabfea_amd import _lib
-for n in (1024, 2048):
+for n in (1024, 1024, 2048):
     mat = FE.Material(); mat.elasticity(E=200.e3, nu=0.3)
     mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
     t0 = time.perf_counter()
@@ -13,17 +14,11 @@ for n in (1024, 2048):
     fe.bcleft(0.); fe.bcbot(0.); fe.bcright(0., 'force'); fe.bctop(0.005 * fe.leny, 'disp')
     fe.mesh(NX=n, NY=n)
     t1 = time.perf_counter()
-    eng = _lib.Context(0)
-    eng.set_materials([mat._record(fe._element_CV(mat))])
+    eng = fe._ensure_engine(); eng.sync()
     t2 = time.perf_counter()
-    eng.set_mesh(fe._conn, fe._mat_id, fe._lxy, fe.Nnode, fe.thick, fe.planestress)
-    eng.sync(); t3 = time.perf_counter()
-    eng.set_grid(n, n)
-    eng.sync(); t4 = time.perf_counter()
-    eng.close()
     fe._max_load_steps = 1
-    t5 = time.perf_counter()
-    fe.solve(min_step=50)
-    t6 = time.perf_counter()
-    print('%d^2: Model.mesh() %.0f ms | context + materials %.0f ms | plfx_set_mesh %.0f ms | plfx_set_grid %.0f ms | first solve() call with 1 load step (incl. engine set-up again) %.0f ms'
-          % (n, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * (t6 - t5)), flush=True)
+    fe.solve(min_step=50); eng.sync()
+    t3 = time.perf_counter()
+    print('%d^2: Model.mesh() %.1f ms | engine (context, materials, plfx_set_mesh_structured, plfx_set_grid) %.1f ms | solve() with 1 load step %.1f ms '
+          '| mesh() + first solve() call = %.1f ms' % (n, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0)), flush=True)
+    fe._drop_engine()
