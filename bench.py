@@ -507,6 +507,9 @@ def main():
     ap.add_argument('--cpu-mesh', type=int, default=448)
     ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-tight-loop', action='store_true',
+                    help='skip the back-to-back V-cycle timing (plfx_precond_bench): hundreds of hipGraph launches without a '
+                         'synchronisation in between crash rocprofv3 (ROCm 7.2); skipped automatically under the profiler')
     ap.add_argument('--no-inclusion', action='store_true', help='skip the heterogeneous (soft inclusion) variant of the workload')
     ap.add_argument('--no-svc', action='store_true', help='skip the bounded config-4 (SVC) sample behind roofline_svc')
     ap.add_argument('--svc-mesh', type=int, default=128)
@@ -758,7 +761,8 @@ def main():
                          'note': 'whole V(2,2) cycle (HIP events, every %d-th cycle); fine level = 4 operator passes at the rate of the '
                                  'roofline kernel; the rest (levels >= 1: transfers, 24 launch-latency-bound kernels replayed from a hipGraph, '
                                  'single-workgroup tail) is latency-bound and has no roofline' % args.sample}
-        if world == 1 and eng.precond_info()[0] == 1:
+        under_profiler = any('rocprof' in os.environ.get(v, '').lower() for v in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+        if world == 1 and eng.precond_info()[0] == 1 and not args.no_tight_loop and not under_profiler:
             # the same cycle measured WITHOUT the solver around it: 200 applications back to back between one pair of HIP events
             # (plfx_precond_bench), and the part below the fine level alone -- reproducible to 1 %, where the in-run figure above
             # carries the sampling events and whatever the stream did before each sampled cycle
@@ -807,7 +811,10 @@ def main():
         out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'generator_exchanges': si[7], 'note': 'since the start of the run (rank 0)'}
     if world > 1 and args.config == 3 and not weak and args.config5_leg_mesh > 0:
         fe._drop_engine()
-        leg = config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, args.config5_leg_mesh)
+        try:
+            leg = config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, args.config5_leg_mesh)
+        except Exception as exc:   # the main line above stands on its own: report, do not lose it
+            leg = {'error': '%s: %s' % (type(exc).__name__, exc)}
         out['config5_leg'] = leg
     if rank == 0 and world == 1:
         fe._drop_engine()        # release the homogeneous model's HBM and stream before the other samples

@@ -2703,7 +2703,10 @@ int plfx_precond_bench(plfx_ctx *c, int reps, double *us_per_cycle, double *us_c
     float ms = 0.f;
     for (int w = 0; w < 3 && !rc; w++) rc = mg_vcycle(c);
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    for (int k = 0; k < reps && !rc; k++) rc = mg_vcycle(c);
+    for (int k = 0; k < reps && !rc; k++) {
+        rc = mg_vcycle(c);
+        if ((k & 63) == 63) HIPCHK(c, hipStreamSynchronize(c->stream));  // bounded queue depth (one drain per ~17 ms of cycles: < 0.2 %)
+    }
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
@@ -3538,6 +3541,10 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
     const int nn = c->nnode, gn = c->grid_nodes;
     const int olo = own_lo(c), ohi = own_hi(c);
     int rc;
+    // LOCK-STEP: the first-use block below holds a collective.  Every rank of a communicator reaches it in the same
+    // solve, because what sends a solve here -- PCG's breakdown / stall flags -- is decided from partial sums that were
+    // all-reduced element-wise (strip) or computed redundantly on identical data (replicated solve): bitwise the same on every
+    // rank; gm_m is reset together with the mesh on all of them.
     if (c->gm_m == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
