@@ -63,7 +63,7 @@ PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494
                            # the sweep per launch: 160.45 MB x 2 fetched + 109.05 MB written when no tangent is rewritten (430.0 MB
                            # against 432.0 MB algorithmic), + 226.5 MB written when all are (counter min / max of the profile)
                            'sweep': (429.95e6, 226.53e6)}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r03n_bench1024_rocprofv3_summary.txt'}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r04m_bench1024_rocprofv3_summary.txt'}
 
 
 def hill_material(FE):
