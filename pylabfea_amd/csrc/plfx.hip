@@ -2172,8 +2172,9 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     dims.push_back({nx, ny});
     // coarsening goes on to 2 x 2 elements (9 nodes, 18 DOFs, dense inverse).  Stopping at 4 x 4 (PLFX_MG_COARSEST_ELEMS=16:
     // 50 DOFs, one level of six workgroup-barrier phases less) saves 4.5 us of the 259 us of a cycle at 1024^2 -- and made four
-    // GMRES solves of config 5 at 2048^2 stall at 1e-6 in load step 16 (130 000 mildly indefinite elements: the 50 x 50
-    // Gauss-Jordan inverse has no pivoting; profiles/r04d_config5_coarsest_level.txt).  Measured, not adopted.
+    // GMRES solves of config 5 at 2048^2 stall at 1e-6 in load step 16 (130 000 mildly indefinite elements by then;
+    // profiles/r04d_config5_coarsest_level.txt -- with partial pivoting in the 50 x 50 inverse the numbers are identical, so it
+    // is the truncated hierarchy on that indefinite operator, not the inversion).  Measured, not adopted.
     static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 4;
     while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 && (long long)dims.back().first * dims.back().second > 4 &&
            ((long long)dims.back().first * dims.back().second > coarsest || dims.size() < 2))  // (at least two levels)
