@@ -1709,6 +1709,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (c->svc_wave_mat >= 0) {
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
@@ -1751,8 +1752,13 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
         HIPCHK(c, hipMemcpyAsync(dld, ld, 48, hipMemcpyHostToDevice, c->stream));
     }
     if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
-    hipLaunchKernelGGL(k_point_eval, dim3(grid_for(n)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
-                       c->dmat, c->nmat, c->svc_lds_need, what, mat, n, dsig, depl, dld, dout, dst);
+    static const bool wave_full = !(getenv("PLFX_FULL_YF_WAVE") && atoi(getenv("PLFX_FULL_YF_WAVE")) == 0);
+    if (what == 3 && wave_full && mat == c->svc_wave_mat && c->svc_wave_lds > 0)   // ML_full_yf of the wave-kernel SVC material: one wave per point
+        hipLaunchKernelGGL(k_full_yf_wave, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                           c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
+    else
+        hipLaunchKernelGGL(k_point_eval, dim3(grid_for(n)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                           c->dmat, c->nmat, c->svc_lds_need, what, mat, n, dsig, depl, dld, dout, dst);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)n * 8 * wout, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, dst, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

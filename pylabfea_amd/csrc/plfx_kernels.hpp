@@ -654,6 +654,43 @@ __device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, 
     return npad;
 }
 
+// ML_full_yf on N points, one WAVE per point (round 4): the ray search of YfSvcWave<4> -- support-vector sums split over the
+// lanes, FP32 sign screen of the marching bracket -- on its own needs 210 VGPRs and no scratch at two waves per SIMD (inside the
+// sub-stepping corrector it shares 256 registers + 720 B of scratch with the loop state).  Entry point of plfx_full_yf_batch for the
+// model's 6-feature SVC material (f3's callers: find_yloc / calc_properties / yield-locus grids call it on (N, 6) arrays).
+__global__ void __launch_bounds__(512)
+k_full_yf_wave(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const double *__restrict__ sig_in,
+               const double *__restrict__ epl_in, const double *__restrict__ ld, double *__restrict__ out, int32_t *__restrict__ status)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    const int npad = stage_svc_wave(smat, mat, 4);
+    __syncthreads();
+    const MatDev &m = smat[mat];
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    double ldv[6];
+    if (ld) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) ldv[c] = ld[c];
+    }
+    for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {  // wave-uniform
+        double s[6], e[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            s[c] = sig_in[6 * (size_t)i + c];
+            e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
+        }
+        const YfSvcWave<4> yf(m, nullptr, nullptr, npad);
+        int st = 0;
+        const double f = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
+        if (lane == 0) {
+            out[i] = f;
+            if (status) status[i] = st;
+        }
+    }
+}
+
 // Both phases run 512-thread workgroups (8 waves share the LDS tables: 2 waves per SIMD, 256 VGPRs).  HEAVY = 0: 2 vectors per
 // lane and trip; HEAVY = 1: 4, with the FP32 sign screen of the marching bracket -- the sub-stepping loop wants 424 registers
 // and ran one wave per SIMD in round 1; two waves per SIMD with 592 B of scratch are 1.3x faster (PLFX_HEAVY_THREADS).
