@@ -1724,6 +1724,8 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_response_batch<7>, bytes));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_light<7>, bytes));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_heavy<7>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_wh_wave<0>, bytes));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_wh_wave<1>, bytes));
     }
     c->M_dirty = true;
     c->memo.valid = false;
@@ -4229,7 +4231,17 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
                            c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1);
         first = 0;
     }
-    if (c->has_svcwh) {
+    // work-hardening SVC materials: one wave per element (PLFX_WH_WAVE=0: one thread per element, rounds 2-3)
+    static const bool wh_wave = !(getenv("PLFX_WH_WAVE") && atoi(getenv("PLFX_WH_WAVE")) == 0);
+    const int grid_wh = std::max(1, std::min((c->nel + 3) / 4, 2048));
+    if (c->has_svcwh && wh_wave) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_wh_wave<0>), dim3(grid_wh), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                           c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
+                           (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl,
+                           c->fyn, c->max_steps, nit, c->flags, c->bflags, c->heavy_list, first, c->kh_el,
+                           wh_seq ? c->kh_out : (double *)nullptr, wh_seq ? c->kh_touch : (int32_t *)nullptr);
+        first = 0;
+    } else if (c->has_svcwh) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
                            wh_seq ? c->kh_touch : (int32_t *)nullptr);
@@ -4256,7 +4268,13 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), -1);
-    if (c->has_svcwh)
+    if (c->has_svcwh && wh_wave)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_wh_wave<1>), dim3(grid_wh), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                           c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
+                           (const double2 *)c->du, c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl,
+                           c->fyn, c->max_steps, nit, c->flags, c->bflags, c->heavy_list, 0, c->kh_el,
+                           wh_seq ? c->kh_out : (double *)nullptr, wh_seq ? c->kh_touch : (int32_t *)nullptr);
+    else if (c->has_svcwh)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
                            wh_seq ? c->kh_touch : (int32_t *)nullptr);

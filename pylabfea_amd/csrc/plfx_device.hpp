@@ -1070,14 +1070,18 @@ struct YfSvcT {
 // every get_sflow / epl_dot / C_tan call reads -- carried from call to call, across elements, in index order.  Inside one
 // response() call that is reproduced exactly (K below); across calls the data-parallel engine carries it per material
 // point (k_sweep_*: kh_el[e]) and the single-call entry points take / return it explicitly.
-struct YfSvcWh {
+// WAVE = 1 (round 4, k_sweep_wh_wave): one wave works on ONE material point -- every lane carries the same point, the
+// support-vector sums are split over the lanes (vector k of lane L: L, L + 64, ...) and closed by a wave reduction; all other
+// arithmetic runs redundantly in lock-step.  WAVE = 0: one thread per point (entry points, calc_scf, the thread sweeps).
+template <int WAVE>
+struct YfSvcWhT {
     const MatDev &m;
     const double *sv;
     const double *dual;
     const double K_in;   // hardening modulus at the entry of the call
     mutable double K;    // ... as of the last gradient evaluation
     mutable int touch = 0;   // a gradient evaluation has overwritten the modulus (else the call hands its entry value on)
-    __device__ YfSvcWh(const MatDev &mm, const double *s, const double *d, double k0) : m(mm), sv(s), dual(d), K_in(k0), K(k0) {}
+    __device__ YfSvcWhT(const MatDev &mm, const double *s, const double *d, double k0) : m(mm), sv(s), dual(d), K_in(k0), K(k0) {}
     __device__ __forceinline__ int touched() const { return touch; }
     __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
     __device__ __forceinline__ void features(const double *s, const double *epl, double *x) const
@@ -1091,7 +1095,7 @@ struct YfSvcWh {
     {
         double f = 0.;
         const double g = -m.gamma * LOG2E;
-        for (int k = 0; k < m.nsv; k++) {
+        for (int k = WAVE ? (int)(threadIdx.x & 63) : 0; k < m.nsv; k += WAVE ? 64 : 1) {
             const double *v = sv + 15 * k;
             double hh = 0.;
 #pragma unroll
@@ -1103,6 +1107,7 @@ struct YfSvcWh {
             for (int i = 12; i < 15; i++) hh = fma(v[i], v[i], hh);
             f = fma(dual[k], exp2_neg(g * hh), f);
         }
+        if (WAVE) f = wave_allsum(f);
         return f + m.intercept;
     }
     __device__ __forceinline__ double plain(const double *s, const double *epl) const
@@ -1122,7 +1127,7 @@ struct YfSvcWh {
 #pragma unroll
         for (int i = 0; i < 12; i++) acc[i] = 0.;
         const double g = -m.gamma * LOG2E;
-        for (int k = 0; k < m.nsv; k++) {
+        for (int k = WAVE ? (int)(threadIdx.x & 63) : 0; k < m.nsv; k += WAVE ? 64 : 1) {
             const double *v = sv + 15 * k;
             double hv[12], hh = 0.;
 #pragma unroll
@@ -1135,6 +1140,10 @@ struct YfSvcWh {
             const double w = dual[k] * exp2_neg(g * hh);
 #pragma unroll
             for (int i = 0; i < 12; i++) acc[i] = fma(w, hv[i], acc[i]);
+        }
+        if (WAVE) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) acc[i] = wave_allsum(acc[i]);
         }
         const double c2 = -2. * m.gamma;
 #pragma unroll
@@ -1213,6 +1222,7 @@ struct YfSvcWh {
     }
 };
 
+typedef YfSvcWhT<0> YfSvcWh;
 typedef YfSvcT<6> YfSvc;
 typedef YfSvcT<2> YfSvc3;
 template <int NC>

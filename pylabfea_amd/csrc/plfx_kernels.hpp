@@ -745,6 +745,66 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
     post_block_flags(lane == 0 ? changed : 0, lane == 0 ? nconv : 0, bflags);
 }
 
+// Wave-per-element sweep of the work-hardening SVC materials (kind 7; round 4): the same two phases with YfSvcWhT<1> -- a
+// 15-feature SVC update costs ~1e8 flop in its support-vector sums, and one THREAD per element (k_sweep_light<7> / _heavy<7>)
+// leaves a 16- or 144-element model on 16 or 144 lanes of the GPU (0.75 s per sweep on 4 x 4 elements).  Tables from LDS when
+// they fit (stage_svc), else from the L2.  kh_el / kh_out / kh_touch as in the thread kernels (lane 0 stores).
+template <int HEAVY>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_wh_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls, int lds_doubles,
+                int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
+                const double2 *__restrict__ du2, const double *__restrict__ sig, const double *__restrict__ epl,
+                double *elstiff, double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
+                int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind,
+                double *kh_el, double *kh_out, int32_t *kh_touch)
+{
+    const int count = HEAVY ? flags[2] : nel;
+    if (count == 0) return;
+    __shared__ SweepTables tb;
+    stage_tables(tb, gmat, nmat, gcls, ncls);
+    __syncthreads();
+    int svc_mat = -1;
+    const double *sv = nullptr, *dual = nullptr;
+    stage_svc(tb.smat, nmat, dyn_lds, lds_doubles, svc_mat, sv, dual, 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int w = blockIdx.x * wpb + (threadIdx.x >> 6), nw = gridDim.x * wpb;
+    int changed = 0, nconv = 0;
+    for (int i = w; i < count; i += nw) {  // wave-uniform
+        const int e = HEAVY ? list[i] : i;
+        const ClassDev &c = tb.scls[cls[e]];
+        const MatDev &m = tb.smat[c.mat];
+        if (!HEAVY && m.kind == 0 && first_kind && lane == 0) fyn[e] = 0.;  // elastic: skipped by the reference
+        if (m.kind != 7) continue;
+        const size_t ge = (size_t)e + e_off;
+        double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            s[k] = sig[(size_t)k * nel + e];
+            ep[k] = epl[(size_t)k * nel + e];
+        }
+        const bool staged = (c.mat == svc_mat);
+        const YfSvcWhT<1> yf(m, staged ? sv : m.sv, staged ? dual : m.dual, kh_el ? kh_el[e] : m.khard);
+        const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+        if (HEAVY) response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
+        if (!HEAVY && st == 2) {
+            if (lane == 0) list[atomicAdd(&flags[2], 1)] = e;
+            continue;
+        }
+        if (lane == 0) {
+            sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, HEAVY ? MAXIT - 1 : 0, elstiff, Mel, mel_stride, res_sig, res_depl, fyn,
+                           max_steps, nit, changed, nconv, yf.kh());
+            if (kh_el) {
+                (kh_out ? kh_out : kh_el)[e] = yf.kh();
+                if (kh_touch) kh_touch[e] = yf.touched();
+            }
+        }
+    }
+    post_block_flags(lane == 0 ? changed : 0, lane == 0 ? nconv : 0, bflags);
+}
+
 // elstiff = CV, M from CV for all owned elements (model.py:1219-1221)
 __global__ void __launch_bounds__(BLOCK)
 k_init_tangent(const MatDev *gmat, const ClassDev *gcls, int nel, const int32_t *cls,
