@@ -424,11 +424,12 @@ def inclusion_variant(FE, n, K, W, device=0):
             'solves_completed_by_fallback_solver': int(fe._engine.solve_fallbacks())}
 
 
-def config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, n, K=2, W=1):
-    """Two load steps of BASELINE config 5 (2048 x 2048 laminate J2 + the Goss-Barlat SVC; load steps 6..8 of 20: the SVC phase has
-    begun to yield, every stiffness iteration sweeps ~1 M SVC elements) on the same ranks: the workload whose time is the material
-    sweep, which shards by elements without any collective -- next to the homogeneous config 3, whose load step is 1.6 ms of
-    launch-latency-bound kernels and cannot gain from strips.  Same timing contract as the main line."""
+def config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, n, K=2, W=0, pre=10):
+    """Two load steps of BASELINE config 5 (laminate J2 + the Goss-Barlat SVC, here on an n x n mesh; load steps 11 and 12 of 20:
+    every SVC element -- a quarter of the mesh -- runs the 50-sub-step corrector in every stiffness iteration) on the same ranks:
+    the workload whose time is the material sweep, which shards by elements without any collective -- next to the homogeneous
+    config 3, whose load step is 1.7 ms of launch-latency-bound kernels and cannot gain from strips.  Same timing contract as
+    the main line; reported at N = 1 as well, so that a scaling record can be read off the lines of one driver run."""
     import warnings
     fe, nsv = laminate_model(FE, n, device=local)
     if dist is not None:
@@ -441,7 +442,6 @@ def config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, n, K=
             dist.broadcast_object_list(uid, src=0)
             fe.distribute(rank, world, uid[0])
     eng = fe._ensure_engine()
-    pre = 5
     marks = {}
 
     def barrier():
@@ -501,9 +501,9 @@ def main():
                     help='BASELINE.json configs[2] (default, the configuration the metric is quoted on) or configs[4]')
     ap.add_argument('--weak', action='store_true',
                     help='N>1: weak scaling (N strips of mesh x mesh elements side by side) instead of strong scaling of the same mesh')
-    ap.add_argument('--config5-leg-mesh', type=int, default=2048,
-                    help='N>1, config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
-                         'strips pay) on this mesh, reported as `config5_leg` of the same JSON line; 0 = skip')
+    ap.add_argument('--config5-leg-mesh', type=int, default=1024,
+                    help='config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
+                         'strips pay) on this mesh, reported as `config5_leg` of the same JSON line; 0 = skip (also skipped with --no-svc at N = 1)')
     ap.add_argument('--cpu-mesh', type=int, default=448)
     ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -809,7 +809,7 @@ def main():
     if strip:
         si = eng.strip_info()
         out['strip_collectives'] = {'halo_refreshes': si[4], 'coarse_gathers': si[5], 'partial_sum_allreduces': si[6], 'generator_exchanges': si[7], 'note': 'since the start of the run (rank 0)'}
-    if world > 1 and args.config == 3 and not weak and args.config5_leg_mesh > 0:
+    if args.config == 3 and not weak and args.config5_leg_mesh > 0 and not (world == 1 and args.no_svc):
         fe._drop_engine()
         try:
             leg = config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, args.config5_leg_mesh)
