@@ -641,6 +641,10 @@ class Model(object):
                         own_nodes=(plan['c0'] * nyn, (self._NX + 1 if last else plan['c1']) * nyn))
             self._strip = plan
             e0, e1 = plan['c0'] * NY, plan['c1'] * NY
+        elif getattr(self, '_explicit_mesh', False):   # the index arrays handed over as arrays (plfx_set_mesh): same engine state
+            emid = remap[self._mat_id]
+            eng.set_mesh(self._conn, emid, self._lxy, self.Nnode, self.thick, self.planestress, e0, e1)
+            eng.set_grid(self._NX, self._NY)
         else:
             eng.set_mesh_structured(self._NX, self._NY, g['dx_col'], g['dy'], self.thick, self.planestress, mat_col=eng_mat_col,
                                     mat_el=eng_mat_el, el_begin=e0, el_end=e1)

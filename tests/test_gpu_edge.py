@@ -128,3 +128,42 @@ def test_facade_errors():
         fe.mesh(NX=2, NY=2, SF=2)
     with pytest.raises(NotImplementedError):
         FE.Model(dim=1)
+
+
+@pytest.mark.gpu
+def test_structured_mesh_description_equals_explicit_index_arrays():
+    """plfx_set_mesh_structured (the library writes Model.mesh's index arrays from the grid description, model.py:893, :935-948)
+    against plfx_set_mesh with the arrays the facade materialises: bit-identical solves -- homogeneous Hill and a laminate whose
+    sections have different element widths (block-ELL operator there)."""
+    import warnings
+    import pylabfea_amd as FE
+
+    def run(kind, explicit):
+        a = FE.Material(num=1)
+        a.elasticity(E=200.e3, nu=0.3)
+        a.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+        fe = FE.Model(dim=2, planestress=False)
+        if kind == 'hill':
+            fe.geom([4.], LY=4.)
+            fe.assign([a])
+        else:
+            b = FE.Material(num=2)
+            b.elasticity(E=100.e3, nu=0.35)
+            fe.geom([2., 1., 2.5], LY=4.)
+            fe.assign([a, b, a])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.003 * fe.leny, 'disp')
+        fe.mesh(NX=16, NY=8)
+        fe._explicit_mesh = explicit
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve()
+        return fe
+
+    for kind in ('hill', 'laminate'):
+        s, e = run(kind, False), run(kind, True)
+        assert s.nsteps == e.nsteps and list(s.niter) == list(e.niter)
+        assert np.array_equal(s.u, e.u) and np.array_equal(s.f, e.f) and np.array_equal(s._state('sig'), e._state('sig'))
+        assert s._engine.precond_info() == e._engine.precond_info() and s._engine.operator_info() == e._engine.operator_info()
