@@ -767,8 +767,16 @@ def main():
             # (plfx_precond_bench), and the part below the fine level alone -- reproducible to 1 %, where the in-run figure above
             # carries the sampling events and whatever the stream did before each sampled cycle
             tl = min(eng.precond_bench(200) for _ in range(3))
-            out['vcycle']['tight_loop_us'] = tl[0]
-            out['vcycle']['tight_loop_coarse_levels_us'] = tl[1]
+            v = out['vcycle']
+            v['in_run_sampled'] = {'avg_us': v['avg_us'], 'fine_level_us': v['fine_level_us'], 'coarse_levels_us': v['coarse_levels_us'],
+                                   'cycles_timed': v['cycles_timed']}
+            v['avg_us'], v['coarse_levels_us'], v['fine_level_us'] = tl[0], tl[1], tl[0] - tl[1]
+            v['cycles_timed'] = 600
+            v['note'] = ('whole V(2,2) cycle, 200 applications back to back between one pair of HIP events (plfx_precond_bench, best of 3); '
+                         'coarse_levels_us = the same loop without the four fine-level operator passes (transfers to / from level 1, 24 '
+                         'launch-latency-bound kernels replayed from a hipGraph, single-workgroup tail: no roofline, see profiles/'
+                         'r04c_vcycle_launches.txt); in_run_sampled = every %d-th cycle of the timed load steps with its own event pairs '
+                         '(includes the instrumentation and the flag round trip of the PCG loop)' % args.sample)
     if dist is not None:
         # per-rank view: roofline of the dominant kernel on every rank's own strip, and the time its stream spent in
         # collectives (HIP events around every RCCL call: includes the wait for the slowest peer)
