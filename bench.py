@@ -505,7 +505,7 @@ def main():
                     help='config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
                          'strips pay) on this mesh, reported as `config5_leg` of the same JSON line; 0 = skip (also skipped with --no-svc at N = 1)')
     ap.add_argument('--cpu-mesh', type=int, default=448)
-    ap.add_argument('--sample', type=int, default=3, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
+    ap.add_argument('--sample', type=int, default=7, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-tight-loop', action='store_true',
                     help='skip the back-to-back V-cycle timing (plfx_precond_bench): hundreds of hipGraph launches without a '
