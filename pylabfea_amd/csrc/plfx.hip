@@ -411,7 +411,8 @@ void tim_begin(plfx_ctx *c, int which, EvPair **out)
     *out = nullptr;
     Timing &t = c->tim;
     if (!t.on || !((t.mask >> which) & 1u)) return;
-    if (t.every > 1 && which != 7 && (t.seen[which]++ % t.every) != 0) return;  // family 7 (collectives): every call  // sampled: two event records per timed launch cost host time
+    // sampled (two event records per timed launch cost host time and a bubble on the stream); family 7 (collectives): every call
+    if (t.every > 1 && which != 7 && (t.seen[which]++ % t.every) != 0) return;
     if (t.ring.empty()) {
         t.ring.resize(2048);
         for (auto &e : t.ring) {
