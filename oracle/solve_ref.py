@@ -44,7 +44,10 @@ class RefSolver(object):
         self.pcg_threads = nthreads if pcg_threads is None else pcg_threads   # rows of the PCG kernels: fewer threads than the sweep pay off on small systems
         self.pcg_iters = []
         self.conn = np.ascontiguousarray(m._conn, dtype=np.int32)
-        self.mat_id = np.ascontiguousarray(m._mat_id, dtype=np.int32)
+        # assign([A, B, A]) lists ONE Python object twice: in the reference its elements share that object -- and with it the mutable
+        # hardening modulus of a work-hardening SVC (material.py:808-814) -- so the element ids point at its first occurrence
+        first = [next(k for k, q in enumerate(m.mat) if q is mat) for mat in m.mat]
+        self.mat_id = np.ascontiguousarray(np.asarray(first, dtype=np.int32)[np.asarray(m._mat_id)], dtype=np.int32)
         self.lxy = np.ascontiguousarray(m._lxy, dtype=float)
         self.nel = len(self.conn)
         self.ndof = m.Ndof

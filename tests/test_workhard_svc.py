@@ -165,6 +165,64 @@ def test_gpu_sequential_chain_equals_the_reference_shear_trace(zc):
     assert abs(m.khard - float(zc['whs_khard_final'])) < 1e-5 * max(1., abs(float(zc['whs_khard_final'])))
 
 
+def laminate_shear_model(zc):
+    """[work-hardening SVC | J2 | the SAME SVC object], 6 x 4 elements, simple shear (second trace of oracle/gen_wh_chain.py)"""
+    import pylabfea_amd as FE
+    m = facade_material(zc)
+    j2 = FE.Material(name='J2', num=2)
+    j2.elasticity(E=200.e3, nu=0.3)
+    j2.plasticity(sy=60., khard=1000., sdim=6)
+    fe = FE.Model(dim=2)
+    fe.geom([2., 2., 2.], LY=4.)
+    fe.assign([m, j2, m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.006 * fe.leny, 'disp', 'x')
+    fe.mesh(NX=6, NY=4)
+    return fe
+
+
+def test_oracle_chain_through_one_object_listed_twice(zc):
+    """assign([A, B, A]) stores ONE object twice: the reference hands its khard from the last element of the first section straight
+    to the first element of the third.  The oracle's element loop against the reference's trace of that laminate."""
+    from oracle.solve_ref import RefSolver
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r = RefSolver(laminate_shear_model(zc)).solve(min_step=6)
+    assert r.nsteps == int(zc['whl_nsteps']) and list(r.niter) == list(zc['whl_niter'])
+    for a, k in ((r.u, 'whl_u'), (r.sig, 'whl_sig'), (r.sgl, 'whl_sgl')):
+        assert np.max(np.abs(a - zc[k])) < 5e-6 * np.max(np.abs(zc[k])), k
+
+
+@pytest.mark.gpu
+def test_gpu_sequential_chain_skips_the_elements_of_other_materials(zc):
+    """The same laminate on the GPU against the REFERENCE's trace (fixture whl_*): the chain of one Material object runs across the
+    elements of another (prefix maximum per material, k_wh_entry).  1e-6, identical counts, the moduli after the calls of the last
+    sweep against the reference's call log, Material.khard after the run (367.17: not zero here), more passes than sweeps."""
+    from pylabfea_amd import _lib
+    fe = laminate_shear_model(zc)
+    m = fe.mat[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=6)
+    seq, nsw, npass = fe._engine.wh_info()
+    print('sequential carry (laminate): %d sweeps resolved in %d passes' % (nsw, npass))
+    assert seq and npass > nsw
+    assert fe.nsteps == int(zc['whl_nsteps'])
+    assert list(fe.niter) == list(zc['whl_niter']) and list(fe.co_nconv) == list(zc['whl_co_nconv'])
+    s = np.max(np.abs(zc['whl_sig']))
+    assert np.max(np.abs(fe.sgl - zc['whl_sgl'])) < 1e-6 * np.max(np.abs(zc['whl_sgl']))
+    assert np.max(np.abs(fe.u - zc['whl_u'])) < 1e-6 * np.max(np.abs(zc['whl_u']))
+    assert np.max(np.abs(fe._state('sig') - zc['whl_sig'])) < 3e-6 * s
+    assert np.max(np.abs(fe._state('epl') - zc['whl_epl'])) < 3e-6 * np.max(np.abs(zc['whl_eps']))
+    wh_el = np.nonzero(np.isin(fe._mat_id, (0, 2)))[0]                       # elements of the SVC object, in index order
+    kh = fe._engine.state_get(_lib.ST_KHARD)[wh_el]
+    ref_last = zc['whl_khard_calls'][-len(wh_el):]
+    assert len(wh_el) == 16 and np.max(np.abs(kh - ref_last)) < 1e-5 * max(1., np.max(np.abs(ref_last)))
+    assert float(zc['whl_khard_final']) > 100. and abs(m.khard - float(zc['whl_khard_final'])) < 1e-5 * float(zc['whl_khard_final'])
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_gpu_point_functions(z):
