@@ -265,7 +265,8 @@ int plfx_sweep(plfx_ctx *ctx, int nit, int *changed, int *conv);
  *       rounds 2-3, the only form on several GPUs (the chain would cross every shard); deviates from the reference by ~1e-4
  *       on its 4 x 4 trace (tests/test_workhard_svc.py). */
 int plfx_set_wh_mode(plfx_ctx *ctx, int sequential);
-int plfx_wh_info(plfx_ctx *ctx, int *sequential_in_use, int64_t *sweeps, int64_t *passes);
+int plfx_wh_info(plfx_ctx *ctx, int *sequential_in_use, int64_t *sweeps, int64_t *passes,
+                 int64_t *unresolved /* sweeps whose chain had not settled after 64 passes (accepted as they were; never observed) */);
 int plfx_wh_carry(plfx_ctx *ctx, int mat, const double *set, double *get);
 /* calc_scf statistics (model.py:1036-1067): sum of entries, sum of squares about the mean, min, count.
  * sld[6] loading direction for SVC materials. */

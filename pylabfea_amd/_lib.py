@@ -346,8 +346,9 @@ class Context(object):
 
     def wh_info(self):
         """(sequential carry in use, sweeps run in that mode, passes they took)"""
-        a, b, c_ = C.c_int(), C.c_int64(), C.c_int64()
-        self._chk(self.lib.plfx_wh_info(self.h, C.byref(a), C.byref(b), C.byref(c_)))
+        a, b, c_, u = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_wh_info(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(u)))
+        self.wh_unresolved = u.value
         return bool(a.value), b.value, c_.value
 
     def wh_carry(self, mat, value=None):

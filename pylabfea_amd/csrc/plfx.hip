@@ -182,7 +182,7 @@ struct plfx_ctx {
     double *kh_out = nullptr, *kh_new = nullptr, *wh_snap_el = nullptr, *wh_snap_M = nullptr;
     int32_t *kh_touch = nullptr, *wh_bmax = nullptr, *wh_cnt = nullptr;
     bool kh_out_valid = false;
-    int64_t n_wh_passes = 0, n_wh_sweeps = 0;
+    int64_t n_wh_passes = 0, n_wh_sweeps = 0, n_wh_unresolved = 0;
     int32_t *max_steps = nullptr, *scf_mult = nullptr, *heavy_list = nullptr;
     // dof vectors
     double *u = nullptr, *f = nullptr, *du = nullptr, *rhs = nullptr, *dinv = nullptr, *diag = nullptr,
@@ -4377,7 +4377,11 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
             fprintf(stderr, "[wh] sweep %lld pass %d: %d entries changed, %d touched, max entry %.6g, max exit %.6g, last touched %d, carry %.6g\n",
                     (long long)c->n_wh_sweeps, pass, nch, nt, imax, kmax, last[0], c->wh_carry[0]);
         }
-        if (nch == 0 || pass + 1 >= max_pass) break;
+        if (nch == 0) break;
+        if (pass + 1 >= max_pass) {  // (never seen: an entry value only moves the yield check of its own call)
+            c->n_wh_unresolved++;
+            break;
+        }
         std::swap(c->kh_el, c->kh_new);
     }
     // the material objects now hold what their last gradient evaluation of this sweep left
@@ -4420,9 +4424,10 @@ int plfx_set_wh_mode(plfx_ctx *c, int sequential)
     return PLFX_OK;
 }
 
-int plfx_wh_info(plfx_ctx *c, int *sequential_in_use, int64_t *sweeps, int64_t *passes)
+int plfx_wh_info(plfx_ctx *c, int *sequential_in_use, int64_t *sweeps, int64_t *passes, int64_t *unresolved)
 {
     if (!c) return PLFX_ERR_STATE;
+    if (unresolved) *unresolved = c->n_wh_unresolved;
     if (sequential_in_use) *sequential_in_use = wh_sequential(c) ? 1 : 0;
     if (sweeps) *sweeps = c->n_wh_sweeps;
     if (passes) *passes = c->n_wh_passes;
