@@ -108,114 +108,97 @@ class Material(object):
 
     # ------------------------------------------------------------------ definition
     def elasticity(self, C11=None, C12=None, C44=None, CV=None, E=None, nu=None):
-        """Define elastic properties (material.py:2401-2464)."""
-        if E is not None:
+        """Define elastic properties (material.py:2401-2464): one of (E, nu), (C11, C12, C44) or the full 6 x 6 matrix;
+        the other descriptions are derived from the one given.  Same exceptions and messages as the reference."""
+        clash = 'Error: Inconsistent definition of material parameters: '
+        cubic = (C11, C12, C44)
+        if E is not None:      # isotropic
             if nu is None:
-                raise ValueError('Error: Inconsistent definition of material parameters: Only E provided')
-            if (C11 is not None) or (C12 is not None) or (C44 is not None):
-                raise ValueError('Error: Inconsistent definition of material parameters: E provided together with C_ij')
+                raise ValueError(clash + 'Only E provided')
+            if any(c is not None for c in cubic):
+                raise ValueError(clash + 'E provided together with C_ij')
             hh = E / ((1. + nu) * (1. - 2. * nu))
-            self.C11 = (1. - nu) * hh
-            self.C12 = nu * hh
-            self.C44 = (0.5 - nu) * hh
-            self.E = E
-            self.nu = nu
-        elif C11 is not None:
+            cubic = ((1. - nu) * hh, nu * hh, (0.5 - nu) * hh)
+        elif C11 is not None:  # cubic
             if nu is not None:
-                raise ValueError('Error: Inconsistent definition of material parameters: nu provided together with C_ij')
-            if (C12 is None) or (C44 is None):
-                raise ValueError('Error: Inconsistent definition of material parameters: C_12 or C_44 values missing')
-            self.C11, self.C12, self.C44 = C11, C12, C44
-            self.nu = C12 / (C11 + C12)
-            self.E = 2 * C44 * (1 + self.nu)
-        elif CV is not None:
+                raise ValueError(clash + 'nu provided together with C_ij')
+            if None in (C12, C44):
+                raise ValueError(clash + 'C_12 or C_44 values missing')
+        elif CV is not None:   # general: Poisson ratio and modulus of the [100] direction
             self.CV = np.array(CV, dtype=float)
-            self.C11 = self.CV[0, 0]
-            self.C12 = self.CV[0, 1]
-            self.C44 = self.CV[3, 3]
-            self.nu = self.C12 / (self.C11 + self.C12)
-            self.E = 2 * self.C44 * (1 + self.nu)
+            cubic = (self.CV[0, 0], self.CV[0, 1], self.CV[3, 3])
         else:
             raise ValueError('elasticity: Inconsistent definition of material parameters')
+        self.C11, self.C12, self.C44 = cubic
+        if E is None:
+            nu = self.C12 / (self.C11 + self.C12)
+            E = 2 * self.C44 * (1 + nu)
+        self.E, self.nu = E, nu
         if CV is None:
-            M = np.zeros((6, 6))
-            M[0, 0] = M[1, 1] = M[2, 2] = self.C11
-            M[0, 1] = M[0, 2] = M[1, 2] = self.C12
-            M[1, 0] = M[2, 0] = M[2, 1] = self.C12
-            M[3, 3] = M[4, 4] = M[5, 5] = self.C44
+            M = np.full((6, 6), 0.)
+            M[:3, :3] = self.C12
+            for k in range(3):
+                M[k, k], M[k + 3, k + 3] = self.C11, self.C44
             self.CV = M
         self._version += 1
 
     def plasticity(self, sy=None, sdim=6, drucker=0., khard=0., tresca=False, barlat=None,
                    barlat_exp=None, hill=None, hill_3p=None, hill_6p=None, rv=None, lhs=None):
-        """Define plastic parameters (material.py:2466-2594)."""
+        """Define plastic parameters (material.py:2466-2594).  Same exceptions, warnings and messages as the reference;
+        the Hill coefficients end up as 6 numbers for sdim = 6 and 3 for sdim = 3, with `hill_6p` / `hill_3p` telling
+        which equivalent-stress form applies (both False: J2)."""
         if sy < 0.:
             raise ValueError('Initial yield strength cannot be negative.')
         if khard < 0.:
             warnings.warn('Strain softening not supported. khard is set to 0.')
-            khard = 0.
         if lhs is not None:
             # the reference stores lhs but calc_seq evaluates `if self.lhs:` on the array
             # (material.py:642), which raises for any 3-vector: the option cannot run there either
             raise NotImplementedError('lhs (Liu-Huang-Stout asymmetry) is not supported')
-        if sdim != 3 and sdim != 6:
+        if sdim not in (3, 6):
             raise ValueError('{} in plasticity: sdim must be either 3 or 6'.format(self.name))
         if barlat is not None and len(barlat) != 18:
             raise ValueError('plasticity: barlat must hold the 18 Yld2004-18p coefficients')
-        if self.sdim is not None and self.sdim != sdim:
+        if self.sdim not in (None, sdim):
             print('plasticity: Parameter sdim is changed. New value:', sdim)
-        self.sdim = sdim
-        self.sy0 = sy
-        self.sy = sy
-        self.khard = khard
-        self.drucker = drucker
-        self.lhs = None
-        if hill is None and rv is None:
-            hill = np.ones(sdim)
-        elif hill is None:
-            hill = np.ones(sdim)
+        self.sdim, self.sy0, self.sy = sdim, sy, sy
+        self.khard, self.drucker, self.lhs = max(khard, 0.), drucker, None
+        if hill is not None:
+            if rv is not None:
+                warnings.warn('plasticity: Both, hill and rv, have been provided. Using Hill parameters.')
+            hill = list(hill)
+        elif rv is None:
+            hill = [1.] * sdim
+        else:  # yield-stress ratios -> Hill coefficients
             if len(rv) != sdim:
                 raise ValueError(f'plasticity: wrong dimension of yield stress ratios, must be {sdim}')
-            rinv = 1. / np.array(rv, dtype=float)
-            hill[0] = rinv[0] ** 2 + rinv[1] ** 2 - rinv[2] ** 2
-            hill[1] = rinv[1] ** 2 + rinv[2] ** 2 - rinv[0] ** 2
-            hill[2] = rinv[2] ** 2 + rinv[0] ** 2 - rinv[1] ** 2
-            if sdim == 6:
-                hill[3] = rinv[3] ** 2
-                hill[4] = rinv[4] ** 2
-                hill[5] = rinv[5] ** 2
-        elif rv is not None:
-            warnings.warn('plasticity: Both, hill and rv, have been provided. Using Hill parameters.')
-        hill = list(hill)
-        lh = len(hill)
-        if hill_6p is None and hill_3p is None:
-            hill_6p = (lh == 6)
-            hill_3p = not hill_6p
-            if hill_3p and hill[0] == 1. and hill[1] == 1. and hill[2] == 1.:
-                hill_3p = False
-        if hill_6p and lh != 6:
+            q = (1. / np.array(rv, dtype=float)) ** 2
+            hill = list(q[:3] + np.roll(q[:3], -1) - np.roll(q[:3], -2)) + list(q[3:])
+        given = len(hill)
+        if hill_6p is None and hill_3p is None:  # decided by the number of coefficients; three ones are J2, not Hill
+            six = given == 6
+            three = not six and not (hill[0] == 1. and hill[1] == 1. and hill[2] == 1.)
+        else:
+            six, three = hill_6p, hill_3p
+        if six and given != 6:
             raise ValueError('plasticity: When hill_6p is set True, 6 Hill parameters must be provided')
-        if hill_3p and lh != 3:
+        if three and given != 3:
             raise ValueError('plasticity: When hill_3p is set True, only 3 Hill parameters can be provided')
-        if hill_6p and sdim == 3:
+        if six and sdim == 3:
             warnings.warn('plasticity: 6 Hill parameters are provided, but sdim=3; ignoring shear parameters')
-            hill_6p = False
-            hill_3p = True
-            hill = hill[0:3]
-        if hill_3p and sdim == 6:
+            six, three = False, True
+            del hill[3:]
+        if three and sdim == 6:
             print('Material', self.name)
             warnings.warn('plasticity: 3 Hill parameters are provided, but sdim=6; shear parameters set to 1')
-            hill_3p = False
-            hill_6p = True
-            hill.extend([1., 1., 1.])
-        if sdim == 6 and lh == 3 and len(hill) == 3:
-            hill.extend([1., 1., 1.])
-        self.hill_6p = bool(hill_6p)
-        self.hill_3p = bool(hill_3p)
+            six, three = True, False
+        if sdim == 6 and len(hill) == 3:
+            hill += [1., 1., 1.]
+        self.hill_6p, self.hill_3p = bool(six), bool(three)
         self.hill = np.array(hill, dtype=float)
         self.tresca = bool(tresca)
-        if barlat is not None:
-            self.barlat = True
+        self.barlat = barlat is not None
+        if self.barlat:
             self.barlat_par = np.array(barlat, dtype=float)
             self.barlat_exp = barlat_exp
             b = self.barlat_par  # the two linear maps of the stress deviator (material.py:2578-2591)
@@ -224,8 +207,6 @@ class Material(object):
                 m[0, 1], m[0, 2], m[1, 0], m[1, 2], m[2, 0], m[2, 1] = -c[0], -c[1], -c[2], -c[3], -c[4], -c[5]
                 m[3, 3], m[4, 4], m[5, 5] = c[6], c[7], c[8]
                 setattr(self, name, m)
-        else:
-            self.barlat = False
         self._version += 1
 
     def set_svc(self, support_vectors, dual_coef, intercept, gamma, scale_seq, dev_only=False, C=None, scale_wh=None):
@@ -280,60 +261,31 @@ class Material(object):
         with 8 numbers per line -- header slots 0..28 (nsv, Ndof, C11, C12, C44, intercept, gamma, epc, scale_seq,
         scale_wh, C22, C33, C13, C23, C55, C66, dev_only flag, Nset, scale_text), dual coefficients from slot 29,
         then the support vectors row by row -- and ``file-svm_meta.json``."""
-        import getpass
-        import json
-        import platform
-        from datetime import date
+        import datetime, getpass, json, platform
         if not self.ML_yf:
             raise AttributeError('export_MLparam: No ML flow rule defined.')
-        if (descr is not None and param is not None) and len(descr) != len(param):
+        if None not in (descr, param) and len(descr) != len(param):
             raise ValueError('Lists for descr and param must have the same lengths.')
-        if file is None:
-            file = 'abq_' + self.name
-        if path[-1] != '/':
-            path += '/'
-        file = path + file
-        dc = self.svc['dual']
-        sv = self.svc['sv']
-        nsv = len(dc)
-        ndof = sv.shape[1]
+        file = (path if path.endswith('/') else path + '/') + ('abq_' + self.name if file is None else file)
+        dc, sv = self.svc['dual'], self.svc['sv']
+        nsv, ndof = sv.shape
         nlin = int((nsv * (ndof + 1) + 30) / 8) + 1
         ndata = nlin * 8
-        props = np.zeros(ndata)
-        props[0] = nsv
-        props[1] = ndof
-        props[2] = self.C11
-        props[3] = self.C12
-        props[4] = self.C44
-        props[5] = self.svc['intercept']
-        props[6] = self.gam_yf
-        props[7] = float(getattr(self, 'epc', 0.) or 0.)          # epc
-        props[8] = self.scale_seq
-        props[9] = self.scale_wh if getattr(self, 'whdat', False) else 1.          # scale_wh
-        if self.CV is None:
-            props[10:16] = -1
-        else:
-            props[10] = self.CV[1, 1]
-            props[11] = self.CV[2, 2]
-            props[12] = self.CV[0, 2]
-            props[13] = self.CV[1, 2]
-            props[14] = self.CV[4, 4]
-            props[15] = self.CV[5, 5]
-        props[16] = -1. if self.dev_only else 0.
-        props[17] = 1          # Nset
-        props[18] = 1.         # scale_text
-        props[29:29 + nsv] = dc
-        nl = (ndof + 1) * nsv + 29
-        props[29 + nsv:nl] = sv.flatten()
+        head = np.zeros(29)
+        head[:10] = (nsv, ndof, self.C11, self.C12, self.C44, self.svc['intercept'], self.gam_yf,
+                     float(getattr(self, 'epc', 0.) or 0.), self.scale_seq,
+                     self.scale_wh if getattr(self, 'whdat', False) else 1.)
+        head[10:16] = -1 if self.CV is None else [self.CV[i, j] for i, j in ((1, 1), (2, 2), (0, 2), (1, 2), (4, 4), (5, 5))]
+        head[16:19] = (-1. if self.dev_only else 0., 1, 1.)   # dev_only flag, Nset, scale_text
+        body = np.concatenate([head, dc, sv.ravel()])
+        props = np.concatenate([body, np.zeros(ndata - len(body))])
         np.savetxt(file + '-svm.csv', props.reshape((nlin, 8)), delimiter=', ', newline='\n')
-        descr = [] if descr is None else list(descr)
-        param = [] if param is None else list(param)
-        descr.extend(['Ndata', 'gamma', 'C'])
-        param.extend([ndata, self.gam_yf, self.C_yf])
+        descr = list(descr or []) + ['Ndata', 'gamma', 'C']
+        param = list(param or []) + [ndata, self.gam_yf, self.C_yf]
         sys_info = platform.uname()
         from . import __version__ as vers
         meta = {
-            'Info': {'Owner': getpass.getuser(), 'Institution': None, 'Date': str(date.today()),
+            'Info': {'Owner': getpass.getuser(), 'Institution': None, 'Date': str(datetime.date.today()),
                      'Description': 'SVC-parameters for plasticity model', 'Method': 'Support Vector Classification',
                      'System': {'sysname': sys_info[0], 'nodename': sys_info[1], 'release': sys_info[2],
                                 'version': sys_info[3], 'machine': sys_info[4]}},
