@@ -941,27 +941,17 @@ class Model(object):
         self._cache = {}
         n_stats0 = len(self.solver_stats)
         dim = 2
-        if self.u is None:
+        first_call = self.u is None
+        if first_call:
             eng.state_reset()
-            self.sgl = np.zeros((1, 6))
-            self.egl = np.zeros((1, 6))
-            self.epgl = np.zeros((1, 6))
-            bcr0 = np.zeros(dim)
-            bct0 = np.zeros(dim)
-            self.bct_mem = np.zeros(dim)
-            self.bcr_mem = np.zeros(dim)
-            if self.noset is not None:
-                bcn0 = np.zeros(dim)
-                self.bcn_mem = np.zeros(dim)
-            first_call = True
-        else:  # resume from the previous solution (model.py:1235-1239)
-            bcr0 = self.bcr_mem
-            bct0 = self.bct_mem
-            if self.noset is not None:
-                bcn0 = self.bcn_mem
-            first_call = False
-        bcl0 = self.bcl
-        bcb0 = self.bcb
+            self.sgl, self.egl, self.epgl = (np.zeros((1, 6)) for _ in range(3))
+            for name in ('bcr_mem', 'bct_mem') + (('bcn_mem',) if self.noset is not None else ()):
+                setattr(self, name, np.zeros(dim))
+        # boundary values reached so far; a second call resumes from the previous solution (model.py:1235-1239)
+        bcr0, bct0 = ((np.zeros(dim), np.zeros(dim)) if first_call else (self.bcr_mem, self.bct_mem))
+        if self.noset is not None:
+            bcn0 = np.zeros(dim) if first_call else self.bcn_mem
+        bcl0, bcb0 = self.bcl, self.bcb
         sgl, egl, epgl = list(self.sgl), list(self.egl), list(self.epgl)
         wh = [(k, m) for k, m in enumerate(getattr(self, '_eng_uniq', [])) if getattr(m, 'whdat', False) and m.ML_yf]
         for k, m in wh:   # the value the Material object holds NOW enters the first response() call (material.py:808-814)
@@ -971,15 +961,10 @@ class Model(object):
         eng.assemble()
         # loading direction for the ML yield-point search (model.py:1245-1258)
         sld = np.zeros(6)
-        if np.abs(self.bcr[0]) > 1.e-6:
-            sld[0] = np.sign(self.bcr[0])
-        if np.abs(self.bct[1]) > 1.e-6:
-            sld[1] = np.sign(self.bct[1])
-        if np.abs(self.bcr[1]) > 1.e-6:
-            sld[5] = np.sign(self.bcr[1])
-        if np.abs(self.bct[0]) > 1.e-6:
-            sld[5] = np.sign(self.bct[0])
-        if np.linalg.norm(sld) < 1.e-3:
+        for bc, k, comp in ((self.bcr, 0, 0), (self.bct, 1, 1), (self.bcr, 1, 5), (self.bct, 0, 5)):  # later entries win
+            if abs(bc[k]) > 1.e-6:
+                sld[comp] = np.sign(bc[k])
+        if not sld.any():
             warnings.warn('solve: inconsistent BC sld={}, bct={}, bcr={}'.format(sld, self.bct, self.bcr))
             sld[0] = 1.
         il = 0
@@ -999,19 +984,12 @@ class Model(object):
         warm = not first_call
         dbcn = None
         while bc_inc:
-            max_dbct = self.bct - bct0
-            max_dbcr = self.bcr - bcr0
-            if min_step is not None:
-                sc = np.maximum(1, min_step - il)
-                max_dbct /= sc
-                max_dbcr /= sc
-            dbcr = max_dbcr
-            dbct = max_dbct
+            # what is left of the boundary values, spread over the load steps still to go (model.py:1262-1285)
+            togo = 1 if min_step is None else max(1, min_step - il)
+            dbcr = max_dbcr = (self.bcr - bcr0) / togo
+            dbct = max_dbct = (self.bct - bct0) / togo
             if self.noset is not None:
-                max_dbcn = self.bcn - bcn0
-                if min_step is not None:
-                    max_dbcn /= np.maximum(1, min_step - il)
-                dbcn = max_dbcn  # alias, exactly as in the reference (model.py:1285)
+                dbcn = max_dbcn = (self.bcn - bcn0) / togo  # ONE array under two names, exactly as in the reference (model.py:1285)
             native = self._native_step and not verb and (self._shard is None or self._dev_coll)
             if native:
                 # the body of the load step runs inside the library (plfx_load_step): predictor, calc_scf, stiffness
@@ -1064,23 +1042,14 @@ class Model(object):
                 while (change or not conv) and nit <= 15:
                     if il < 6 and nit > 1:
                         # reduce the load increment to reach convergence (model.py:1308-1330)
-                        hs = 0.5
+                        # halve it, but stay between 5 % of the planned increment and what is left to the target value
+                        edges = [(max_dbcr, self.bcr, bcr0, dbcr), (max_dbct, self.bct, bct0, dbct)]
+                        if self.noset is not None:
+                            edges.append((max_dbcn, self.bcn, bcn0, dbcn))
                         for k in range(dim):
-                            for (mx, tot, cur0, d) in ((max_dbcr, self.bcr, bcr0, dbcr),
-                                                       (max_dbct, self.bct, bct0, dbct)):
-                                if mx[k] >= 0:
-                                    hh = np.minimum(tot[k] - cur0[k], d[k] * hs)
-                                    d[k] = np.maximum(0.05 * mx[k], hh)
-                                else:
-                                    hh = np.maximum(tot[k] - cur0[k], d[k] * hs)
-                                    d[k] = np.minimum(0.05 * mx[k], hh)
-                            if self.noset is not None:
-                                if max_dbcn[k] >= 0:
-                                    hh = np.minimum(self.bcn[k] - bcn0[k], dbcn[k] * hs)
-                                    dbcn[k] = np.maximum(0.05 * max_dbcn[k], hh)
-                                else:
-                                    hh = np.maximum(self.bcn[k] - bcn0[k], dbcn[k] * hs)
-                                    dbcn[k] = np.minimum(0.05 * max_dbcn[k], hh)
+                            for (mx, tot, cur0, d) in edges:
+                                inner, outer = (np.minimum, np.maximum) if mx[k] >= 0 else (np.maximum, np.minimum)
+                                d[k] = outer(0.05 * mx[k], inner(tot[k] - cur0[k], d[k] * 0.5))
                     eng.assemble()  # updated tangent stiffness (model.py:1333)
                     self._solve_lin(eng, (bcl0, bcb0, dbcr, dbct, dbcn), True)
                     change, conv = eng.sweep(nit)  # material response of every element (model.py:1340-1361)
@@ -1104,17 +1073,14 @@ class Model(object):
             il += 1
             niter.append(nit - 1)
             co_nconv.append(nconv)
-            bcr0 += dbcr
-            hl0 = np.abs(bcr0[0] - self.bcr[0]) > 1.e-6 and np.abs(self.bcr[0]) > 1.e-9
-            hl1 = np.abs(bcr0[1] - self.bcr[1]) > 1.e-6 and np.abs(self.bcr[1]) > 1.e-9
-            bct0 += dbct
-            hr0 = np.abs(bct0[0] - self.bct[0]) > 1.e-6 and np.abs(self.bct[0]) > 1.e-9
-            hr1 = np.abs(bct0[1] - self.bct[1]) > 1.e-6 and np.abs(self.bct[1]) > 1.e-9
+            # another load step while any non-zero boundary value is not reached yet (model.py:1395-1411)
+            reached = [(bcr0, dbcr, self.bcr), (bct0, dbct, self.bct)]
             if self.noset is not None:
-                bcn0 += dbcn
-                hr0 = hr0 or (np.abs(bcn0[0] - self.bcn[0]) > 1.e-6 and np.abs(self.bcn[0]) > 1.e-9)
-                hr1 = hr1 or (np.abs(bcn0[1] - self.bcn[1]) > 1.e-6 and np.abs(self.bcn[1]) > 1.e-9)
-            bc_inc = bool(hr0 or hr1 or hl0 or hl1)
+                reached.append((bcn0, dbcn, self.bcn))
+            bc_inc = False
+            for cur0, d, tot in reached:
+                cur0 += d
+                bc_inc = bc_inc or bool(np.any((np.abs(cur0 - tot) > 1.e-6) & (np.abs(tot) > 1.e-9)))
             if native and defer:
                 if pending is not None:
                     record_global(eng.finish_fetch(pending))

@@ -7,13 +7,12 @@ Two documented differences are normalised before comparing:
     2566-2567: a 9-vector of which only the first 6 are ever read); the package keeps 6."""
 import json
 import os
-import sys
 
 import pytest
 
+from oracle.gen_material_api import run  # test infrastructure: the recorder's own harness, applied to the package
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
-from gen_material_api import run  # noqa: E402  (test infrastructure: the recorder's own harness, applied to the package)
 
 with open(os.path.join(HERE, 'golden', 'material_api.json')) as fp:
     CASES = json.load(fp)
