@@ -39,6 +39,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / device-memory sharing across the ranks of one node needs dmabuf IPC on this host driver; the images export this
+# already -- keep it if a launcher scrubbed the environment (must be set before the HIP runtime loads)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 PREROLL = 6          # untimed elastic increments before warm-up (part of set-up) of the 50-increment schedule
 
