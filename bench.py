@@ -62,11 +62,11 @@ HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achieva
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
 # calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
 PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
-               'matfree': {'mg_smooth': 120.45e6, 'spmv': 132.8e6, 'cg_update': 117.9e6,
+               'matfree': {'mg_smooth': 120.41e6, 'spmv': 132.8e6, 'cg_update': 117.9e6,
                            # the sweep per launch: 160.45 MB x 2 fetched + 109.05 MB written when no tangent is rewritten (430.0 MB
                            # against 432.0 MB algorithmic), + 226.5 MB written when all are (counter min / max of the profile)
                            'sweep': (429.95e6, 226.53e6)}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r04m_bench1024_rocprofv3_summary.txt'}
+PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r04y_bench1024_rocprofv3_summary.txt'}
 
 
 def hill_material(FE):
