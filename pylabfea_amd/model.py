@@ -19,7 +19,6 @@ import warnings
 import numpy as np
 
 from . import _lib
-from .basic import eps_eq, sig_eq_j2, yf_tolerance
 
 
 class _ElementView(object):
