@@ -390,6 +390,13 @@ void dfree(T *&p)
     p = nullptr;
 }
 
+// blocks of the kernels that reduce the 18 element sums of calc_global (part_g): k_update_state<1> at 1024^2, same-box
+// rocprofv3 averages (tools/probes/r04_sumpart_ab.sh): 1024 blocks with 18 sequential block sums 86-88 us; the 18 sums behind
+// ONE barrier (block_sums_to_partials, bit-identical) 81-83; and then 2048 blocks 74, 4096 blocks 78
+#ifndef PLFX_SUMPART
+#define PLFX_SUMPART 2048
+#endif
+constexpr int SUMPART = PLFX_SUMPART;
 int grid_for(size_t n, int cap = MAXPART)
 {
     size_t g = (n + BLOCK - 1) / BLOCK;
@@ -1531,7 +1538,7 @@ int plfx_create(int device, plfx_ctx **out)
     c->lds_doubles = lds > reserve ? (int)((lds - reserve) / 8) : 0;
     int rc;
     if ((rc = dalloc(c, &c->part, (size_t)8 * MAXPART))) return rc;
-    if ((rc = dalloc(c, &c->part_g, (size_t)18 * MAXPART))) return rc;
+    if ((rc = dalloc(c, &c->part_g, (size_t)18 * SUMPART))) return rc;
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
     if ((rc = dalloc(c, &c->flags, 8))) return rc;  // [0..3] working flags of a sweep, [4..7] its results (k_sweep_flags)
     if ((rc = dalloc(c, &c->bflags, (size_t)2 * SWEEP_SLOTS))) return rc;
@@ -3375,43 +3382,50 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
     if (rc) return rc;
     hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
-    const int g = grid_for(c->nel, MAXPART);
+    const int g = grid_for(c->nel, SUMPART);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<1>), dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, c->nel,
                        c->e0, c->dconn, c->dcls_id, (const double2 *)c->du, (const double2 *)c->u, c->sig, c->epl,
                        c->eps, c->elstiff, c->res_sig, c->res_depl, c->nonlin ? 1 : 0, c->part_g,
                        c->strip.on ? c->strip.eown_lo : 0, c->strip.on ? c->strip.eown_hi : 0x7fffffff);
     const int n = c->fin_n;
-    if (n > 0) {
-        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, c->fin_dev);
-        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, c->fin_dev + n);
+    const int tot = 2 * n + 18;
+    const int sl = c->fin_defer;  // >= 0: post into that pinned slot and return without waiting (plfx_finish_fetch collects)
+    c->fin_defer = -1;
+    if (sl >= 0 && c->fin_pin_n < tot) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int q = 0; q < 2; q++) {
+            if (c->fin_pin[q]) hipHostFree(c->fin_pin[q]);
+            c->fin_pin[q] = nullptr;
+            HIPCHK(c, hipHostMalloc((void **)&c->fin_pin[q], (size_t)8 * tot, hipHostMallocMapped | hipHostMallocCoherent));
+            if (!c->fin_box[q]) {
+                HIPCHK(c, hipHostMalloc((void **)&c->fin_box[q], sizeof(CgMbox), hipHostMallocMapped | hipHostMallocCoherent));
+                memset(c->fin_box[q], 0, sizeof(CgMbox));
+            }
+            c->fin_pending[q] = false;
+        }
+        c->fin_pin_n = tot;
     }
-    hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->fin_dev + 2 * (size_t)n);
+    // Deferred and no all-reduce pending: the gather / reduction kernels write the pinned slot themselves (32 + 32 + 18 blocks
+    // instead of one workgroup pushing 131 KB through PCIe: 25 -> 4 us on the stream at 1024^2) and the post only publishes the
+    // sequence number -- their stores are visible to the host before the post kernel starts (kernel boundary on one stream)
+    static const bool direct_ok = !(getenv("PLFX_FINISH_DIRECT") && atoi(getenv("PLFX_FINISH_DIRECT")) == 0);
+    const bool direct = sl >= 0 && direct_ok && !comm_active(c);
+    double *out = direct ? c->fin_pin[sl] : c->fin_dev;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, out);
+        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, out + n);
+    }
+    hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, out + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
     if (comm_active(c) &&  // element sums of the whole mesh (calc_global, model.py:1473-1511)
         (rc = allreduce(c, c->fin_dev + 2 * (size_t)n, 18, NCCL_FLOAT64, NCCL_SUM, "sums")))
         return rc;
-    if (c->fin_defer >= 0) {  // post into the pinned slot and return without waiting (plfx_finish_fetch collects)
-        const int sl = c->fin_defer;
-        c->fin_defer = -1;
-        const int tot = 2 * n + 18;
-        if (c->fin_pin_n < tot) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int q = 0; q < 2; q++) {
-                if (c->fin_pin[q]) hipHostFree(c->fin_pin[q]);
-                c->fin_pin[q] = nullptr;
-                HIPCHK(c, hipHostMalloc((void **)&c->fin_pin[q], (size_t)8 * tot, hipHostMallocMapped | hipHostMallocCoherent));
-                if (!c->fin_box[q]) {
-                    HIPCHK(c, hipHostMalloc((void **)&c->fin_box[q], sizeof(CgMbox), hipHostMallocMapped | hipHostMallocCoherent));
-                    memset(c->fin_box[q], 0, sizeof(CgMbox));
-                }
-                c->fin_pending[q] = false;
-            }
-            c->fin_pin_n = tot;
-        }
+    if (sl >= 0) {
         // a slot that was never collected (caller left its loop early) is simply overwritten: the sequence number tells
         // plfx_finish_fetch which post it is waiting for
         const unsigned long long seq = ++c->fin_seq[sl];
-        hipLaunchKernelGGL(k_mbox_post, dim3(1), dim3(BLOCK), 0, c->stream, c->fin_dev, tot, c->fin_pin[sl], c->fin_box[sl], seq);
+        hipLaunchKernelGGL(k_mbox_post, dim3(1), dim3(BLOCK), 0, c->stream, c->fin_dev, direct ? 0 : tot, c->fin_pin[sl],
+                           c->fin_box[sl], seq);
         HIPCHK(c, hipGetLastError());
         c->fin_pending[sl] = true;
         return PLFX_OK;
@@ -4552,7 +4566,7 @@ int plfx_global_sums(plfx_ctx *c, double *out18)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (!out18) return fail(c, PLFX_ERR_ARG, "null output");
-    const int g = grid_for(c->nel, MAXPART);  // same grid as the fused sums of plfx_finish_step: identical numbers
+    const int g = grid_for(c->nel, SUMPART);  // same grid as the fused sums of plfx_finish_step: identical numbers
     hipLaunchKernelGGL(k_global_partials, dim3(g), dim3(BLOCK), 0, c->stream, c->dcls, c->nel, c->dcls_id,
                        c->sig, c->eps, c->epl, c->part_g);
     hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);

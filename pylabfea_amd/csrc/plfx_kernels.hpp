@@ -60,6 +60,27 @@ __device__ __forceinline__ double block_sum(double v, double *sh /* [BLOCK/64] *
     return t;
 }
 
+// NA block-wide sums at once, written to part[k * gridDim.x + blockIdx.x]: the same operation order per scalar as block_sum
+// (wave sums, then the BLOCK / 64 wave results added in wave order: bit-identical), but one barrier instead of 2 NA
+template <int NA>
+__device__ __forceinline__ void block_sums_to_partials(const double (&v)[NA], double *__restrict__ part)
+{
+    __shared__ double shn[NA][BLOCK / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        const double t = wave_sum(v[k]);
+        if (lane == 0) shn[k][w] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        double t = 0.;
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; i++) t += shn[threadIdx.x][i];
+        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // every block sums the same partial array in the same order -> identical scalar on all blocks
 __device__ __forceinline__ double sum_partials(const double *part, int n, double *sh)
 {
@@ -1898,7 +1919,6 @@ k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcl
                int sum_lo = 0, int sum_hi = 0x7fffffff /* elements that enter the sums (strip: owned columns) */)
 {
     // SUMS = 1 fuses calc_global's element sums (k_global_partials: same grid, same order -> identical numbers)
-    __shared__ double sh[BLOCK / 64];
     double acc[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) acc[k] = 0.;
@@ -1943,13 +1963,7 @@ k_update_state(const MatDev *__restrict__ gmat, const ClassDev *__restrict__ gcl
             }
         }
     }
-    if (SUMS) {
-#pragma unroll
-        for (int k = 0; k < 18; k++) {
-            const double t = block_sum(acc[k], sh);
-            if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = t;
-        }
-    }
+    if (SUMS) block_sums_to_partials(acc, part);
 }
 
 // calc_global sums (model.py:1500-1507): partials of sum(x*Vel) for the 18 components
@@ -1957,7 +1971,6 @@ __global__ void __launch_bounds__(BLOCK)
 k_global_partials(const ClassDev *__restrict__ gcls, int nel, const int32_t *__restrict__ cls, const double *__restrict__ sig,
                   const double *__restrict__ eps, const double *__restrict__ epl, double *__restrict__ part /* [18][gridDim.x] */)
 {
-    __shared__ double sh[BLOCK / 64];
     double acc[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) acc[k] = 0.;
@@ -1970,11 +1983,7 @@ k_global_partials(const ClassDev *__restrict__ gcls, int nel, const int32_t *__r
             acc[12 + k] = fma(epl[(size_t)k * nel + e], v, acc[12 + k]);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const double t = block_sum(acc[k], sh);
-        if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = t;
-    }
+    block_sums_to_partials(acc, part);
 }
 
 // out[k] = sum of row k of part[nrows][npart]; one block per row (launch with nrows blocks), fixed order
