@@ -1697,14 +1697,21 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             m.intercept = s.intercept;
             m.scale_seq = s.scale_seq;
             m.scale_wh = (s.kind == PLFX_SVC_WH) ? s.scale_wh : 1.;
+            for (int i = 0; i < s.nsv; i++) {
+                double vv = 0.;
+                for (int f = 0; f < nf; f++) vv += s.sv[(size_t)i * nf + f] * s.sv[(size_t)i * nf + f];
+                m.svc_vvmax = std::max(m.svc_vvmax, vv);
+                m.svc_sabs += std::fabs(s.dual[i]);
+            }
             if (s.nsv * (nf + 1) <= c->lds_doubles) c->svc_lds_need = std::max(c->svc_lds_need, s.nsv * (nf + 1));
             if (s.kind == PLFX_SVC6) c->has_svc = true; else if (s.kind == PLFX_SVC3) c->has_svc3 = true; else c->has_svcwh = true;
             if (s.kind == PLFX_SVC6) {
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
-                if (c->svc_wave_mat < 0 && c->want_svc_wave && 9 * npad <= c->lds_doubles && npad <= 2048) {
+                if (c->svc_wave_mat < 0 && c->want_svc_wave && 9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
                     c->svc_wave_mat = k;
-                    c->svc_wave_lds = 9 * npad * 8;  // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32
+                    // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form
+                    c->svc_wave_lds = (9 * npad + SVC_WAVE_EXTRA) * 8;
                 }
             }
         }
@@ -1715,9 +1722,12 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->svc_wave_mat >= 0) {
-        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0>, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1>, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, false>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, false>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave<false>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave<true>, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
@@ -1738,6 +1748,13 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     c->M_dirty = true;
     c->memo.valid = false;
     return PLFX_OK;
+}
+
+// Sampled-ray form of the SVC ray search (YfSvcT::ray_sample; PLFX_SVC_POLY=0: the FP32-screened evaluations of rounds 2-4)
+static bool svc_poly()
+{
+    static const bool on = !(getenv("PLFX_SVC_POLY") && atoi(getenv("PLFX_SVC_POLY")) == 0);
+    return on;
 }
 
 // ------------------------------------------------------------------------------ batched point evaluation
@@ -1763,10 +1780,14 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
     }
     if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
     static const bool wave_full = !(getenv("PLFX_FULL_YF_WAVE") && atoi(getenv("PLFX_FULL_YF_WAVE")) == 0);
-    if (what == 3 && wave_full && mat == c->svc_wave_mat && c->svc_wave_lds > 0)   // ML_full_yf of the wave-kernel SVC material: one wave per point
-        hipLaunchKernelGGL(k_full_yf_wave, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
-                           c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
-    else
+    if (what == 3 && wave_full && mat == c->svc_wave_mat && c->svc_wave_lds > 0) {  // ML_full_yf of the wave-kernel SVC material: one wave per point
+        if (svc_poly())
+            hipLaunchKernelGGL(k_full_yf_wave<true>, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                               c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
+        else
+            hipLaunchKernelGGL(k_full_yf_wave<false>, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                               c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
+    } else
         hipLaunchKernelGGL(k_point_eval, dim3(grid_for(n)), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                            c->dmat, c->nmat, c->svc_lds_need, what, mat, n, dsig, depl, dld, dout, dst);
     HIPCHK(c, hipGetLastError());
@@ -4237,8 +4258,12 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         first = 0;
     }
     if (c->has_svc && wm >= 0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
-                           c->stream, WAVE_ARGS, first, wm);
+        if (svc_poly())
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0, true>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, first, wm);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0, false>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, first, wm);
         first = 0;
     }
     if (c->has_svc3) {
@@ -4248,7 +4273,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     }
     // work-hardening SVC materials: one wave per element (PLFX_WH_WAVE=0: one thread per element, rounds 2-3)
     static const bool wh_wave = !(getenv("PLFX_WH_WAVE") && atoi(getenv("PLFX_WH_WAVE")) == 0);
-    const int grid_wh = std::max(1, std::min((c->nel + 3) / 4, 2048));
+    const int grid_wh = std::max(1, std::min((c->nel + 3) / 4, SWEEP_SLOTS));  // one bflags slot pair per block (the kernel grid-strides)
     if (c->has_svcwh && wh_wave) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_wh_wave<0>), dim3(grid_wh), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                            c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
@@ -4277,9 +4302,14 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     if (svc_thread)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), wm);
-    if (c->has_svc && wm >= 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
-                           c->stream, WAVE_ARGS, 0, wm);
+    if (c->has_svc && wm >= 0) {
+        if (svc_poly())
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1, true>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, 0, wm);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1, false>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, 0, wm);
+    }
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), -1);

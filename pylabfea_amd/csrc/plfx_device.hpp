@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "plfx_raypoly.hpp"
 
 namespace plfx {
 
@@ -94,6 +95,7 @@ struct MatDev {
     double E, nu;
     double gamma, intercept, scale_seq;
     double scale_wh;     // SVC with work-hardening features: scaling of the plastic-strain features (material.py:2343)
+    double svc_sabs, svc_vvmax;  // sum |dual_k| and max |v_k|^2 over the support vectors (error bounds of YfSvcT::ray_sample)
     const double *sv;    // device pointer [nsv*nfeat]
     const double *dual;  // device pointer [nsv]
     double barlat[18], barlat_exp;  // Yld2004-18p coefficients
@@ -697,7 +699,7 @@ struct BrentState {
 // lanes: lane L takes the vectors L, L+64, ... from the SoA tables in dynamic LDS (stride-1 across lanes: conflict-free
 // ds_read_b64, no dependent flat loads), followed by one wave reduction.  npad = vectors padded to a multiple of 64 NC
 // with dual = 0.  Tables: v[6][npad] at dyn_lds[0], dual[npad] at dyn_lds[6*npad].
-template <int NF, int WAVE = 0>
+template <int NF, int WAVE = 0, bool POLY = false>
 struct YfSvcT {
     const MatDev &m;
     const double *sv;
@@ -746,7 +748,7 @@ struct YfSvcT {
     static constexpr int MAXTRIP = 2048 / (64 * NC);   // 64 NC MAXTRIP >= npad: up to 2048 support vectors
     // FP32 sign screen of the marching bracket (ray_screen): in the corrector kernel (4 vectors per lane and trip, one wave
     // per SIMD, registers to spare); the streaming kernel (2 waves per SIMD, 256 VGPRs) has no room for the FP32 copies
-    static constexpr bool SCREEN = WAVE >= 4 && NF == 6;
+    static constexpr bool SCREEN = WAVE >= 4 && NF == 6 && !POLY;
     struct RaySetup {
         double DD;
         double ck[WAVE > 0 ? MAXTRIP : 1][NC];
@@ -873,6 +875,127 @@ struct YfSvcT {
         for (int c = 1; c < NC; c++) tsum += f[c];
         return wave_allsum(tsum) + m.intercept;
     }
+    // ---- sampled-ray form of the ray search (round 5; POLY, wave mode, 6 stress features).  Along x = t su every kernel
+    // term is a Gaussian in t, d_k exp(-gamma (DD t^2 - 2 c_k t + |v_k|^2)), so on equally spaced points t_j = lo + j dl
+    //   term_k(t_j) = [d_k e^{-gamma h_k(lo)}] rho_k^j e^{-gamma DD dl^2 j^2},   rho_k = e^{2 gamma dl (c_k - DD lo)}:
+    // ONE pass over the support vectors (two exp per vector, then one multiply and one add per sample) yields NS samples
+    // of the decision function, the fixed matrix RAYPOLY_MT turns them into the Chebyshev coefficients of the
+    // interpolating polynomial p on [lo, hi], and the 2 % marching bracket of ML_full_yf (material.py:468-486) and the
+    // brentq iterates (:501-503) are evaluated on p -- 32 instructions per point in lock-step instead of a pass over the
+    // vectors (~10 FP64 + ~20 FP32 passes per call before).  f along a ray is entire with length scale 1/sqrt(2 gamma DD):
+    //   |f - p| <= sum|d_k| K sqrt(NS!) / (4 NS) (sqrt(2 gamma DD) dl)^NS          (K = 1.0865: Cramer's bound on Hermite functions)
+    // on the whole interval; the interval is shrunk about the start of the march until that bound is <= 1e-7 (a root shift of
+    // <= 2e-6 MPa at the decision function's slope; measured |f - p| ~ 4e-11, the conditioning of the equispaced samples).  March
+    // decisions use p only where |p| exceeds the bound + a round-off allowance, and any point outside [lo, hi] or closer to zero
+    // than that is evaluated as before (decision_wave on x su): the bracket is the reference's, the root the one brentq finds on p.
+    static constexpr int NS = RAYPOLY_N;
+    struct RayPoly {
+        double c[NS];              // Chebyshev coefficients (wave-uniform)
+        double lo, hi, ua, ub;     // u = ua x + ub maps [lo, hi] to [-1, 1]
+        double margin;             // |p| <= margin: the sign of f is not decided by p
+        bool ok;
+        __device__ __forceinline__ bool covers(double x) const { return ok && x >= lo && x <= hi; }
+        __device__ __forceinline__ double eval(double x) const   // Clenshaw
+        {
+            const double u = fma(ua, x, ub), u2 = u + u;
+            double b1 = 0., b2 = 0.;
+#pragma unroll
+            for (int k = NS - 1; k >= 1; k--) {
+                const double t = fma(u2, b1, c[k] - b2);
+                b2 = b1;
+                b1 = t;
+            }
+            return fma(u, b1, c[0] - b2);
+        }
+    };
+    // tables behind the support-vector tables in dynamic LDS (stage_svc_wave): RAYPOLY_MT, 0.98^i, 1.02^i (i < 64)
+    __device__ __forceinline__ const double *poly_tab() const { return dyn_lds + 9 * npad; }
+    __device__ __forceinline__ void ray_sample(const double *su, double x0, bool halved, RayPoly &P) const
+    {
+        P.ok = false;
+        if (!(WAVE > 0 && NF == 6 && POLY)) return;
+        double D[6];
+        svc_features(m, su, D);
+        double DD = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++) DD = fma(D[i], D[i], DD);
+        // the march starts at x0 = sflow and goes down or up, or at x0 = sflow / 2 (material.py:468-473) and goes up
+        double lo = halved ? 0.94 * x0 : 0.72 * x0, hi = halved ? 2.7 * x0 : 1.30 * x0;
+        double dl = (hi - lo) * (1. / (NS - 1));
+        const double q = sqrt(2. * m.gamma * DD);
+        constexpr double KN = 1.0865 * 4574143.623 / (4. * NS);   // K sqrt(16!) / (4 N)
+        static_assert(NS == 16, "KN and the 16th power below are written for 16 samples");
+        double b = q * dl;
+        b *= b; b *= b; b *= b; b *= b;
+        double bound = m.svc_sabs * KN * b;
+        if (!(bound <= 1.e-7)) {
+            if (!(bound < 1.e300)) return;
+            const double sh = sqrt(sqrt(sqrt(sqrt(1.e-7 / bound))));   // (1e-7 / bound)^(1/16)
+            lo = x0 - (x0 - lo) * sh;
+            hi = x0 + (hi - x0) * sh;
+            dl = (hi - lo) * (1. / (NS - 1));
+            bound = 1.e-7;
+        }
+        // the recurrence multiplies by rho_k up to NS - 1 times: keep its exponent range harmless
+        const double sD = sqrt(DD);
+        if (!(2. * m.gamma * dl * (NS - 1) * sD * (sqrt(m.svc_vvmax) + sD * hi) < 60.) || !(hi > lo)) return;
+        const double g = -m.gamma * LOG2E;
+        const double A0 = g * DD * lo * lo, A1 = -2. * g * lo;   // log2(w_k / d_k) = A0 + A1 c_k + g |v_k|^2
+        const double R1 = -2. * g * dl, R0 = -R1 * DD * lo;      // log2 rho_k = R1 c_k + R0
+        double acc[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) acc[j] = 0.;
+        for (int k = threadIdx.x & 63; k < npad; k += 64 * NC) {
+            double v[NC][8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + 64 * c];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
+                             "+v"(v[c][6]), "+v"(v[c][7]));
+            double w[NC], rho[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                double ck = 0.;
+#pragma unroll
+                for (int i = 0; i < 6; i++) ck = fma(D[i], v[c][i], ck);
+                w[c] = v[c][6] * exp2_neg(fma(g, v[c][7], fma(A1, ck, A0)));
+                rho[c] = exp2_neg(fma(R1, ck, R0));
+            }
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    acc[j] += w[c];
+                    if (j < NS - 1) w[c] *= rho[c];
+                }
+        }
+        // f_j = b + G_j sum_k (...), G_j = 2^(g DD dl^2 j^2) by recurrence: G_{j+1} = G_j t_j, t_{j+1} = t_j G_1^2
+        const double G1 = exp2_neg(g * DD * dl * dl);
+        double G = 1., t = G1;
+        const double r = G1 * G1;
+        const double *tab = poly_tab();
+        const int li = threadIdx.x & (NS - 1);
+        double ci = 0.;   // lane i (mod NS): Chebyshev coefficient i
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const double fj = fma(G, wave_allsum(acc[j]), m.intercept);
+            ci = fma(tab[j * NS + li], fj, ci);
+            G *= t;
+            t *= r;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) P.c[i] = readlane_f64(ci, i);
+        P.lo = lo;
+        P.hi = hi;
+        P.ua = 2. / (hi - lo);
+        P.ub = -(hi + lo) / (hi - lo);
+        P.margin = bound + 4.e-12 * m.svc_sabs;
+        P.ok = true;
+    }
     __device__ __forceinline__ double decision_wave(const double *s) const
     {
         double x[6];
@@ -969,15 +1092,35 @@ struct YfSvcT {
         // brentq search (:501-503) are driven as one state machine so that f has a single call site (the wave-mode
         // evaluation is a long unrolled loop).  Evaluation order and arithmetic are those of the straight-line form.
         RaySetup ray;
-        ray_setup(su, ray);
+        if (!POLY) ray_setup(su, ray);
         double x0 = sflow;
-        if (su[0] * su[1] < -1.e-5) x0 *= 0.5;  // material.py:468-473
+        const bool halved = su[0] * su[1] < -1.e-5;
+        if (halved) x0 *= 0.5;  // material.py:468-473
+        RayPoly P;
+        ray_sample(su, x0, halved, P);
         double x1 = x0, f0 = 0., f1 = 0., xs = 0.;
         bool conv = true;
         BrentState br;
         int phase = 0;  // 0 first point, 1 marching down (:475-480), 2 marching up (:481-486), 3 brentq
         double xq = x0;
         for (;;) {
+            if (POLY && P.ok && (phase == 1 || phase == 2)) {
+                // lane i looks at the i-th next point of the march (i = 0: xq itself): the leading run of points at which
+                // p decides that the march goes on is skipped; the products are then repeated one by one so that the point
+                // the march stops at (a bracket end) carries the reference's rounding
+                const double fac = (phase == 1) ? 0.98 : 1.02;
+                const double z = xq * poly_tab()[NS * NS + (phase == 1 ? 0 : 64) + (threadIdx.x & 63)];
+                const double pv = P.eval(z);
+                const bool on = z >= P.lo && z <= P.hi &&
+                                ((phase == 1) ? (pv > P.margin && z > 0.010000001) : (pv < -P.margin && z < 4.9999999 * sflow));
+                const unsigned long long stop = ~__ballot(on);
+                const int k = stop ? __ffsll((long long)stop) - 1 : 64;
+                double xx = xq;
+                for (int i = 0; i < k; i++) xx *= fac;
+                if (phase == 1) x0 = xx; else x1 = xx;
+                xq = xx;
+                if (k == 64) continue;
+            }
             if (SCREEN && (phase == 1 || phase == 2)) {  // marching: the sign alone decides whether it goes on
                 double mg;
                 const double fe = ray_screen(ray, xq, mg);
@@ -992,7 +1135,22 @@ struct YfSvcT {
                     continue;
                 }
             }
-            const double fq = ray_eval(su, ray, xq);
+            double fq;
+            if (POLY) {
+                bool direct = true;
+                if (P.covers(xq)) {
+                    fq = P.eval(xq);
+                    direct = phase < 3 && fabs(fq) <= P.margin;
+                }
+                if (direct) {
+                    double xs6[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) xs6[i] = xq * su[i];
+                    fq = decision(xs6);
+                }
+            } else {
+                fq = ray_eval(su, ray, xq);
+            }
             if (phase == 0) {
                 f0 = f1 = fq;
                 phase = 1;
@@ -1225,8 +1383,8 @@ struct YfSvcWhT {
 typedef YfSvcWhT<0> YfSvcWh;
 typedef YfSvcT<6> YfSvc;
 typedef YfSvcT<2> YfSvc3;
-template <int NC>
-using YfSvcWave = YfSvcT<6, NC>;
+template <int NC, bool POLY = false>
+using YfSvcWave = YfSvcT<6, NC, POLY>;
 
 // ---------------------------------------------------------------------------------------------
 // Material.response (material.py:207-346) for one point, in two phases so that the sweep can run

@@ -672,13 +672,28 @@ __device__ __forceinline__ int stage_svc_wave(const MatDev *smat, int wave_mat, 
         reinterpret_cast<float2 *>(dyn_lds + 8 * npad)[i] =
             make_float2((i < n) ? (float)m.dual[i] : 0.f, (float)(-m.gamma * LOG2E * vv));
     }
+    // tables of the sampled-ray form (YfSvcT::ray_sample): samples -> Chebyshev coefficients, and the march factors
+    // 0.98^i / 1.02^i as sequential products
+    double *ext = dyn_lds + 9 * npad;
+    for (int i = threadIdx.x; i < RAYPOLY_N * RAYPOLY_N; i += blockDim.x) ext[i] = RAYPOLY_MT[i];
+    if (threadIdx.x < 64) {
+        double a = 1., b = 1.;
+        for (int i = 0; i < (int)threadIdx.x; i++) {
+            a *= 0.98;
+            b *= 1.02;
+        }
+        ext[RAYPOLY_N * RAYPOLY_N + threadIdx.x] = a;
+        ext[RAYPOLY_N * RAYPOLY_N + 64 + threadIdx.x] = b;
+    }
     return npad;
 }
+constexpr int SVC_WAVE_EXTRA = RAYPOLY_N * RAYPOLY_N + 128;   // doubles behind the 9 npad of the support-vector tables
 
 // ML_full_yf on N points, one WAVE per point (round 4): the ray search of YfSvcWave<4> -- support-vector sums split over the
 // lanes, FP32 sign screen of the marching bracket -- on its own needs 210 VGPRs and no scratch at two waves per SIMD (inside the
 // sub-stepping corrector it shares 256 registers + 720 B of scratch with the loop state).  Entry point of plfx_full_yf_batch for the
 // model's 6-feature SVC material (f3's callers: find_yloc / calc_properties / yield-locus grids call it on (N, 6) arrays).
+template <bool POLY>
 __global__ void __launch_bounds__(512)
 k_full_yf_wave(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const double *__restrict__ sig_in,
                const double *__restrict__ epl_in, const double *__restrict__ ld, double *__restrict__ out, int32_t *__restrict__ status)
@@ -702,7 +717,7 @@ k_full_yf_wave(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
             s[c] = sig_in[6 * (size_t)i + c];
             e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
         }
-        const YfSvcWave<4> yf(m, nullptr, nullptr, npad);
+        const YfSvcWave<4, POLY> yf(m, nullptr, nullptr, npad);
         int st = 0;
         const double f = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
         if (lane == 0) {
@@ -715,7 +730,7 @@ k_full_yf_wave(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
 // Both phases run 512-thread workgroups (8 waves share the LDS tables: 2 waves per SIMD, 256 VGPRs).  HEAVY = 0: 2 vectors per
 // lane and trip; HEAVY = 1: 4, with the FP32 sign screen of the marching bracket -- the sub-stepping loop wants 424 registers
 // and ran one wave per SIMD in round 1; two waves per SIMD with 592 B of scratch are 1.3x faster (PLFX_HEAVY_THREADS).
-template <int HEAVY>
+template <int HEAVY, bool POLY>
 __global__ void __launch_bounds__(HEAVY ? PLFX_HEAVY_THREADS : 512)
 k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
                  int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
@@ -749,7 +764,7 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
             s[k] = sig[(size_t)k * nel + e];
             ep[k] = epl[(size_t)k * nel + e];
         }
-        const YfSvcWave<NC> yf(m, nullptr, nullptr, npad);
+        const YfSvcWave<NC, POLY> yf(m, nullptr, nullptr, npad);
         const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
         if (HEAVY) {
             response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
