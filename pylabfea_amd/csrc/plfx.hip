@@ -1551,6 +1551,15 @@ void plfx_destroy(plfx_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
+#ifdef PLFX_PROF_REGIONS
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) == hipSuccess && h[7]) {
+            static const char *nm[8] = {"fgrad", "plain", "ray_sample pass", "ray_sample post", "march", "brentq", "full() in corrector", "corrector loop"};
+            for (int i = 0; i < 8; i++) fprintf(stderr, "[prof] %-22s %14llu ticks  %5.1f %% of the corrector loop\n", nm[i], h[i], 100. * h[i] / h[7]);
+        }
+    }
+#endif
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto &e : c->tim.ring) {
         hipEventDestroy(e.a);
@@ -1728,6 +1737,9 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, true>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, true>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave<true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<0>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<1>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_row, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
@@ -1751,10 +1763,11 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
 }
 
 // Sampled-ray form of the SVC ray search (YfSvcT::ray_sample; PLFX_SVC_POLY=0: the FP32-screened evaluations of rounds 2-4)
-static bool svc_poly()
+// 2 (default): 16 lanes per element (k_sweep_svc_row); 1: one wave per element; 0: the FP32-screened evaluations of rounds 2-4
+static int svc_poly()
 {
-    static const bool on = !(getenv("PLFX_SVC_POLY") && atoi(getenv("PLFX_SVC_POLY")) == 0);
-    return on;
+    static const int v = getenv("PLFX_SVC_POLY") ? atoi(getenv("PLFX_SVC_POLY")) : 2;
+    return v;
 }
 
 // ------------------------------------------------------------------------------ batched point evaluation
@@ -1781,7 +1794,10 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
     if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
     static const bool wave_full = !(getenv("PLFX_FULL_YF_WAVE") && atoi(getenv("PLFX_FULL_YF_WAVE")) == 0);
     if (what == 3 && wave_full && mat == c->svc_wave_mat && c->svc_wave_lds > 0) {  // ML_full_yf of the wave-kernel SVC material: one wave per point
-        if (svc_poly())
+        if (svc_poly() == 2)
+            hipLaunchKernelGGL(k_full_yf_row, dim3(std::max(1, std::min((n + 31) / 32, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                               c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
+        else if (svc_poly())
             hipLaunchKernelGGL(k_full_yf_wave<true>, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
                                c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
         else
@@ -4234,6 +4250,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     const bool svc_thread = c->has_svc && (wm < 0 || c->n_svc6 > 1);
     // one wave per element, one block per CU and round (the tables fill most of the LDS): 4 waves x 1024 blocks
     const int grid_w = std::max(1, std::min((c->nel + 3) / 4, 1024));
+    const int grid_r = std::max(1, std::min((c->nel + 31) / 32, 1024));   // 16 lanes per element: 32 elements per block and round
 #define WAVE_ARGS c->dmat, c->nmat, c->dcls, c->ncls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,  \
                   c->sig, c->epl, c->elstiff, c->Mel + c->e0, c->nel_total, c->res_sig, c->res_depl, c->fyn,         \
                   c->max_steps, nit, c->flags, c->bflags, c->heavy_list
@@ -4258,7 +4275,10 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         first = 0;
     }
     if (c->has_svc && wm >= 0) {
-        if (svc_poly())
+        if (svc_poly() == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<0>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, first, wm);
+        else if (svc_poly())
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0, true>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
                                c->stream, WAVE_ARGS, first, wm);
         else
@@ -4303,7 +4323,10 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), wm);
     if (c->has_svc && wm >= 0) {
-        if (svc_poly())
+        if (svc_poly() == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<1>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
+                               c->stream, WAVE_ARGS, 0, wm);
+        else if (svc_poly())
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1, true>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
                                c->stream, WAVE_ARGS, 0, wm);
         else

@@ -22,6 +22,20 @@ namespace plfx {
 
 extern __shared__ double dyn_lds[];
 
+// Region timers of the wave-per-element SVC kernels (probe builds only: -DPLFX_PROF_REGIONS, tools/probes/svc_regions.sh):
+// lane 0 of every wave adds the shader-clock ticks it spent in a region; plfx_destroy prints the totals.
+#ifdef PLFX_PROF_REGIONS
+__device__ unsigned long long g_prof[16];
+#define PROF_T0(t) const unsigned long long prof_##t = __builtin_readcyclecounter()
+#define PROF_ADD(r, t)                                                                                         \
+    do {                                                                                                      \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[r], (unsigned long long)__builtin_readcyclecounter() - prof_##t); \
+    } while (0)
+#else
+#define PROF_T0(t) do { } while (0)
+#define PROF_ADD(r, t) do { } while (0)
+#endif
+
 // 2^y for the RBF kernel sums, y <= 0 (tiny positive round-off allowed); the callers fold log2(e) into -gamma.
 // n = rint(y), r = y - n exactly (|r| <= 0.5), 2^r by the degree-11 interpolating polynomial on Chebyshev nodes
 // (max relative error 2.2e-16 = 1 ulp, checked against 50-digit arithmetic), 2^n added to the exponent field.
@@ -945,6 +959,7 @@ struct YfSvcT {
         double acc[NS];
 #pragma unroll
         for (int j = 0; j < NS; j++) acc[j] = 0.;
+        PROF_T0(a);
         for (int k = threadIdx.x & 63; k < npad; k += 64 * NC) {
             double v[NC][8];
 #pragma unroll
@@ -973,7 +988,9 @@ struct YfSvcT {
                     if (j < NS - 1) w[c] *= rho[c];
                 }
         }
+        PROF_ADD(2, a);
         // f_j = b + G_j sum_k (...), G_j = 2^(g DD dl^2 j^2) by recurrence: G_{j+1} = G_j t_j, t_{j+1} = t_j G_1^2
+        PROF_T0(b);
         const double G1 = exp2_neg(g * DD * dl * dl);
         double G = 1., t = G1;
         const double r = G1 * G1;
@@ -995,6 +1012,7 @@ struct YfSvcT {
         P.ub = -(hi + lo) / (hi - lo);
         P.margin = bound + 4.e-12 * m.svc_sabs;
         P.ok = true;
+        PROF_ADD(3, b);
     }
     __device__ __forceinline__ double decision_wave(const double *s) const
     {
@@ -1098,6 +1116,9 @@ struct YfSvcT {
         if (halved) x0 *= 0.5;  // material.py:468-473
         RayPoly P;
         ray_sample(su, x0, halved, P);
+#ifdef PLFX_PROF_REGIONS
+        unsigned long long prof_m = __builtin_readcyclecounter();
+#endif
         double x1 = x0, f0 = 0., f1 = 0., xs = 0.;
         bool conv = true;
         BrentState br;
@@ -1180,11 +1201,18 @@ struct YfSvcT {
                     return seqv - 0.85 * sflow;
                 }
                 phase = 3;
+#ifdef PLFX_PROF_REGIONS
+                if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[4], (unsigned long long)__builtin_readcyclecounter() - prof_m);
+                prof_m = __builtin_readcyclecounter();
+#endif
                 if (!br.start(x0, x1, f0, f1)) break;
             }
             if (!br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) break;
             xq = br.xcur;
         }
+#ifdef PLFX_PROF_REGIONS
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[5], (unsigned long long)__builtin_readcyclecounter() - prof_m);
+#endif
         xs = br.root;
         conv = br.converged;
         if (conv && xs < 4. * sflow) return seqv - xs * seq(su);  // material.py:507
@@ -1380,6 +1408,408 @@ struct YfSvcWhT {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// 6-feature RBF-SVC, SIXTEEN LANES PER MATERIAL POINT (round 5, k_sweep_svc_row / k_full_yf_row).  The wave-per-point
+// form above runs the scalar part of response() -- predictor / corrector algebra, the ray search's control flow, the
+// polynomial evaluations of the sampled-ray form -- redundantly in all 64 lanes, and once the ray search needs one pass over
+// the support vectors instead of thirty that part is half of the instructions of a sub-step.  Here a DPP row (16 lanes)
+// carries one point and a wave four: the support-vector sums cost what they cost before (lane L of a row takes the vectors
+// L, L + 16, ...; the four rows read the same LDS addresses), the scalar part a quarter.  A row is also exactly what the
+// cross-lane hardware offers without LDS: sums by four DPP butterfly steps inside the row, broadcasts of one lane's value
+// to its row by v_mov_b64_dpp row_newbcast.  Every value that steers control flow is bit-identical in the 16 lanes of a row
+// (same inputs, same operations, commutative butterfly), so rows diverge from each other but never inside.
+// The ray search is the sampled-ray form (see YfSvcT::ray_sample): NS = 16 samples, lane i of the row computes and keeps
+// Chebyshev coefficient i; p(x) is Clenshaw's recurrence with the coefficients broadcast from their lanes.  With 16 lanes a
+// row looks at 16 points per polynomial evaluation:
+//  * the 2 % marching bracket (material.py:475-486): lane i tests the (i+1)-th next point of the march; the leading run of
+//    points at which p decides the sign (|p| > margin, inside [lo, hi]) is skipped, the first point it does not decide is
+//    evaluated as before (p, or the support-vector sum itself when p is closer to zero than its error bound or the point lies
+//    outside the sampled interval) and the reference's loop condition is applied to that value;
+//  * the root (:501-503): the reference calls brentq(xtol = 1e-5) on [x0, x1]; here the last step of the march, which
+//    brackets the sign change the march found, is cut into 16 cells four times (lane i evaluates p at the i-th cell
+//    boundary, the first lane with p >= 0 closes the cell that holds the root) and a secant step on the last cell gives the
+//    root of p to ~1e-12 -- SURVEY 8(c): any bracketing root finder within brentq's own tolerance.  Brackets that p does
+//    not cover are searched by the brentq replay on the support-vector sums (BrentState), as in rounds 1-4.
+template <int NC>
+struct YfSvcRow {
+    static constexpr int GS = 16, NS = RAYPOLY_N;
+    static constexpr bool FUSED = true;   // fgrad_plain(): gradient at one point and decision function at another in one pass
+    static_assert(NS == GS, "lane i of a row holds Chebyshev coefficient i");
+    const MatDev &m;
+    int npad;
+    __device__ YfSvcRow(const MatDev &mm, int np) : m(mm), npad(np) {}
+    __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
+    // sum over the 16 lanes of a DPP row, result (bit-identical) in every lane of the row
+    __device__ __forceinline__ static double row_allsum(double v)
+    {
+        v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_f64<0x141>(v);  // row_half_mirror
+        v += dpp_f64<0x140>(v);  // row_mirror
+        return v;
+    }
+    template <int N>
+    __device__ __forceinline__ static double row_bcast(double v)   // value of lane N of the row, in every lane of the row
+    {
+        return __builtin_amdgcn_update_dpp(0., v, 0x150 + N, 0xf, 0xf, false);   // row_newbcast:N
+    }
+    // features without the reference's six divisions (x = sig / scale_seq): one reciprocal, 1 ulp -- the row kernels are
+    // held to 1e-6 sy like every SVC path (brentq's xtol), not to the bit
+    __device__ __forceinline__ void features(const double *s, double *x) const
+    {
+        const double inv = 1. / m.scale_seq;
+        const double p = m.dev_only ? (s[0] + s[1] + s[2]) / 3. : 0.;
+        x[0] = (s[0] - p) * inv;
+        x[1] = (s[1] - p) * inv;
+        x[2] = (s[2] - p) * inv;
+        x[3] = s[3] * inv;
+        x[4] = s[4] * inv;
+        x[5] = s[5] * inv;
+    }
+    __device__ __forceinline__ void load7(int k, double (*v)[7]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + GS * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
+                         "+v"(v[c][6]));
+    }
+    __device__ __forceinline__ double decision_x(const double *x) const
+    {
+        const double g = -m.gamma * LOG2E;
+        double f[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) f[c] = 0.;
+        for (int k = threadIdx.x & (GS - 1); k < npad; k += GS * NC) {
+            double v[NC][7], h[NC];
+            load7(k, v);
+#pragma unroll
+            for (int c = 0; c < NC; c++) h[c] = 0.;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const double d = x[i] - v[c][i];
+                    h[c] = fma(d, d, h[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < NC; c++) f[c] = fma(v[c][6], exp2_neg(g * h[c]), f[c]);
+        }
+        double t = f[0];
+#pragma unroll
+        for (int c = 1; c < NC; c++) t += f[c];
+        return row_allsum(t) + m.intercept;
+    }
+    __device__ __forceinline__ double decision(const double *s) const
+    {
+        double x[6];
+        features(s, x);
+        return decision_x(x);
+    }
+    __device__ __forceinline__ double plain(const double *s, const double *epl) const
+    {
+        (void)epl;
+        return decision(s);
+    }
+    // gradient at s (material.py:765-815) and, in the same pass over the support vectors, the decision function at s2
+    // (epl_dot's calc_yf(sig + dsig), :1032): |x2 - v|^2 = |x - v|^2 + 2 (x2 - x).(x - v) + |x2 - x|^2
+    template <bool WITH2>
+    __device__ __forceinline__ double fgrad_impl(const double *s, const double *s2, double *a) const
+    {
+        double x[6], dx[6], acc[6] = {0., 0., 0., 0., 0., 0.}, f2[NC], dd = 0.;
+        features(s, x);
+        if (WITH2) {
+            features(s2, dx);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                dx[i] -= x[i];
+                dd = fma(dx[i], dx[i], dd);
+                dx[i] += dx[i];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) f2[c] = 0.;
+        const double g = -m.gamma * LOG2E;
+        for (int k = threadIdx.x & (GS - 1); k < npad; k += GS * NC) {
+            double v[NC][7], h[NC], h2[NC];
+            load7(k, v);
+#pragma unroll
+            for (int c = 0; c < NC; c++) h[c] = 0., h2[c] = dd;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    v[c][i] = x[i] - v[c][i];
+                    h[c] = fma(v[c][i], v[c][i], h[c]);
+                    if (WITH2) h2[c] = fma(dx[i], v[c][i], h2[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const double w = v[c][6] * exp2_neg(g * h[c]);
+                if (WITH2) f2[c] = fma(v[c][6], exp2_neg(g * (h[c] + h2[c])), f2[c]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc[i] = fma(w, v[c][i], acc[i]);
+            }
+        }
+        const double sc = -2. * m.gamma / m.scale_seq;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = row_allsum(acc[i]) * sc;
+        if (!WITH2) return 0.;
+        double t = f2[0];
+#pragma unroll
+        for (int c = 1; c < NC; c++) t += f2[c];
+        return row_allsum(t) + m.intercept;
+    }
+    __device__ __forceinline__ void fgrad(const double *s, double *a) const { fgrad_impl<false>(s, nullptr, a); }
+    __device__ __forceinline__ void fgrad(const double *s, const double *epl, double *a) const { (void)epl; fgrad(s, a); }
+    __device__ __forceinline__ double fgrad_plain(const double *s, const double *epl, const double *s2, double *a) const
+    {
+        (void)epl;
+        return fgrad_impl<true>(s, s2, a);
+    }
+    // ---- sampled ray (see YfSvcT::ray_sample for the mathematics and the error bound)
+    struct RowPoly {
+        double ci;                 // Chebyshev coefficient (lane & 15) of the interpolant on [lo, hi]
+        double lo, hi, ua, ub, margin;
+        bool ok;
+        __device__ __forceinline__ double eval(double x) const   // Clenshaw; x may differ from lane to lane
+        {
+            const double u = fma(ua, x, ub), u2 = u + u;
+            double b1 = 0., b2 = 0., t;
+#define PLFX_CLENSHAW(K) t = fma(u2, b1, row_bcast<K>(ci) - b2); b2 = b1; b1 = t;
+            PLFX_CLENSHAW(15) PLFX_CLENSHAW(14) PLFX_CLENSHAW(13) PLFX_CLENSHAW(12) PLFX_CLENSHAW(11) PLFX_CLENSHAW(10)
+            PLFX_CLENSHAW(9) PLFX_CLENSHAW(8) PLFX_CLENSHAW(7) PLFX_CLENSHAW(6) PLFX_CLENSHAW(5) PLFX_CLENSHAW(4)
+            PLFX_CLENSHAW(3) PLFX_CLENSHAW(2) PLFX_CLENSHAW(1)
+#undef PLFX_CLENSHAW
+            return fma(u, b1, row_bcast<0>(ci) - b2);
+        }
+    };
+    __device__ __forceinline__ const double *poly_tab() const { return dyn_lds + 9 * npad; }
+    __device__ __forceinline__ void ray_sample(const double *su, double x0, bool halved, RowPoly &P) const
+    {
+        P.ok = false;
+        P.ci = 0.;
+        P.lo = P.hi = P.ua = P.ub = P.margin = 0.;
+        double D[6];
+        features(su, D);
+        double DD = 0.;
+#pragma unroll
+        for (int i = 0; i < 6; i++) DD = fma(D[i], D[i], DD);
+        // the march starts at x0 = sflow and goes down or up, or at x0 = sflow / 2 (material.py:468-473) and goes up
+        double lo = halved ? 0.94 * x0 : 0.72 * x0, hi = halved ? 2.7 * x0 : 1.30 * x0;
+        double dl = (hi - lo) * (1. / (NS - 1));
+        const double q = sqrt(2. * m.gamma * DD);
+        constexpr double KN = 1.0865 * 4574143.623 / (4. * NS);   // K sqrt(16!) / (4 N)
+        static_assert(NS == 16, "KN and the 16th power below are written for 16 samples");
+        double b = q * dl;
+        b *= b; b *= b; b *= b; b *= b;
+        double bound = m.svc_sabs * KN * b;
+        if (!(bound <= 1.e-7)) {
+            if (!(bound < 1.e300)) return;
+            const double sh = sqrt(sqrt(sqrt(sqrt(1.e-7 / bound))));   // (1e-7 / bound)^(1/16)
+            lo = x0 - (x0 - lo) * sh;
+            hi = x0 + (hi - x0) * sh;
+            dl = (hi - lo) * (1. / (NS - 1));
+            bound = 1.e-7;
+        }
+        const double sD = sqrt(DD);
+        if (!(2. * m.gamma * dl * (NS - 1) * sD * (sqrt(m.svc_vvmax) + sD * hi) < 60.) || !(hi > lo)) return;
+        const double g = -m.gamma * LOG2E;
+        const double A0 = g * DD * lo * lo, A1 = -2. * g * lo;   // log2(w_k / d_k) = A0 + A1 c_k + g |v_k|^2
+        const double R1 = -2. * g * dl, R0 = -R1 * DD * lo;      // log2 rho_k = R1 c_k + R0
+        double acc[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) acc[j] = 0.;
+        for (int k = threadIdx.x & (GS - 1); k < npad; k += GS * NC) {
+            double v[NC][8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + GS * c];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
+                             "+v"(v[c][6]), "+v"(v[c][7]));
+            double w[NC], rho[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                double ck = 0.;
+#pragma unroll
+                for (int i = 0; i < 6; i++) ck = fma(D[i], v[c][i], ck);
+                w[c] = v[c][6] * exp2_neg(fma(g, v[c][7], fma(A1, ck, A0)));
+                rho[c] = exp2_neg(fma(R1, ck, R0));
+            }
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    acc[j] += w[c];
+                    if (j < NS - 1) w[c] *= rho[c];
+                }
+        }
+        // f_j = b + G_j sum_k (...), G_j = 2^(g DD dl^2 j^2) by recurrence: G_{j+1} = G_j t_j, t_{j+1} = t_j G_1^2
+        const double G1 = exp2_neg(g * DD * dl * dl);
+        double G = 1., t = G1;
+        const double r = G1 * G1;
+        const double *tab = poly_tab();
+        const int li = threadIdx.x & (NS - 1);
+        double ci = 0.;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const double fj = fma(G, row_allsum(acc[j]), m.intercept);
+            ci = fma(tab[j * NS + li], fj, ci);
+            G *= t;
+            t *= r;
+        }
+        P.ci = ci;
+        P.lo = lo;
+        P.hi = hi;
+        P.ua = 2. / (hi - lo);
+        P.ub = -(hi + lo) / (hi - lo);
+        P.margin = bound + 4.e-12 * m.svc_sabs;
+        P.ok = true;
+    }
+    // f(x su): the polynomial where it decides (phase < 3: and is farther from zero than its error bound), the support-vector
+    // sum otherwise
+    __device__ __forceinline__ double evalx(const double *su, const RowPoly &P, double x, bool need_sign) const
+    {
+        double f = 0.;
+        bool direct = true;
+        if (P.ok && x >= P.lo && x <= P.hi) {
+            f = P.eval(x);
+            direct = need_sign && fabs(f) <= P.margin;
+        }
+        if (direct) {
+            double xs[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) xs[i] = x * su[i];
+            f = decision(xs);
+        }
+        return f;
+    }
+    // the marching loops of material.py:475-480 (DOWN: while f0 >= 0 and x0 > 0.01: x0 *= 0.98) and :481-486 (up: while
+    // f1 < 0 and x1 < 5 sflow: x1 *= 1.02), entered with the loop condition true at (x, fx); leaves the point the loop ends at
+    // in (x, fx) and the point before it in xprev.  pw[i] = 0.98^i / 1.02^i as sequential products.
+    template <bool DOWN>
+    __device__ __forceinline__ void march(const double *su, const RowPoly &P, double sflow, double &x, double &fx, double &xprev) const
+    {
+        const double *pw = poly_tab() + NS * NS + (DOWN ? 0 : 64);
+        const int l = threadIdx.x & (GS - 1);
+        for (;;) {
+            int k = 0;
+            if (P.ok) {
+                const double y = x * pw[l + 1];   // the (l + 1)-th next point of the march
+                const double pv = P.eval(y);
+                const bool on = y >= P.lo && y <= P.hi &&
+                                (DOWN ? (pv > P.margin && y > 0.010000001) : (pv < -P.margin && y < 4.9999999 * sflow));
+                const unsigned row = (unsigned)(__ballot(on) >> (threadIdx.x & 48)) & 0xffffu;
+                k = (row == 0xffffu) ? GS : __ffs((int)~row) - 1;   // leading run of points at which the march goes on
+            }
+            if (k == GS) {
+                x *= pw[GS];
+                continue;
+            }
+            xprev = x * pw[k];
+            x *= pw[k + 1];
+            fx = evalx(su, P, x, true);
+            if (!(DOWN ? (fx >= 0. && x > 0.01) : (fx < 0. && x < 5. * sflow))) return;
+        }
+    }
+    // ML_full_yf (material.py:414-516): distance to the yield locus along the ray through s (ld == nullptr) or along ld
+    __device__ inline double full_ld(const double *s, const double *epl, const double *ld, int *status) const
+    {
+        const double seqv = seq(s);
+        const double sflow = sflow_of(m, epl);
+        if (status) *status = 0;
+        if (seqv < 0.01 && ld == nullptr) return seqv - 0.85 * sflow;
+        double su[6];
+        if (ld == nullptr) {
+            const double inv = 1. / seqv;
+#pragma unroll
+            for (int i = 0; i < 6; i++) su[i] = s[i] * inv;
+        } else {
+            double hh = 0.;   // su = ld * sqrt(1.5) / |ld|  (material.py:455-462)
+#pragma unroll
+            for (int i = 0; i < 6; i++) hh += ld[i] * ld[i];
+            hh = sqrt(hh);
+            if (hh < 1.e-3) {
+                su[0] = sqrt(1.5);
+#pragma unroll
+                for (int i = 1; i < 6; i++) su[i] = 0.;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) su[i] = ld[i] * sqrt(1.5) / hh;
+            }
+        }
+        double x0 = sflow;
+        const bool halved = su[0] * su[1] < -1.e-5;   // material.py:468-473
+        if (halved) x0 *= 0.5;
+        RowPoly P;
+        ray_sample(su, x0, halved, P);
+        double f0 = evalx(su, P, x0, true), x1 = x0, f1 = f0, xp0 = x0, xp1 = x0;
+        const bool down = f0 >= 0. && x0 > 0.01;
+        if (down) march<true>(su, P, sflow, x0, f0, xp0);
+        const bool up = f1 < 0. && x1 < 5. * sflow;
+        if (up) march<false>(su, P, sflow, x1, f1, xp1);
+        if (f0 * f1 > 0.) {  // material.py:495-499
+            if (status) *status = 1;
+            return seqv - 0.85 * sflow;
+        }
+        double xs;
+        bool conv = true;
+        // the last step of the march brackets the sign change: f < 0 at its lower end, f >= 0 at its upper end
+        double lo = down ? x0 : xp1, hi = down ? xp0 : x1;
+        if (f0 == 0.) {
+            xs = x0;   // brentq returns an end of the bracket at which f vanishes
+        } else if (f1 == 0.) {
+            xs = x1;
+        } else if ((down || up) && P.ok && lo >= P.lo && hi <= P.hi && lo < hi) {
+            const int l = threadIdx.x & (GS - 1);
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) {
+                const double h = (hi - lo) * (1. / GS);
+                const double y = (l == GS - 1) ? hi : fma(h, (double)(l + 1), lo);
+                const double pv = P.eval(y);
+                const unsigned row = (unsigned)(__ballot(pv < 0.) >> (threadIdx.x & 48)) & 0x7fffu;   // lane 15 is hi: f >= 0
+                const int k = __ffs((int)~row) - 1;   // first cell boundary with p >= 0 (0 ... 15)
+                if (k < GS - 1) hi = fma(h, (double)(k + 1), lo);
+                lo = fma(h, (double)k, lo);
+            }
+            // secant on the last cell (even lanes evaluate its lower end, odd lanes its upper end)
+            const double pe = P.eval((l & 1) ? hi : lo);
+            const double plo = row_bcast<0>(pe), phi = row_bcast<1>(pe);
+            xs = (phi > plo) ? fmin(fmax(lo - plo * (hi - lo) / (phi - plo), lo), hi) : 0.5 * (lo + hi);
+        } else {
+            // brentq on the reference's bracket [x0, x1] with the support-vector sums (the polynomial does not cover it)
+            BrentState br;
+            if (br.start(x0, x1, f0, f1)) {
+                while (br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) br.fcur = evalx(su, P, br.xcur, false);
+            }
+            xs = br.root;
+            conv = br.converged;
+        }
+        if (conv && xs < 4. * sflow) return seqv - xs * seq(su);  // material.py:507
+        if (status) *status = 2;
+        return seqv - 0.85 * sflow;  // material.py:510
+    }
+    __device__ __forceinline__ double full(const double *s, const double *epl) const { return full_ld(s, epl, nullptr, nullptr); }
+    __device__ __forceinline__ double full0(const double *s, double fy0) const   // material.py:265: epl = 0
+    {
+        (void)fy0;
+        const double z[6] = {0., 0., 0., 0., 0., 0.};
+        return full_ld(s, z, nullptr, nullptr);
+    }
+    __device__ __forceinline__ double kh() const { return m.khard; }
+    __device__ __forceinline__ int touched() const { return 0; }
+    __device__ __forceinline__ double sflow(const double *epl) const { return sflow_of(m, epl); }
+    __device__ __forceinline__ double sflow_entry(const double *epl) const { return sflow_of(m, epl); }
+};
+
 typedef YfSvcWhT<0> YfSvcWh;
 typedef YfSvcT<6> YfSvc;
 typedef YfSvcT<2> YfSvc3;
@@ -1398,6 +1828,20 @@ using YfSvcWave = YfSvcT<6, NC, POLY>;
 //   increment and st_scal the plastic share; fy/depl/Ct are not valid yet.
 // response_heavy: the maxit = 50 sub-steps with radial scale-back (:295-344).
 // In/out: sig (updated to the end of the step).  Out: fy, depl, Ct (21 symmetric entries).
+// yf.fgrad(sig) followed by yf.plain(s2): one pass over the support vectors for policies that offer it (YfSvcRow)
+template <class YF>
+__device__ __forceinline__ auto grad_and_yf(const YF &yf, const double *sig, const double *epl, const double *s2, double *a)
+    -> decltype(yf.fgrad_plain(sig, epl, s2, a))
+{
+    return yf.fgrad_plain(sig, epl, s2, a);
+}
+template <class YF, class... X>
+__device__ __forceinline__ double grad_and_yf(const YF &yf, const double *sig, const double *epl, const double *s2, double *a, X...)
+{
+    yf.fgrad(sig, epl, a);
+    return yf.plain(s2, epl);
+}
+
 template <class YF>
 __device__ inline int response_light(const MatDev &m, const YF &yf, double *sig, const double *epl,
                                      const double *deps, double &fy, double *depl, double *Ct,
@@ -1444,12 +1888,11 @@ __device__ inline int response_light(const MatDev &m, const YF &yf, double *sig,
     // trial step with the full remaining increment (:277-293)
     {
         symv(CV, deps_r, dsr);
-        yf.fgrad(sig, epl, a);
-        symv(CV, a, ca);
-        const double hh = dot6(a, ca) + yf.kh();
 #pragma unroll
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
-        const double yfun = yf.plain(tmp, epl);  // epl_dot :1032, absolute tolerance :1041
+        const double yfun = grad_and_yf(yf, sig, epl, tmp, a);  // gradient at sig; epl_dot's calc_yf(sig + dsig) :1032, absolute tolerance :1041
+        symv(CV, a, ca);
+        const double hh = dot6(a, ca) + yf.kh();
         const double lam = (yfun <= YF_TOL) ? 0. : dot6(a, dsr) / hh;
         const double cd = dot6(ca, deps_r) / hh;
 #pragma unroll
@@ -1498,13 +1941,15 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
     double R[21];
 #pragma unroll
     for (int i = 0; i < 21; i++) R[i] = 0.;
+    PROF_T0(w);
     for (int it = 0; it < nsteps; it++) {  // :295
-        yf.fgrad(sig, epl, a);
-        symv(CV, a, ca);
-        const double hh = dot6(a, ca) + yf.kh();
 #pragma unroll
         for (int i = 0; i < 6; i++) tmp[i] = sig[i] + dsr[i];
-        const double yfun = yf.plain(tmp, epl);  // NB entry epl, absolute tolerance (:299, :1041)
+        PROF_T0(g);
+        const double yfun = grad_and_yf(yf, sig, epl, tmp, a);  // NB entry epl, absolute tolerance (:299, :1041)
+        PROF_ADD(0, g);
+        symv(CV, a, ca);
+        const double hh = dot6(a, ca) + yf.kh();
         const double lam = (yfun <= YF_TOL) ? 0. : dot6(a, dsr) / hh;
         const double cd = dot6(ca, deps_r) / hh;
 #pragma unroll
@@ -1513,7 +1958,9 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
             sig[i] += dsr[i] - ca[i] * cd;
             eplt[i] = epl[i] + depl[i] + ddepl[i];
         }
+        PROF_T0(f);
         fy1 = yf.full(sig, eplt);
+        PROF_ADD(6, f);
         const double ih = 1. / hh;
 #pragma unroll
         for (int i = 0; i < 6; i++)
@@ -1563,6 +2010,7 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
 #pragma unroll
         for (int i = 0; i < 6; i++) depl[i] += ddepl[i];  // :344
     }
+    PROF_ADD(7, w);
     const double w = st_scal / nsteps;
 #pragma unroll
     for (int i = 0; i < 21; i++) Ct[i] = fma(-w, R[i], CV[i]);

@@ -781,6 +781,92 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
     post_block_flags(lane == 0 ? changed : 0, lane == 0 ? nconv : 0, bflags);
 }
 
+// Row-per-element variants (round 5; YfSvcRow): 16 lanes = one DPP row per element, four elements per wave, the ray search in
+// its sampled form.  Same tables in LDS, same two phases, same list and flags as k_sweep_svc_wave; lane 0 of a row stores.
+__global__ void __launch_bounds__(512)
+k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const double *__restrict__ sig_in,
+              const double *__restrict__ epl_in, const double *__restrict__ ld, double *__restrict__ out, int32_t *__restrict__ status)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    const int npad = stage_svc_wave(smat, mat, 4);
+    __syncthreads();
+    const MatDev &m = smat[mat];
+    const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
+    double ldv[6];
+    if (ld) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) ldv[c] = ld[c];
+    }
+    for (int i = blockIdx.x * rpb + (threadIdx.x >> 4); i < n; i += gridDim.x * rpb) {  // row-uniform
+        double s[6], e[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            s[c] = sig_in[6 * (size_t)i + c];
+            e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
+        }
+        const YfSvcRow<4> yf(m, npad);
+        int st = 0;
+        const double f = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
+        if (l16 == 0) {
+            out[i] = f;
+            if (status) status[i] = st;
+        }
+    }
+}
+
+template <int HEAVY>
+__global__ void __launch_bounds__(512)
+k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
+                int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
+                const double2 *__restrict__ du2, const double *__restrict__ sig, const double *__restrict__ epl,
+                double *elstiff, double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
+                int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int wave_mat)
+{
+    const int count = HEAVY ? flags[2] : nel;
+    if (count == 0) return;
+    __shared__ SweepTables tb;
+    stage_tables(tb, gmat, nmat, gcls, ncls);
+    __syncthreads();
+    constexpr int NC = 4;
+    const int npad = stage_svc_wave(tb.smat, wave_mat, NC);
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    const int rpb = blockDim.x >> 4;
+    const int w = blockIdx.x * rpb + (threadIdx.x >> 4), nw = gridDim.x * rpb;
+    int changed = 0, nconv = 0;
+    for (int i = w; i < count; i += nw) {  // row-uniform
+        const int e = HEAVY ? list[i] : i;
+        const ClassDev &c = tb.scls[cls[e]];
+        const MatDev &m = tb.smat[c.mat];
+        if (!HEAVY && m.kind == 0 && first_kind && l16 == 0) fyn[e] = 0.;  // elastic: skipped by the reference
+        if (c.mat != wave_mat) continue;
+        const size_t ge = (size_t)e + e_off;
+        double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            s[k] = sig[(size_t)k * nel + e];
+            ep[k] = epl[(size_t)k * nel + e];
+        }
+        const YfSvcRow<NC> yf(m, npad);
+        const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
+        if (HEAVY) {
+            response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
+            if (l16 == 0)
+                sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, MAXIT - 1, elstiff, Mel, mel_stride, res_sig,
+                               res_depl, fyn, max_steps, nit, changed, nconv);
+        } else if (st == 2) {
+            if (l16 == 0) list[atomicAdd(&flags[2], 1)] = e;
+        } else if (l16 == 0) {
+            sweep_epilogue(c, m, e, nel, s, ep, depl, Ct, fy, 0, elstiff, Mel, mel_stride, res_sig, res_depl, fyn,
+                           max_steps, nit, changed, nconv);
+        }
+    }
+    post_block_flags(l16 == 0 ? changed : 0, l16 == 0 ? nconv : 0, bflags);
+}
+
 // Wave-per-element sweep of the work-hardening SVC materials (kind 7; round 4): the same two phases with YfSvcWhT<1> -- a
 // 15-feature SVC update costs ~1e8 flop in its support-vector sums, and one THREAD per element (k_sweep_light<7> / _heavy<7>)
 // leaves a 16- or 144-element model on 16 or 144 lanes of the GPU (0.75 s per sweep on 4 x 4 elements).  Tables from LDS when

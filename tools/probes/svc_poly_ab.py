@@ -1,6 +1,6 @@
 """A/B of the SVC ray search: sampled-ray form (PLFX_SVC_POLY=1, default) against the FP32-screened evaluations of rounds 2-4
 (PLFX_SVC_POLY=0) on a bounded config-4 sample.  Each variant runs in a process of its own (the knob is read once).
-usage: python tools/probes/svc_poly_ab.py [n=128]            -> runs both, compares fields, prints kernel times
+usage: python tools/probes/svc_poly_ab.py [n=128 [va vb]]    -> runs variants va and vb (default 0 and 2), compares fields, prints kernel times
        python tools/probes/svc_poly_ab.py run <n> <out.npz>  -> one variant (env decides)"""
 import os
 import subprocess
@@ -47,13 +47,14 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'run':
         return run(int(sys.argv[2]), sys.argv[3])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    va, vb = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ('0', '2')
     outs = {}
-    for v in ('0', '1'):
+    for v in (va, vb):
         out = '/tmp/svc_poly_%s.npz' % v
         env = dict(os.environ, PLFX_SVC_POLY=v)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'run', str(n), out], env=env)
         outs[v] = np.load(out)
-    a, b = outs['0'], outs['1']
+    a, b = outs[va], outs[vb]
     print('nsteps', int(a['nsteps']), int(b['nsteps']), 'niter equal', np.array_equal(a['niter'], b['niter']), 'sweeps', int(a['sweeps']), int(b['sweeps']))
     for k in ('sgl', 'egl', 'epgl', 'u', 'f', 'sig', 'epl'):
         if a[k].shape != b[k].shape:
