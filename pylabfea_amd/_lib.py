@@ -52,6 +52,7 @@ SYMBOLS = [
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
+    'plfx_svc_info',
 ]
 
 _lib = None
@@ -318,6 +319,13 @@ class Context(object):
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.lib.plfx_sweep_info(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def svc_info(self):
+        """(bit mask of the 6-feature SVC materials on the 16-lanes-per-element kernels, mask of those run one thread per
+        element, sweep launches of either form) since the context was created"""
+        a, b, r, t = C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_svc_info(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(t)))
+        return a.value, b.value, r.value, t.value
 
     def reuse_info(self):
         """(assemblies, BC applications, solves) answered from unchanged inputs since the context was created"""

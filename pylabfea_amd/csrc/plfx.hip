@@ -142,7 +142,9 @@ struct plfx_ctx {
     bool has_svcwh = false;      // SVC with work-hardening features (PLFX_SVC_WH)
     int n_noflow = 0;            // materials without a flow rule (Tresca, Barlat without the native normal)
     int svc_lds_need = 0;
-    int svc_wave_mat = -1;       // 6-feature SVC material run by the wave-per-element sweep kernels (-1: none)
+    int svc_wave_mat = -1;       // first 6-feature SVC material whose tables fit the LDS (-1: none): the one the wave-per-element kernels of rounds 1-4 run
+    unsigned svc_row_all = 0;    // bit k: material k is a 6-feature SVC with tables that fit the LDS (row kernels: one launch per material)
+    unsigned svc6_mask = 0;      // bit k: material k is a 6-feature SVC
     int svc_wave_lds = 0;        // bytes of its SoA tables (7 x nsv padded to 64)
     int n_svc6 = 0;              // number of 6-feature SVC materials
     int want_svc_wave = 1;       // PLFX_SVC_WAVE
@@ -227,6 +229,7 @@ struct plfx_ctx {
     struct { bool valid = false; double rtol = 0., relres = 0.; } memo;
     int n_reuse_assemble = 0, n_reuse_bc = 0, n_reuse_solve = 0;
     long long n_sweeps = 0, n_tangents_rewritten = 0;  // plfx_sweep_info
+    long long n_svc_row_launches = 0, n_svc_thread_launches = 0;  // plfx_svc_info
     // registered boundary-condition plan (plfx_set_bc_plan): calc_BC's index structure, fixed for a load history
     struct BcPlan {
         int nseg = 0;
@@ -1627,6 +1630,20 @@ int plfx_sync(plfx_ctx *c)
     return PLFX_OK;
 }
 
+// Sampled-ray form of the SVC ray search (YfSvcT::ray_sample; PLFX_SVC_POLY=0: the FP32-screened evaluations of rounds 2-4)
+// 2 (default): 16 lanes per element (k_sweep_svc_row); 1: one wave per element; 0: the FP32-screened evaluations of rounds 2-4
+static int svc_poly()
+{
+    static const int v = getenv("PLFX_SVC_POLY") ? atoi(getenv("PLFX_SVC_POLY")) : 2;
+    return v;
+}
+// materials that run on the row kernels (mode 2: every 6-feature SVC that fits the LDS) or on the wave kernels (modes 0, 1: the first)
+static unsigned svc_fast_mask(const plfx_ctx *c)
+{
+    if (c->svc_wave_mat < 0) return 0u;
+    return svc_poly() == 2 ? c->svc_row_all : (1u << c->svc_wave_mat);
+}
+
 // ------------------------------------------------------------------------------ materials
 int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
 {
@@ -1639,6 +1656,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     c->n_noflow = 0;
     c->svc_lds_need = 0;
     c->svc_wave_mat = -1;
+    c->svc_row_all = c->svc6_mask = 0;
     c->svc_wave_lds = 0;
     c->n_svc6 = 0;
     c->nonlin = false;
@@ -1717,10 +1735,12 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
             if (s.kind == PLFX_SVC6) {
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
-                if (c->svc_wave_mat < 0 && c->want_svc_wave && 9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
-                    c->svc_wave_mat = k;
+                c->svc6_mask |= 1u << k;
+                if (c->want_svc_wave && 9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
+                    if (c->svc_wave_mat < 0) c->svc_wave_mat = k;
+                    c->svc_row_all |= 1u << k;
                     // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form
-                    c->svc_wave_lds = (9 * npad + SVC_WAVE_EXTRA) * 8;
+                    c->svc_wave_lds = std::max(c->svc_wave_lds, (9 * npad + SVC_WAVE_EXTRA) * 8);
                 }
             }
         }
@@ -1740,6 +1760,8 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<0>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<1>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_full_yf_row, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_response_row, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_scf_row, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
@@ -1762,13 +1784,6 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     return PLFX_OK;
 }
 
-// Sampled-ray form of the SVC ray search (YfSvcT::ray_sample; PLFX_SVC_POLY=0: the FP32-screened evaluations of rounds 2-4)
-// 2 (default): 16 lanes per element (k_sweep_svc_row); 1: one wave per element; 0: the FP32-screened evaluations of rounds 2-4
-static int svc_poly()
-{
-    static const int v = getenv("PLFX_SVC_POLY") ? atoi(getenv("PLFX_SVC_POLY")) : 2;
-    return v;
-}
 
 // ------------------------------------------------------------------------------ batched point evaluation
 static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, const double *epl,
@@ -1793,7 +1808,7 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
     }
     if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
     static const bool wave_full = !(getenv("PLFX_FULL_YF_WAVE") && atoi(getenv("PLFX_FULL_YF_WAVE")) == 0);
-    if (what == 3 && wave_full && mat == c->svc_wave_mat && c->svc_wave_lds > 0) {  // ML_full_yf of the wave-kernel SVC material: one wave per point
+    if (what == 3 && wave_full && ((svc_fast_mask(c) >> mat) & 1u) && c->svc_wave_lds > 0) {  // ML_full_yf of a row / wave-kernel SVC material
         if (svc_poly() == 2)
             hipLaunchKernelGGL(k_full_yf_row, dim3(std::max(1, std::min((n + 31) / 32, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
                                c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
@@ -1883,9 +1898,15 @@ static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
     if (c->has_barlat)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<5>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
-    if (c->has_svc)
+    const bool resp_row = !(getenv("PLFX_RESPONSE_ROW") && atoi(getenv("PLFX_RESPONSE_ROW")) == 0);   // read per call: tests compare the two forms
+    const unsigned rmask = (resp_row && svc_poly() == 2) ? svc_fast_mask(c) : 0u;
+    if (c->has_svc && (c->svc6_mask & ~rmask))
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<3>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, RB_ARGS(c->svc_lds_need));
+                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)nullptr, (double *)nullptr, rmask);
+    for (int k = 0; k < c->nmat; k++)   // 6-feature SVC materials with tables in LDS: 16 lanes per point (the code path of the sweeps)
+        if ((rmask >> k) & 1u)
+            hipLaunchKernelGGL(k_response_row, dim3(std::max(1, std::min((n + 31) / 32, 1024))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                               c->dmat, c->nmat, k, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<6>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, RB_ARGS(c->svc_lds_need));
@@ -2636,6 +2657,17 @@ int plfx_sweep_info(plfx_ctx *c, int64_t *sweeps, int64_t *tangents_rewritten)
     if (!c) return PLFX_ERR_ARG;
     if (sweeps) *sweeps = c->n_sweeps;
     if (tangents_rewritten) *tangents_rewritten = c->n_tangents_rewritten;
+    return PLFX_OK;
+}
+
+int plfx_svc_info(plfx_ctx *c, int *row_materials, int *thread_materials, int64_t *row_launches, int64_t *thread_launches)
+{
+    if (!c) return PLFX_ERR_ARG;
+    const unsigned fast = (svc_poly() == 2) ? svc_fast_mask(c) : 0u;
+    if (row_materials) *row_materials = (int)fast;
+    if (thread_materials) *thread_materials = (int)(c->svc6_mask & ~svc_fast_mask(c));
+    if (row_launches) *row_launches = c->n_svc_row_launches;
+    if (thread_launches) *thread_launches = c->n_svc_thread_launches;
     return PLFX_OK;
 }
 
@@ -4246,8 +4278,9 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
                         c->res_sig, c->res_depl, c->fyn, c->max_steps, nit, c->flags, c->bflags, c->heavy_list
     // phase 1 per material kind present (the first launched instantiation also clears fyn of elastic elements)
     int first = 1;
-    const int wm = c->svc_wave_mat;  // this SVC material runs wave-per-element, the thread-per-element kernels skip it
-    const bool svc_thread = c->has_svc && (wm < 0 || c->n_svc6 > 1);
+    const int wm = c->svc_wave_mat;  // modes 0 / 1: this SVC material runs wave-per-element
+    const unsigned fast = svc_fast_mask(c);   // these materials run on the row (wave) kernels, the thread-per-element kernels skip them
+    const bool svc_thread = c->has_svc && (c->svc6_mask & ~fast);
     // one wave per element, one block per CU and round (the tables fill most of the LDS): 4 waves x 1024 blocks
     const int grid_w = std::max(1, std::min((c->nel + 3) / 4, 1024));
     const int grid_r = std::max(1, std::min((c->nel + 31) / 32, 1024));   // 16 lanes per element: 32 elements per block and round
@@ -4256,29 +4289,35 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
                   c->max_steps, nit, c->flags, c->bflags, c->heavy_list
     if (c->has_analytic || (c->has_elastic && !c->has_princ && !c->has_svc && !c->has_svc3 && !c->has_barlat && !c->has_svcwh)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), first, -1);
+                           SWEEP_ARGS(0), first, 0u);
         first = 0;
     }
     if (c->has_princ) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), first, -1);
+                           SWEEP_ARGS(0), first, 0u);
         first = 0;
     }
     if (c->has_barlat) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<5>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), first, -1);
+                           SWEEP_ARGS(0), first, 0u);
         first = 0;
     }
     if (svc_thread) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, wm);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, fast);
         first = 0;
+        c->n_svc_thread_launches++;
     }
     if (c->has_svc && wm >= 0) {
-        if (svc_poly() == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<0>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
-                               c->stream, WAVE_ARGS, first, wm);
-        else if (svc_poly())
+        if (svc_poly() == 2) {
+            for (int k = 0; k < c->nmat; k++)   // one launch per material: its tables fill the LDS
+                if ((fast >> k) & 1u) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<0>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
+                                       c->stream, WAVE_ARGS, first, k);
+                    first = 0;
+                    c->n_svc_row_launches++;
+                }
+        } else if (svc_poly())
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<0, true>), dim3(grid_w), dim3(512), (size_t)c->svc_wave_lds,
                                c->stream, WAVE_ARGS, first, wm);
         else
@@ -4288,7 +4327,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     }
     if (c->has_svc3) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, 0u);
         first = 0;
     }
     // work-hardening SVC materials: one wave per element (PLFX_WH_WAVE=0: one thread per element, rounds 2-3)
@@ -4303,7 +4342,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         first = 0;
     } else if (c->has_svcwh) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_light<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), first, 0u, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
                            wh_seq ? c->kh_touch : (int32_t *)nullptr);
         first = 0;
     }
@@ -4312,21 +4351,23 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     // phase 2 reads the list length from the device; an empty list costs one empty launch
     if (c->has_analytic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<1>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), -1);
+                           SWEEP_ARGS(0), 0u);
     if (c->has_princ)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<2>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), -1);
+                           SWEEP_ARGS(0), 0u);
     if (c->has_barlat)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<5>), dim3(c->grid_el), dim3(BLOCK), 0, c->stream,
-                           SWEEP_ARGS(0), -1);
+                           SWEEP_ARGS(0), 0u);
     if (svc_thread)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), wm);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), fast);
     if (c->has_svc && wm >= 0) {
-        if (svc_poly() == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<1>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
-                               c->stream, WAVE_ARGS, 0, wm);
-        else if (svc_poly())
+        if (svc_poly() == 2) {
+            for (int k = 0; k < c->nmat; k++)
+                if ((fast >> k) & 1u)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<1>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
+                                       c->stream, WAVE_ARGS, 0, k);
+        } else if (svc_poly())
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1, true>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
                                c->stream, WAVE_ARGS, 0, wm);
         else
@@ -4335,7 +4376,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     }
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<6>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1);
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), 0u);
     if (c->has_svcwh && wh_wave)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_wh_wave<1>), dim3(grid_wh), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
                            c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn, c->dcls_id,
@@ -4344,7 +4385,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
                            wh_seq ? c->kh_out : (double *)nullptr, wh_seq ? c->kh_touch : (int32_t *)nullptr);
     else if (c->has_svcwh)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<7>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, SWEEP_ARGS(c->svc_lds_need), -1, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
+                           c->stream, SWEEP_ARGS(c->svc_lds_need), 0u, c->kh_el, wh_seq ? c->kh_out : (double *)nullptr,
                            wh_seq ? c->kh_touch : (int32_t *)nullptr);
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
@@ -4509,6 +4550,21 @@ int plfx_wh_carry(plfx_ctx *c, int mat, const double *set, double *get)
     return PLFX_OK;
 }
 
+// calc_scf per element: hh and multiplicity of every owned element into scf_hh / scf_mult (sld at small + 32)
+static void launch_scf_elements(plfx_ctx *c)
+{
+    const unsigned fast = (svc_poly() == 2) ? svc_fast_mask(c) : 0u;
+    hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
+                       c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
+                       c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
+                       c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c), fast);
+    for (int k = 0; k < c->nmat; k++)
+        if ((fast >> k) & 1u)
+            hipLaunchKernelGGL(k_scf_row, dim3(std::max(1, std::min((c->nel + 31) / 32, 1024))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
+                               c->dmat, c->nmat, c->dcls, k, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
+                               c->sig, c->epl, c->elstiff, c->small + 32, c->scf_hh, c->scf_mult);
+}
+
 int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c, double *minv,
                    int64_t *count, double mean_in, int pass)
 {
@@ -4517,10 +4573,7 @@ int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c,
     if (pass == 0) {
         if (!sld) return fail(c, PLFX_ERR_ARG, "sld required");
         HIPCHK(c, hipMemcpyAsync(c->small + 32, sld, 48, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
-                           c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
-                           c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                           c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c));
+        launch_scf_elements(c);
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult,
@@ -4551,10 +4604,7 @@ int plfx_scf_all(plfx_ctx *c, const double *sld, int64_t *count, double *minv, d
     if (!sld) return fail(c, PLFX_ERR_ARG, "sld required");
     const int g = grid_for(c->nel, 256);
     HIPCHK(c, hipMemcpyAsync(c->small + 32, sld, 48, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_scf_elements, dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
-                       c->dmat, c->nmat, c->dcls, c->ncls, c->svc_lds_need, c->nel, c->e0, c->dconn,
-                       c->dcls_id, (const double2 *)c->du, c->sig, c->epl, c->elstiff,
-                       c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c));
+    launch_scf_elements(c);
     const int elo = c->strip.on ? c->strip.eown_lo : 0, ehi = c->strip.on ? c->strip.eown_hi : 0x7fffffff;
     hipLaunchKernelGGL(k_scf_reduce, dim3(g), dim3(BLOCK), 0, c->stream, c->nel, c->scf_hh, c->scf_mult, 0., 0,
                        c->part_g, (const double *)nullptr, elo, ehi);

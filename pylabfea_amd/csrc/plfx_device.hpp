@@ -1425,11 +1425,9 @@ struct YfSvcWhT {
 //    points at which p decides the sign (|p| > margin, inside [lo, hi]) is skipped, the first point it does not decide is
 //    evaluated as before (p, or the support-vector sum itself when p is closer to zero than its error bound or the point lies
 //    outside the sampled interval) and the reference's loop condition is applied to that value;
-//  * the root (:501-503): the reference calls brentq(xtol = 1e-5) on [x0, x1]; here the last step of the march, which
-//    brackets the sign change the march found, is cut into 16 cells four times (lane i evaluates p at the i-th cell
-//    boundary, the first lane with p >= 0 closes the cell that holds the root) and a secant step on the last cell gives the
-//    root of p to ~1e-12 -- SURVEY 8(c): any bracketing root finder within brentq's own tolerance.  Brackets that p does
-//    not cover are searched by the brentq replay on the support-vector sums (BrentState), as in rounds 1-4.
+//  * the root (:501-503): brentq(xtol = 1e-5) on [x0, x1] is replayed iterate for iterate (BrentState) with p as the function
+//    (the support-vector sums where p does not cover an iterate), so the value response() branches on is the reference's
+//    last iterate to ~1e-11, not a better root.
 template <int NC>
 struct YfSvcRow {
     static constexpr int GS = 16, NS = RAYPOLY_N;
@@ -1694,9 +1692,9 @@ struct YfSvcRow {
     }
     // the marching loops of material.py:475-480 (DOWN: while f0 >= 0 and x0 > 0.01: x0 *= 0.98) and :481-486 (up: while
     // f1 < 0 and x1 < 5 sflow: x1 *= 1.02), entered with the loop condition true at (x, fx); leaves the point the loop ends at
-    // in (x, fx) and the point before it in xprev.  pw[i] = 0.98^i / 1.02^i as sequential products.
+    // in (x, fx).  pw[i] = 0.98^i / 1.02^i as sequential products.
     template <bool DOWN>
-    __device__ __forceinline__ void march(const double *su, const RowPoly &P, double sflow, double &x, double &fx, double &xprev) const
+    __device__ __forceinline__ void march(const double *su, const RowPoly &P, double sflow, double &x, double &fx) const
     {
         const double *pw = poly_tab() + NS * NS + (DOWN ? 0 : 64);
         const int l = threadIdx.x & (GS - 1);
@@ -1710,12 +1708,10 @@ struct YfSvcRow {
                 const unsigned row = (unsigned)(__ballot(on) >> (threadIdx.x & 48)) & 0xffffu;
                 k = (row == 0xffffu) ? GS : __ffs((int)~row) - 1;   // leading run of points at which the march goes on
             }
-            if (k == GS) {
-                x *= pw[GS];
-                continue;
-            }
-            xprev = x * pw[k];
-            x *= pw[k + 1];
+            // the products one by one: the point the march stops at is an end of brentq's bracket and carries the reference's rounding
+            const int steps = (k == GS) ? GS : k + 1;
+            for (int i = 0; i < steps; i++) x *= DOWN ? 0.98 : 1.02;
+            if (k == GS) continue;
             fx = evalx(su, P, x, true);
             if (!(DOWN ? (fx >= 0. && x > 0.01) : (fx < 0. && x < 5. * sflow))) return;
         }
@@ -1751,41 +1747,21 @@ struct YfSvcRow {
         if (halved) x0 *= 0.5;
         RowPoly P;
         ray_sample(su, x0, halved, P);
-        double f0 = evalx(su, P, x0, true), x1 = x0, f1 = f0, xp0 = x0, xp1 = x0;
-        const bool down = f0 >= 0. && x0 > 0.01;
-        if (down) march<true>(su, P, sflow, x0, f0, xp0);
-        const bool up = f1 < 0. && x1 < 5. * sflow;
-        if (up) march<false>(su, P, sflow, x1, f1, xp1);
+        double f0 = evalx(su, P, x0, true), x1 = x0, f1 = f0;
+        if (f0 >= 0. && x0 > 0.01) march<true>(su, P, sflow, x0, f0);
+        if (f1 < 0. && x1 < 5. * sflow) march<false>(su, P, sflow, x1, f1);
         if (f0 * f1 > 0.) {  // material.py:495-499
             if (status) *status = 1;
             return seqv - 0.85 * sflow;
         }
+        // brentq(xtol = 1e-5) on the reference's bracket [x0, x1] (material.py:501-503), iterate for iterate (BrentState), with
+        // the polynomial as the function wherever it covers the iterate: the reference's result is brentq's LAST ITERATE, up
+        // to 1e-5 MPa away from the root, and the branch tests of response() (fy1 > toler, :310) read it -- a root finder
+        // that converges further (measured: lane-parallel subdivision + secant, 1e-12) flips such a test in 1 of 60 000
+        // seeded calls and moves that call's stress by 1.4e-3 sy; the replay on p differs from the reference by ~1e-11
         double xs;
         bool conv = true;
-        // the last step of the march brackets the sign change: f < 0 at its lower end, f >= 0 at its upper end
-        double lo = down ? x0 : xp1, hi = down ? xp0 : x1;
-        if (f0 == 0.) {
-            xs = x0;   // brentq returns an end of the bracket at which f vanishes
-        } else if (f1 == 0.) {
-            xs = x1;
-        } else if ((down || up) && P.ok && lo >= P.lo && hi <= P.hi && lo < hi) {
-            const int l = threadIdx.x & (GS - 1);
-#pragma unroll 1
-            for (int r = 0; r < 4; r++) {
-                const double h = (hi - lo) * (1. / GS);
-                const double y = (l == GS - 1) ? hi : fma(h, (double)(l + 1), lo);
-                const double pv = P.eval(y);
-                const unsigned row = (unsigned)(__ballot(pv < 0.) >> (threadIdx.x & 48)) & 0x7fffu;   // lane 15 is hi: f >= 0
-                const int k = __ffs((int)~row) - 1;   // first cell boundary with p >= 0 (0 ... 15)
-                if (k < GS - 1) hi = fma(h, (double)(k + 1), lo);
-                lo = fma(h, (double)k, lo);
-            }
-            // secant on the last cell (even lanes evaluate its lower end, odd lanes its upper end)
-            const double pe = P.eval((l & 1) ? hi : lo);
-            const double plo = row_bcast<0>(pe), phi = row_bcast<1>(pe);
-            xs = (phi > plo) ? fmin(fmax(lo - plo * (hi - lo) / (phi - plo), lo), hi) : 0.5 * (lo + hi);
-        } else {
-            // brentq on the reference's bracket [x0, x1] with the support-vector sums (the polynomial does not cover it)
+        {
             BrentState br;
             if (br.start(x0, x1, f0, f1)) {
                 while (br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) br.fcur = evalx(su, P, br.xcur, false);
@@ -1958,14 +1934,16 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
             sig[i] += dsr[i] - ca[i] * cd;
             eplt[i] = epl[i] + depl[i] + ddepl[i];
         }
+        {   // (before the ray search, which it does not depend on: a, ca, hh are dead across yf.full())
+            const double ih = 1. / hh;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) R[sym_idx(i, j)] = fma(ca[i] * ih, ca[j], R[sym_idx(i, j)]);
+        }
         PROF_T0(f);
         fy1 = yf.full(sig, eplt);
         PROF_ADD(6, f);
-        const double ih = 1. / hh;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = i; j < 6; j++) R[sym_idx(i, j)] = fma(ca[i] * ih, ca[j], R[sym_idx(i, j)]);
         if (fy1 > toler) {  // radial scale-back :310-342
             const double sq = yf.seq(sig);
             const double fr = fy1 / sq;

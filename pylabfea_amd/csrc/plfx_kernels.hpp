@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
                  const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
                  double *sig_out, double *depl_out, double *ct_out, int32_t *nsteps,
-                 const double *kh_in = nullptr, double *kh_out = nullptr)
+                 const double *kh_in = nullptr, double *kh_out = nullptr, unsigned skip_mask = 0u /* materials run by k_response_row */)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -247,6 +247,7 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
         const int mid = mat_id ? mat_id[i] : 0;
         const MatDev &m = smat[mid];
         if (m.kind != KIND && !(m.kind == 0 && KIND == 1)) continue;  // handled by another instantiation
+        if ((skip_mask >> mid) & 1u) continue;
         double sig[6], epl[6], deps[6], depl[6], Ct[21], f = 0.;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
@@ -535,7 +536,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, int skip_mat,
+              int32_t *max_steps, int nit, int *flags, int *bflags, int32_t *list, int first_kind, unsigned skip_mask,
               double *kh_el = nullptr /* KIND 7: hardening modulus of every material point, carried from sweep to sweep */,
               double *kh_out = nullptr, int32_t *kh_touch = nullptr /* sequential-carry mode: kh_el is read only; the exit
               modulus and "a gradient evaluation overwrote it" go here */)
@@ -559,7 +560,7 @@ k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
             const MatDev &m = tb.smat[c.mat];
             if (m.kind == 0) {  // elastic material: skipped by the reference (model.py:1341, 1358)
                 if (first_kind) fyn[e] = 0.;
-            } else if (m.kind == KIND && c.mat != skip_mat) {  // skip_mat: handled by the wave-per-element kernels
+            } else if (m.kind == KIND && !((skip_mask >> c.mat) & 1u)) {  // skip_mask: materials handled by the row / wave kernels
                 const size_t ge = (size_t)e + e_off;
                 double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
                 class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -606,7 +607,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
               const double *__restrict__ sig, const double *__restrict__ epl, double *elstiff,
               double *Mel, int mel_stride, double *res_sig, double *res_depl, double *fyn,
-              int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, int skip_mat,
+              int32_t *max_steps, int nit, int *flags, int *bflags, const int32_t *__restrict__ list, unsigned skip_mask,
               double *kh_el = nullptr, double *kh_out = nullptr, int32_t *kh_touch = nullptr)
 {
     const int count = flags[2];
@@ -625,7 +626,7 @@ k_sweep_heavy(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restr
         const int e = list[i];
         const ClassDev &c = tb.scls[cls[e]];
         const MatDev &m = tb.smat[c.mat];
-        if (m.kind != KIND || c.mat == skip_mat) continue;
+        if (m.kind != KIND || ((skip_mask >> c.mat) & 1u)) continue;
         const size_t ge = (size_t)e + e_off;
         double deps[6], s[6], ep[6], depl[6], Ct[21], dr[6], fy, st_scal;
         class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], deps);
@@ -790,7 +791,7 @@ k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const d
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
     __syncthreads();
-    const int npad = stage_svc_wave(smat, mat, 4);
+    const int npad = stage_svc_wave(smat, mat, 1);   // rows take 16 x 4 vectors per trip: padded to 64
     __syncthreads();
     const MatDev &m = smat[mat];
     const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
@@ -816,6 +817,48 @@ k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const d
     }
 }
 
+// Material.response on n points of the row-kernel SVC material `mat` (host-layout arrays as in k_response_batch; points of
+// other materials are left to k_response_batch<3>): the same code path as the sweeps of a model, callable point by point
+__global__ void __launch_bounds__(512)
+k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const int32_t *__restrict__ mat_id,
+               const double *__restrict__ sig_in, const double *__restrict__ epl_in, const double *__restrict__ deps_in,
+               double *__restrict__ fy, double *__restrict__ sig_out, double *__restrict__ depl_out, double *__restrict__ ct_out,
+               int32_t *__restrict__ nsteps)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    const int npad = stage_svc_wave(smat, mat, 1);
+    __syncthreads();
+    const MatDev &m = smat[mat];
+    const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
+    for (int i = blockIdx.x * rpb + (threadIdx.x >> 4); i < n; i += gridDim.x * rpb) {  // row-uniform
+        if ((mat_id ? mat_id[i] : 0) != mat) continue;
+        double sig[6], epl[6], deps[6], depl[6], Ct[21], f = 0.;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            sig[c] = sig_in[6 * (size_t)i + c];
+            epl[c] = epl_in[6 * (size_t)i + c];
+            deps[c] = deps_in[6 * (size_t)i + c];
+        }
+        const YfSvcRow<4> yf(m, npad);
+        const int ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
+        if (l16 == 0) {
+            fy[i] = f;
+            nsteps[i] = ns;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                sig_out[6 * (size_t)i + c] = sig[c];
+                depl_out[6 * (size_t)i + c] = depl[c];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) ct_out[36 * (size_t)i + r * 6 + c] = Ct[sym_idx(r, c)];
+        }
+    }
+}
+
 template <int HEAVY>
 __global__ void __launch_bounds__(512)
 k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
@@ -830,7 +873,7 @@ k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__res
     stage_tables(tb, gmat, nmat, gcls, ncls);
     __syncthreads();
     constexpr int NC = 4;
-    const int npad = stage_svc_wave(tb.smat, wave_mat, NC);
+    const int npad = stage_svc_wave(tb.smat, wave_mat, 1);   // rows take 16 x 4 vectors per trip: padded to 64
     __syncthreads();
     const int l16 = threadIdx.x & 15;
     const int rpb = blockDim.x >> 4;
@@ -2104,7 +2147,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls, int lds_doubles, int nel,
                int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
                const double *__restrict__ sig, const double *__restrict__ epl, const double *__restrict__ elstiff, const double *__restrict__ sld,
-               double *__restrict__ hh_out, int32_t *__restrict__ mult_out, const double *__restrict__ kh_el = nullptr)
+               double *__restrict__ hh_out, int32_t *__restrict__ mult_out, const double *__restrict__ kh_el = nullptr,
+               unsigned skip_mask = 0u /* materials done by k_scf_row */)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -2119,6 +2163,7 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
     for (int k = 0; k < 6; k++) ld[k] = sld[k];
     for (int e = blockIdx.x * BLOCK + threadIdx.x; e < nel; e += gridDim.x * BLOCK) {
         const ClassDev &c = gcls[cls[e]];
+        if ((skip_mask >> c.mat) & 1u) continue;
         const MatDev &m = smat[c.mat];
         const size_t ge = (size_t)e + e_off;
         double de[6], D[21], ds[6];
@@ -2178,6 +2223,62 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
         }
         hh_out[e] = hh;
         mult_out[e] = mult;
+    }
+}
+
+// calc_scf for the elements of the 6-feature SVC material `mat`, 16 lanes per element (YfSvcRow; ML_full_yf along the
+// loading direction is a ray search, model.py:1049-1052) -- the thread-per-element form above took 4.5 ms per call on
+// 16 384 elements, a quarter of a 50-sub-step corrector launch
+__global__ void __launch_bounds__(512)
+k_scf_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int mat, int nel,
+          int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
+          const double *__restrict__ sig, const double *__restrict__ epl, const double *__restrict__ elstiff, const double *__restrict__ sld,
+          double *__restrict__ hh_out, int32_t *__restrict__ mult_out)
+{
+    __shared__ MatDev smat[MAXMAT];
+    stage_materials(smat, gmat, nmat);
+    __syncthreads();
+    const int npad = stage_svc_wave(smat, mat, 1);
+    __syncthreads();
+    const MatDev &m = smat[mat];
+    const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
+    double ld[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ld[k] = sld[k];
+    for (int e = blockIdx.x * rpb + (threadIdx.x >> 4); e < nel; e += gridDim.x * rpb) {  // row-uniform
+        const ClassDev &c = gcls[cls[e]];
+        if (c.mat != mat) continue;
+        const size_t ge = (size_t)e + e_off;
+        double de[6], D[21], ds[6];
+        class_strain(c, du2, conn[ge * 4], conn[ge * 4 + 1], conn[ge * 4 + 2], conn[ge * 4 + 3], de);
+#pragma unroll
+        for (int k = 0; k < 21; k++) D[k] = elstiff[(size_t)k * nel + e];
+        symv(D, de, ds);
+        int mult = 0;
+        double hh = 0.;
+        const double sref = hill_seq(m, ds);   // Stress(el.dsig()).seq(el.Mat) (model.py:1040)
+        if (sref > 0.1) {
+            double s[6], ep[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                s[k] = sig[(size_t)k * nel + e];
+                ep[k] = epl[(size_t)k * nel + e];
+            }
+            const YfSvcRow<4> yf(m, npad);
+            double yf0 = yf.plain(s, ep);
+            if (yf0 < SPLIT_THRESHOLD) {  // branch test on the decision function (model.py:1046-1048)
+                yf0 = yf.full_ld(s, ep, ld, nullptr);  // model.py:1049-1052
+                hh = fmin(1., -yf0 / sref);
+                mult = 2;  // appended twice (model.py:1054 and :1058)
+            } else {
+                hh = fmin(1., sqrt(1.5) * sflow_of(m, ep) / sref);
+                mult = 1;
+            }
+        }
+        if (l16 == 0) {
+            hh_out[e] = hh;
+            mult_out[e] = mult;
+        }
     }
 }
 
