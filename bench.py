@@ -825,6 +825,10 @@ def main():
         try:
             leg = config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, args.config5_leg_mesh)
         except Exception as exc:   # the main line above stands on its own: report, do not lose it
+            if world > 1:
+                # the leg runs collectives: a rank that drops out of it alone would leave the others waiting in the next one
+                # -- with several ranks the failure is fatal for the launch (torch.distributed.run tears the group down)
+                raise
             leg = {'error': '%s: %s' % (type(exc).__name__, exc)}
         out['config5_leg'] = leg
     if rank == 0 and world == 1:

@@ -52,7 +52,7 @@ SYMBOLS = [
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
-    'plfx_svc_info',
+    'plfx_svc_info', 'plfx_sqmr_info',
 ]
 
 _lib = None
@@ -319,6 +319,12 @@ class Context(object):
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.lib.plfx_sweep_info(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def sqmr_info(self):
+        """solves with an indefinite tangent stiffness that SQMR completed on its own (plfx_indefinite_info counts all of them)"""
+        a = C.c_int64()
+        self._chk(self.lib.plfx_sqmr_info(self.h, C.byref(a)))
+        return a.value
 
     def svc_info(self):
         """(bit mask of the 6-feature SVC materials on the 16-lanes-per-element kernels, mask of those run one thread per

@@ -182,6 +182,7 @@ struct plfx_ctx {
     int wh_mode = 1;           // 1 = sequential carry (default on one GPU), 0 = one modulus per material point
     double wh_carry[16] = {0};
     double *kh_out = nullptr, *kh_new = nullptr, *wh_snap_el = nullptr, *wh_snap_M = nullptr;
+    int32_t *wh_snap_ms = nullptr;   // max_steps at the start of a sequential-carry sweep
     int32_t *kh_touch = nullptr, *wh_bmax = nullptr, *wh_cnt = nullptr;
     bool kh_out_valid = false;
     int64_t n_wh_passes = 0, n_wh_sweeps = 0, n_wh_unresolved = 0;
@@ -275,6 +276,7 @@ struct plfx_ctx {
     int n_sur = 0;             // surrogate hierarchies built
     long long sur_replaced = 0; // elements replaced in the last one
     int n_sur_minres = 0;      // solves MINRES completed with the surrogate V-cycle
+    int n_sqmr = 0;            // solves SQMR completed (the default indefinite-system solver)
     bool strip_jacobi = false;  // strip-local engine during such a fall-back: the V-cycle is replaced by z = D^-1 r
     int grid_nodes = 0, grid_el = 0;
 
@@ -722,7 +724,7 @@ void free_mesh(plfx_ctx *c)
     dfree(c->fyn);
     dfree(c->scf_hh);
     dfree(c->kh_el);
-    dfree(c->kh_out); dfree(c->kh_new); dfree(c->wh_snap_el); dfree(c->wh_snap_M);
+    dfree(c->kh_out); dfree(c->kh_new); dfree(c->wh_snap_el); dfree(c->wh_snap_M); dfree(c->wh_snap_ms);
     dfree(c->kh_touch); dfree(c->wh_bmax); dfree(c->wh_cnt);
     c->kh_out_valid = false;
     dfree(c->max_steps);
@@ -2762,6 +2764,13 @@ int plfx_precond_info(plfx_ctx *c, int *kind, int *levels)
     return PLFX_OK;
 }
 
+int plfx_sqmr_info(plfx_ctx *c, int64_t *by_sqmr)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (by_sqmr) *by_sqmr = c->n_sqmr;
+    return PLFX_OK;
+}
+
 int plfx_indefinite_info(plfx_ctx *c, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres, int64_t *surrogates_built,
                          int64_t *elements_shifted)
 {
@@ -3937,6 +3946,119 @@ restart:
     return 1;
 }
 
+// Preconditioned SQMR on P K P x = P b from the iterate in c->x (see plfx_mg.hpp).  Returns 0 = converged to |r| <= rtol |b|
+// (true residual), 1 = iteration limit, 2 = breakdown (p.Kp = 0 or r.Br = 0) or the recurrences stalled short of the tolerance
+// (the caller continues with GMRES from the iterate), < 0 = error.
+int sqmr_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
+{
+    const size_t nd = c->ndof;
+    const int nn = c->nnode, gn = c->grid_nodes;
+    const int olo = own_lo(c), ohi = own_hi(c);
+    int rc;
+    if (!c->mr_w && (rc = dalloc(c, &c->mr_w, nd))) return rc;
+    double *P0 = c->part, *P_rz = c->part + 3 * MAXPART, *P_rr = c->part + 4 * MAXPART, *P_bb = c->part + 5 * MAXPART;
+    const bool use_mg = mg_active(c);
+    const bool dbg = getenv("PLFX_SOLVE_DEBUG") != nullptr;
+    int itn = 0, restarts = 0;
+    double bb = 0., rr = 0., rl = 0., last_rl = 1e300;
+    auto precond = [&](double *rz_out) -> int {  // z = B r, r.z
+        int e;
+        if (c->strip.on && (e = halo_refresh(c, c->r))) return e;
+        if (use_mg) {
+            if ((e = mg_vcycle(c))) return e;
+        } else {
+            hipLaunchKernelGGL(k_jacobi_z, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->dinv,
+                               (const double2 *)c->r, (double2 *)c->z, c->sc);
+        }
+        hipLaunchKernelGGL(k_dot_rz, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, (const double2 *)c->r, (const double2 *)c->z, P0);
+        HIPCHK(c, hipGetLastError());
+        return host_sums(c, P0, 1, gn, rz_out);
+    };
+    auto finish = [&](int code) {
+        if (iters) *iters = itn;
+        if (relres) *relres = rl;
+        return code;
+    };
+    for (;;) {
+        // r = P (b - K x) in c->r
+        LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, 1, (const double2 *)c->x, (const double2 *)c->rhs,
+                   (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz, P_rr, P_bb, olo, ohi);
+        HIPCHK(c, hipGetLastError());
+        double o[3];
+        if ((rc = host_sums(c, P_rz, 3, gn, o))) return rc;
+        rr = o[1];
+        bb = o[2];
+        hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol, c->sc);  // clears the sticky done flag
+        const double tol2 = rtol * rtol * bb;
+        rl = bb > 0. ? std::sqrt(rr / bb) : 0.;
+        if (dbg) fprintf(stderr, "[sqmr] (re)start %d at iteration %d: true relative residual %.3e\n", restarts, itn, rl);
+        if (rr <= tol2) return finish(0);
+        if (itn >= maxit) return finish(1);
+        if (restarts > 0 && rl > 0.5 * last_rl) return finish(2);   // a whole leg bought less than a factor of two
+        last_rl = rl;
+        double rho;
+        if ((rc = precond(&rho))) return rc;
+        if (!(rho != 0.) || !std::isfinite(rho)) return finish(2);
+        HIPCHK(c, hipMemsetAsync(c->mr_w, 0, 8 * nd, c->stream));   // d
+        double tau = std::sqrt(rr), theta = 0., beta = 0.;
+        double *qo = c->p[1], *qn = c->p[0];   // (beta = 0 in the first iteration: qo is read but does not contribute)
+        HIPCHK(c, hipMemsetAsync(qo, 0, 8 * nd, c->stream));
+        double check_at = 1.;
+        int leg = 0, worse = 0;
+        double best_tau = tau;
+        bool again = false;
+        while (itn < maxit) {
+            itn++;
+            leg++;
+            double sigma, rr_n;
+            LAUNCH_OP1(k_sqmr_apply, matfree(c), dim3(gn), c->op, nn, beta, (const double2 *)c->z, (const double2 *)qo,
+                       (const double2 *)c->dinv, (double2 *)qn, (double2 *)c->q, P0, olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = host_sums(c, P0, 1, gn, &sigma))) return rc;
+            if (!(sigma != 0.) || !std::isfinite(sigma)) return finish(2);
+            const double alpha = rho / sigma;
+            hipLaunchKernelGGL(k_sqmr_update_r, dim3(gn), dim3(BLOCK), 0, c->stream, nn, alpha, (const double2 *)c->q, (double2 *)c->r, P0, olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = host_sums(c, P0, 1, gn, &rr_n))) return rc;
+            if (!std::isfinite(rr_n)) return finish(2);
+            const double theta_n = std::sqrt(rr_n) / tau;
+            const double cn2 = 1. / (1. + theta_n * theta_n);
+            tau = tau * theta_n * std::sqrt(cn2);
+            hipLaunchKernelGGL(k_sqmr_update_x, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, cn2 * theta * theta, cn2 * alpha,
+                               (const double2 *)qn, (double2 *)c->mr_w, (double2 *)c->x);
+            HIPCHK(c, hipGetLastError());
+            theta = theta_n;
+            std::swap(qo, qn);
+            // |r_qmr| <= sqrt(leg + 1) tau: look at the true residual when that bound reaches the tolerance (or stops falling)
+            const double est2 = (leg + 1.) * tau * tau;
+            if (tau < best_tau) best_tau = tau, worse = 0;
+            else worse++;
+            if (est2 <= check_at * check_at * tol2 || itn == maxit || worse >= 50) {
+                LAUNCH_OP1(k_resid_norm, matfree(c), dim3(gn), c->op, nn, (const double2 *)c->x, (const double2 *)c->rhs,
+                           (const double2 *)c->dinv, P0, olo, ohi);
+                HIPCHK(c, hipGetLastError());
+                double rt;
+                if ((rc = host_sums(c, P0, 1, gn, &rt))) return rc;
+                rl = bb > 0. ? std::sqrt(rt / bb) : 0.;
+                if (dbg) fprintf(stderr, "[sqmr] iteration %d: bound %.3e, true relative residual %.3e\n", itn, std::sqrt(est2 / (bb > 0. ? bb : 1.)), rl);
+                if (rt <= tol2) return finish(0);
+                if (worse >= 50 || rt > 100. * est2) {   // the recurrences have drifted from the true residual: start again from it
+                    again = true;
+                    break;
+                }
+                check_at = 0.5 * std::sqrt(est2 / tol2);
+            }
+            double rho_n;
+            if ((rc = precond(&rho_n))) return rc;
+            if (!(rho_n != 0.) || !std::isfinite(rho_n)) return finish(2);
+            beta = rho_n / rho;
+            rho = rho_n;
+        }
+        if (!again) return finish(1);
+        if (++restarts > 6) return finish(2);
+    }
+}
+
 }  // namespace
 
 int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
@@ -4169,7 +4291,9 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         //   minres           MINRES with the V-cycle of the indefinite operator itself (not positive definite in about half
         //                    of config 5's solves: hands over to GMRES after a few wasted iterations)
         const char *isv = getenv("PLFX_INDEFINITE_SOLVER");
-        const int imode = !isv ? 1 : (!strcmp(isv, "surrogate") ? 0 : (!strcmp(isv, "minres") ? 2 : 1));
+        //   sqmr (default, round 5)  simplified QMR with the V-cycle of the operator as it is (symmetric, need not be definite):
+        //                    CG-like short recurrences; GMRES takes over from its iterate on a breakdown or stall
+        const int imode = !isv ? 3 : (!strcmp(isv, "surrogate") ? 0 : (!strcmp(isv, "minres") ? 2 : (!strcmp(isv, "gmres") ? 1 : 3)));
         int rcm = 2;
         if (imode == 0) {
             long long nrep = c->sur_replaced;
@@ -4189,6 +4313,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             rcm = minres_solve(c, rtol, maxit_all, &itm, &rl);
             if (rcm < 0) return rcm;
             if (solve_debug) fprintf(stderr, "[plfx_solve] MINRES: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
+        }
+        else if (imode == 3) {
+            rcm = sqmr_solve(c, rtol, maxit_all, &itm, &rl);
+            if (rcm < 0) return rcm;
+            if (rcm == 0) c->n_sqmr++;
+            else rcm = 2;   // iteration limit or stall: GMRES continues from the iterate
+            if (solve_debug) fprintf(stderr, "[plfx_solve] SQMR: rc %d, %d iterations, relative residual %.3e\n", rcm, itm, rl);
         }
         c->n_minres++;
         if (rcm == 2) {
@@ -4331,7 +4462,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         first = 0;
     }
     // work-hardening SVC materials: one wave per element (PLFX_WH_WAVE=0: one thread per element, rounds 2-3)
-    static const bool wh_wave = !(getenv("PLFX_WH_WAVE") && atoi(getenv("PLFX_WH_WAVE")) == 0);
+    const bool wh_wave = !(getenv("PLFX_WH_WAVE") && atoi(getenv("PLFX_WH_WAVE")) == 0);   // read per sweep: tests compare the two forms
     const int grid_wh = std::max(1, std::min((c->nel + 3) / 4, SWEEP_SLOTS));  // one bflags slot pair per block (the kernel grid-strides)
     if (c->has_svcwh && wh_wave) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_wh_wave<0>), dim3(grid_wh), dim3(BLOCK), dyn_lds_bytes(c), c->stream,
@@ -4431,26 +4562,34 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
     if (!c->kh_out) {
         if ((rc = dalloc(c, &c->kh_out, ne)) || (rc = dalloc(c, &c->kh_new, ne)) || (rc = dalloc(c, &c->kh_touch, ne)) ||
             (rc = dalloc(c, &c->wh_bmax, (size_t)nblk)) || (rc = dalloc(c, &c->wh_cnt, 4)) ||
-            (rc = dalloc(c, &c->wh_snap_el, 21 * ne)) || (rc = dalloc(c, &c->wh_snap_M, (size_t)6 * c->nel_total)))
+            (rc = dalloc(c, &c->wh_snap_el, 21 * ne)) || (rc = dalloc(c, &c->wh_snap_M, (size_t)6 * c->nel_total)) ||
+            (rc = dalloc(c, &c->wh_snap_ms, ne)))
             return rc;
     }
     HIPCHK(c, hipMemcpyAsync(c->wh_snap_el, c->elstiff, 21 * ne * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->wh_snap_M, c->Mel, (size_t)6 * c->nel_total * 8, hipMemcpyDeviceToDevice, c->stream));
+    // max_steps is a running maximum (sweep_epilogue): passes that ran with entry moduli the chain does not confirm must not leave their counts
+    HIPCHK(c, hipMemcpyAsync(c->wh_snap_ms, c->max_steps, ne * 4, hipMemcpyDeviceToDevice, c->stream));
     const int64_t sw0 = c->n_sweeps, tr0 = c->n_tangents_rewritten;
     int64_t tr_before = tr0;
     bool any_changed = false;
+    const bool dirty0 = c->M_dirty;
     int32_t last[16];
-    const int max_pass = (int)std::min<size_t>(ne + 2, 64);
+    // every pass confirms at least one more element of the chain (the first one whose entry value was wrong now runs with the
+    // right one, everything before it is final), so ne + 2 passes always reach the sequential loop's sweep; two or three do
+    // on every trace seen so far (the exit modulus of a call hardly depends on its entry modulus)
+    const int max_pass = (int)std::min<size_t>(ne + 2, 0x7fffffff);
     int pass = 0;
     for (;; pass++) {
         if (pass > 0) {
             HIPCHK(c, hipMemcpyAsync(c->elstiff, c->wh_snap_el, 21 * ne * 8, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->Mel, c->wh_snap_M, (size_t)6 * c->nel_total * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->max_steps, c->wh_snap_ms, ne * 4, hipMemcpyDeviceToDevice, c->stream));
         }
         int ch = 0, cv = 0;
         tr_before = c->n_tangents_rewritten;
         if ((rc = sweep_once(c, nit, &ch, &cv, true))) return rc;
-        any_changed = any_changed || ch;
+        any_changed = (ch != 0);   // of the accepted (last) pass: the earlier ones are undone by the snapshot
         if (changed) *changed = ch;
         if (conv) *conv = cv;
         // entry values this pass implies
@@ -4486,7 +4625,7 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
                     (long long)c->n_wh_sweeps, pass, nch, nt, imax, kmax, last[0], c->wh_carry[0]);
         }
         if (nch == 0) break;
-        if (pass + 1 >= max_pass) {  // (never seen: an entry value only moves the yield check of its own call)
+        if (pass + 1 >= max_pass) {  // (cannot happen, see max_pass; counted and reported by plfx_wh_info all the same)
             c->n_wh_unresolved++;
             break;
         }
@@ -4500,7 +4639,7 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
     c->n_wh_sweeps++;
     c->n_sweeps = sw0 + 1;   // one sweep of the load-step loop, however many passes it took
     c->n_tangents_rewritten = tr0 + (c->n_tangents_rewritten - tr_before);   // ... and the rewrites of its last pass
-    if (any_changed) c->M_dirty = true;
+    c->M_dirty = dirty0 || any_changed;   // (sweep_once set it in passes the snapshot has undone)
     return PLFX_OK;
 }
 

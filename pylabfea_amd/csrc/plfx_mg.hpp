@@ -390,6 +390,76 @@ k_resid_norm(KOp op, int nnode, const double2 *__restrict__ x, const double2 *__
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// ---------------------------------------------------------------------------------------------- SQMR
+// Simplified QMR for symmetric indefinite systems with a symmetric, possibly INDEFINITE preconditioner (Freund & Nachtigal 1994,
+// algorithm without look-ahead, right preconditioning): the coupled two-term recurrences of preconditioned CG -- which do not
+// need positivity, only p.Kp != 0 and r.Br != 0 -- and a quasi-minimal-residual smoothing of the iterates:
+//   t = K q;  sigma = q.t;  alpha = rho / sigma;  r -= alpha t;  theta = |r| / tau;  c = 1 / sqrt(1 + theta^2);  tau *= theta c
+//   d = (c theta_old)^2 d + c^2 alpha q;  x += d;  z = B r;  rho_new = r.z;  q = z + (rho_new / rho) q
+// Short recurrences like MINRES (no Krylov basis, no orthogonalisation: a GMRES iteration at 2048^2 reads its j basis vectors
+// four times -- 27 us each -- against ~1 ms for the V-cycle) and, unlike MINRES, the V-cycle built on the indefinite operator
+// itself is admissible (it is symmetric: same smoother before and after, restriction = prolongation^T).
+// k_sqmr_apply: q_new = z + beta q_old (written to the other buffer), t = P K q_new, partials of q_new . t
+template <int GRID>
+__global__ void __launch_bounds__(BLOCK)
+k_sqmr_apply(KOp op, int nnode, double beta, const double2 *__restrict__ z, const double2 *__restrict__ qold,
+             const double2 *__restrict__ dinv, double2 *__restrict__ qnew, double2 *__restrict__ t, double *__restrict__ part,
+             int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
+    const int nb = gridDim.x;
+    for (int tl = xcd_tile(blockIdx.x, nb); tl * BLOCK < nnode; tl += nb) {
+        const int i = tl * BLOCK + threadIdx.x;
+        if (i >= nnode) continue;
+        const double2 kv = op_apply<GRID>(op, i, [&](int j) {
+            const double2 zj = z[j], qj = qold[j];
+            return make_double2(fma(beta, qj.x, zj.x), fma(beta, qj.y, zj.y));
+        });
+        const double2 zi = z[i], qo = qold[i], di = dinv[i];
+        const double2 qi = make_double2(fma(beta, qo.x, zi.x), fma(beta, qo.y, zi.y));
+        const double2 ti = make_double2(di.x != 0. ? kv.x : 0., di.y != 0. ? kv.y : 0.);
+        qnew[i] = qi;
+        t[i] = ti;
+        if (i >= own_lo && i < own_hi) acc = fma(qi.x, ti.x, fma(qi.y, ti.y, acc));
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// r -= alpha t; partials of |r|^2 over the owned nodes
+__global__ void __launch_bounds__(BLOCK)
+k_sqmr_update_r(int nn, double alpha, const double2 *__restrict__ t, double2 *__restrict__ r, double *__restrict__ part, int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 ti = t[i];
+        double2 ri = r[i];
+        ri.x = fma(-alpha, ti.x, ri.x);
+        ri.y = fma(-alpha, ti.y, ri.y);
+        r[i] = ri;
+        if (i >= own_lo && i < own_hi) acc = fma(ri.x, ri.x, fma(ri.y, ri.y, acc));
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// d = cd d + cq q;  x += d
+__global__ void __launch_bounds__(BLOCK)
+k_sqmr_update_x(int nn, double cd, double cq, const double2 *__restrict__ q, double2 *__restrict__ d, double2 *__restrict__ x)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 qi = q[i], di = d[i];
+        double2 xi = x[i];
+        const double2 dn = make_double2(fma(cd, di.x, cq * qi.x), fma(cd, di.y, cq * qi.y));
+        d[i] = dn;
+        xi.x += dn.x;
+        xi.y += dn.y;
+        x[i] = xi;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- GMRES
 // Restarted GMRES with the V-cycle as RIGHT preconditioner: the solver of last resort for indefinite tangent stiffness when
 // the V-cycle built on such an operator is not positive definite either (MINRES needs an SPD preconditioner, GMRES needs

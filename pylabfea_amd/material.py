@@ -264,7 +264,7 @@ class Material(object):
         import datetime, getpass, json, platform
         if not self.ML_yf:
             raise AttributeError('export_MLparam: No ML flow rule defined.')
-        if None not in (descr, param) and len(descr) != len(param):
+        if descr is not None and param is not None and len(descr) != len(param):
             raise ValueError('Lists for descr and param must have the same lengths.')
         file = (path if path.endswith('/') else path + '/') + ('abq_' + self.name if file is None else file)
         dc, sv = self.svc['dual'], self.svc['sv']
@@ -280,8 +280,8 @@ class Material(object):
         body = np.concatenate([head, dc, sv.ravel()])
         props = np.concatenate([body, np.zeros(ndata - len(body))])
         np.savetxt(file + '-svm.csv', props.reshape((nlin, 8)), delimiter=', ', newline='\n')
-        descr = list(descr or []) + ['Ndata', 'gamma', 'C']
-        param = list(param or []) + [ndata, self.gam_yf, self.C_yf]
+        descr = ([] if descr is None else list(descr)) + ['Ndata', 'gamma', 'C']
+        param = ([] if param is None else list(param)) + [ndata, self.gam_yf, self.C_yf]
         sys_info = platform.uname()
         from . import __version__ as vers
         meta = {

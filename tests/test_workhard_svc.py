@@ -325,6 +325,29 @@ def test_gpu_model_equals_the_sequential_oracle(z, n):
     assert np.max(np.abs(fe._state('epl') - r.epl)) < 1e-6 * np.max(np.abs(r.eps))
 
 
+@pytest.mark.gpu
+def test_gpu_wave_kernels_on_a_mesh_beyond_the_flag_slots(z, monkeypatch):
+    """72 x 72 = 5184 elements (> 4 x 1024: more wave-kernel blocks than per-block flag slots if the grid were not capped;
+    ADVICE r4): the wave-per-element kernels against the thread-per-element ones (PLFX_WH_WAVE=0) -- same changed /
+    converged flags (identical iteration counts) and the same fields.  Per-point carry: one data-parallel pass per sweep."""
+    out = []
+    for wave in ('1', '0'):
+        monkeypatch.setenv('PLFX_WH_WAVE', wave)
+        fe = wh_model(z, 72)
+        fe.wh_carry = 'per_point'
+        fe._max_load_steps = 6       # five elastic load steps, then 15 stiffness iterations with every element on the corrector
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=8)
+        out.append((fe.nsteps, list(fe.niter), list(fe.co_nconv), np.array(fe.sgl), fe._state('sig').copy(), fe._state('epl').copy(),
+                    fe._state('elstiff').copy()))
+    a, b = out
+    assert a[:3] == b[:3] and sum(a[1]) > 0
+    assert np.max(np.abs(a[4])) > 0. and np.max(np.abs(a[5])) > 0.          # plastic
+    for k in (3, 4, 5, 6):
+        assert np.max(np.abs(a[k] - b[k])) <= 1e-9 * np.max(np.abs(b[k])), k
+
+
 def wh_model(z, n=4):
     import pylabfea_amd as FE
     m = facade_material(z)
