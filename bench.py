@@ -59,14 +59,71 @@ def schedule(K, W):
     return ninc, pre
 
 HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
-# calibration in profiles/r01_bench1024_rocprofv3_summary.txt), 1 GPU, 1024^2
-PMC_TRAFFIC = {'assembled': {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6},
-               'matfree': {'mg_smooth': 120.41e6, 'spmv': 132.8e6, 'cg_update': 117.9e6,
-                           # the sweep per launch: 160.45 MB x 2 fetched + 109.05 MB written when no tangent is rewritten (430.0 MB
-                           # against 432.0 MB algorithmic), + 226.5 MB written when all are (counter min / max of the profile)
-                           'sweep': (429.95e6, 226.53e6)}}
-PMC_SOURCE = {'assembled': 'profiles/r01d_bench1024_final_rocprofv3_summary.txt', 'matfree': 'profiles/r04y_bench1024_rocprofv3_summary.txt'}
+# HBM bytes per launch of the block-ELL operator form (PLFX_MATFREE=0; round-1 profile, kept for that knob only)
+PMC_TRAFFIC_ASSEMBLED = {'mg_smooth': 417.1e6, 'spmv': 428.2e6, 'sweep': 494.6e6, 'cg_update': 117.9e6}
+PMC_SOURCE_ASSEMBLED = 'profiles/r01d_bench1024_final_rocprofv3_summary.txt'
+PROFILE_KERNELS = {'mg_smooth': 'k_mg_smooth<1,1>', 'spmv': 'k_spmv_march<1>', 'sweep': 'k_sweep_light<1>', 'cg_update': 'k_cg_update_mg'}
+
+
+def committed_profile():
+    """HBM traffic per launch and rocprofv3 launch durations of the roofline kernels, PARSED from the newest
+    profiles/r*_bench1024_rocprofv3_summary.txt (tools/profile_round.sh + tools/prof_summary.py of this workload, 1 GPU,
+    1024^2, matrix-free operator): traffic = 2 x FETCH_SIZE + WRITE_SIZE (calibration profiles/r03e_probe_pmc_calibration.txt:
+    FETCH_SIZE reports half of the bytes, WRITE_SIZE all of them); the sweep as (bytes without a rewritten tangent, extra bytes
+    when all are rewritten) from the counter minimum / maximum.  Fails loudly when a kernel of the line is not in the profile
+    (renamed or replaced kernel: the profile has to be redone, tools/profile_round.sh)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench1024_rocprofv3_summary.txt')))
+    if not files:
+        return None
+    path = files[-1]
+    sec, tab = None, {'dur': {}, 'fetch': {}, 'write': {}}
+    for ln in open(path):
+        if ln.startswith('=='):
+            sec = ('dur' if 'productive launches only' in ln and 'pmc' not in ln else
+                   'fetch' if 'FETCH_SIZE' in ln else 'write' if 'WRITE_SIZE' in ln else None)
+            continue
+        if sec is None or not ln.strip():
+            continue
+        name = ln.split()[0]
+        if sec == 'dur':
+            m = re.search(r'avg\s+([0-9.]+) us', ln)
+            if m:
+                tab['dur'][name] = float(m.group(1)) * 1e-6
+        else:
+            m = re.search(r'=\s+([0-9.]+) MB\s+\(min ([0-9.]+) MB, max ([0-9.]+) MB\)', ln)
+            if m:
+                tab[sec][name] = tuple(float(v) * 1e6 for v in m.groups())
+    out = {'source': os.path.relpath(path, ROOT), 'traffic': {}, 'duration_s': {}}
+    for fam, k in PROFILE_KERNELS.items():
+        if k not in tab['fetch'] or k not in tab['write'] or k not in tab['dur']:
+            raise RuntimeError('%s: kernel %s of the bench line is not in the committed profile -- redo it (tools/profile_round.sh)'
+                               % (out['source'], k))
+        f, w = tab['fetch'][k], tab['write'][k]
+        out['traffic'][fam] = (2. * f[0] + w[1], w[2] - w[1]) if fam == 'sweep' else 2. * f[0] + w[0]
+        out['duration_s'][fam] = tab['dur'][k]
+    return out
+
+
+def committed_svc_profile():
+    """VALU / FP64 instruction counts per element update of the SVC corrector kernel, PARSED from the newest
+    profiles/r*_svc_rocprofv3_summary.txt that holds the kernel the library runs now (tools/svc_profile_round.sh)."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_svc_rocprofv3_summary.txt')), reverse=True):
+        txt = open(path).read()
+        i = txt.find('\nk_sweep_svc_row<1>\n')   # the block of the counter section (the kernel-time table has the name followed by numbers)
+        if i < 0:
+            continue
+        blk = txt[i:]
+        j = blk.find('\nk_', 1)
+        blk = blk if j < 0 else blk[:j]
+        mv = re.search(r'VALU wave-instructions per element update: ([0-9.]+)', blk)
+        mf = re.search(r'=> ([0-9.e+]+) FP64 flop per element update', blk)
+        if mv:
+            return {'source': os.path.relpath(path, ROOT), 'valu': float(mv.group(1)), 'fp64_flop': float(mf.group(1)) if mf else None}
+    return None
 
 
 def hill_material(FE):
@@ -264,12 +321,6 @@ def cpu_baseline(n, steps, warmup, n1=128, gpu_mesh=1024):
 # SIMD) = 614 G wave-instructions/s = 78.6 TFLOP/s when every one is an FMA (MI355X_MICROARCH.md: FP64 vector 78.6 TFLOP/s)
 VALU_FP64_PEAK_TFLOPS = 78.6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.   # wave64 FP64 instructions per second of the whole GPU
-# VALU wave-instructions per element update of the SVC corrector / streaming kernels (rocprofv3 --pmc SQ_INSTS_VALU over the
-# same sample, profiles/r02_svc_*): filled from the committed profile, not measured in the run
-SVC_VALU_PER_ELEMENT = {'corrector': 910606., 'streaming': 804363926.5 / 16384.}
-# FP64 flop per element update, (2 FMA + ADD + MUL) x 64 lanes (same profile)
-SVC_FP64_FLOP_PER_ELEMENT = {'corrector': 3.5910e7}
-SVC_PROFILE = 'profiles/r03_svc_rocprofv3_summary.txt'
 
 
 def svc_sample(FE, _lib, n=128, device=0):
@@ -301,28 +352,30 @@ def svc_sample(FE, _lib, n=128, device=0):
                        'min_step=10: whole solve, %d load steps, %d sweeps' % (n, n, nsv, fe.nsteps, fe.n_sweeps),
            'seconds': dt, 'value': fe.Nel * fe.n_sweeps / dt, 'unit': 'element-updates/s', 'sweeps': int(fe.n_sweeps),
            'pcg_iterations': int(sum(q[0] for q in fe.solver_stats)),
-           'kernel_ms': {'k_sweep_svc_wave<0> (streaming phase)': round(ms_l, 3), 'k_sweep_svc_wave<1> (50-sub-step corrector)': round(ms_h, 3)},
+           'kernel_ms': {'k_sweep_svc_row<0> (streaming phase)': round(ms_l, 3), 'k_sweep_svc_row<1> (50-sub-step corrector)': round(ms_h, 3)},
            'launches': {'streaming': int(n_l), 'corrector': int(n_h)}}
     heavy_el = fe.Nel  # on this workload every sweep of the last load step puts every element on the corrector list
-    vc = SVC_VALU_PER_ELEMENT['corrector']
+    prof = committed_svc_profile()
+    vc = prof['valu'] if prof else None
     n_prod = int(fe.niter[-1]) + 1     # corrector launches with a non-empty list: the stiffness iterations of the last load step
     out['launches']['corrector_productive'] = n_prod
+    out['us_per_element_update'] = (ms_h * 1e3 / n_prod / heavy_el) if n_h > 0 else None
     if n_h > 0 and vc:
         per_launch_s = ms_h * 1e-3 / n_prod   # (the empty launches of the ten elastic steps take ~5 us each)
         # two figures: the TRUE FP64 flop rate -- (2 FMA + ADD + MUL) x 64 lanes per element update from the
         # committed rocprofv3 pass over SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 -- against the 78.6 TFLOP/s FP64 vector peak, and the
         # share of the VALU issue slots the kernel fills (every VALU wave-instruction, FP64 or not, against 614 G/s)
         issue = vc * heavy_el / per_launch_s / VALU_ISSUE_PEAK
-        fl = SVC_FP64_FLOP_PER_ELEMENT['corrector']
+        fl = prof['fp64_flop']
         ach = (fl * heavy_el / per_launch_s / 1e12) if fl else None
-        out['roofline'] = {'kernel': 'k_sweep_svc_wave<1> (one wave per element: 50 sub-steps of the plastic corrector, support-'
-                                     'vector sums split over the lanes, tables in LDS)',
+        out['roofline'] = {'kernel': 'k_sweep_svc_row<1> (16 lanes per element, four elements per wave: 50 sub-steps of the plastic corrector, '
+                                     'support-vector sums split over the lanes of a DPP row, ray search on 16 samples per ray, tables in LDS)',
                            'bound': 'valu_fp64', 'achieved': ach, 'peak': VALU_FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': (ach / VALU_FP64_PEAK_TFLOPS) if ach else None,
                            'fp64_flop_per_element_update': fl,
                            'valu_issue_slot_utilisation': issue,
                            'valu_wave_instructions_per_element': vc,
-                           'counter_source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, ' + SVC_PROFILE,
+                           'counter_source': 'rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, ' + prof['source'] + ' (parsed; not measured in this run)',
                            'avg_launch_ms': per_launch_s * 1e3, 'elements_per_launch': heavy_el, 'traffic': None,
                            'us_per_element_update': per_launch_s * 1e6 / heavy_el * 1.0}
     return out
@@ -372,6 +425,48 @@ def roofline_2048(FE, _lib, device=0, n=2048, K=4, W=1):
             out[k] = {'kernel': names[k], 'bound': 'hbm', 'achieved': byts[k] / avg / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': byts[k] / avg / 1e9 / HBM_PEAK_GBS, 'avg_launch_us': avg * 1e6, 'launches': cnt,
                       'bytes_per_launch': byts[k], 'traffic': None}
+    fe._drop_engine()
+    return out
+
+
+def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0):
+    """The bench workload (config 3 material / loading / schedule) on an n x n mesh, wall-clock of the load steps
+    pre+W+pre_extra .. +K, optionally with the unchanged-input reuse switched off (PLFX_REUSE is read when the engine is created)."""
+    old = os.environ.get('PLFX_REUSE')
+    if not reuse:
+        os.environ['PLFX_REUSE'] = '0'
+    try:
+        fe = tension_model(FE, hill_material(FE), n, 0.005, device=device)
+        eng = fe._ensure_engine()
+    finally:
+        if not reuse:
+            if old is None:
+                del os.environ['PLFX_REUSE']
+            else:
+                os.environ['PLFX_REUSE'] = old
+    ninc, pre = schedule(K, W + pre_extra)
+    marks = {}
+    first = pre + W + pre_extra
+
+    def hook(il):
+        if il == first:
+            eng.sync()
+            gc.collect()
+            gc.disable()
+            marks['t0'], marks['sw0'], marks['so0'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
+        if il == first + K:
+            eng.sync()
+            marks['t1'], marks['sw1'], marks['so1'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
+            gc.enable()
+
+    fe._step_hook = hook
+    fe._max_load_steps = first + K
+    fe.solve(min_step=ninc)
+    dt = marks['t1'] - marks['t0']
+    its = [q[0] for q in fe.solver_stats[marks['so0']:marks['so1']]]
+    out = {'mesh': '%dx%d' % (n, n), 'load_steps': '%d..%d of %d' % (first, first + K, ninc), 'ms_per_step': 1e3 * dt / K,
+           'value': fe.Nel * (marks['sw1'] - marks['sw0']) / dt, 'unit': 'element-updates/s', 'sweeps': int(marks['sw1'] - marks['sw0']),
+           'solves': len(its), 'pcg_iterations': int(np.sum(its)), 'unchanged_inputs_reused': bool(reuse)}
     fe._drop_engine()
     return out
 
@@ -504,12 +599,14 @@ def main():
                     help='BASELINE.json configs[2] (default, the configuration the metric is quoted on) or configs[4]')
     ap.add_argument('--weak', action='store_true',
                     help='N>1: weak scaling (N strips of mesh x mesh elements side by side) instead of strong scaling of the same mesh')
-    ap.add_argument('--config5-leg-mesh', type=int, default=1024,
+    ap.add_argument('--config5-leg-mesh', type=int, default=2048,
                     help='config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
-                         'strips pay) on this mesh, reported as `config5_leg` of the same JSON line; 0 = skip (also skipped with --no-svc at N = 1)')
+                         'strips pay) on this mesh -- 2048 = BASELINE configs[4] itself, at every N so that the driver can form the ratio -- '
+                         'reported as `config5_leg` of the same JSON line; 0 = skip (also skipped with --no-svc at N = 1)')
     ap.add_argument('--cpu-mesh', type=int, default=448)
     ap.add_argument('--sample', type=int, default=7, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-reuse-off', action='store_true', help='skip the extra timed window with PLFX_REUSE=0 (ms_per_step_reuse_off)')
     ap.add_argument('--no-tight-loop', action='store_true',
                     help='skip the back-to-back V-cycle timing (plfx_precond_bench): hundreds of hipGraph launches without a '
                          'synchronisation in between crash rocprofv3 (ROCm 7.2); skipped automatically under the profiler')
@@ -692,6 +789,8 @@ def main():
     cands = [k for k in ('mg_smooth', 'spmv', 'sweep', 'cg_update') if tim[k][1] > 0]
     dominant = max(cands, key=lambda k: weight[k] * tim[k][0]) if cands else 'sweep'
 
+    prof = committed_profile() if rank == 0 else None
+
     def roof(k):
         ms, cnt = tim[k]
         if cnt == 0:
@@ -700,8 +799,9 @@ def main():
         ach = bytes_per[k] / avg_s / 1e9
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled and
         # WRITE_SIZE as calibrated there, MI355X_MICROARCH.md 'HBM'); measured on this workload (1 GPU, 1024^2)
-        pmc = PMC_TRAFFIC['matfree' if mf else 'assembled']
-        traffic = pmc.get(k) if (world == 1 and n == 1024 and args.config == 3) else None   # from the committed profile of this workload, not this run
+        same = world == 1 and n == 1024 and args.config == 3      # the workload the committed profile was taken on
+        pmc = (prof['traffic'] if (mf and prof) else PMC_TRAFFIC_ASSEMBLED if not mf else {})
+        traffic = pmc.get(k) if same else None   # from the committed profile of this workload, not this run
         if isinstance(traffic, tuple):   # sweep: base + extra bytes per rewritten tangent, with THIS run's share of rewritten tangents
             traffic = traffic[0] + traffic[1] * rewritten / max(n_sw * nel_rank, 1)
         opname = 'matrix-free stencil from the element stiffness generators' if mf else 'block-ELL SpMV'
@@ -713,8 +813,14 @@ def main():
                            'mg_smooth': 'k_mg_smooth<1,%d> (fine-level damped-Jacobi post-smoothing sweep of the '
                                         'multigrid V-cycle: %s + update)' % (1 if mf else 0, opname)}[k],
                 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload committed as ' + PMC_SOURCE['matfree' if mf else 'assembled'] + ' (not measured in this run)') if traffic else None,
+                'frac': ach / HBM_PEAK_GBS,
+                'clock': 'HIP events recorded on the library stream around every %d-th launch of this run (includes the event records and the launch gap)' % max(1, args.sample),
+                # the same bytes over the kernel duration of the committed rocprofv3 kernel trace of this workload (the figure a
+                # profile reader recomputes; the in-run clock reads 10-15 % longer)
+                'frac_rocprof': (bytes_per[k] / prof['duration_s'][k] / 1e9 / HBM_PEAK_GBS) if (same and mf and prof and k in prof['duration_s']) else None,
+                'rocprof_avg_launch_us': (prof['duration_s'][k] * 1e6) if (same and mf and prof and k in prof['duration_s']) else None,
+                'traffic': traffic,
+                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, parsed from ' + (prof['source'] if mf else PMC_SOURCE_ASSEMBLED) + ' (2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)') if traffic else None,
                 'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
 
     out = {
@@ -839,18 +945,34 @@ def main():
         out['inclusion_variant'] = inclusion_variant(FE, n, K, W, device=local)
     if rank == 0 and world == 1 and not args.no_svc:
         out['roofline_svc'] = svc_sample(FE, _lib, args.svc_mesh, device=local)
+    if rank == 0 and world == 1 and args.config == 3 and not args.no_reuse_off:
+        # the same timed window with every assembly / BC application / solve recomputed (PLFX_REUSE=0): the headline answers
+        # repeated identical calls of the reference's loop from the previous call (unchanged_inputs_reused above)
+        ro = window_run(FE, n, K, W, device=local, reuse=False)
+        out['ms_per_step_reuse_off'] = ro['ms_per_step']
+        out['reuse_off'] = ro
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cb = cpu_baseline(args.cpu_mesh, max(1, min(K, 3)), 0, gpu_mesh=n)
+        # CPU window = load steps 11.. of 50 (past the ten calc_scf-scaled steps, like the GPU line's default window 8..18 mostly
+        # is), nothing reused (the oracle recomputes every call): the GPU is run on the SAME mesh, window and reuse setting below
+        cpu_steps, cpu_warm = max(1, min(K, 3)), 5
+        out['cpu_baseline'] = cb = cpu_baseline(args.cpu_mesh, cpu_steps, cpu_warm, gpu_mesh=n)
+        same = window_run(FE, args.cpu_mesh, cpu_steps, cpu_warm, device=local, reuse=False)
+        cb['gpu_same_mesh_window_no_reuse'] = same
         # north star: ">= 10x reference-CPU throughput ... at 1 GPU".  `vs_baseline` stays null (BASELINE.md holds no published
         # number for this metric); the measured ratios against the two CPU baselines of BASELINE.md section 3 are given here,
         # with what they compare: the CPU sample runs a smaller mesh of the same workload (the rate per element update is what
         # is compared; Jacobi-PCG iteration counts on the CPU grow with the mesh, so the ratio at equal size would be larger)
         best = max(cb['all_cores']['value'], cb['one_thread']['value'])
         out['vs_cpu_baseline'] = {
+            # like for like: same mesh, same load steps, every assembly / solve computed on both sides (the solvers differ:
+            # multigrid-PCG on the GPU, Jacobi-PCG on the CPU -- each side's own); the 1024^2 mesh of the headline does not fit the
+            # CPU leg's time budget (Jacobi-PCG needs ~8 NX iterations per cold solve)
+            'same_mesh_same_window_no_reuse': same['value'] / cb['all_cores']['value'],
             'same_host_port_best_of_all_cores_and_one_thread': value / best,
             'reference_python_one_core': (value / cb['reference_python']['value']) if cb.get('reference_python') else None,
             'north_star_10x_met': bool(value >= 10. * best),
-            'note': 'value / cpu_baseline; GPU: %dx%d mesh, multigrid-PCG; CPU port: %s mesh (all cores) and %s (one thread), '
+            'note': 'same_mesh_same_window_no_reuse = cpu_baseline.gpu_same_mesh_window_no_reuse.value / cpu_baseline.all_cores.value; the other '
+                    'ratios are value / cpu_baseline with different meshes: GPU: %dx%d mesh, multigrid-PCG; CPU port: %s mesh (all cores) and %s (one thread), '
                     'Jacobi-PCG on CSR, same material / loading / schedule / tolerance; reference_python: unmodified pyLabFEA '
                     'on 8x8 elements in the build container' % (fe._NX, fe._NY, cb['all_cores']['mesh'], cb['one_thread']['mesh'])}
     elif rank == 0:

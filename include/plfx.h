@@ -182,12 +182,11 @@ int plfx_solve_fallbacks(plfx_ctx *ctx, int64_t *count);
  * last one.  Any pointer may be NULL. */
 int plfx_indefinite_info(plfx_ctx *ctx, int64_t *solves, int64_t *by_minres_surrogate, int64_t *by_gmres,
                          int64_t *surrogates_built, int64_t *elements_shifted);
-/* Since round 5 the solver that completes such a solve from PCG's last iterate is, by default, SQMR (simplified QMR for
- * symmetric indefinite systems, Freund & Nachtigal 1994): the recurrences of preconditioned CG without its positivity
+/* PLFX_INDEFINITE_SOLVER=sqmr (round 5, not the default): SQMR (simplified QMR for symmetric indefinite systems, Freund &
+ * Nachtigal 1994) completes such a solve from PCG's last iterate -- the recurrences of preconditioned CG without its positivity
  * requirements plus a quasi-minimal-residual smoothing of the iterates, preconditioned by the V-cycle of the operator as it is
- * (symmetric, not necessarily definite).  No Krylov basis: a GMRES(400) iteration at 2048^2 reads its basis four times.  GMRES
- * continues from SQMR's iterate on a breakdown or when the true residual stalls (PLFX_INDEFINITE_SOLVER=gmres / surrogate /
- * minres select the round 2-4 solvers).  *by_sqmr: solves SQMR completed on its own. */
+ * (symmetric, not necessarily definite); no Krylov basis.  GMRES continues from SQMR's iterate on a breakdown or when the true
+ * residual stalls.  *by_sqmr: solves SQMR completed on its own. */
 int plfx_sqmr_info(plfx_ctx *ctx, int64_t *by_sqmr);
 /* Form of the stiffness operator in plfx_solve / plfx_update_state / plfx_apply_bc: kind 1 (default) applies
  * K matrix-free from the element stiffness generators (Element.calc_Kel never materialised, Model.setupK reduced to

@@ -226,8 +226,8 @@ BAD_TANGENT_21 = [3.06119e+05, 2.30987e+05, 2.44365e+05, -7.10713e+02, 8.16221e+
 @pytest.mark.parametrize('nx,ny,mg', [(64, 64, True), (48, 24, True), (13, 6, False)])
 def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkeypatch):
     """A stiffness matrix with negative eigenvalues: PCG meets a direction of negative curvature and the solve is completed
-    by SQMR (default since round 5: short recurrences, symmetric indefinite V-cycle admissible), by right-preconditioned
-    GMRES(400) (the default of rounds 2-4), by preconditioned MINRES with the V-cycle rebuilt on the SPD surrogate
+    by right-preconditioned GMRES(400) (default), by SQMR (round 5: short recurrences, a symmetric indefinite V-cycle is
+    admissible), by preconditioned MINRES with the V-cycle rebuilt on the SPD surrogate
     operator (every indefinite element matrix shifted by its most negative eigenvalue; needs no GMRES here), or by MINRES
     with the V-cycle of the indefinite operator itself (GMRES takes over when that is not positive definite); the solution
     must be the one a direct solver (the reference's numpy.linalg.solve) finds."""
@@ -290,7 +290,7 @@ def test_indefinite_tangent_solved_like_the_reference(nx, ny, mg, solver, monkey
     elif solver == 'gmres':
         assert info['by_gmres'] == 1 and info['surrogates_built'] == 0
     elif solver == 'sqmr':
-        # the default since round 5: CG-like recurrences that do not need definiteness, V-cycle of the operator as it is; no GMRES
+        # CG-like recurrences that do not need definiteness, V-cycle of the operator as it is; no GMRES on this problem
         assert eng.sqmr_info() == 1 and info['by_gmres'] == 0 and info['surrogates_built'] == 0
     du = eng.state_get(_lib.ST_DU)
     K = eng.get_csr().tocsr()

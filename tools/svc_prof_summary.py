@@ -27,7 +27,7 @@ for f in sorted(glob.glob('%s/pmc*/*counter_collection.csv' % d)):
     one = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = short(r['Kernel_Name'])
-        if k.startswith('k_sweep_svc_wave'):
+        if k.startswith('k_sweep_svc_wave') or k.startswith('k_sweep_svc_row'):
             one[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, c in one.items():
         keep = [i for i, v in enumerate(c.get('SQ_INSTS_VALU', [])) if v > 1e6]
