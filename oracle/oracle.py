@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, 'libplfx_oracle.so')
+LIB = os.environ.get('PLFO_LIB', os.path.join(HERE, 'libplfx_oracle.so'))   # PLFO_LIB: the sanitizer build (make -C oracle asan)
 
 ELASTIC, HILL6, PRINC3, SVC6, TRESCA, BARLAT, SVC3, SVC_WH = 0, 1, 2, 3, 4, 5, 6, 7
 

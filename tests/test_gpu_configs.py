@@ -196,6 +196,31 @@ def test_config5_real_materials_64x32_vs_oracle(golden_dir):
     assert np.max(np.abs(fe.sgl - ref.sgl)) < 2e-6 * s
 
 
+def test_config5_real_materials_32x16_vs_oracle_all_load_steps(golden_dir):
+    """... and ALL 20 load steps on 32x16 elements (the SVC phase only starts yielding in load step 5, the 64x32
+    comparison above ends after step 6): every plastic step of the SVC columns, the indefinite tangents of the last steps and
+    the solves they need, field by field against the oracle's sparse direct solve"""
+    from oracle.solve_ref import RefSolver
+    fe = laminate_cfg5(golden_dir, 32, 16)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=20)
+        ref = RefSolver(laminate_cfg5(golden_dir, 32, 16)).solve(min_step=20)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+    assert fe._engine.svc_info()[0] == 0b10 and fe._engine.svc_info()[3] == 0          # the SVC phase on the row kernels
+    assert fe.nsteps == ref.nsteps == 20
+    # K-iteration counts: equal while the fields are smooth; the last load steps end when the largest tangent change of any
+    # element falls below 1e-3 (model.py:1346-1355), a test on a maximum that round-off moves by an iteration
+    assert list(fe.niter[:12]) == list(ref.niter[:12])
+    assert np.max(np.abs(np.asarray(fe.niter) - np.asarray(ref.niter))) <= 2
+    s = np.max(np.abs(ref.sig))
+    assert np.max(np.abs(np.asarray(fe.sgl) - np.asarray(ref.sgl))) < 5e-6 * s
+    assert np.max(np.abs(fe.u - ref.u)) < 2e-5 * np.max(np.abs(ref.u))
+    assert np.max(np.abs(fe._state('sig') - ref.sig)) < 2e-5 * s
+    assert np.max(np.abs(fe._state('epl') - ref.epl)) < 2e-5 * np.max(np.abs(ref.eps))
+    assert np.max(np.abs(ref.epl[fe._mat_id == 1])) > 1e-3                            # deep in the plastic regime of the SVC phase
+
+
 def test_config5_sgl_does_not_depend_on_the_mesh(golden_dir):
     """Size-independent property of BASELINE config 5 (laminate [2,1,2,1,2] along y, J2 + the SVC trained on Barlat
     Yld2004-18p, eps = 0.003, min_step = 20): the fields are uniform along y and piecewise constant per section, so the
