@@ -209,11 +209,11 @@ int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *s
  * plus 216 B per rewritten tangent. */
 int plfx_sweep_info(plfx_ctx *ctx, int64_t *sweeps, int64_t *tangents_rewritten);
 /* Which kernels run the 6-feature SVC materials (Material.response with an ML yield function, material.py:398-405 evaluates
- * any trained svm_yf): bit k of *row_materials = material k runs with 16 lanes per element / point, its support-vector
- * tables in LDS (one launch per material and sweep phase; every 6-feature SVC whose tables fit the 160 KB of a CU);
- * bit k of *thread_materials = material k runs one thread per element / point (tables too large for the LDS, or the row
- * kernels switched off by PLFX_SVC_POLY / PLFX_SVC_WAVE).  Launch counters of the sweep kernels of either form since
- * plfx_create. */
+ * any trained svm_yf): bit k of *row_materials = material k runs with 16 lanes per element / point (one launch per material
+ * and sweep phase), its support-vector tables staged in LDS when they fit the 160 KB of a CU (up to ~2200 vectors) and read
+ * from device memory otherwise -- no limit on the number of 6-feature SVC materials or of their support vectors;
+ * bit k of *thread_materials = material k runs one thread per element / point (only when the row kernels are switched off
+ * by PLFX_SVC_POLY / PLFX_SVC_WAVE).  Launch counters of the sweep kernels of either form since plfx_create. */
 int plfx_svc_info(plfx_ctx *ctx, int *row_materials, int *thread_materials, int64_t *row_launches, int64_t *thread_launches);
 /* B matrices of element e at its 4 Gauss points, [4*6*8] (Element.calc_Bmat, model.py:439) */
 int plfx_get_bmat(plfx_ctx *ctx, int e, double *B);

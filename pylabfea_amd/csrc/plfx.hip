@@ -143,7 +143,8 @@ struct plfx_ctx {
     int n_noflow = 0;            // materials without a flow rule (Tresca, Barlat without the native normal)
     int svc_lds_need = 0;
     int svc_wave_mat = -1;       // first 6-feature SVC material whose tables fit the LDS (-1: none): the one the wave-per-element kernels of rounds 1-4 run
-    unsigned svc_row_all = 0;    // bit k: material k is a 6-feature SVC with tables that fit the LDS (row kernels: one launch per material)
+    unsigned svc_row_all = 0;    // bit k: material k is a 6-feature SVC run by the row kernels (one launch per material)
+    unsigned svc_row_lds = 0;    // ... of these, the ones whose tables fit the LDS of a CU (the others are read from device memory)
     unsigned svc6_mask = 0;      // bit k: material k is a 6-feature SVC
     int svc_wave_lds = 0;        // bytes of its SoA tables (7 x nsv padded to 64)
     int n_svc6 = 0;              // number of 6-feature SVC materials
@@ -1642,9 +1643,24 @@ static int svc_poly()
 // materials that run on the row kernels (mode 2: every 6-feature SVC that fits the LDS) or on the wave kernels (modes 0, 1: the first)
 static unsigned svc_fast_mask(const plfx_ctx *c)
 {
-    if (c->svc_wave_mat < 0) return 0u;
-    return svc_poly() == 2 ? c->svc_row_all : (1u << c->svc_wave_mat);
+    if (svc_poly() == 2) return c->svc_row_all;
+    return c->svc_wave_mat < 0 ? 0u : (1u << c->svc_wave_mat);
 }
+// launch a row kernel for material k: tables in LDS when they fit, else read from device memory (no dynamic LDS)
+#define LAUNCH_ROW1(c, k, kern, grid, ...)                                                                                 \
+    do {                                                                                                                 \
+        if (((c)->svc_row_lds >> (k)) & 1u)                                                                              \
+            hipLaunchKernelGGL(kern<true>, grid, dim3(512), (size_t)(c)->svc_wave_lds, (c)->stream, __VA_ARGS__);        \
+        else                                                                                                             \
+            hipLaunchKernelGGL(kern<false>, grid, dim3(512), 0, (c)->stream, __VA_ARGS__);                               \
+    } while (0)
+#define LAUNCH_ROW2(c, k, kern, H, grid, ...)                                                                              \
+    do {                                                                                                                 \
+        if (((c)->svc_row_lds >> (k)) & 1u)                                                                              \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<H, true>), grid, dim3(512), (size_t)(c)->svc_wave_lds, (c)->stream, __VA_ARGS__);   \
+        else                                                                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<H, false>), grid, dim3(512), 0, (c)->stream, __VA_ARGS__);           \
+    } while (0)
 
 // ------------------------------------------------------------------------------ materials
 int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
@@ -1658,7 +1674,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     c->n_noflow = 0;
     c->svc_lds_need = 0;
     c->svc_wave_mat = -1;
-    c->svc_row_all = c->svc6_mask = 0;
+    c->svc_row_all = c->svc_row_lds = c->svc6_mask = 0;
     c->svc_wave_lds = 0;
     c->n_svc6 = 0;
     c->nonlin = false;
@@ -1738,11 +1754,42 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
                 c->n_svc6++;
                 const int npad = (s.nsv + 255) & ~255;  // padded for 4 vectors per lane and trip
                 c->svc6_mask |= 1u << k;
-                if (c->want_svc_wave && 9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
-                    if (c->svc_wave_mat < 0) c->svc_wave_mat = k;
+                if (c->want_svc_wave) {
+                    // the tables of the row kernels in device memory, in the layout of their LDS copy (stage_svc_wave): read from
+                    // there by the kernels when the material has more support vectors than the LDS of a CU holds
+                    const int rp = (s.nsv + 63) & ~63;
+                    std::vector<double> T((size_t)9 * rp + SVC_WAVE_EXTRA, 0.);
+                    for (int i = 0; i < s.nsv; i++) {
+                        double vv = 0.;
+                        for (int f = 0; f < 6; f++) {
+                            T[(size_t)f * rp + i] = s.sv[(size_t)i * 6 + f];
+                            vv = std::fma(s.sv[(size_t)i * 6 + f], s.sv[(size_t)i * 6 + f], vv);
+                        }
+                        T[(size_t)6 * rp + i] = s.dual[i];
+                        T[(size_t)7 * rp + i] = vv;
+                    }
+                    double *ext = T.data() + (size_t)9 * rp;
+                    memcpy(ext, RAYPOLY_MT_HOST, sizeof(double) * RAYPOLY_N * RAYPOLY_N);
+                    double a = 1., b = 1.;
+                    for (int i = 0; i < 64; i++) {
+                        ext[RAYPOLY_N * RAYPOLY_N + i] = a;
+                        ext[RAYPOLY_N * RAYPOLY_N + 64 + i] = b;
+                        a *= 0.98;
+                        b *= 1.02;
+                    }
+                    double *dT = nullptr;
+                    HIPCHK(c, hipMalloc((void **)&dT, T.size() * 8));
+                    c->dsv.push_back(dT);
+                    HIPCHK(c, hipMemcpy(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice));
+                    m.rowtab = dT;
+                    m.rowpad = rp;
                     c->svc_row_all |= 1u << k;
-                    // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form
-                    c->svc_wave_lds = std::max(c->svc_wave_lds, (9 * npad + SVC_WAVE_EXTRA) * 8);
+                    if (9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
+                        if (c->svc_wave_mat < 0) c->svc_wave_mat = k;
+                        c->svc_row_lds |= 1u << k;
+                        // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form
+                        c->svc_wave_lds = std::max(c->svc_wave_lds, (9 * npad + SVC_WAVE_EXTRA) * 8);
+                    }
                 }
             }
         }
@@ -1759,11 +1806,11 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, true>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, true>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave<true>, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<0>, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<1>, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_row, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_response_row, c->svc_wave_lds));
-        HIPCHK(c, set_dyn_lds((const void *)k_scf_row, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<0, true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_row<1, true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_full_yf_row<true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_response_row<true>, c->svc_wave_lds));
+        HIPCHK(c, set_dyn_lds((const void *)k_scf_row<true>, c->svc_wave_lds));
     }
     if (c->has_svc || c->has_svc3 || c->has_svcwh) {  // opt in to > 64 KiB dynamic LDS for the SVC kernels
         const int bytes = (int)dyn_lds_bytes(c);
@@ -1810,10 +1857,10 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
     }
     if (status) HIPCHK(c, hipMalloc((void **)&dst, (size_t)n * 4));
     static const bool wave_full = !(getenv("PLFX_FULL_YF_WAVE") && atoi(getenv("PLFX_FULL_YF_WAVE")) == 0);
-    if (what == 3 && wave_full && ((svc_fast_mask(c) >> mat) & 1u) && c->svc_wave_lds > 0) {  // ML_full_yf of a row / wave-kernel SVC material
+    if (what == 3 && wave_full && ((svc_fast_mask(c) >> mat) & 1u)) {  // ML_full_yf of a row / wave-kernel SVC material
         if (svc_poly() == 2)
-            hipLaunchKernelGGL(k_full_yf_row, dim3(std::max(1, std::min((n + 31) / 32, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
-                               c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
+            LAUNCH_ROW1(c, mat, k_full_yf_row, dim3(std::max(1, std::min((n + 31) / 32, 2048))),
+                       c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
         else if (svc_poly())
             hipLaunchKernelGGL(k_full_yf_wave<true>, dim3(std::max(1, std::min((n + 7) / 8, 2048))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
                                c->dmat, c->nmat, mat, n, dsig, depl, dld, dout, dst);
@@ -1907,8 +1954,8 @@ static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const 
                            c->stream, RB_ARGS(c->svc_lds_need), (const double *)nullptr, (double *)nullptr, rmask);
     for (int k = 0; k < c->nmat; k++)   // 6-feature SVC materials with tables in LDS: 16 lanes per point (the code path of the sweeps)
         if ((rmask >> k) & 1u)
-            hipLaunchKernelGGL(k_response_row, dim3(std::max(1, std::min((n + 31) / 32, 1024))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
-                               c->dmat, c->nmat, k, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
+            LAUNCH_ROW1(c, k, k_response_row, dim3(std::max(1, std::min((n + 31) / 32, 1024))),
+                       c->dmat, c->nmat, k, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<6>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, RB_ARGS(c->svc_lds_need));
@@ -4442,12 +4489,11 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
         first = 0;
         c->n_svc_thread_launches++;
     }
-    if (c->has_svc && wm >= 0) {
+    if (c->has_svc && fast) {
         if (svc_poly() == 2) {
             for (int k = 0; k < c->nmat; k++)   // one launch per material: its tables fill the LDS
                 if ((fast >> k) & 1u) {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<0>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
-                                       c->stream, WAVE_ARGS, first, k);
+                    LAUNCH_ROW2(c, k, k_sweep_svc_row, 0, dim3(grid_r), WAVE_ARGS, first, k);
                     first = 0;
                     c->n_svc_row_launches++;
                 }
@@ -4495,12 +4541,10 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
     if (svc_thread)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_heavy<3>), dim3(c->grid_el), dim3(BLOCK), dyn_lds_bytes(c),
                            c->stream, SWEEP_ARGS(c->svc_lds_need), fast);
-    if (c->has_svc && wm >= 0) {
+    if (c->has_svc && fast) {
         if (svc_poly() == 2) {
             for (int k = 0; k < c->nmat; k++)
-                if ((fast >> k) & 1u)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_row<1>), dim3(grid_r), dim3(512), (size_t)c->svc_wave_lds,
-                                       c->stream, WAVE_ARGS, 0, k);
+                if ((fast >> k) & 1u) LAUNCH_ROW2(c, k, k_sweep_svc_row, 1, dim3(grid_r), WAVE_ARGS, 0, k);
         } else if (svc_poly())
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_svc_wave<1, true>), dim3(grid_w), dim3(PLFX_HEAVY_THREADS), (size_t)c->svc_wave_lds,
                                c->stream, WAVE_ARGS, 0, wm);
@@ -4702,9 +4746,9 @@ static void launch_scf_elements(plfx_ctx *c)
                        c->small + 32, c->scf_hh, c->scf_mult, scf_moduli(c), fast);
     for (int k = 0; k < c->nmat; k++)
         if ((fast >> k) & 1u)
-            hipLaunchKernelGGL(k_scf_row, dim3(std::max(1, std::min((c->nel + 31) / 32, 1024))), dim3(512), (size_t)c->svc_wave_lds, c->stream,
-                               c->dmat, c->nmat, c->dcls, k, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
-                               c->sig, c->epl, c->elstiff, c->small + 32, c->scf_hh, c->scf_mult);
+            LAUNCH_ROW1(c, k, k_scf_row, dim3(std::max(1, std::min((c->nel + 31) / 32, 1024))),
+                       c->dmat, c->nmat, c->dcls, k, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
+                       c->sig, c->epl, c->elstiff, c->small + 32, c->scf_hh, c->scf_mult);
 }
 
 int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c, double *minv,

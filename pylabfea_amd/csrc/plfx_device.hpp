@@ -110,6 +110,10 @@ struct MatDev {
     double gamma, intercept, scale_seq;
     double scale_wh;     // SVC with work-hardening features: scaling of the plastic-strain features (material.py:2343)
     double svc_sabs, svc_vvmax;  // sum |dual_k| and max |v_k|^2 over the support vectors (error bounds of YfSvcT::ray_sample)
+    const double *rowtab;        // 6-feature SVC: the tables of the row kernels in device memory, laid out like their LDS copy
+                                 // (v[6][rowpad], dual, |v|^2, -, RAYPOLY_MT, 0.98^i, 1.02^i) -- read from here (L2) when the
+                                 // tables do not fit the LDS of a CU (k_*_row<..., false>)
+    int32_t rowpad, _pad_row;    // support vectors padded to a multiple of 64
     const double *sv;    // device pointer [nsv*nfeat]
     const double *dual;  // device pointer [nsv]
     double barlat[18], barlat_exp;  // Yld2004-18p coefficients
@@ -1428,7 +1432,7 @@ struct YfSvcWhT {
 //  * the root (:501-503): brentq(xtol = 1e-5) on [x0, x1] is replayed iterate for iterate (BrentState) with p as the function
 //    (the support-vector sums where p does not cover an iterate), so the value response() branches on is the reference's
 //    last iterate to ~1e-11, not a better root.
-template <int NC>
+template <int NC, bool INLDS = true>
 struct YfSvcRow {
     static constexpr int GS = 16, NS = RAYPOLY_N;
     static constexpr bool FUSED = true;   // fgrad_plain(): gradient at one point and decision function at another in one pass
@@ -1436,6 +1440,9 @@ struct YfSvcRow {
     const MatDev &m;
     int npad;
     __device__ YfSvcRow(const MatDev &mm, int np) : m(mm), npad(np) {}
+    // the tables: dynamic LDS (staged by stage_svc_wave), or the material's copy in device memory (INLDS = false: more support
+    // vectors than the LDS holds; the 16 lanes of a row read 128 consecutive bytes, the four rows of a wave the same ones)
+    __device__ __forceinline__ const double *tabs() const { return INLDS ? dyn_lds : m.rowtab; }
     __device__ __forceinline__ double seq(const double *s) const { return hill_seq(m, s); }
     // sum over the 16 lanes of a DPP row, result (bit-identical) in every lane of the row
     __device__ __forceinline__ static double row_allsum(double v)
@@ -1466,10 +1473,11 @@ struct YfSvcRow {
     }
     __device__ __forceinline__ void load7(int k, double (*v)[7]) const
     {
+        const double *T = tabs();
 #pragma unroll
         for (int i = 0; i < 7; i++)
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + GS * c];
+            for (int c = 0; c < NC; c++) v[c][i] = T[i * npad + k + GS * c];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NC; c++)
@@ -1586,7 +1594,7 @@ struct YfSvcRow {
             return fma(u, b1, row_bcast<0>(ci) - b2);
         }
     };
-    __device__ __forceinline__ const double *poly_tab() const { return dyn_lds + 9 * npad; }
+    __device__ __forceinline__ const double *poly_tab() const { return tabs() + 9 * npad; }
     __device__ __forceinline__ void ray_sample(const double *su, double x0, bool halved, RowPoly &P) const
     {
         P.ok = false;
@@ -1622,12 +1630,13 @@ struct YfSvcRow {
         double acc[NS];
 #pragma unroll
         for (int j = 0; j < NS; j++) acc[j] = 0.;
+        const double *T = tabs();
         for (int k = threadIdx.x & (GS - 1); k < npad; k += GS * NC) {
             double v[NC][8];
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int c = 0; c < NC; c++) v[c][i] = dyn_lds[i * npad + k + GS * c];
+                for (int c = 0; c < NC; c++) v[c][i] = T[i * npad + k + GS * c];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NC; c++)

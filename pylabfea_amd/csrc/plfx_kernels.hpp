@@ -784,6 +784,7 @@ k_sweep_svc_wave(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__re
 
 // Row-per-element variants (round 5; YfSvcRow): 16 lanes = one DPP row per element, four elements per wave, the ray search in
 // its sampled form.  Same tables in LDS, same two phases, same list and flags as k_sweep_svc_wave; lane 0 of a row stores.
+template <bool INLDS>
 __global__ void __launch_bounds__(512)
 k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const double *__restrict__ sig_in,
               const double *__restrict__ epl_in, const double *__restrict__ ld, double *__restrict__ out, int32_t *__restrict__ status)
@@ -791,7 +792,7 @@ k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const d
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
     __syncthreads();
-    const int npad = stage_svc_wave(smat, mat, 1);   // rows take 16 x 4 vectors per trip: padded to 64
+    const int npad = INLDS ? stage_svc_wave(smat, mat, 1) : smat[mat].rowpad;   // rows take 16 x 4 vectors per trip: padded to 64
     __syncthreads();
     const MatDev &m = smat[mat];
     const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
@@ -807,7 +808,7 @@ k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const d
             s[c] = sig_in[6 * (size_t)i + c];
             e[c] = epl_in ? epl_in[6 * (size_t)i + c] : 0.;
         }
-        const YfSvcRow<4> yf(m, npad);
+        const YfSvcRow<4, INLDS> yf(m, npad);
         int st = 0;
         const double f = yf.full_ld(s, e, ld ? ldv : nullptr, &st);
         if (l16 == 0) {
@@ -819,6 +820,7 @@ k_full_yf_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const d
 
 // Material.response on n points of the row-kernel SVC material `mat` (host-layout arrays as in k_response_batch; points of
 // other materials are left to k_response_batch<3>): the same code path as the sweeps of a model, callable point by point
+template <bool INLDS>
 __global__ void __launch_bounds__(512)
 k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const int32_t *__restrict__ mat_id,
                const double *__restrict__ sig_in, const double *__restrict__ epl_in, const double *__restrict__ deps_in,
@@ -828,7 +830,7 @@ k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
     __syncthreads();
-    const int npad = stage_svc_wave(smat, mat, 1);
+    const int npad = INLDS ? stage_svc_wave(smat, mat, 1) : smat[mat].rowpad;
     __syncthreads();
     const MatDev &m = smat[mat];
     const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
@@ -841,7 +843,7 @@ k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
             epl[c] = epl_in[6 * (size_t)i + c];
             deps[c] = deps_in[6 * (size_t)i + c];
         }
-        const YfSvcRow<4> yf(m, npad);
+        const YfSvcRow<4, INLDS> yf(m, npad);
         const int ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
         if (l16 == 0) {
             fy[i] = f;
@@ -859,7 +861,7 @@ k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
     }
 }
 
-template <int HEAVY>
+template <int HEAVY, bool INLDS>
 __global__ void __launch_bounds__(512)
 k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
                 int nel, int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls,
@@ -873,7 +875,7 @@ k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__res
     stage_tables(tb, gmat, nmat, gcls, ncls);
     __syncthreads();
     constexpr int NC = 4;
-    const int npad = stage_svc_wave(tb.smat, wave_mat, 1);   // rows take 16 x 4 vectors per trip: padded to 64
+    const int npad = INLDS ? stage_svc_wave(tb.smat, wave_mat, 1) : tb.smat[wave_mat].rowpad;   // rows take 16 x 4 vectors per trip: padded to 64
     __syncthreads();
     const int l16 = threadIdx.x & 15;
     const int rpb = blockDim.x >> 4;
@@ -893,7 +895,7 @@ k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__res
             s[k] = sig[(size_t)k * nel + e];
             ep[k] = epl[(size_t)k * nel + e];
         }
-        const YfSvcRow<NC> yf(m, npad);
+        const YfSvcRow<NC, INLDS> yf(m, npad);
         const int st = response_light(m, yf, s, ep, deps, fy, depl, Ct, dr, st_scal);
         if (HEAVY) {
             response_heavy(m, yf, s, ep, dr, st_scal, fy, depl, Ct);
@@ -2229,6 +2231,7 @@ k_scf_elements(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__rest
 // calc_scf for the elements of the 6-feature SVC material `mat`, 16 lanes per element (YfSvcRow; ML_full_yf along the
 // loading direction is a ray search, model.py:1049-1052) -- the thread-per-element form above took 4.5 ms per call on
 // 16 384 elements, a quarter of a 50-sub-step corrector launch
+template <bool INLDS>
 __global__ void __launch_bounds__(512)
 k_scf_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int mat, int nel,
           int e_off, const int32_t *__restrict__ conn, const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
@@ -2238,7 +2241,7 @@ k_scf_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict_
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
     __syncthreads();
-    const int npad = stage_svc_wave(smat, mat, 1);
+    const int npad = INLDS ? stage_svc_wave(smat, mat, 1) : smat[mat].rowpad;
     __syncthreads();
     const MatDev &m = smat[mat];
     const int l16 = threadIdx.x & 15, rpb = blockDim.x >> 4;
@@ -2264,7 +2267,7 @@ k_scf_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict_
                 s[k] = sig[(size_t)k * nel + e];
                 ep[k] = epl[(size_t)k * nel + e];
             }
-            const YfSvcRow<4> yf(m, npad);
+            const YfSvcRow<4, INLDS> yf(m, npad);
             double yf0 = yf.plain(s, ep);
             if (yf0 < SPLIT_THRESHOLD) {  // branch test on the decision function (model.py:1046-1048)
                 yf0 = yf.full_ld(s, ep, ld, nullptr);  // model.py:1049-1052

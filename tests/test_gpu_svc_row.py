@@ -123,12 +123,54 @@ def test_row_search_outside_the_sampled_interval(ctx, golden_dir, factor):
     assert np.max(np.abs(fy - fy2)) < 1e-6 * sy
 
 
-def three_phase_model(golden_dir, NX, NY, module=None):
+def split_vectors(z, times):
+    """the same decision function with `times` as many support vectors: every vector listed `times` times with 1 / times of its
+    dual coefficient (sum_k d_k K(x, v_k) is unchanged)"""
+    sv = np.repeat(z['par_sv'], times, axis=0)
+    dual = np.repeat(z['par_dual'], times) / times
+    return sv, dual
+
+
+def test_svc_with_more_vectors_than_the_lds_holds(ctx, golden_dir):
+    """4755 support vectors (3 x 1585; the LDS of a CU holds the tables of ~2200): the row kernels read the tables from device
+    memory instead (k_*_row<false>) -- same code, same results; reference: material.py:398-405 evaluates any trained svm_yf"""
+    from pylabfea_amd import _lib
+    from oracle import oracle as O
+    z = np.load(os.path.join(golden_dir, 'svc_hill.npz'))
+    sv, dual = split_vectors(z, 3)
+    svc = dict(sv=sv, dual=dual, gamma=float(z['par_gamma']), intercept=float(z['par_intercept']),
+               scale_seq=float(z['par_scale_seq']), dev_only=bool(z['par_dev_only']))
+    CV, sy = z['rpe_CV'], float(z['par_sy'])
+    rec = _lib.pack_material(_lib.SVC6, CV, E=float(z['par_E']), nu=float(z['par_nu']), sy=sy, khard=float(z['par_khard']),
+                             hill=z['par_hill'], svc=svc)
+    ctx.set_materials([rec])
+    assert ctx.svc_info()[:2] == (1, 0)                        # on the row kernels all the same
+    sig, epl, deps = seeded_points(z, 400, 5)
+    fy, so, dp, ct, ns = ctx.response(sig, epl, deps)
+    om = O.Material(kind=O.SVC6, E=float(z['par_E']), nu=float(z['par_nu']), sy=sy, khard=float(z['par_khard']), hill=z['par_hill'],
+                    sv=sv, dual=dual, gamma=svc['gamma'], intercept=svc['intercept'], scale_seq=svc['scale_seq'], dev_only=svc['dev_only'])
+    fy2, so2, dp2, ct2, ns2 = O.response(om, CV, sig, epl, deps)
+    assert np.sum(ns2 == 49) > 30 and np.array_equal(ns, ns2)
+    assert np.max(np.abs(so - so2)) < 1e-6 * sy and np.max(np.abs(fy - fy2)) < 1e-6 * sy
+    f, st = ctx.full_yf(0, sig)
+    f2, st2 = O.ML_full_yf(om, sig)
+    assert np.array_equal(st, st2) and np.max(np.abs(f - f2)) < 1e-6 * sy
+    # ... and equal to the 1585-vector form of the same function on the LDS path
+    load_svc(ctx, z)
+    fy3, so3 = ctx.response(sig, epl, deps)[:2]
+    assert np.max(np.abs(so - so3)) < 1e-7 * sy
+
+
+def three_phase_model(golden_dir, NX, NY, big=False):
     """laminate of two DIFFERENT trained SVCs (Hill reference material of examples/train_hill.py, 1585 vectors; Barlat /
     Goss texture of examples/train_goss_barlat.py, 1418 vectors) around a J2 core"""
     ma = svc_material(golden_dir, 'hill')
     mb = make_material('j2')
     mc = svc_material(golden_dir, 'gossbarlat')
+    if big:   # the Goss-Barlat SVC with 4254 support vectors (each listed three times): more than the LDS holds
+        z = np.load(os.path.join(golden_dir, 'svc_gossbarlat.npz'))
+        sv, dual = split_vectors(z, 3)
+        mc.set_svc(sv, dual, float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']), dev_only=bool(z['par_dev_only']))
     ma.num, mb.num, mc.num = 1, 2, 3
     fe = FE().Model(dim=2, planestress=False)
     fe.geom([2, 1, 2], LY=4.)
@@ -141,13 +183,16 @@ def three_phase_model(golden_dir, NX, NY, module=None):
     return fe
 
 
-def test_two_svc_phases_in_one_model_vs_oracle(golden_dir):
+@pytest.mark.parametrize('big', [False, True])
+def test_two_svc_phases_in_one_model_vs_oracle(golden_dir, big):
+    """two distinct 6-feature SVC phases (big: one of them with 4254 support vectors, its tables in device memory) and a J2
+    phase: every SVC element on the row kernels, no thread-per-element SVC launch (plfx_svc_info)"""
     from oracle.solve_ref import RefSolver
-    fe = three_phase_model(golden_dir, 20, 8)
+    fe = three_phase_model(golden_dir, 20, 8, big)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         fe.solve(min_step=6)
-        ref = RefSolver(three_phase_model(golden_dir, 20, 8)).solve(min_step=6)
+        ref = RefSolver(three_phase_model(golden_dir, 20, 8, big)).solve(min_step=6)
     row, thread, nrow, nthread = fe._engine.svc_info()
     assert row == 0b101 and thread == 0 and nthread == 0 and nrow >= 2 * fe.n_sweeps   # both SVCs on the row kernels, no thread launch
     assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
