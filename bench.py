@@ -837,7 +837,7 @@ def main():
                                 'min_step=20; timed load steps %d..%d of 20 (after %d untimed elastic pre-roll steps)'
                                 % ('%dx%d' % (fe._NX, fe._NY), nsv5, pre + W, pre + W + K, pre)),
                    'elements': fe.Nel, 'dofs': fe.Ndof,
-                   'parallelism': ('single GPU' if world == 1 else
+                   'parallelism': ('single GPU' if (world == 1 and not strip) else
                                    ('strip-local engine x%d: %d owned + %d halo element columns per GPU, halo refresh of the residual '
                                     '(ncclSend/ncclRecv) + coarse right-hand-side all-reduce (level %d, replicated %d-level coarse '
                                     'hierarchy) + 3 all-reduces of 8 KB partial sums per PCG iteration, stiffness generators of the '
@@ -871,7 +871,7 @@ def main():
                                  'roofline kernel; the rest (levels >= 1: transfers, 24 launch-latency-bound kernels replayed from a hipGraph, '
                                  'single-workgroup tail) is latency-bound and has no roofline' % args.sample}
         under_profiler = any('rocprof' in os.environ.get(v, '').lower() for v in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
-        if world == 1 and eng.precond_info()[0] == 1 and not args.no_tight_loop and not under_profiler:
+        if world == 1 and dist is None and eng.precond_info()[0] == 1 and not args.no_tight_loop and not under_profiler:
             # the same cycle measured WITHOUT the solver around it: 200 applications back to back between one pair of HIP events
             # (plfx_precond_bench), and the part below the fine level alone -- reproducible to 1 %, where the in-run figure above
             # carries the sampling events and whatever the stream did before each sampled cycle

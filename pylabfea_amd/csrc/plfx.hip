@@ -328,6 +328,9 @@ struct plfx_ctx {
     void *host_ar_user = nullptr;
     std::vector<char> host_ar_buf;
     int rank = 0, nranks = 1;
+    const char *last_coll = nullptr;   // the collective enqueued last on this context's stream, and how many there have been:
+    long long n_coll = 0;              // named in the error a wait for device results ends with after coll_timeout_s
+    double coll_timeout_s = 300.;      // PLFX_COLL_TIMEOUT (seconds; 0 = wait for ever): a peer that never arrives must not hang the job
 
     // Strip-local engine (plfx_set_strip): this context holds ONE x-strip of a larger structured grid as
     // a standalone local grid -- the owned element columns [oc0, oc1) plus W halo columns on every interior side.  Three
@@ -470,6 +473,26 @@ void tim_flush(plfx_ctx *c)
         }
 }
 
+// hipStreamSynchronize of the context's stream -- with peers, bounded like mbox_wait: a collective whose partner never arrives
+// ends the call with an error that names it instead of hanging the job
+hipError_t stream_sync(plfx_ctx *c)
+{
+    if (c->n_coll == 0 || !(c->coll_timeout_s > 0.)) return hipStreamSynchronize(c->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->coll_timeout_s) {
+            fail(c, PLFX_ERR_HIP, "rank %d of %d: stream not drained after %.0f s -- stuck behind collective #%lld, the last one enqueued "
+                 "being '%s'; PLFX_COLL_TIMEOUT sets the limit", c->rank, c->nranks, c->coll_timeout_s, c->n_coll, c->last_coll ? c->last_coll : "?");
+            fprintf(stderr, "[plfx] %s\n", c->err.c_str());
+            return hipErrorLaunchTimeOut;
+        }
+    }
+}
+
 // wait until a kernel has posted `seq` to the pinned mailbox (a failed launch or a hung queue must not spin forever)
 int mbox_wait(plfx_ctx *c, unsigned long long seq, CgMbox *box = nullptr)
 {
@@ -478,6 +501,8 @@ int mbox_wait(plfx_ctx *c, unsigned long long seq, CgMbox *box = nullptr)
     // of SVC elements takes seconds); fails on a stream error, or when the stream has drained and the post never arrived
     unsigned spins = 0;
     int idle_seen = 0;
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
     while (__atomic_load_n(&box->seq, __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {
@@ -486,6 +511,19 @@ int mbox_wait(plfx_ctx *c, unsigned long long seq, CgMbox *box = nullptr)
                 return fail(c, PLFX_ERR_HIP, "stream error while waiting for device results: %s", hipGetErrorString(e));
             if (e == hipSuccess && ++idle_seen > 8)
                 return fail(c, PLFX_ERR_HIP, "device results were not posted although the stream has drained");
+            // with peers: work that stays in flight for minutes is a collective whose partner never arrived (the longest
+            // kernel of a strip, a corrector sweep over its SVC elements, takes seconds)
+            if (c->n_coll > 0 && c->coll_timeout_s > 0.) {
+                if (!timing) {
+                    t0 = std::chrono::steady_clock::now();
+                    timing = true;
+                } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->coll_timeout_s) {
+                    return fail(c, PLFX_ERR_HIP, "rank %d of %d: no device results after %.0f s -- the stream is stuck behind collective "
+                                "#%lld, the last one enqueued being '%s' (a peer that left the schedule, or a transport that never "
+                                "completes); PLFX_COLL_TIMEOUT sets the limit", c->rank, c->nranks, c->coll_timeout_s, c->n_coll,
+                                c->last_coll ? c->last_coll : "?");
+                }
+            }
         }
     }
     return 0;
@@ -497,7 +535,7 @@ int fetch_results(plfx_ctx *c, const double *src_dev, int n, double *dst_host)
 {
     if (!c->mbox || n > c->mb_cap) {
         HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         return 0;
     }
     const unsigned long long seq = ++c->mbox_seq;
@@ -877,6 +915,8 @@ bool comm_active(const plfx_ctx *c) { return c->comm != nullptr || c->host_ar !=
 // in-place all-reduce of a device buffer on the library's stream: RCCL, or the host-staged callback transport
 int allreduce(plfx_ctx *c, void *dev, size_t count, int nccl_dtype, int nccl_op, const char *what)
 {
+    c->last_coll = what;
+    c->n_coll++;
     if (c->comm) {
         EvPair *ev;
         tim_begin(c, 7, &ev);  // family 7: collectives (time on the stream incl. the wait for the slowest peer)
@@ -889,12 +929,12 @@ int allreduce(plfx_ctx *c, void *dev, size_t count, int nccl_dtype, int nccl_op,
         const size_t bytes = count * (nccl_dtype == NCCL_INT32 ? 4 : 8);
         if (c->host_ar_buf.size() < bytes) c->host_ar_buf.resize(bytes);
         HIPCHK(c, hipMemcpyAsync(c->host_ar_buf.data(), dev, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         if (c->host_ar(c->host_ar_user, c->host_ar_buf.data(), count, nccl_dtype == NCCL_INT32 ? 1 : 0,
                        nccl_op == NCCL_MIN ? 3 : 0) != 0)
             return fail(c, PLFX_ERR_HIP, "host all-reduce callback failed (%s)", what);
         HIPCHK(c, hipMemcpyAsync(dev, c->host_ar_buf.data(), bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         return 0;
     }
     return 0;
@@ -949,6 +989,8 @@ int halo_refresh(plfx_ctx *c, double *v)
     double *sendL = v + (size_t)2 * (S.oc0 + 1) * nyn, *recvL = v + (size_t)2 * (S.oc0 - S.W) * nyn;
     double *sendR = v + (size_t)2 * (S.oc1 - S.W) * nyn, *recvR = v + (size_t)2 * (S.oc1 + 1) * nyn;
     S.n_halo++;
+    c->last_coll = "halo refresh (ncclSend / ncclRecv with the strip neighbours)";
+    c->n_coll++;
     if (c->comm) {
         if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
             return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
@@ -972,12 +1014,12 @@ int halo_refresh(plfx_ctx *c, double *v)
         S.hbuf.assign(2 * n, 0.);
         if (S.has_left) HIPCHK(c, hipMemcpyAsync(S.hbuf.data(), sendL, 8 * n, hipMemcpyDeviceToHost, c->stream));
         if (S.has_right) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + n, sendR, 8 * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         if (c->host_ar(c->host_ar_user, S.hbuf.data(), 2 * n, 0, 100) != 0)
             return fail(c, PLFX_ERR_HIP, "host halo-exchange callback failed");
         if (S.has_left) HIPCHK(c, hipMemcpyAsync(recvL, S.hbuf.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
         if (S.has_right) HIPCHK(c, hipMemcpyAsync(recvR, S.hbuf.data() + n, 8 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     return 0;
 }
@@ -997,6 +1039,8 @@ int strip_sync_M(plfx_ctx *c)
     double *M = c->Mel;
     const size_t sL = (size_t)S.oc0 * ny, rL = (size_t)(S.oc0 - S.W) * ny, sR = (size_t)(S.oc1 - S.W) * ny, rR = (size_t)S.oc1 * ny;
     S.n_gen++;
+    c->last_coll = "stiffness generators of the halo columns (ncclSend / ncclRecv with the strip neighbours)";
+    c->n_coll++;
     if (c->comm) {
         if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
             return fail(c, PLFX_ERR_UNSUPPORTED, "this RCCL has no ncclSend/ncclRecv");
@@ -1024,14 +1068,14 @@ int strip_sync_M(plfx_ctx *c)
             if (S.has_left) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + k * n, M + k * tot + sL, 8 * n, hipMemcpyDeviceToHost, c->stream));
             if (S.has_right) HIPCHK(c, hipMemcpyAsync(S.hbuf.data() + (6 + k) * n, M + k * tot + sR, 8 * n, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         if (c->host_ar(c->host_ar_user, S.hbuf.data(), 12 * n, 0, 100) != 0)
             return fail(c, PLFX_ERR_HIP, "host halo-exchange callback failed (generators)");
         for (int k = 0; k < 6; k++) {
             if (S.has_left) HIPCHK(c, hipMemcpyAsync(M + k * tot + rL, S.hbuf.data() + k * n, 8 * n, hipMemcpyHostToDevice, c->stream));
             if (S.has_right) HIPCHK(c, hipMemcpyAsync(M + k * tot + rR, S.hbuf.data() + (6 + k) * n, 8 * n, hipMemcpyHostToDevice, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     return 0;
 }
@@ -1520,6 +1564,7 @@ int plfx_create(int device, plfx_ctx **out)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char *e2 = getenv("PLFX_MATFREE")) c->want_matfree = atoi(e2) ? 1 : 0;
     if (const char *e3 = getenv("PLFX_SVC_WAVE")) c->want_svc_wave = atoi(e3) ? 1 : 0;
+    if (const char *e4 = getenv("PLFX_COLL_TIMEOUT")) c->coll_timeout_s = atof(e4);
     if (const char *e4 = getenv("PLFX_MG_GRAPH")) c->want_mg_graph = atoi(e4) ? 1 : 0;
     if (const char *e8 = getenv("PLFX_REUSE")) c->reuse = atoi(e8) != 0;
     {
@@ -1549,14 +1594,14 @@ int plfx_create(int device, plfx_ctx **out)
     if ((rc = dalloc(c, &c->flags, 8))) return rc;  // [0..3] working flags of a sweep, [4..7] its results (k_sweep_flags)
     if ((rc = dalloc(c, &c->bflags, (size_t)2 * SWEEP_SLOTS))) return rc;
     if ((rc = dalloc(c, &c->small, 64))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
 void plfx_destroy(plfx_ctx *c)
 {
     if (!c) return;
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) stream_sync(c);
 #ifdef PLFX_PROF_REGIONS
     {
         unsigned long long h[16];
@@ -1629,7 +1674,7 @@ void *plfx_stream(plfx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int plfx_sync(plfx_ctx *c)
 {
     if (!c || !c->stream) return PLFX_ERR_STATE;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -1798,7 +1843,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     int rc = dalloc(c, &c->dmat, (size_t)nmat);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     if (c->svc_wave_mat >= 0) {
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, false>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, false>, c->svc_wave_lds));
@@ -1873,7 +1918,7 @@ static int point_eval(plfx_ctx *c, int what, int mat, int n, const double *sig, 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)n * 8 * wout, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, dst, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     hipFree(dsig);
     hipFree(dout);
     if (depl) hipFree(depl);
@@ -1936,7 +1981,7 @@ static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const 
         for (size_t i = 0; i < N; i++) k0[i] = kh_in ? kh_in[i] : c->hmat[mat_id ? mat_id[i] : 0].khard;
         HIPCHK(c, hipMemcpyAsync(d_kh, k0.data(), N * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_kh + N, d_kh, N * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     EvPair *ev;
     tim_begin(c, 0, &ev);
@@ -1976,7 +2021,7 @@ static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const 
         else
             for (size_t i = 0; i < N; i++) kh_out[i] = kh_in ? kh_in[i] : c->hmat[mat_id ? mat_id[i] : 0].khard;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     hipFree(d_in);
     hipFree(d_out);
     hipFree(d_ns);
@@ -2019,7 +2064,7 @@ int plfx_fgrad_batch_wh(plfx_ctx *c, int mat, int n, const double *sig, const do
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fgrad, dout, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
     if (khard_raw) HIPCHK(c, hipMemcpyAsync(khard_raw, dkh, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     hipFree(dsig);
     hipFree(dout);
     hipFree(dkh);
@@ -2187,7 +2232,7 @@ static int set_mesh_impl(plfx_ctx *c, int nel, int nnode, const int32_t *conn, c
         HIPCHK(c, hipMemcpyAsync(c->dcol, c->hcol.data(), c->hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->dcontrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     c->grid_nodes = grid_xcd(nnode);
     c->grid_el = grid_xcd(nown);
     c->grid_ok = false;
@@ -2306,7 +2351,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     if (!c->mg_cls) {
         if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->mg_cls, &geom, sizeof(ClassDev), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     c->mg.resize(dims.size());
     for (size_t l = 0; l < dims.size(); l++) {
@@ -2368,7 +2413,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             HIPCHK(c, hipMemcpyAsync(L.col, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(L.contrib, hcontrib.data(), hcontrib.size() * 4, hipMemcpyHostToDevice, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     {
         auto &Lc = c->mg.back();
@@ -2447,7 +2492,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
         dfree(c->mg_dev);
         if ((rc = dalloc(c, &c->mg_dev, hd.size()))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->mg_dev, hd.data(), hd.size() * sizeof(MgLevDev), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     return PLFX_OK;
 }
@@ -2507,7 +2552,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             }
         if (!c->dtab && (rc = dalloc(c, &c->dtab, 64))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->dtab, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         if ((rc = dalloc(c, &c->Mop, (size_t)6 * c->nel_total))) return rc;
         c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, nx, ny, c->nel_total, c->Mop);
         c->grid_ok = true;
@@ -2670,7 +2715,7 @@ int plfx_allreduce_host(plfx_ctx *c, double *buf, int n, int op)
     const int rc = allreduce(c, c->small, n, NCCL_FLOAT64, op == 3 ? NCCL_MIN : NCCL_SUM, "host scalars");
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(buf, c->small, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -2847,7 +2892,7 @@ int plfx_precond_bench(plfx_ctx *c, int reps, double *us_per_cycle, double *us_c
     HIPCHK(c, hipEventRecord(e0, c->stream));
     for (int k = 0; k < reps && !rc; k++) {
         rc = mg_vcycle(c);
-        if ((k & 63) == 63) HIPCHK(c, hipStreamSynchronize(c->stream));  // bounded queue depth (one drain per ~17 ms of cycles: < 0.2 %)
+        if ((k & 63) == 63) HIPCHK(c, stream_sync(c));  // bounded queue depth (one drain per ~17 ms of cycles: < 0.2 %)
     }
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
@@ -2910,7 +2955,7 @@ int plfx_state_reset(plfx_ctx *c)
         std::vector<double> kh(c->nel);
         for (int e = 0; e < c->nel; e++) kh[e] = c->hmat[c->hcls[c->hcls_id[c->e0 + e]].mat].khard;
         HIPCHK(c, hipMemcpyAsync(c->kh_el, kh.data(), (size_t)8 * c->nel, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         for (int m = 0; m < c->nmat && m < 16; m++) c->wh_carry[m] = c->hmat[m].khard;
         c->kh_out_valid = false;
     }
@@ -2953,7 +2998,7 @@ int plfx_state_get(plfx_ctx *c, int which, double *out)
     if (which == 10) {
         std::vector<int32_t> t(c->nel);
         HIPCHK(c, hipMemcpyAsync(t.data(), c->max_steps, (size_t)4 * c->nel, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         for (int e = 0; e < c->nel; e++) out[e] = t[e];
         return PLFX_OK;
     }
@@ -2964,12 +3009,12 @@ int plfx_state_get(plfx_ctx *c, int which, double *out)
     if (rc) return rc;
     if (!soa) {
         HIPCHK(c, hipMemcpyAsync(out, p, 8 * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         return PLFX_OK;
     }
     std::vector<double> t(comps * n);
     HIPCHK(c, hipMemcpyAsync(t.data(), p, 8 * comps * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     if (comps == 6) {
         for (size_t e = 0; e < n; e++)
             for (int k = 0; k < 6; k++) out[6 * e + k] = t[(size_t)k * n + e];
@@ -2994,7 +3039,7 @@ int plfx_state_set(plfx_ctx *c, int which, const double *in)
     if (!soa) {
         c->x_is_du = false;  // u / f / du written from outside
         HIPCHK(c, hipMemcpyAsync(p, in, 8 * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         return PLFX_OK;
     }
     std::vector<double> t(comps * n);
@@ -3015,7 +3060,7 @@ int plfx_state_set(plfx_ctx *c, int which, const double *in)
         int rcm = sync_M(c);
         if (rcm) return rcm;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -3034,7 +3079,7 @@ int plfx_gather(plfx_ctx *c, int which, int n, const int32_t *idx, double *out)
     hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->idx_tmp, src, c->val_tmp);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->val_tmp, (size_t)8 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -3096,7 +3141,7 @@ int plfx_get_csr(plfx_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *colidx, do
     }
     std::vector<double> hv((size_t)ns * 4 * nn);
     HIPCHK(c, hipMemcpyAsync(hv.data(), c->dval, hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     int64_t pos = 0;
     for (int i = 0; i < nn; i++)
         for (int rr = 0; rr < 2; rr++) {
@@ -3164,7 +3209,7 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
                 HIPCHK(c, hipMemcpyAsync(c->bc_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
             if (!c->kw && (rc = dalloc(c, &c->kw, nd))) return rc;
             HIPCHK(c, hipMemsetAsync(c->kw, 0, 8 * nd, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));  // `rows` goes out of scope
+            HIPCHK(c, stream_sync(c));  // `rows` goes out of scope
         }
         c->bc_valid = true;
     }
@@ -3186,7 +3231,7 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
         HIPCHK(c, hipGetLastError());
     } else if (n > 0) {
         if ((size_t)n > c->stage_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, stream_sync(c));
             if (c->stage) hipHostFree(c->stage);
             c->stage = nullptr;
             HIPCHK(c, hipHostMalloc((void **)&c->stage, (size_t)32 * n));
@@ -3221,7 +3266,7 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     hipLaunchKernelGGL(k_bc_finish, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd,
                        fext ? c->fext : nullptr, c->kw, c->diag, c->is_presc, c->rhs, c->dinv);
     HIPCHK(c, hipGetLastError());
-    if (fext) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fext) HIPCHK(c, stream_sync(c));
     if (c->sur_active)  // level 0 of the V-cycle runs on the surrogate operator: its Jacobi scaling with the new mask
         hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
     if (mg_active(c)) {
@@ -3298,7 +3343,7 @@ int plfx_set_bc_plan(plfx_ctx *c, int nseg, const int32_t *seg_len, const int32_
             int rc = dalloc(c, &P.seg4, t.size());
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(P.seg4, t.data(), t.size() * 4, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, stream_sync(c));
         }
     }
     P.valid = true;
@@ -3481,7 +3526,7 @@ int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)
     if (n < 0 || (n > 0 && !idx)) return fail(c, PLFX_ERR_ARG, "bad argument");
     for (int k = 0; k < n; k++)
         if (idx[k] < 0 || idx[k] >= c->ndof) return fail(c, PLFX_ERR_ARG, "idx[%d] out of range", k);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     dfree(c->fin_idx);
     dfree(c->fin_dev);
     c->fin_pin_n = 0;  // slots are re-allocated for the new set at the next deferred step
@@ -3493,7 +3538,7 @@ int plfx_set_finish_set(plfx_ctx *c, int n, const int32_t *idx)
     if ((rc = dalloc(c, &c->fin_dev, (size_t)2 * n + 18))) return rc;
     HIPCHK(c, hipHostMalloc((void **)&c->fin_host, ((size_t)2 * n + 18) * 8));
     if (n > 0) HIPCHK(c, hipMemcpyAsync(c->fin_idx, idx, (size_t)4 * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     c->fin_n = n;
     return PLFX_OK;
 }
@@ -3517,7 +3562,7 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     const int sl = c->fin_defer;  // >= 0: post into that pinned slot and return without waiting (plfx_finish_fetch collects)
     c->fin_defer = -1;
     if (sl >= 0 && c->fin_pin_n < tot) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         for (int q = 0; q < 2; q++) {
             if (c->fin_pin[q]) hipHostFree(c->fin_pin[q]);
             c->fin_pin[q] = nullptr;
@@ -3599,7 +3644,7 @@ int cg_check_wait(plfx_ctx *c, unsigned long long seq, CgScalars *hs)
 {
     if (!c->mbox) {  // note: waits for everything enqueued so far
         HIPCHK(c, hipMemcpyAsync(hs, c->sc, sizeof(*hs), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         return 0;
     }
     HIPCHK(c, hipGetLastError());
@@ -3657,7 +3702,7 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
     HIPCHK(c, hipGetLastError());
     std::vector<int> h(g);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->sur_cnt, (size_t)4 * g, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     long long nb = 0;
     for (int v : h) nb += v;
     *replaced = nb;
@@ -4260,13 +4305,13 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         HIPCHK(c, hipGetLastError());
         if (!mg) {
             HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, stream_sync(c));
         }
         done = hs.done;
     }
     static const bool solve_debug = getenv("PLFX_SOLVE_DEBUG") && atoi(getenv("PLFX_SOLVE_DEBUG")) != 0;
     if (solve_debug && mg && done != 1) {  // what made multigrid-PCG give up: sums of the last iteration, NaN census
-        hipStreamSynchronize(c->stream);
+        stream_sync(c);
         std::vector<double> hp((size_t)6 * MAXPART), hv(nd);
         hipMemcpy(hp.data(), c->part, hp.size() * 8, hipMemcpyDeviceToHost);
         auto psum = [&](int slot) { double t = 0.; for (int i = 0; i < gn; i++) t += hp[(size_t)slot * MAXPART + i]; return t; };
@@ -4425,7 +4470,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         // the convergence test of iteration `it` has not run yet: evaluate the last residual
         hipLaunchKernelGGL(k_cg_final, dim3(1), dim3(BLOCK), 0, c->stream, P_rr[(it - 1) & 1], gn, c->sc);
         HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
     }
     if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;  // x is valid on owned + 2 columns: complete the halo
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
@@ -4652,12 +4697,12 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
             HIPCHK(c, hipGetLastError());
             int32_t h2[2];
             HIPCHK(c, hipMemcpyAsync(h2, c->wh_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, stream_sync(c));
             last[m] = h2[1];   // (h2[0] accumulates over the materials)
         }
         int32_t nch = 0;
         HIPCHK(c, hipMemcpyAsync(&nch, c->wh_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         c->n_wh_passes++;
         if (getenv("PLFX_WH_DEBUG")) {
             std::vector<double> ko(ne), ki(ne);
@@ -4767,7 +4812,7 @@ int plfx_scf_stats(plfx_ctx *c, const double *sld, double *sum, double *sumsq_c,
     HIPCHK(c, hipGetLastError());
     std::vector<double> h((size_t)3 * g);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->part_g, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     double s = 0., cnt = 0., mn = 1.e300;
     for (int b = 0; b < g; b++) {
         s += h[b];
@@ -4847,7 +4892,7 @@ int plfx_matvec(plfx_ctx *c, const double *x, double *y)
     int rc = plain_spmv(c, c->p[0], c->q);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(y, c->q, 8 * nd, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -4861,7 +4906,7 @@ int plfx_global_sums(plfx_ctx *c, double *out18)
     hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, c->small);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out18, c->small, 18 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return PLFX_OK;
 }
 
@@ -4932,7 +4977,7 @@ int plfx_comm_selftest(plfx_ctx *c)
     const int r3 = g_rccl.AllReduce(buf + 2 * n, buf + 2 * n, n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream);
     HIPCHK(c, hipMemcpyAsync(back.data(), buf + n, 8 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(red.data(), buf + 2 * n, 8 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     dfree(buf);
     if (r1 || r2 || r3) return fail(c, PLFX_ERR_HIP, "RCCL self test: send/recv %d, group end %d, all-reduce %d", r1, r2, r3);
     for (int i = 0; i < n; i++)
@@ -4973,7 +5018,7 @@ int plfx_timing_enable(plfx_ctx *c, int on)
             hipEventRecord(e.a, c->stream);
             hipEventRecord(e.b, c->stream);
         }
-        hipStreamSynchronize(c->stream);
+        stream_sync(c);
     }
     return PLFX_OK;
 }

@@ -286,6 +286,36 @@ def test_strip_local_engine_on_one_gpu(golden_dir, case, world, monkeypatch):
     assert sorted(res[r]['e0'] for r in res)[0] == 0 and max(res[r]['e1'] for r in res) == fe.Nel
 
 
+def test_bench_one_rank_with_rccl_collectives_forced():
+    """The code path the driver launches for --gpus N, at N = 1 on real RCCL: the whole bench.py with a
+    1-rank NCCL process group, the model distributed as ONE strip and every collective of the strip engine forced on
+    (PLFX_STRIP_FORCE_COLL=1: ncclAllReduce of partial sums / coarse right-hand sides / coarse generators, the ncclGroup of
+    the halo refresh, the flag and calc_global all-reduces) -- same sweeps, solves and PCG iterations as the plain single-GPU
+    run, a JSON line with the per-rank budget, and the collective time on the stream reported."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '3', '--warmup', '1', '--mesh', '256', '--no-cpu', '--svc-mesh', '16', '--no-inclusion', '--no-2048', '--no-reuse-off',
+              '--config5-leg-mesh', '128']
+    env = dict(os.environ, PLFX_FORCE_DIST='1', PLFX_STRIP_FORCE_COLL='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), PLFX_COLL_TIMEOUT='120')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common, env=env, capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and 'strip-local engine x1' in d['config']['parallelism']
+    sc = d['strip_collectives']
+    assert sc['halo_refreshes'] > 0 and sc['coarse_gathers'] > 0 and sc['partial_sum_allreduces'] > 0
+    assert d['per_rank'][0]['collectives_per_step'] > 0 and d['collective_ms_per_step'] > 0.
+    assert d['config5_leg']['sweeps'] > 0 and 'error' not in d['config5_leg']
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + common, capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    assert (d['sweeps'], d['solves'], d['pcg_iterations']) == (d1['sweeps'], d1['solves'], d1['pcg_iterations'])
+    assert abs(d['config5_leg']['sgl_yy'] - d1['config5_leg']['sgl_yy']) < 1e-8 * abs(d1['config5_leg']['sgl_yy'])
+
+
 @pytest.mark.parametrize('mode', ['strong', 'weak', 'strong4'])
 def test_bench_two_ranks(tmp_path, mode):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
