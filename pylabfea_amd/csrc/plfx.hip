@@ -1115,7 +1115,11 @@ int mg_assemble(plfx_ctx *c)
 {
     const bool mf = matfree(c);
     const int nl = (int)c->mg.size();
-    c->mg_dinv_current = mf && c->bc_valid;  // the matrix-free levels get their Jacobi scaling with the known Dirichlet mask
+    // the matrix-free levels get their Jacobi scaling with the known Dirichlet mask (taken straight from the finest grid: only
+    // where every level halves exactly -- odd-sized levels inherit the mask level by level, k_mg_coarse_dinv)
+    bool odd = false;
+    for (int l = 0; l + 1 < nl; l++) odd = odd || (c->mg[l].nx & 1) || (c->mg[l].ny & 1);
+    c->mg_dinv_current = mf && c->bc_valid && !odd;
     for (int l = 1; l < nl; l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
@@ -1127,7 +1131,7 @@ int mg_assemble(plfx_ctx *c)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
                                (double *)nullptr, (l + 1 < nl) ? c->mg[l + 1].Mel : (double *)nullptr,
                                (const double2 *)c->dinv, c->mg[0].ny + 1, l,
-                               c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr);
+                               c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr, c->mg[0].nx + 1);
         else
             hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
                                L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag, mf ? 1 : 0);
@@ -1147,7 +1151,7 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
             continue;  // written by mg_assemble already
         hipLaunchKernelGGL(k_mg_coarse_dinv, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1,
                            L.ny + 1, F.ny + 1, (const double2 *)F.dinv, (const double2 *)L.diag,
-                           (double2 *)L.dinv);
+                           (double2 *)L.dinv, F.nx + 1);
     }
     auto &Lc = c->mg.back();
     if (Lc.ainv && !(c->mg_inv_valid && same_set)) {
@@ -1829,10 +1833,14 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
                     m.rowtab = dT;
                     m.rowpad = rp;
                     c->svc_row_all |= 1u << k;
-                    if (9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048) {
-                        if (c->svc_wave_mat < 0) c->svc_wave_mat = k;
+                    // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form: the row kernels
+                    // pad the vectors to 64 (up to 2176 vectors fit the 160 KB of a CU), the wave kernels of rounds 1-4 to 256
+                    if (9 * rp + SVC_WAVE_EXTRA <= c->lds_doubles) {
                         c->svc_row_lds |= 1u << k;
-                        // v[6], dual, |v|^2 in FP64 + (dual, g |v|^2) pairs in FP32 + the tables of the sampled-ray form
+                        c->svc_wave_lds = std::max(c->svc_wave_lds, (9 * rp + SVC_WAVE_EXTRA) * 8);
+                    }
+                    if (9 * npad + SVC_WAVE_EXTRA <= c->lds_doubles && npad <= 2048 && c->svc_wave_mat < 0) {
+                        c->svc_wave_mat = k;
                         c->svc_wave_lds = std::max(c->svc_wave_lds, (9 * npad + SVC_WAVE_EXTRA) * 8);
                     }
                 }
@@ -1844,7 +1852,7 @@ int plfx_set_materials(plfx_ctx *c, int nmat, const plfx_material *mats)
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->dmat, c->hmat.data(), sizeof(MatDev) * nmat, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, stream_sync(c));
-    if (c->svc_wave_mat >= 0) {
+    if (c->svc_wave_lds > 0) {
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<0, false>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_sweep_svc_wave<1, false>, c->svc_wave_lds));
         HIPCHK(c, set_dyn_lds((const void *)k_full_yf_wave<false>, c->svc_wave_lds));
@@ -2344,9 +2352,26 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     // profiles/r04d_config5_coarsest_level.txt -- with partial pivoting in the 50 x 50 inverse the numbers are identical, so it
     // is the truncated hierarchy on that indefinite operator, not the inversion).  Measured, not adopted.
     static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 4;
-    while (dims.back().first % 2 == 0 && dims.back().second % 2 == 0 && (long long)dims.back().first * dims.back().second > 4 &&
-           ((long long)dims.back().first * dims.back().second > coarsest || dims.size() < 2))  // (at least two levels)
-        dims.push_back({dims.back().first / 2, dims.back().second / 2});
+    // Meshes with an odd number of elements in a direction (round 5) used to have no hierarchy at all (Jacobi-PCG, ~8 NX
+    // iterations per cold solve).  Now, if the FINEST grid is odd and large, every level has ceil(n / 2) elements per direction:
+    // where n is odd the last coarse element covers one fine element and a ghost of zero stiffness beyond the edge (k_grid_setup,
+    // k_mg_coarsen_M), the ghost node line and the last coincident one take the Dirichlet mask of the fine edge
+    // (k_mg_coarse_dinv); the transfers only ever read nodes that exist.  Measured (tools/probes/odd_mesh_probe.py,
+    // profiles/r05j_*): a ghost line behind a FREE edge costs nothing (127 x 128, tension in y: 28 PCG iterations, as on
+    // 128 x 128), behind a DIRICHLET edge ~10x the iterations (128 x 127: 288) -- still 2.8x faster than Jacobi-PCG at 999^2
+    // (17.7 vs 49.5 ms per load step), not below ~300^2.  Grids whose finest level is even keep the exact-halving rule (1000^2:
+    // four levels + Chebyshev on 125^2, 39 iterations -- ghost levels there: 314).  PLFX_MG_ODD=0: never, 1: every odd level.
+    static const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 2;
+    const bool finest_odd = ((nx | ny) & 1) && (long long)(nx + 1) * (ny + 1) > 150000;
+    for (;;) {
+        const int fx = dims.back().first, fy = dims.back().second;
+        const long long ne = (long long)fx * fy;
+        const bool exact = fx % 2 == 0 && fy % 2 == 0;
+        const bool big = (long long)(fx + 1) * (fy + 1) > MG_COARSE_MAX;
+        if (!(ne > 4 && (ne > coarsest || dims.size() < 2))) break;   // (at least two levels)
+        if (!exact && !((odd_mode == 1 || (odd_mode == 2 && finest_odd)) && big && fx >= 2 && fy >= 2)) break;
+        dims.push_back({(fx + 1) / 2, (fy + 1) / 2});
+    }
     if (dims.size() < 2) return PLFX_OK;
     if (!c->mg_cls) {
         if ((rc = dalloc(c, &c->mg_cls, 1))) return rc;

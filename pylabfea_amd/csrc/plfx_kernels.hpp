@@ -1529,11 +1529,13 @@ __device__ __forceinline__ void grid_march(const KOp &g, XF xf, EM emit)
 template <int SRC_PAIR>
 __global__ void __launch_bounds__(BLOCK)
 k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, double *__restrict__ Mc,
-             const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv)
+             const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv, int mask_nxn = 0x7fffffff)
 {
     const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
-    const int nyc = nye >> 1;
-    const size_t nel_c = (size_t)(nxe >> 1) * nyc;
+    // the next coarser level has ceil(n / 2) elements per direction: where n is odd its last coarse element covers ONE fine
+    // element and a ghost of zero stiffness beyond the edge of the grid (mean of four children with the missing ones = 0)
+    const int nyc = (nye + 1) >> 1;
+    const size_t nel_c = (size_t)((nxe + 1) >> 1) * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < g.nnode; i += gridDim.x * BLOCK) {
         const int j = i / nyn, k = i - j * nyn;
         double dx = 0., dy = 0.;
@@ -1571,20 +1573,23 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
             }
         diag[i] = make_double2(dx, dy);
         if (dinv) {
-            const double2 df = mask_dinv[(size_t)(j << shift) * mask_nyn + (k << shift)];
+            // (a coarse node beyond the edge of an odd-sized level takes the mask of the edge node it extends)
+            const double2 df = mask_dinv[(size_t)min(j << shift, mask_nxn - 1) * mask_nyn + min(k << shift, mask_nyn - 1)];
             double2 o;
             o.x = (df.x != 0.) ? (fabs(dx) > 1e-300 ? 1. / fabs(dx) : 1.) : 0.;
             o.y = (df.y != 0.) ? (fabs(dy) > 1e-300 ? 1. / fabs(dy) : 1.) : 0.;
             dinv[i] = o;
         }
-        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {  // nxe, nye are even on levels that are coarsened
+        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {
             const size_t e00 = (size_t)j * nye + k, e10 = e00 + nye;
             const size_t ec = (size_t)(j >> 1) * nyc + (k >> 1);
+            const bool hj = j + 1 < nxe, hk = k + 1 < nye;   // children beyond the edge of an odd-sized level: zero stiffness
             double mc[6];
 #pragma unroll
             for (int c = 0; c < 6; c++)
-                mc[c] = 0.25 * (own[c] + g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] + g.M[gen_index(SRC_PAIR, c, g.nel, e10)] +
-                                g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)]);
+                mc[c] = 0.25 * (own[c] + (hk ? g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] : 0.) +
+                                (hj ? g.M[gen_index(SRC_PAIR, c, g.nel, e10)] : 0.) +
+                                (hj && hk ? g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)] : 0.));
             double2 *C2 = reinterpret_cast<double2 *>(Mc);
             C2[ec] = make_double2(mc[0], mc[1]);
             C2[nel_c + ec] = make_double2(mc[2], mc[3]);

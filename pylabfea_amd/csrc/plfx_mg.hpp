@@ -259,27 +259,44 @@ __global__ void __launch_bounds__(BLOCK)
 k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ M_f, double *__restrict__ M_c,
                int pair_f, int pair_c /* layouts of the two arrays (gen_index) */)
 {
-    const int nel_c = nxc * nyc;
+    const int nel_c = nxc * nyc, nxf = nel_f / nyf;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nel_c; i += gridDim.x * BLOCK) {
         const int J = i / nyc, K = i - J * nyc;
         const size_t e00 = (size_t)(2 * J) * nyf + 2 * K, e10 = e00 + nyf;
+        const bool hj = 2 * J + 1 < nxf, hk = 2 * K + 1 < nyf;   // (odd-sized fine level: children beyond its edge count as zero)
 #pragma unroll
         for (int c = 0; c < 6; c++)
             M_c[gen_index(pair_c, c, nel_c, i)] =
-                0.25 * (M_f[gen_index(pair_f, c, nel_f, e00)] + M_f[gen_index(pair_f, c, nel_f, e00 + 1)] +
-                        M_f[gen_index(pair_f, c, nel_f, e10)] + M_f[gen_index(pair_f, c, nel_f, e10 + 1)]);
+                0.25 * (M_f[gen_index(pair_f, c, nel_f, e00)] + (hk ? M_f[gen_index(pair_f, c, nel_f, e00 + 1)] : 0.) +
+                        (hj ? M_f[gen_index(pair_f, c, nel_f, e10)] : 0.) + (hj && hk ? M_f[gen_index(pair_f, c, nel_f, e10 + 1)] : 0.));
     }
 }
 
 // coarse Dirichlet mask from the coincident fine nodes; dinv_c = free ? 1/|diag_c| : 0
 __global__ void __launch_bounds__(BLOCK)
 k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ dinv_f,
-                 const double2 *__restrict__ diag_c, double2 *__restrict__ dinv_c)
+                 const double2 *__restrict__ diag_c, double2 *__restrict__ dinv_c, int nxf_nodes)
 {
     const int nc = nxc_nodes * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
         const int J = i / nyc, K = i - J * nyc;
-        const double2 df = dinv_f[(size_t)(2 * J) * nyf + 2 * K];
+        // Odd-sized fine level: its edge node line has no coincident coarse line.  The ghost line beyond it takes the mask of
+        // the edge (clamped index), and so does the last coincident line next to it: a Dirichlet edge must sit INSIDE the
+        // coarse problem's idea of the boundary, never outside -- a clamp one fine cell too far out halves the stiffness the
+        // coarse level sees near that edge, its corrections overshoot by up to 2x and are not damped (measured: 319 instead
+        // of 28 PCG iterations on 128 x 127 elements); one cell too far in only under-corrects the line the smoother handles
+        const int jf = min(2 * J, nxf_nodes - 1), kf = min(2 * K, nyf - 1);
+        double2 df = dinv_f[(size_t)jf * nyf + kf];
+        if (2 * J + 1 == nxf_nodes - 1) {
+            const double2 d2 = dinv_f[(size_t)(nxf_nodes - 1) * nyf + kf];
+            if (d2.x == 0.) df.x = 0.;
+            if (d2.y == 0.) df.y = 0.;
+        }
+        if (2 * K + 1 == nyf - 1) {
+            const double2 d2 = dinv_f[(size_t)jf * nyf + nyf - 1];
+            if (d2.x == 0.) df.x = 0.;
+            if (d2.y == 0.) df.y = 0.;
+        }
         const double2 dg = diag_c[i];
         double2 o;
         o.x = (df.x != 0.) ? (fabs(dg.x) > 1e-300 ? 1. / fabs(dg.x) : 1.) : 0.;

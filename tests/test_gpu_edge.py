@@ -104,6 +104,44 @@ def test_single_element_model_and_force_bc():
     assert abs(fe.glob['sbc1'] - 50.) < 1e-9
 
 
+def test_large_mesh_with_odd_dimensions_gets_a_multigrid_hierarchy():
+    """401 x 399 elements (Model.mesh accepts any NX, NY, model.py:758-952): no exact halving; since round 5 the hierarchy has
+    ceil(n / 2) elements per level with a zero-stiffness ghost element beyond the odd edge.  The preconditioner
+    only changes the iteration count: results equal the Jacobi-PCG / assembled-operator path of the same library, with a
+    fraction of its iterations."""
+    import warnings
+    import pylabfea_amd as FE
+
+    def run(precond, operator):
+        m = FE.Material()
+        m.elasticity(E=200.e3, nu=0.3)
+        m.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+        fe = FE.Model(dim=2, planestress=False)
+        fe.precond, fe.operator = precond, operator
+        fe.geom([4.], LY=4. * 399 / 401)
+        fe.assign([m])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.004 * fe.leny, 'disp')
+        fe.mesh(NX=401, NY=399)
+        fe._max_load_steps = 4
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=6)
+        return fe, sum(q[0] for q in fe.solver_stats)
+
+    a, ita = run(None, None)
+    assert a._engine.precond_info()[0] == 1 and a._engine.precond_info()[1] >= 4 and a._engine.operator_info()[0] == 1
+    b, itb = run(0, 0)
+    assert b._engine.precond_info()[0] == 0
+    assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter) and np.max(np.abs(a._state('epl'))) > 0.
+    assert ita < 0.1 * itb
+    assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(b.sgl))
+    assert np.max(np.abs(a.u - b.u)) < 1e-7 * np.max(np.abs(b.u))
+    assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))   # (both solves stop at rtol 1e-10)
+
+
 def test_facade_errors():
     import pylabfea_amd as FE
     m = FE.Material()
