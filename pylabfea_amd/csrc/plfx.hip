@@ -289,6 +289,8 @@ struct plfx_ctx {
         double *x = nullptr, *b = nullptr, *t = nullptr, *res = nullptr;
         double *ainv = nullptr;  // dense inverse (coarsest level, small grids)
         KOp op{};                // operator descriptor (block-ELL arrays + grid/generator form)
+        double rx = 1., ry = 1.; // relative size of the level's last element column / row (levels of an odd-sized mesh, KOp::rx)
+        ClassDev *cls4 = nullptr; // geometry tables of its four cell shapes (interior, last column, last row, corner), when assembled
         bool matfree = false;    // applied from the generators (no assembled matrix on this level)
         bool owned = false;  // level 0 aliases the fine-grid arrays of the context
     };
@@ -1083,9 +1085,11 @@ int strip_sync_M(plfx_ctx *c)
 
 bool mg_active(const plfx_ctx *c) { return c->precond == 1 && c->mg.size() >= 2; }
 KOp make_op(const plfx_ctx *c, int nnode, int nslot, const int32_t *col, const double *val, int nx, int ny, int nel,
-            const double *M)
+            const double *M, double rx = 1., double ry = 1.)
 {
     KOp o;
+    o.rx = rx;
+    o.ry = ry;
     o.nnode = nnode;
     o.nslot = nslot;
     o.col = col;
@@ -1110,31 +1114,34 @@ int assemble_fine_val(plfx_ctx *c)
     return 0;
 }
 
+// the level halves exactly and all its cells have one size (every level of a mesh whose sizes are multiples of 2^levels)
+static bool level_plain(const plfx_ctx::MgLevel &L) { return !(L.nx & 1) && !(L.ny & 1) && L.rx == 1. && L.ry == 1.; }
+
 // coarse operators: restrict M level by level and re-assemble (called after the fine assembly)
 int mg_assemble(plfx_ctx *c)
 {
     const bool mf = matfree(c);
     const int nl = (int)c->mg.size();
-    // the matrix-free levels get their Jacobi scaling with the known Dirichlet mask (taken straight from the finest grid: only
-    // where every level halves exactly -- odd-sized levels inherit the mask level by level, k_mg_coarse_dinv)
-    bool odd = false;
-    for (int l = 0; l + 1 < nl; l++) odd = odd || (c->mg[l].nx & 1) || (c->mg[l].ny & 1);
-    c->mg_dinv_current = mf && c->bc_valid && !odd;
+    // the matrix-free levels get their Jacobi scaling with the known Dirichlet mask (taken straight from the finest grid: the
+    // node lines of every level, the last one included, coincide with node lines of the finest grid)
+    c->mg_dinv_current = mf && c->bc_valid;
     for (int l = 1; l < nl; l++) {
         auto &F = c->mg[l - 1];
         auto &L = c->mg[l];
-        if (!(mf && (F.matfree || tail_mf(c))))  // otherwise the parent's setup kernel has already produced this level's generators
+        // (otherwise the parent's setup kernel has already produced this level's generators -- parents that halve exactly only)
+        if (!(mf && (F.matfree || tail_mf(c))) || !level_plain(F))
             hipLaunchKernelGGL(k_mg_coarsen_M, dim3(grid_for(L.nel)), dim3(BLOCK), 0, c->stream, L.nx, L.ny, F.ny,
-                               F.nel, F.Mel, L.Mel, mf ? 1 : 0, mf ? 1 : 0);  // matrix-free mode: pair layout on every level >= 1
+                               F.nel, (l == 1 && mf) ? c->mg[0].op.M : F.Mel, L.Mel, mf ? 1 : 0, mf ? 1 : 0, F.rx, F.ry);  // matrix-free mode: pair
+                               // layout on every level >= 1 and in the snapshot of level 0 (the live array of level 0 is SoA)
         const bool setup_mf = mf && (L.matfree || (tail_mf(c) && l < nl - 1));  // coarsest: assembled for the dense inverse
         if (setup_mf)  // only the diagonal (Jacobi smoother) is needed
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
-                               (double *)nullptr, (l + 1 < nl) ? c->mg[l + 1].Mel : (double *)nullptr,
+                               (double *)nullptr, (l + 1 < nl && level_plain(L)) ? c->mg[l + 1].Mel : (double *)nullptr,
                                (const double2 *)c->dinv, c->mg[0].ny + 1, l,
                                c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr, c->mg[0].nx + 1);
         else
-            hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, c->mg_cls, 1,
-                               L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag, mf ? 1 : 0);
+            hipLaunchKernelGGL(k_assemble, dim3(grid_for(L.nnode), L.nslot), dim3(BLOCK), 0, c->stream, L.cls4 ? L.cls4 : c->mg_cls,
+                               L.cls4 ? 4 : 1, L.nnode, L.nslot, L.nq, L.nel, L.contrib, L.cls0, L.Mel, L.col, L.val, L.diag, mf ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     c->mg_inv_valid = false;
@@ -1151,7 +1158,7 @@ int mg_update_dinv(plfx_ctx *c, bool same_set)
             continue;  // written by mg_assemble already
         hipLaunchKernelGGL(k_mg_coarse_dinv, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1,
                            L.ny + 1, F.ny + 1, (const double2 *)F.dinv, (const double2 *)L.diag,
-                           (double2 *)L.dinv, F.nx + 1);
+                           (double2 *)L.dinv, F.nx + 1, F.rx, F.ry);
     }
     auto &Lc = c->mg.back();
     if (Lc.ainv && !(c->mg_inv_valid && same_set)) {
@@ -1219,7 +1226,7 @@ int mg_down_level(plfx_ctx *c, int l)
         LAUNCH_OP2(k_mg_residual, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                    (const double2 *)L.x, (double2 *)L.res, c->sc);
     hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
-                       L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b);
+                       L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b, L.rx, L.ry);
     return 0;
 }
 
@@ -1232,7 +1239,7 @@ int mg_up_level(plfx_ctx *c, int l)
     const bool mf = L.matfree && matfree(c);
     const int nu = level_nu(c, l);
     hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
-                       C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x);
+                       C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x, L.rx, L.ry);
     double *src = L.x, *dst = L.t;
     for (int k = 0; k < nu; k++) {
         EvPair *ev = nullptr;
@@ -1536,7 +1543,7 @@ void strip_free(plfx_ctx *c)
                 dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
                 dfree(L.Mel); dfree(L.x); dfree(L.b);
             }
-            dfree(L.t); dfree(L.res); dfree(L.ainv);
+            dfree(L.t); dfree(L.res); dfree(L.ainv); dfree(L.cls4);
         }
         dfree(k->mg_cls);
         dfree(k->mg_dev);
@@ -2353,24 +2360,36 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     // is the truncated hierarchy on that indefinite operator, not the inversion).  Measured, not adopted.
     static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 4;
     // Meshes with an odd number of elements in a direction (round 5) used to have no hierarchy at all (Jacobi-PCG, ~8 NX
-    // iterations per cold solve).  Now, if the FINEST grid is odd and large, every level has ceil(n / 2) elements per direction:
-    // where n is odd the last coarse element covers one fine element and a ghost of zero stiffness beyond the edge (k_grid_setup,
-    // k_mg_coarsen_M), the ghost node line and the last coincident one take the Dirichlet mask of the fine edge
-    // (k_mg_coarse_dinv); the transfers only ever read nodes that exist.  Measured (tools/probes/odd_mesh_probe.py,
-    // profiles/r05j_*): a ghost line behind a FREE edge costs nothing (127 x 128, tension in y: 28 PCG iterations, as on
-    // 128 x 128), behind a DIRICHLET edge ~10x the iterations (128 x 127: 288) -- still 2.8x faster than Jacobi-PCG at 999^2
-    // (17.7 vs 49.5 ms per load step), not below ~300^2.  Grids whose finest level is even keep the exact-halving rule (1000^2:
-    // four levels + Chebyshev on 125^2, 39 iterations -- ghost levels there: 314).  PLFX_MG_ODD=0: never, 1: every odd level.
+    // iterations per cold solve).  Now, if the FINEST grid is odd and large, every level covers exactly the fine grid with cells
+    // of one size except the last column / row, whose relative size r stays in [1/2, 3/2): n cells are paired; an odd n leaves a
+    // lone last cell (r >= 1) or puts three children into the last coarse cell (r < 1) -- mg_coarse_cells / mg_coarse_ratio.
+    // The stiffness integrals of the last cells scale with their shape (KOp::rx, ry), the transfers take the position-dependent
+    // weights of bilinear interpolation (mg_tr1d), the coarse generators are area-weighted means of the children, the last node
+    // line of every level is the edge of the grid (Dirichlet masks as before): the coarse spaces are nested in the fine one and
+    // the re-discretised coarse operators are the Galerkin ones of a homogeneous field, as on grids that halve exactly
+    // (elastic cold solves: 11-12 PCG iterations on 512 x 511 / 511 x 512 / 512 x 512 alike).  Two earlier versions, measured:
+    // a zero-stiffness ghost element beyond the edge (exact behind free edges, ~10x the iterations of the homogeneous plastic
+    // workload behind a Dirichlet edge); lone narrow cells only (1025 cells: r = 1/2, 1/4, 1/8 ... slivers, 795 iterations).
+    // Grids whose finest level is even keep the exact-halving rule.  PLFX_MG_ODD=0: never, 1: every odd level that is large.
     static const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 2;
-    const bool finest_odd = ((nx | ny) & 1) && (long long)(nx + 1) * (ny + 1) > 150000;
+    const bool finest_odd = ((nx | ny) & 1) && (long long)(nx + 1) * (ny + 1) > 150000 && c->want_matfree;
+    std::vector<std::pair<double, double>> ratio;
+    ratio.push_back({1., 1.});
     for (;;) {
         const int fx = dims.back().first, fy = dims.back().second;
+        const double rx = ratio.back().first, ry = ratio.back().second;
         const long long ne = (long long)fx * fy;
-        const bool exact = fx % 2 == 0 && fy % 2 == 0;
+        const bool plain = fx % 2 == 0 && fy % 2 == 0 && rx == 1. && ry == 1.;
         const bool big = (long long)(fx + 1) * (fy + 1) > MG_COARSE_MAX;
         if (!(ne > 4 && (ne > coarsest || dims.size() < 2))) break;   // (at least two levels)
-        if (!exact && !((odd_mode == 1 || (odd_mode == 2 && finest_odd)) && big && fx >= 2 && fy >= 2)) break;
-        dims.push_back({(fx + 1) / 2, (fy + 1) / 2});
+        if (!plain && !((odd_mode == 1 || (odd_mode == 2 && finest_odd)) && (big || rx != 1. || ry != 1.) && fx >= 2 && fy >= 2)) break;
+        if (plain) {
+            ratio.push_back({1., 1.});
+            dims.push_back({fx / 2, fy / 2});
+        } else {
+            ratio.push_back({mg_coarse_ratio(fx, rx), mg_coarse_ratio(fy, ry)});
+            dims.push_back({mg_coarse_cells(fx, rx), mg_coarse_cells(fy, ry)});
+        }
     }
     if (dims.size() < 2) return PLFX_OK;
     if (!c->mg_cls) {
@@ -2383,6 +2402,8 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
         auto &L = c->mg[l];
         L.nx = dims[l].first;
         L.ny = dims[l].second;
+        L.rx = ratio[l].first;
+        L.ry = ratio[l].second;
         L.nnode = (L.nx + 1) * (L.ny + 1);
         L.nel = L.nx * L.ny;
         L.grid = grid_xcd(L.nnode);
@@ -2431,6 +2452,25 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
         if ((rc = dalloc(c, &L.Mel, (size_t)6 * L.nel))) return rc;
         if ((rc = dalloc(c, &L.x, (size_t)2 * L.nnode))) return rc;
         if ((rc = dalloc(c, &L.b, (size_t)2 * L.nnode))) return rc;
+        if (L.rx != 1. || L.ry != 1.) {
+            // assembled form of such a level (coarsest level: dense inverse; tail levels when the matrix-free tail is not in use):
+            // four cell shapes, class id = (last column) + 2 (last row); Sxx ~ ly / lx, Syy ~ lx / ly, Sxy independent of the size
+            ClassDev h4[4];
+            for (int q = 0; q < 4; q++) {
+                h4[q] = geom;
+                const double sx = (q & 1) ? L.rx : 1., sy = (q & 2) ? L.ry : 1.;
+                for (int t = 0; t < 16; t++) {
+                    h4[q].Sxx[t] *= sy / sx;
+                    h4[q].Syy[t] *= sx / sy;
+                }
+            }
+            if ((rc = dalloc(c, &L.cls4, 4))) return rc;
+            HIPCHK(c, hipMemcpyAsync(L.cls4, h4, sizeof(h4), hipMemcpyHostToDevice, c->stream));
+            std::vector<int32_t> hc((size_t)L.nel);
+            for (int e = 0; e < L.nel; e++) hc[e] = ((e / L.ny == L.nx - 1) ? 1 : 0) + ((e % L.ny == L.ny - 1) ? 2 : 0);
+            HIPCHK(c, hipMemcpyAsync(L.cls0, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, stream_sync(c));
+        }
         if (closed) {
             hipLaunchKernelGGL(k_structured_pattern, dim3(grid_for(L.nnode)), dim3(256), 0, c->stream, L.nx, L.ny, L.col, L.contrib);
             HIPCHK(c, hipGetLastError());
@@ -2468,7 +2508,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             if (c->mg_tail >= 0)
                 for (size_t m = c->mg_tail; m < l; m++) eoff += c->mg[m].nel;
             hd[l] = MgLevDev{L.nx, L.ny, L.nnode, L.nslot, L.ainv, off, 0, L.col, L.val, (const double2 *)L.dinv,
-                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res, L.Mel, L.nel, eoff};
+                             (double2 *)L.x, (double2 *)L.b, (double2 *)L.t, (double2 *)L.res, L.Mel, L.nel, eoff, L.rx, L.ry};
         }
         c->mg_tail_T = 0;
         if (c->mg_tail >= 0 && c->mg.back().ainv && c->mg_nu == 2) {
@@ -2509,7 +2549,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             }
             for (int l = 0; l < nl; l++) {
                 auto &L = c->mg[l];
-                L.op = make_op(c, L.nnode, L.nslot, L.col, L.val, L.nx, L.ny, L.nel, l == 0 ? c->Mop : L.Mel);
+                L.op = make_op(c, L.nnode, L.nslot, L.col, L.val, L.nx, L.ny, L.nel, l == 0 ? c->Mop : L.Mel, L.rx, L.ry);
                 L.matfree = l < lt || (c->mg_cheby > 0 && l == nl - 1);
             }
             if (c->mg_cheby == 0 && c->mg.back().nnode > MG_COARSE_MAX) c->precond = 0;  // no usable coarse solver
@@ -2547,7 +2587,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
             dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
             dfree(L.Mel); dfree(L.x); dfree(L.b);
         }
-        dfree(L.t); dfree(L.res); dfree(L.ainv);
+        dfree(L.t); dfree(L.res); dfree(L.ainv); dfree(L.cls4);
     }
     c->mg.clear();
     c->grid_ok = false;
@@ -2641,7 +2681,7 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
             dfree(L.col); dfree(L.contrib); dfree(L.cls0); dfree(L.val); dfree(L.diag); dfree(L.dinv);
             dfree(L.Mel); dfree(L.x); dfree(L.b);
         }
-        dfree(L.t); dfree(L.res); dfree(L.ainv);
+        dfree(L.t); dfree(L.res); dfree(L.ainv); dfree(L.cls4);
     }
     c->mg.resize(Ld + 1);
     dfree(c->mg.back().ainv);
@@ -3123,7 +3163,7 @@ int plfx_assemble(plfx_ctx *c)
         KOp live = c->op;
         live.M = c->Mel;  // diagonal + snapshot of the generators (+ generators of multigrid level 1) in one pass
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
-                           c->Mop, mg_active(c) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
+                           c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
                            (double2 *)nullptr);
         c->val_valid = false;
     } else {
@@ -3737,7 +3777,8 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
     sop.M = c->Msur;
     // diagonal of the surrogate + generators of level 1, then the coarser levels, Jacobi scalings and the coarse inverse
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, sop,
-                       (double2 *)c->diag_sur, (double *)nullptr, c->mg[1].Mel, (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
+                       (double2 *)c->diag_sur, (double *)nullptr, level_plain(c->mg[0]) ? c->mg[1].Mel : (double *)nullptr,
+                       (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
     hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
     HIPCHK(c, hipGetLastError());
     L0.op.M = c->Msur;

@@ -1252,7 +1252,48 @@ struct KOp {
     int nxn, nyn, nel;   // nodes per row / column, elements
     const double *M;     // generators XX XY XS YY YS SS: pair layout [3][nel] double2 (gen_index), k_grid_setup<0> reads SoA [6][nel]
     const double *tab;   // [4 positions][4 b][sxx_ab, syy_ab, sxy_ab, sxy_ba]; position p = pj*2+pk <-> element (j-1+pj, k-1+pk)
+    // size of the LAST element column / row relative to the others (1 on every grid whose size halves exactly; coarse levels
+    // of a mesh with an odd number of elements end in a narrower cell so that the level covers exactly the fine grid, DESIGN
+    // 10.7).  The stiffness integrals of a cell of size (rx lx, ry ly): Sxx ~ ly / lx scales with ry / rx, Syy with rx / ry,
+    // Sxy does not depend on the size.
+    double rx = 1., ry = 1.;
 };
+
+// Coarsening of one direction of a level with n cells, the last of relative size r (all others 1):
+//   n even           pairs; the last coarse cell has children (1, r)                       -> n / 2 cells,       r' = (1 + r) / 2
+//   n odd, r >= 1    pairs + the lone last cell                                            -> (n + 1) / 2 cells, r' = r / 2
+//   n odd, r <  1    pairs, the last coarse cell takes THREE children (1, 1, r)             -> (n - 1) / 2 cells, r' = (2 + r) / 2
+// so that r stays in [1/2, 3/2) on every level (a lone narrow cell halved again and again would end as a sliver: measured,
+// 1025 cells: 795 instead of ~230 PCG iterations).  The last node line of every level is the edge of the grid.
+__host__ __device__ __forceinline__ int mg_coarse_cells(int n, double r) { return (n & 1) ? (r >= 1. ? (n + 1) >> 1 : (n - 1) >> 1) : n >> 1; }
+__host__ __device__ __forceinline__ double mg_coarse_ratio(int n, double r)
+{
+    return (n & 1) ? (r >= 1. ? 0.5 * r : 0.5 * (2. + r)) : 0.5 * (1. + r);
+}
+// fine node of this level that coarse node J coincides with
+__host__ __device__ __forceinline__ int mg_fine_node(int J, int n, double r) { return J == mg_coarse_cells(n, r) ? n : 2 * J; }
+// 1-d transfer stencil (bilinear interpolation): fine node j takes w0 of coarse node J0 and w1 of J0 + 1
+__host__ __device__ __forceinline__ void mg_tr1d(int j, int n, double r, int &J0, double &w0, double &w1)
+{
+    const bool odd = n & 1, triple = odd && r < 1.;
+    if (j == n) {                       // the edge: last coarse node
+        J0 = mg_coarse_cells(n, r);
+        w0 = 1.;
+        w1 = 0.;
+    } else if (triple && j >= n - 2) {  // the two interior nodes of the last coarse cell (children 1, 1, r), left node (n - 3) / 2
+        J0 = (n - 3) >> 1;
+        w1 = (j == n - 2 ? 1. : 2.) / (2. + r);
+        w0 = 1. - w1;
+    } else if (!(j & 1)) {              // coincident
+        J0 = j >> 1;
+        w0 = 1.;
+        w1 = 0.;
+    } else {                            // between the two children of coarse cell (j - 1) / 2
+        J0 = j >> 1;
+        w1 = (!odd && j == n - 1) ? 1. / (1. + r) : 0.5;
+        w0 = 1. - w1;
+    }
+}
 
 // Row pair i of K times a vector given as a functor xf(node) -> double2, from the element generators.
 // With a = local number of node i in the element and u_b the vector at the element's node b:
@@ -1321,9 +1362,11 @@ __device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const
 // the same with the generators in pair layout: mf2(q) = pair number q = c2 * nel + e; the vector comes as xjk(jj, kk) = entry
 // of node (column jj, row kk) (callers that interpolate the entry on the fly need the grid position, not the node number)
 template <class MF2, class XJK>
-__device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel, const double *tab, int j, int k, MF2 mf2, XJK xjk)
+__device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel, const double *tab, int j, int k, MF2 mf2, XJK xjk,
+                                                       double rx = 1., double ry = 1.)
 {
     const int nye = nyn - 1, nxe = nxn - 1;
+    const bool ragged = rx != 1. || ry != 1.;   // (uniform per level)
     double2 u[3][3];
 #pragma unroll
     for (int dj = 0; dj < 3; dj++) {
@@ -1370,6 +1413,14 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
                 A7 = fma(syx, ub.x, A7);
                 A8 = fma(syx, ub.y, A8);
             }
+            if (ragged) {   // a cell of the last column / row: Sxx ~ ly / lx, Syy ~ lx / ly
+                const double sx = (j - 1 + pj == nxe - 1) ? rx : 1., sy = (k - 1 + pk == nye - 1) ? ry : 1.;
+                const double f = sy / sx, fi = sx / sy;
+                A1 *= f;
+                A2 *= f;
+                A3 *= fi;
+                A4 *= fi;
+            }
             const double Mxx = m[p][0], Mxy = m[p][1], Mxs = m[p][2], Myy = m[p][3], Mys = m[p][4], Mss = m[p][5];
             qx = fma(Mxx, A1, fma(Mxs, A5 + A7 + A2, fma(Mss, A3 + A8, fma(Mxy, A6, fma(Mys, A4, qx)))));
             qy = fma(Mxy, A7, fma(Mys, A3 + A8 + A6, fma(Mxs, A1, fma(Mss, A5 + A2, fma(Myy, A4, qy)))));
@@ -1378,17 +1429,18 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
 }
 
 template <class MF2, class XF>
-__device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf)
+__device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf,
+                                                    double rx = 1., double ry = 1.)
 {
     const int j = i / nyn, k = i - j * nyn;
-    return grid_apply_pairs_jk(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); });
+    return grid_apply_pairs_jk(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); }, rx, ry);
 }
 
 template <class XF>
 __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
 {
     const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
-    return grid_apply_pairs(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf);
+    return grid_apply_pairs(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf, g.rx, g.ry);
 }
 
 template <int GRID, class XF>
@@ -1532,10 +1584,8 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
              const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv, int mask_nxn = 0x7fffffff)
 {
     const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
-    // the next coarser level has ceil(n / 2) elements per direction: where n is odd its last coarse element covers ONE fine
-    // element and a ghost of zero stiffness beyond the edge of the grid (mean of four children with the missing ones = 0)
-    const int nyc = (nye + 1) >> 1;
-    const size_t nel_c = (size_t)((nxe + 1) >> 1) * nyc;
+    const int nyc = nye >> 1;
+    const size_t nel_c = (size_t)(nxe >> 1) * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < g.nnode; i += gridDim.x * BLOCK) {
         const int j = i / nyn, k = i - j * nyn;
         double dx = 0., dy = 0.;
@@ -1549,7 +1599,8 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                 const size_t e = (size_t)ej * nye + ek;
                 const int a = (1 - pj) * 2 + (1 - pk);
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
-                const double sxx = T[0], syy = T[1], sxy = T[2], syx = T[3];
+                const double csx = (ej == nxe - 1) ? g.rx : 1., csy = (ek == nye - 1) ? g.ry : 1.;   // size of this cell (KOp::rx, ry)
+                const double sxx = T[0] * (csy / csx), syy = T[1] * (csx / csy), sxy = T[2], syx = T[3];
                 double Mxx, Mxy, Mxs, Myy, Mys, Mss;
                 if (SRC_PAIR) {
                     const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
@@ -1573,23 +1624,22 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
             }
         diag[i] = make_double2(dx, dy);
         if (dinv) {
-            // (a coarse node beyond the edge of an odd-sized level takes the mask of the edge node it extends)
-            const double2 df = mask_dinv[(size_t)min(j << shift, mask_nxn - 1) * mask_nyn + min(k << shift, mask_nyn - 1)];
+            // (interior node lines of a level are node lines j << level of the finest grid, its last line is the edge)
+            const int mj = (j == nxe) ? mask_nxn - 1 : min(j << shift, mask_nxn - 1), mk = (k == nye) ? mask_nyn - 1 : min(k << shift, mask_nyn - 1);
+            const double2 df = mask_dinv[(size_t)mj * mask_nyn + mk];
             double2 o;
             o.x = (df.x != 0.) ? (fabs(dx) > 1e-300 ? 1. / fabs(dx) : 1.) : 0.;
             o.y = (df.y != 0.) ? (fabs(dy) > 1e-300 ? 1. / fabs(dy) : 1.) : 0.;
             dinv[i] = o;
         }
-        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {
+        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {  // (levels that halve exactly; otherwise the host runs k_mg_coarsen_M)
             const size_t e00 = (size_t)j * nye + k, e10 = e00 + nye;
             const size_t ec = (size_t)(j >> 1) * nyc + (k >> 1);
-            const bool hj = j + 1 < nxe, hk = k + 1 < nye;   // children beyond the edge of an odd-sized level: zero stiffness
             double mc[6];
 #pragma unroll
             for (int c = 0; c < 6; c++)
-                mc[c] = 0.25 * (own[c] + (hk ? g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] : 0.) +
-                                (hj ? g.M[gen_index(SRC_PAIR, c, g.nel, e10)] : 0.) +
-                                (hj && hk ? g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)] : 0.));
+                mc[c] = 0.25 * (own[c] + g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] + g.M[gen_index(SRC_PAIR, c, g.nel, e10)] +
+                                g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)]);
             double2 *C2 = reinterpret_cast<double2 *>(Mc);
             C2[ec] = make_double2(mc[0], mc[1]);
             C2[nel_c + ec] = make_double2(mc[2], mc[3]);

@@ -190,29 +190,92 @@ k_mg_cheby(KOp op, const double2 *__restrict__ dinv, const double2 *__restrict__
     }
 }
 
-// full-weighting restriction b_c = P^T res_f (coarse node (J,K) <-> fine node (2J,2K)); nyf/nyc = nodes per column
-__global__ void __launch_bounds__(BLOCK)
-k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__restrict__ res_f,
-              const double2 *__restrict__ dinv_c, double2 *__restrict__ b_c)
+// transfer weight of fine node (jf, kf) towards coarse node (J, K) -- the 2-d product of mg_tr1d; levels that halve exactly:
+// 1, 1/2, 1/4
+__device__ __forceinline__ double mg_tr_weight(int jf, int kf, int J, int K, int nfx, int nfy, double rxf, double ryf)
 {
-    const int nc = nxc_nodes * nyc;
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
-        const int J = i / nyc, K = i - J * nyc;
-        double sx = 0., sy = 0.;
+    int J0, K0;
+    double a0, a1, b0, b1;
+    mg_tr1d(jf, nfx, rxf, J0, a0, a1);
+    mg_tr1d(kf, nfy, ryf, K0, b0, b1);
+    const double wj = (J0 == J) ? a0 : (J0 + 1 == J ? a1 : 0.);
+    const double wk = (K0 == K) ? b0 : (K0 + 1 == K ? b1 : 0.);
+    return wj * wk;
+}
+
+// value of the coarse vector xc (nyc nodes per column) interpolated at fine node (j, k)
+template <class XC>
+__device__ __forceinline__ double2 mg_interpolate(int j, int k, int nfx, int nfy, double rxf, double ryf, int nyc, XC xc)
+{
+    int J0, K0;
+    double a0, a1, b0, b1;
+    mg_tr1d(j, nfx, rxf, J0, a0, a1);
+    mg_tr1d(k, nfy, ryf, K0, b0, b1);
+    double2 v = xc(J0 * nyc + K0);
+    double cx = a0 * b0 * v.x, cy = a0 * b0 * v.y;
+    if (a1 != 0.) {
+        v = xc((J0 + 1) * nyc + K0);
+        cx = fma(a1 * b0, v.x, cx), cy = fma(a1 * b0, v.y, cy);
+    }
+    if (b1 != 0.) {
+        v = xc(J0 * nyc + K0 + 1);
+        cx = fma(a0 * b1, v.x, cx), cy = fma(a0 * b1, v.y, cy);
+    }
+    if (a1 != 0. && b1 != 0.) {
+        v = xc((J0 + 1) * nyc + K0 + 1);
+        cx = fma(a1 * b1, v.x, cx), cy = fma(a1 * b1, v.y, cy);
+    }
+    return make_double2(cx, cy);
+}
+
+// (P^T res)(J, K): res(jf, kf) -> double2 reads the fine residual.  plain: the level halves exactly (weights 1, 1/2, 1/4 of the
+// nine fine nodes around (2J, 2K), summed in the order the kernels always used)
+template <class RES>
+__device__ __forceinline__ double2 mg_restrict_at(int J, int K, int nfx, int nfy, double rxf, double ryf, bool plain, RES res)
+{
+    double sx = 0., sy = 0.;
+    if (plain) {
 #pragma unroll
         for (int dj = -1; dj <= 1; dj++) {
             const int jf = 2 * J + dj;
-            if (jf < 0 || jf >= nxf_nodes) continue;
+            if (jf < 0 || jf > nfx) continue;
 #pragma unroll
             for (int dk = -1; dk <= 1; dk++) {
                 const int kf = 2 * K + dk;
-                if (kf < 0 || kf >= nyf) continue;
+                if (kf < 0 || kf > nfy) continue;
                 const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
-                const double2 r = res_f[(size_t)jf * nyf + kf];
+                const double2 r = res(jf, kf);
                 sx = fma(w, r.x, sx);
                 sy = fma(w, r.y, sy);
             }
         }
+    } else {
+        const int jc = mg_fine_node(J, nfx, rxf), kc = mg_fine_node(K, nfy, ryf);   // fine nodes within two lines of the coincident one
+        for (int jf = max(jc - 2, 0); jf <= min(jc + 2, nfx); jf++)
+            for (int kf = max(kc - 2, 0); kf <= min(kc + 2, nfy); kf++) {
+                const double w = mg_tr_weight(jf, kf, J, K, nfx, nfy, rxf, ryf);
+                if (w == 0.) continue;
+                const double2 r = res(jf, kf);
+                sx = fma(w, r.x, sx);
+                sy = fma(w, r.y, sy);
+            }
+    }
+    return make_double2(sx, sy);
+}
+
+// restriction b_c = P^T res_f (P: bilinear interpolation, mg_tr1d per direction); nyf/nyc = nodes per column; rxf, ryf =
+// relative size of the fine level's last cell
+__global__ void __launch_bounds__(BLOCK)
+k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__restrict__ res_f,
+              const double2 *__restrict__ dinv_c, double2 *__restrict__ b_c, double rxf = 1., double ryf = 1.)
+{
+    const int nc = nxc_nodes * nyc;
+    const int nfx = nxf_nodes - 1, nfy = nyf - 1;   // cells of the fine level
+    const bool plain = !(nfx & 1) && !(nfy & 1) && rxf == 1. && ryf == 1.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
+        const int J = i / nyc, K = i - J * nyc;
+        const double2 sr = mg_restrict_at(J, K, nfx, nfy, rxf, ryf, plain, [&](int jf, int kf) { return res_f[(size_t)jf * nyf + kf]; });
+        const double sx = sr.x, sy = sr.y;
         const double2 d = dinv_c[i];
         b_c[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
     }
@@ -221,31 +284,55 @@ k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__r
 // x_f += P x_c on free fine DOFs
 __global__ void __launch_bounds__(BLOCK)
 k_mg_prolong_add(int nxf_nodes, int nyf, int nyc, const double2 *__restrict__ x_c,
-                 const double2 *__restrict__ dinv_f, double2 *__restrict__ x_f)
+                 const double2 *__restrict__ dinv_f, double2 *__restrict__ x_f, double rxf = 1., double ryf = 1.)
 {
     const int nf = nxf_nodes * nyf;
+    const int nfx = nxf_nodes - 1, nfy = nyf - 1;
+    const bool plain = !(nfx & 1) && !(nfy & 1) && rxf == 1. && ryf == 1.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nf; i += gridDim.x * BLOCK) {
         const int j = i / nyf, k = i - j * nyf;
-        const int J0 = j >> 1, K0 = k >> 1;
-        const int oj = j & 1, ok = k & 1;
-        double2 v = x_c[(size_t)J0 * nyc + K0];
-        double cx = v.x, cy = v.y;
-        if (oj) {
-            v = x_c[(size_t)(J0 + 1) * nyc + K0];
-            cx += v.x;
-            cy += v.y;
+        double cx, cy, w = 1.;
+        if (plain) {
+            const int J0 = j >> 1, K0 = k >> 1;
+            const int oj = j & 1, ok = k & 1;
+            double2 v = x_c[(size_t)J0 * nyc + K0];
+            cx = v.x, cy = v.y;
+            if (oj) {
+                v = x_c[(size_t)(J0 + 1) * nyc + K0];
+                cx += v.x;
+                cy += v.y;
+            }
+            if (ok) {
+                v = x_c[(size_t)J0 * nyc + K0 + 1];
+                cx += v.x;
+                cy += v.y;
+            }
+            if (oj && ok) {
+                v = x_c[(size_t)(J0 + 1) * nyc + K0 + 1];
+                cx += v.x;
+                cy += v.y;
+            }
+            w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+        } else {
+            int J0, K0;
+            double a0, a1, b0, b1;
+            mg_tr1d(j, nfx, rxf, J0, a0, a1);
+            mg_tr1d(k, nfy, ryf, K0, b0, b1);
+            double2 v = x_c[(size_t)J0 * nyc + K0];
+            cx = a0 * b0 * v.x, cy = a0 * b0 * v.y;
+            if (a1 != 0.) {
+                v = x_c[(size_t)(J0 + 1) * nyc + K0];
+                cx = fma(a1 * b0, v.x, cx), cy = fma(a1 * b0, v.y, cy);
+            }
+            if (b1 != 0.) {
+                v = x_c[(size_t)J0 * nyc + K0 + 1];
+                cx = fma(a0 * b1, v.x, cx), cy = fma(a0 * b1, v.y, cy);
+            }
+            if (a1 != 0. && b1 != 0.) {
+                v = x_c[(size_t)(J0 + 1) * nyc + K0 + 1];
+                cx = fma(a1 * b1, v.x, cx), cy = fma(a1 * b1, v.y, cy);
+            }
         }
-        if (ok) {
-            v = x_c[(size_t)J0 * nyc + K0 + 1];
-            cx += v.x;
-            cy += v.y;
-        }
-        if (oj && ok) {
-            v = x_c[(size_t)(J0 + 1) * nyc + K0 + 1];
-            cx += v.x;
-            cy += v.y;
-        }
-        const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
         const double2 d = dinv_f[i];
         double2 xf = x_f[i];
         if (d.x != 0.) xf.x = fma(w, cx, xf.x);
@@ -254,49 +341,51 @@ k_mg_prolong_add(int nxf_nodes, int nyf, int nyc, const double2 *__restrict__ x_
     }
 }
 
-// coarse stiffness generator: mean of the four children (element id = j*NY + k, model.py:935)
+// coarse stiffness generator: mean of the children (element id = j*NY + k, model.py:935) -- four equal ones on levels that
+// halve exactly; otherwise the children mg_coarse_cells gives the cell (one, two or three per direction), weighted with their areas
 __global__ void __launch_bounds__(BLOCK)
 k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ M_f, double *__restrict__ M_c,
-               int pair_f, int pair_c /* layouts of the two arrays (gen_index) */)
+               int pair_f, int pair_c /* layouts of the two arrays (gen_index) */, double rxf = 1., double ryf = 1.)
 {
     const int nel_c = nxc * nyc, nxf = nel_f / nyf;
+    const bool plain = !(nxf & 1) && !(nyf & 1) && rxf == 1. && ryf == 1.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nel_c; i += gridDim.x * BLOCK) {
         const int J = i / nyc, K = i - J * nyc;
-        const size_t e00 = (size_t)(2 * J) * nyf + 2 * K, e10 = e00 + nyf;
-        const bool hj = 2 * J + 1 < nxf, hk = 2 * K + 1 < nyf;   // (odd-sized fine level: children beyond its edge count as zero)
+        if (plain) {
+            const size_t e00 = (size_t)(2 * J) * nyf + 2 * K, e10 = e00 + nyf;
 #pragma unroll
-        for (int c = 0; c < 6; c++)
-            M_c[gen_index(pair_c, c, nel_c, i)] =
-                0.25 * (M_f[gen_index(pair_f, c, nel_f, e00)] + (hk ? M_f[gen_index(pair_f, c, nel_f, e00 + 1)] : 0.) +
-                        (hj ? M_f[gen_index(pair_f, c, nel_f, e10)] : 0.) + (hj && hk ? M_f[gen_index(pair_f, c, nel_f, e10 + 1)] : 0.));
+            for (int c = 0; c < 6; c++)
+                M_c[gen_index(pair_c, c, nel_c, i)] =
+                    0.25 * (M_f[gen_index(pair_f, c, nel_f, e00)] + M_f[gen_index(pair_f, c, nel_f, e00 + 1)] +
+                            M_f[gen_index(pair_f, c, nel_f, e10)] + M_f[gen_index(pair_f, c, nel_f, e10 + 1)]);
+            continue;
+        }
+        // children columns [2J, jend) and rows [2K, kend): the last coarse cell of a direction takes what is left
+        const int jend = (J == nxc - 1) ? nxf : 2 * J + 2, kend = (K == nyc - 1) ? nyf : 2 * K + 2;
+        double acc[6] = {0., 0., 0., 0., 0., 0.}, wsum = 0.;
+        for (int jf = 2 * J; jf < jend; jf++)
+            for (int kf = 2 * K; kf < kend; kf++) {
+                const double w = ((jf == nxf - 1) ? rxf : 1.) * ((kf == nyf - 1) ? ryf : 1.);
+                const size_t e = (size_t)jf * nyf + kf;
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[c] = fma(w, M_f[gen_index(pair_f, c, nel_f, e)], acc[c]);
+                wsum += w;
+            }
+#pragma unroll
+        for (int c = 0; c < 6; c++) M_c[gen_index(pair_c, c, nel_c, i)] = acc[c] / wsum;
     }
 }
 
 // coarse Dirichlet mask from the coincident fine nodes; dinv_c = free ? 1/|diag_c| : 0
 __global__ void __launch_bounds__(BLOCK)
 k_mg_coarse_dinv(int nxc_nodes, int nyc, int nyf, const double2 *__restrict__ dinv_f,
-                 const double2 *__restrict__ diag_c, double2 *__restrict__ dinv_c, int nxf_nodes)
+                 const double2 *__restrict__ diag_c, double2 *__restrict__ dinv_c, int nxf_nodes, double rxf = 1., double ryf = 1.)
 {
     const int nc = nxc_nodes * nyc;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nc; i += gridDim.x * BLOCK) {
         const int J = i / nyc, K = i - J * nyc;
-        // Odd-sized fine level: its edge node line has no coincident coarse line.  The ghost line beyond it takes the mask of
-        // the edge (clamped index), and so does the last coincident line next to it: a Dirichlet edge must sit INSIDE the
-        // coarse problem's idea of the boundary, never outside -- a clamp one fine cell too far out halves the stiffness the
-        // coarse level sees near that edge, its corrections overshoot by up to 2x and are not damped (measured: 319 instead
-        // of 28 PCG iterations on 128 x 127 elements); one cell too far in only under-corrects the line the smoother handles
-        const int jf = min(2 * J, nxf_nodes - 1), kf = min(2 * K, nyf - 1);
-        double2 df = dinv_f[(size_t)jf * nyf + kf];
-        if (2 * J + 1 == nxf_nodes - 1) {
-            const double2 d2 = dinv_f[(size_t)(nxf_nodes - 1) * nyf + kf];
-            if (d2.x == 0.) df.x = 0.;
-            if (d2.y == 0.) df.y = 0.;
-        }
-        if (2 * K + 1 == nyf - 1) {
-            const double2 d2 = dinv_f[(size_t)jf * nyf + nyf - 1];
-            if (d2.x == 0.) df.x = 0.;
-            if (d2.y == 0.) df.y = 0.;
-        }
+        // (the last coarse node line coincides with the last fine one, however the fine level is coarsened)
+        const double2 df = dinv_f[(size_t)mg_fine_node(J, nxf_nodes - 1, rxf) * nyf + mg_fine_node(K, nyf - 1, ryf)];
         const double2 dg = diag_c[i];
         double2 o;
         o.x = (df.x != 0.) ? (fabs(dg.x) > 1e-300 ? 1. / fabs(dg.x) : 1.) : 0.;
@@ -564,7 +653,11 @@ struct MgLevDev {
     double2 *x, *b, *t, *res;
     const double *Mel;   // stiffness generators of the level, SoA [6][nel] (matrix-free tail)
     int nel, elem_off;   // elements of the level, element offset inside the LDS arena of k_mg_tail_mf
+    double rx, ry;       // relative size of the level's last element column / row (KOp::rx, ry)
 };
+
+// the level halves exactly and all its cells have one size: the transfer weights to the next level are 1, 1/2, 1/4
+__device__ __forceinline__ bool mg_level_plain(const MgLevDev &L) { return !(L.nx & 1) && !(L.ny & 1) && L.rx == 1. && L.ry == 1.; }
 
 __device__ inline void coarse_solve_block(int nnode, int nslot, const int32_t *__restrict__ col,
                                           const double *__restrict__ val, const double2 *__restrict__ dinv,
@@ -784,24 +877,13 @@ __device__ inline void blk_residual(const MgLevDev &L)
 
 __device__ inline void blk_restrict(const MgLevDev &F, const MgLevDev &Cc)
 {
-    const int nyc = Cc.ny + 1, nyf = F.ny + 1, nxf = F.nx + 1;
+    const int nyc = Cc.ny + 1, nyf = F.ny + 1;
+    const bool plain = mg_level_plain(F);
     for (int i = threadIdx.x; i < Cc.nnode; i += blockDim.x) {
         const int J = i / nyc, K = i - J * nyc;
-        double sx = 0., sy = 0.;
-        for (int dj = -1; dj <= 1; dj++) {
-            const int jf = 2 * J + dj;
-            if (jf < 0 || jf >= nxf) continue;
-            for (int dk = -1; dk <= 1; dk++) {
-                const int kf = 2 * K + dk;
-                if (kf < 0 || kf >= nyf) continue;
-                const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
-                const double2 r = F.res[(size_t)jf * nyf + kf];
-                sx = fma(w, r.x, sx);
-                sy = fma(w, r.y, sy);
-            }
-        }
+        const double2 sr = mg_restrict_at(J, K, F.nx, F.ny, F.rx, F.ry, plain, [&](int jf, int kf) { return F.res[(size_t)jf * nyf + kf]; });
         const double2 d = Cc.dinv[i];
-        Cc.b[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
+        Cc.b[i] = make_double2(d.x != 0. ? sr.x : 0., d.y != 0. ? sr.y : 0.);
     }
     __syncthreads();
 }
@@ -812,24 +894,30 @@ __device__ inline void blk_prolong_add(const MgLevDev &F, const MgLevDev &Cc)
     for (int i = threadIdx.x; i < F.nnode; i += blockDim.x) {
         const int j = i / nyf, k = i - j * nyf;
         const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
-        double2 v = Cc.x[(size_t)J0 * nyc + K0];
-        double cx = v.x, cy = v.y;
-        if (oj) {
-            v = Cc.x[(size_t)(J0 + 1) * nyc + K0];
-            cx += v.x;
-            cy += v.y;
+        double cx, cy, w = 1.;
+        if (mg_level_plain(F)) {
+            double2 v = Cc.x[(size_t)J0 * nyc + K0];
+            cx = v.x, cy = v.y;
+            if (oj) {
+                v = Cc.x[(size_t)(J0 + 1) * nyc + K0];
+                cx += v.x;
+                cy += v.y;
+            }
+            if (ok) {
+                v = Cc.x[(size_t)J0 * nyc + K0 + 1];
+                cx += v.x;
+                cy += v.y;
+            }
+            if (oj && ok) {
+                v = Cc.x[(size_t)(J0 + 1) * nyc + K0 + 1];
+                cx += v.x;
+                cy += v.y;
+            }
+            w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+        } else {
+            const double2 v = mg_interpolate(j, k, F.nx, F.ny, F.rx, F.ry, nyc, [&](int q) { return Cc.x[q]; });
+            cx = v.x, cy = v.y;
         }
-        if (ok) {
-            v = Cc.x[(size_t)J0 * nyc + K0 + 1];
-            cx += v.x;
-            cy += v.y;
-        }
-        if (oj && ok) {
-            v = Cc.x[(size_t)(J0 + 1) * nyc + K0 + 1];
-            cx += v.x;
-            cy += v.y;
-        }
-        const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
         const double2 d = F.dinv[i];
         double2 xf = F.x[i];
         if (d.x != 0.) xf.x = fma(w, cx, xf.x);
@@ -971,22 +1059,12 @@ k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double om
             v.res[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
         }
         __syncthreads();
-        const int nyc = Cc.ny + 1, nyf = L.ny + 1, nxf = L.nx + 1;
+        const int nyc = Cc.ny + 1, nyf = L.ny + 1;
+        const bool plain_l = mg_level_plain(L);
         for (int i = threadIdx.x; i < Cc.nnode; i += nt) {  // b_c = P^T res
             const int J = i / nyc, K = i - J * nyc;
-            double sx = 0., sy = 0.;
-            for (int dj = -1; dj <= 1; dj++) {
-                const int jf = 2 * J + dj;
-                if (jf < 0 || jf >= nxf) continue;
-                for (int dk = -1; dk <= 1; dk++) {
-                    const int kf = 2 * K + dk;
-                    if (kf < 0 || kf >= nyf) continue;
-                    const double w = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
-                    const double2 r = v.res[jf * nyf + kf];
-                    sx = fma(w, r.x, sx);
-                    sy = fma(w, r.y, sy);
-                }
-            }
+            const double2 sr = mg_restrict_at(J, K, L.nx, L.ny, L.rx, L.ry, plain_l, [&](int jf, int kf) { return v.res[jf * nyf + kf]; });
+            const double sx = sr.x, sy = sr.y;
             const double2 d = Cc.dinv[i];
             vc.b[i] = make_double2(d.x != 0. ? sx : 0., d.y != 0. ? sy : 0.);
         }
@@ -1013,24 +1091,30 @@ k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double om
         for (int i = threadIdx.x; i < L.nnode; i += nt) {
             const int j = i / nyf, k = i - j * nyf;
             const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
-            double2 c = vc.x[J0 * nyc + K0];
-            double cx = c.x, cy = c.y;
-            if (oj) {
-                c = vc.x[(J0 + 1) * nyc + K0];
-                cx += c.x;
-                cy += c.y;
+            double cx, cy, w = 1.;
+            if (mg_level_plain(L)) {
+                double2 c = vc.x[J0 * nyc + K0];
+                cx = c.x, cy = c.y;
+                if (oj) {
+                    c = vc.x[(J0 + 1) * nyc + K0];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                if (ok) {
+                    c = vc.x[J0 * nyc + K0 + 1];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                if (oj && ok) {
+                    c = vc.x[(J0 + 1) * nyc + K0 + 1];
+                    cx += c.x;
+                    cy += c.y;
+                }
+                w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+            } else {
+                const double2 c = mg_interpolate(j, k, L.nx, L.ny, L.rx, L.ry, nyc, [&](int q) { return vc.x[q]; });
+                cx = c.x, cy = c.y;
             }
-            if (ok) {
-                c = vc.x[J0 * nyc + K0 + 1];
-                cx += c.x;
-                cy += c.y;
-            }
-            if (oj && ok) {
-                c = vc.x[(J0 + 1) * nyc + K0 + 1];
-                cx += c.x;
-                cy += c.y;
-            }
-            const double w = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
             const double2 d = L.dinv[i];
             double2 xf = v.x[i];
             if (d.x != 0.) xf.x = fma(w, cx, xf.x);
@@ -1114,7 +1198,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             if (i < nn) {
                 const double2 di = r ? dB : dA;
                 const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
-                                               [&](int j) { return w[j]; });
+                                               [&](int j) { return w[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], x1 = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
             }
@@ -1126,7 +1210,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             if (i < nn) {
                 const double2 di = r ? dB : dA;
                 const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
-                                               [&](int j) { return x[j]; });
+                                               [&](int j) { return x[j]; }, L.rx, L.ry);
                 const double2 bi = b[i];
                 w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
             }
@@ -1136,19 +1220,8 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
         if (tid < Cc.nnode) {  // b_c = P^T res   (a coarse level of the tail has at most nt nodes)
             const int i = tid;
             const int J = i / nyc, K = i - J * nyc;
-            double sx = 0., sy = 0.;
-            for (int dj = -1; dj <= 1; dj++) {
-                const int jf = 2 * J + dj;
-                if (jf < 0 || jf >= nxn) continue;
-                for (int dk = -1; dk <= 1; dk++) {
-                    const int kf = 2 * K + dk;
-                    if (kf < 0 || kf >= nyn) continue;
-                    const double wt = (dj == 0 ? 1. : 0.5) * (dk == 0 ? 1. : 0.5);
-                    const double2 rr = w[jf * nyn + kf];
-                    sx = fma(wt, rr.x, sx);
-                    sy = fma(wt, rr.y, sy);
-                }
-            }
+            const double2 sr = mg_restrict_at(J, K, L.nx, L.ny, L.rx, L.ry, mg_level_plain(L), [&](int jf, int kf) { return w[jf * nyn + kf]; });
+            const double sx = sr.x, sy = sr.y;
             bc[i] = make_double2(dC.x != 0. ? sx : 0., dC.y != 0. ? sy : 0.);
         }
         __syncthreads();
@@ -1182,24 +1255,30 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
                 const double2 d = r ? dB : dA;
                 const int j = i / nyn, k = i - j * nyn;
                 const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
-                double2 c = xc[J0 * nyc + K0];
-                double cx = c.x, cy = c.y;
-                if (oj) {
-                    c = xc[(J0 + 1) * nyc + K0];
-                    cx += c.x;
-                    cy += c.y;
+                double cx, cy, wt = 1.;
+                if (mg_level_plain(L)) {
+                    double2 c = xc[J0 * nyc + K0];
+                    cx = c.x, cy = c.y;
+                    if (oj) {
+                        c = xc[(J0 + 1) * nyc + K0];
+                        cx += c.x;
+                        cy += c.y;
+                    }
+                    if (ok) {
+                        c = xc[J0 * nyc + K0 + 1];
+                        cx += c.x;
+                        cy += c.y;
+                    }
+                    if (oj && ok) {
+                        c = xc[(J0 + 1) * nyc + K0 + 1];
+                        cx += c.x;
+                        cy += c.y;
+                    }
+                    wt = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
+                } else {
+                    const double2 c = mg_interpolate(j, k, L.nx, L.ny, L.rx, L.ry, nyc, [&](int q) { return xc[q]; });
+                    cx = c.x, cy = c.y;
                 }
-                if (ok) {
-                    c = xc[J0 * nyc + K0 + 1];
-                    cx += c.x;
-                    cy += c.y;
-                }
-                if (oj && ok) {
-                    c = xc[(J0 + 1) * nyc + K0 + 1];
-                    cx += c.x;
-                    cy += c.y;
-                }
-                const double wt = (oj ? 0.5 : 1.) * (ok ? 0.5 : 1.);
                 double2 xf = x[i];
                 if (d.x != 0.) xf.x = fma(wt, cx, xf.x);
                 if (d.y != 0.) xf.y = fma(wt, cy, xf.y);
@@ -1213,7 +1292,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             if (i < nn) {
                 const double2 di = r ? dB : dA;
                 const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
-                                               [&](int j) { return x[j]; });
+                                               [&](int j) { return x[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], xi = x[i];
                 w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
             }
@@ -1225,7 +1304,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             if (i < nn) {
                 const double2 di = r ? dB : dA;
                 const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
-                                               [&](int j) { return w[j]; });
+                                               [&](int j) { return w[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], wi = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));
             }

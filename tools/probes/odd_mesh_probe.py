@@ -19,6 +19,8 @@ def run(nx, ny, steps=14):
         fe.bcright(0., 'force'); fe.bctop(0.005 * fe.leny, 'disp')
     fe.mesh(NX=nx, NY=ny)
     eng = fe._ensure_engine()
+    if os.environ.get('MG_OMEGA'):
+        eng.set_precond(1, float(os.environ['MG_OMEGA']), int(os.environ.get('MG_NU', '2')))
     marks = {}
     def hook(il):
         if il == 8: eng.sync(); marks['t0'] = time.perf_counter(); marks['s0'] = len(fe.solver_stats)
