@@ -22,8 +22,11 @@ namespace plfx {
 
 extern __shared__ double dyn_lds[];
 
-// Region timers of the wave-per-element SVC kernels (probe builds only: -DPLFX_PROF_REGIONS, tools/probes/svc_regions.sh):
-// lane 0 of every wave adds the shader-clock ticks it spent in a region; plfx_destroy prints the totals.
+// Region timers of the wave-per-element SVC kernels (probe builds only: hipcc ... -DPLFX_PROF_REGIONS -o libplfx_prof.so, loaded
+// through PLFX_LIB): lane 0 of every wave adds the shader-clock ticks it spent in a region; plfx_destroy prints the totals.
+// CAVEAT (measured, round 5): s_memtime waits for all outstanding memory operations, which serialises the software-pipelined
+// LDS reads -- the instrumented corrector runs 4x slower and the shares are distorted; the scaling probe
+// tools/probes/svc_scalar_share.py (time against the number of support vectors) is the measurement DESIGN 10.2 quotes.
 #ifdef PLFX_PROF_REGIONS
 __device__ unsigned long long g_prof[16];
 #define PROF_T0(t) const unsigned long long prof_##t = __builtin_readcyclecounter()
