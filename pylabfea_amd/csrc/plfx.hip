@@ -894,6 +894,21 @@ bool tail_mf(const plfx_ctx *c)
         else                                                                                                   \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
     } while (0)
+// ... and on a multigrid level whose last element column / row has another size (KOp::rx, ry): instantiation 2
+#define LAUNCH_OP1R(KERN, mf, op, grid, ...)                                                                   \
+    do {                                                                                                       \
+        if ((mf) && ((op).rx != 1. || (op).ry != 1.))                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<2>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
+        else                                                                                                   \
+            LAUNCH_OP1(KERN, mf, grid, __VA_ARGS__);                                                           \
+    } while (0)
+#define LAUNCH_OP2R(KERN, A, mf, op, grid, ...)                                                                \
+    do {                                                                                                       \
+        if ((mf) && ((op).rx != 1. || (op).ry != 1.))                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 2>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
+        else                                                                                                   \
+            LAUNCH_OP2(KERN, A, mf, grid, __VA_ARGS__);                                                        \
+    } while (0)
 #define LAUNCH_OP2(KERN, A, mf, grid, ...)                                                                     \
     do {                                                                                                       \
         if (mf)                                                                                                \
@@ -1201,7 +1216,7 @@ int mg_down_level(plfx_ctx *c, int l)
             LAUNCH_OP2(k_mg_smooth2_zero, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (double2 *)L.x, om, c->sc);
         else
-            LAUNCH_OP2(k_mg_smooth2_zero, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+            LAUNCH_OP2R(k_mg_smooth2_zero, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (double2 *)L.x, om, c->sc);
     } else {
         double *src = nullptr, *dst = (nu & 1) ? L.x : L.t;
@@ -1210,7 +1225,7 @@ int mg_down_level(plfx_ctx *c, int l)
                 LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                            (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
             else
-                LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                LAUNCH_OP2R(k_mg_smooth, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                            (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
             src = dst;
             dst = (dst == L.x) ? L.t : L.x;
@@ -1223,7 +1238,7 @@ int mg_down_level(plfx_ctx *c, int l)
         LAUNCH_OP2(k_mg_residual, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                    (const double2 *)L.x, (double2 *)L.res, c->sc);
     else
-        LAUNCH_OP2(k_mg_residual, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+        LAUNCH_OP2R(k_mg_residual, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                    (const double2 *)L.x, (double2 *)L.res, c->sc);
     hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
                        L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b, L.rx, L.ry);
@@ -1259,7 +1274,7 @@ int mg_up_level(plfx_ctx *c, int l)
             LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (const double2 *)src, (double2 *)dst, om, 0, c->sc, dot);
         else
-            LAUNCH_OP2(k_mg_smooth, 0, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+            LAUNCH_OP2R(k_mg_smooth, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (const double2 *)src, (double2 *)dst, om, 0, c->sc);
         if (l == 0) tim_end(c, ev);
         std::swap(src, dst);
@@ -1307,10 +1322,16 @@ int mg_coarse_part(plfx_ctx *c)
     } else {
         auto &L = c->mg[nl - 1];
         const size_t lds = (size_t)L.nnode * 4 * sizeof(double2);
-        if (lt < nl - 1 && tail_mf(c))
-            hipLaunchKernelGGL(k_mg_tail_mf, dim3(1), dim3(MG_TAIL_BLOCK),
-                               c->mg_tail_lds,
-                               c->stream, c->mg_dev, lt, nl, c->mg_tail_T, c->mg_tail_E, c->dtab, om, c->sc);
+        if (lt < nl - 1 && tail_mf(c)) {
+            bool ragged = false;   // some level of the tail is not "all cells alike, halving exactly" (hierarchy of an odd-sized mesh)
+            for (int l = lt; l < nl - 1; l++) ragged = ragged || !level_plain(c->mg[l]);
+            if (ragged)
+                hipLaunchKernelGGL(k_mg_tail_mf<true>, dim3(1), dim3(MG_TAIL_BLOCK), c->mg_tail_lds,
+                                   c->stream, c->mg_dev, lt, nl, c->mg_tail_T, c->mg_tail_E, c->dtab, om, c->sc);
+            else
+                hipLaunchKernelGGL(k_mg_tail_mf<false>, dim3(1), dim3(MG_TAIL_BLOCK), c->mg_tail_lds,
+                                   c->stream, c->mg_dev, lt, nl, c->mg_tail_T, c->mg_tail_E, c->dtab, om, c->sc);
+        }
         else if (lt < nl - 1 && c->mg_tail_T > 0 && c->mg_nu == 2)
             hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(MG_TAIL_BLOCK),
                                (size_t)c->mg_tail_T * (4 * sizeof(double2) + 9 * sizeof(int)), c->stream, c->mg_dev,
@@ -1330,11 +1351,11 @@ int mg_coarse_part(plfx_ctx *c)
             const double theta = 0.5 * (bmax + amin), delta = 0.5 * (bmax - amin), sigma = theta / delta;
             double rho = 1. / sigma;
             double *cur = (m & 1) ? L.x : L.t, *oth = (m & 1) ? L.t : L.x;  // the m-th result lands in L.x
-            LAUNCH_OP1(k_mg_cheby, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+            LAUNCH_OP1R(k_mg_cheby, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                        (const double2 *)nullptr, (double2 *)cur, (double2 *)L.res, 0., 1. / theta, 1, c->sc);
             for (int k = 1; k < m; k++) {
                 const double rho_new = 1. / (2. * sigma - rho);
-                LAUNCH_OP1(k_mg_cheby, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
+                LAUNCH_OP1R(k_mg_cheby, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                            (const double2 *)cur, (double2 *)oth, (double2 *)L.res, rho_new * rho, 2. * rho_new / delta, 0,
                            c->sc);
                 std::swap(cur, oth);
@@ -2531,7 +2552,8 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             c->mg_tail_E = 0;
             if (c->grid_ok && bytes_mf <= 154 * 1024 && E > 0 && c->mg.size() <= 16) {  // + 2 KB static LDS (level table)
                 c->mg_tail_E = E;
-                HIPCHK(c, set_dyn_lds((const void *)k_mg_tail_mf, (int)bytes_mf));
+                HIPCHK(c, set_dyn_lds((const void *)k_mg_tail_mf<false>, (int)bytes_mf));
+                HIPCHK(c, set_dyn_lds((const void *)k_mg_tail_mf<true>, (int)bytes_mf));
             }
         }
         {   // levels above the tail are applied matrix-free; the tail and the coarsest level keep assembled matrices

@@ -1361,12 +1361,14 @@ __device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const
 
 // the same with the generators in pair layout: mf2(q) = pair number q = c2 * nel + e; the vector comes as xjk(jj, kk) = entry
 // of node (column jj, row kk) (callers that interpolate the entry on the fly need the grid position, not the node number)
-template <class MF2, class XJK>
+// RAGGED: the level's last element column / row has another size than the rest (KOp::rx, ry) -- a compile-time variant, so
+// that the code of levels whose cells are all alike is what it was (the extra registers of a run-time test cost the fine-level
+// kernels 12-27 % and doubled the single-workgroup tail: measured, profiles/r05m)
+template <bool RAGGED = false, class MF2, class XJK>
 __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel, const double *tab, int j, int k, MF2 mf2, XJK xjk,
                                                        double rx = 1., double ry = 1.)
 {
     const int nye = nyn - 1, nxe = nxn - 1;
-    const bool ragged = rx != 1. || ry != 1.;   // (uniform per level)
     double2 u[3][3];
 #pragma unroll
     for (int dj = 0; dj < 3; dj++) {
@@ -1413,7 +1415,7 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
                 A7 = fma(syx, ub.x, A7);
                 A8 = fma(syx, ub.y, A8);
             }
-            if (ragged) {   // a cell of the last column / row: Sxx ~ ly / lx, Syy ~ lx / ly
+            if (RAGGED) {   // a cell of the last column / row: Sxx ~ ly / lx, Syy ~ lx / ly
                 const double sx = (j - 1 + pj == nxe - 1) ? rx : 1., sy = (k - 1 + pk == nye - 1) ? ry : 1.;
                 const double f = sy / sx, fi = sx / sy;
                 A1 *= f;
@@ -1428,25 +1430,27 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
     return make_double2(qx, qy);
 }
 
-template <class MF2, class XF>
+template <bool RAGGED = false, class MF2, class XF>
 __device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf,
                                                     double rx = 1., double ry = 1.)
 {
     const int j = i / nyn, k = i - j * nyn;
-    return grid_apply_pairs_jk(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); }, rx, ry);
+    return grid_apply_pairs_jk<RAGGED>(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); }, rx, ry);
 }
 
-template <class XF>
+template <bool RAGGED = false, class XF>
 __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
 {
     const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
-    return grid_apply_pairs(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf, g.rx, g.ry);
+    return grid_apply_pairs<RAGGED>(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf, g.rx, g.ry);
 }
 
+// GRID: 0 block-ELL matrix, 1 matrix-free (all cells alike), 2 matrix-free on a level whose last column / row differs (KOp::rx, ry)
 template <int GRID, class XF>
 __device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
 {
-    if (GRID) return grid_apply(o, i, xf);
+    if (GRID == 2) return grid_apply<true>(o, i, xf);
+    if (GRID) return grid_apply<false>(o, i, xf);
     return bell_apply(o.nnode, o.nslot, o.col, o.val, i, xf);
 }
 
@@ -1599,8 +1603,13 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                 const size_t e = (size_t)ej * nye + ek;
                 const int a = (1 - pj) * 2 + (1 - pk);
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
-                const double csx = (ej == nxe - 1) ? g.rx : 1., csy = (ek == nye - 1) ? g.ry : 1.;   // size of this cell (KOp::rx, ry)
-                const double sxx = T[0] * (csy / csx), syy = T[1] * (csx / csy), sxy = T[2], syx = T[3];
+                double sxx = T[0], syy = T[1];
+                const double sxy = T[2], syx = T[3];
+                if (g.rx != 1. || g.ry != 1.) {   // (uniform per level) size of this cell, KOp::rx, ry
+                    const double csx = (ej == nxe - 1) ? g.rx : 1., csy = (ek == nye - 1) ? g.ry : 1.;
+                    sxx *= csy / csx;
+                    syy *= csx / csy;
+                }
                 double Mxx, Mxy, Mxs, Myy, Mys, Mss;
                 if (SRC_PAIR) {
                     const double2 *M2 = reinterpret_cast<const double2 *>(g.M);

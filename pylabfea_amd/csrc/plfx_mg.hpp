@@ -1145,6 +1145,9 @@ k_mg_tail_lds(const MgLevDev *__restrict__ lev, int l0, int nl, int T, double om
 //      1364 elements = 137.6 KB).  A smoothing step then touches no global memory except the node's own dinv (the
 //      block-ELL tail reads 288 B of matrix per node and application through ONE compute unit: 5-7 us per application
 //      on the 33 x 33 level, measured with in-kernel timestamps).  The residual is written over w.
+// RAGGED: some level of the tail has an odd number of cells or a last cell of another size (hierarchies of odd-sized meshes):
+// general transfer weights and shape-scaled stiffness integrals; the plain instantiation is the kernel of rounds 3-4
+template <bool RAGGED>
 __global__ void __launch_bounds__(MG_TAIL_BLOCK)
 k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, const double *__restrict__ tab,
              double omega, const CgScalars *sc)
@@ -1197,7 +1200,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
+                const double2 q = grid_apply_pairs<RAGGED>(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return w[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], x1 = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, x1.x), fma(omega * di.y, bi.y - q.y, x1.y));
@@ -1209,7 +1212,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
+                const double2 q = grid_apply_pairs<RAGGED>(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return x[j]; }, L.rx, L.ry);
                 const double2 bi = b[i];
                 w[i] = make_double2(di.x != 0. ? bi.x - q.x : 0., di.y != 0. ? bi.y - q.y : 0.);
@@ -1220,7 +1223,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
         if (tid < Cc.nnode) {  // b_c = P^T res   (a coarse level of the tail has at most nt nodes)
             const int i = tid;
             const int J = i / nyc, K = i - J * nyc;
-            const double2 sr = mg_restrict_at(J, K, L.nx, L.ny, L.rx, L.ry, mg_level_plain(L), [&](int jf, int kf) { return w[jf * nyn + kf]; });
+            const double2 sr = mg_restrict_at(J, K, L.nx, L.ny, L.rx, L.ry, !RAGGED || mg_level_plain(L), [&](int jf, int kf) { return w[jf * nyn + kf]; });
             const double sx = sr.x, sy = sr.y;
             bc[i] = make_double2(dC.x != 0. ? sx : 0., dC.y != 0. ? sy : 0.);
         }
@@ -1256,7 +1259,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
                 const int j = i / nyn, k = i - j * nyn;
                 const int J0 = j >> 1, K0 = k >> 1, oj = j & 1, ok = k & 1;
                 double cx, cy, wt = 1.;
-                if (mg_level_plain(L)) {
+                if (!RAGGED || mg_level_plain(L)) {
                     double2 c = xc[J0 * nyc + K0];
                     cx = c.x, cy = c.y;
                     if (oj) {
@@ -1291,7 +1294,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
+                const double2 q = grid_apply_pairs<RAGGED>(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return x[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], xi = x[i];
                 w[i] = make_double2(fma(omega * di.x, bi.x - q.x, xi.x), fma(omega * di.y, bi.y - q.y, xi.y));
@@ -1303,7 +1306,7 @@ k_mg_tail_mf(const MgLevDev *__restrict__ lev, int l0, int nl, int T, int E, con
             const int i = tid + r * nt;
             if (i < nn) {
                 const double2 di = r ? dB : dA;
-                const double2 q = grid_apply_pairs(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
+                const double2 q = grid_apply_pairs<RAGGED>(nxn, nyn, nel, tab, i, [&](int m) { return reinterpret_cast<const double2 *>(Ml)[m]; },
                                                [&](int j) { return w[j]; }, L.rx, L.ry);
                 const double2 bi = b[i], wi = w[i];
                 x[i] = make_double2(fma(omega * di.x, bi.x - q.x, wi.x), fma(omega * di.y, bi.y - q.y, wi.y));

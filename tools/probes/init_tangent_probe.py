@@ -9,7 +9,8 @@ mat.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
 for trial in range(2):
     fe = FE.Model(dim=2, planestress=False); fe.geom([4.], LY=4.); fe.assign([mat])
     fe.bcleft(0.); fe.bcbot(0.); fe.bcright(0., 'force'); fe.bctop(0.005 * fe.leny, 'disp')
-    fe.mesh(NX=1024, NY=1024)
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    fe.mesh(NX=N, NY=N)
     t0 = time.perf_counter()
     eng = fe._ensure_engine()
     eng.sync()
