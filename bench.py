@@ -273,17 +273,18 @@ def cpu_sweep_only(n, nthreads, reps=3):
 
 
 def cpu_worker(argv):
-    """`bench.py --cpu-worker n steps warmup n1 nthreads gpu_mesh`: the CPU legs in a process of their own, started with
+    """`bench.py --cpu-worker n steps warmup n1 nthreads gpu_mesh n_extra`: the CPU legs in a process of their own, started with
     OMP_NUM_THREADS / OMP_PLACES=cores / OMP_PROC_BIND=spread in its environment (libgomp reads them once, at start-up)."""
-    n, steps, warmup, n1, nthr, gmesh = (int(v) for v in argv)
+    n, steps, warmup, n1, nthr, gmesh, nx = (int(v) for v in argv)
     allc = cpu_run(n, steps, warmup, nthr, 'pcg', pcg_threads=nthr)
+    extra = cpu_run(nx, steps, warmup, nthr, 'pcg', pcg_threads=nthr) if nx > 0 and nx != n else None
     one = cpu_run(n1, max(1, min(steps, 2)), 0, 1, 'pcg')
     sw_all = cpu_sweep_only(gmesh, nthr)
     sw_one = cpu_sweep_only(gmesh, 1, reps=1)
-    print('CPUWORKER ' + json.dumps({'all': allc, 'one': one, 'sweep_all': sw_all, 'sweep_one': sw_one}))
+    print('CPUWORKER ' + json.dumps({'all': allc, 'extra': extra, 'one': one, 'sweep_all': sw_all, 'sweep_one': sw_one}))
 
 
-def cpu_baseline(n, steps, warmup, n1=128, gpu_mesh=1024):
+def cpu_baseline(n, steps, warmup, n1=128, gpu_mesh=1024, n_extra=0):
     """Same hot path on the host cores (baseline 2): the pinned CPU oracle -- OpenMP material sweep,
     CSR assembly, OpenMP Jacobi-PCG (oracle/plfx_oracle.c:plfo_pcg_csr) -- on a bounded sample of the same workload, on all
     USABLE cores (cgroup quota, see usable_cores) and on one thread; the sweep-only leg on the same mesh as the GPU line; the
@@ -292,7 +293,7 @@ def cpu_baseline(n, steps, warmup, n1=128, gpu_mesh=1024):
     cores, quota = usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PLACES='cores', OMP_PROC_BIND='spread', OMP_DYNAMIC='false')
     r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(n), str(steps), str(warmup), str(n1),
-                        str(cores), str(gpu_mesh)], env=env, capture_output=True, text=True, timeout=900)
+                        str(cores), str(gpu_mesh), str(n_extra)], env=env, capture_output=True, text=True, timeout=1500)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('CPUWORKER ')]
     if r.returncode != 0 or not line:
         raise RuntimeError('cpu worker failed: ' + r.stderr[-2000:])
@@ -306,6 +307,7 @@ def cpu_baseline(n, steps, warmup, n1=128, gpu_mesh=1024):
                      % (allc['mesh'], allc['load_steps'], allc['sweeps'], allc['solves'], allc['seconds'], cores),
            'ms_per_step': allc['ms_per_step'],
            'all_cores': dict(allc, cores=cores),
+           'all_cores_smaller_mesh': dict(w['extra'], cores=cores) if w.get('extra') else None,
            'one_thread': dict(one, cores=1),
            'sweep_only': {'all_cores': w['sweep_all']['value'], 'one_thread': w['sweep_one']['value'],
                           'speedup': w['sweep_all']['value'] / w['sweep_one']['value'], 'threads': cores,
@@ -603,7 +605,8 @@ def main():
                     help='config 3: also time two load steps of BASELINE config 5 (the sweep-dominated workload: where element '
                          'strips pay) on this mesh -- 2048 = BASELINE configs[4] itself, at every N so that the driver can form the ratio -- '
                          'reported as `config5_leg` of the same JSON line; 0 = skip (also skipped with --no-svc at N = 1)')
-    ap.add_argument('--cpu-mesh', type=int, default=448)
+    ap.add_argument('--cpu-mesh', type=int, default=0, help='mesh of the CPU leg (cpu_baseline.all_cores) and of the GPU run beside it; 0 = --mesh')
+    ap.add_argument('--cpu-extra-mesh', type=int, default=448, help='a second, smaller CPU sample (all_cores_smaller_mesh); 0 = skip')
     ap.add_argument('--sample', type=int, default=7, help='HIP-event timing of every n-th launch of the roofline kernels (two event records per timed launch cost host time and a bubble on the stream)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-reuse-off', action='store_true', help='skip the extra timed window with PLFX_REUSE=0 (ms_per_step_reuse_off)')
@@ -954,25 +957,26 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         # CPU window = load steps 11.. of 50 (past the ten calc_scf-scaled steps, like the GPU line's default window 8..18 mostly
         # is), nothing reused (the oracle recomputes every call): the GPU is run on the SAME mesh, window and reuse setting below
-        cpu_steps, cpu_warm = max(1, min(K, 3)), 5
-        out['cpu_baseline'] = cb = cpu_baseline(args.cpu_mesh, cpu_steps, cpu_warm, gpu_mesh=n)
-        same = window_run(FE, args.cpu_mesh, cpu_steps, cpu_warm, device=local, reuse=False)
+        # (round 5: on the headline's own mesh by default -- two load steps, ~ 50 s of host time with the ten steps before them;
+        # the 448^2 sample of the earlier rounds stays as `all_cores_smaller_mesh`)
+        cpu_mesh = args.cpu_mesh if args.cpu_mesh > 0 else n
+        cpu_steps, cpu_warm = max(1, min(K, 2 if cpu_mesh >= 1024 else 3)), 5
+        out['cpu_baseline'] = cb = cpu_baseline(cpu_mesh, cpu_steps, cpu_warm, gpu_mesh=n, n_extra=args.cpu_extra_mesh)
+        same = window_run(FE, cpu_mesh, cpu_steps, cpu_warm, device=local, reuse=False)
         cb['gpu_same_mesh_window_no_reuse'] = same
         # north star: ">= 10x reference-CPU throughput ... at 1 GPU".  `vs_baseline` stays null (BASELINE.md holds no published
         # number for this metric); the measured ratios against the two CPU baselines of BASELINE.md section 3 are given here,
-        # with what they compare: the CPU sample runs a smaller mesh of the same workload (the rate per element update is what
-        # is compared; Jacobi-PCG iteration counts on the CPU grow with the mesh, so the ratio at equal size would be larger)
+        # with what they compare
         best = max(cb['all_cores']['value'], cb['one_thread']['value'])
         out['vs_cpu_baseline'] = {
-            # like for like: same mesh, same load steps, every assembly / solve computed on both sides (the solvers differ:
-            # multigrid-PCG on the GPU, Jacobi-PCG on the CPU -- each side's own); the 1024^2 mesh of the headline does not fit the
-            # CPU leg's time budget (Jacobi-PCG needs ~8 NX iterations per cold solve)
+            # like for like: same mesh (the headline's), same load steps, every assembly / solve computed on both sides (the
+            # solvers differ: multigrid-PCG on the GPU, Jacobi-PCG on the CPU -- each side's own)
             'same_mesh_same_window_no_reuse': same['value'] / cb['all_cores']['value'],
             'same_host_port_best_of_all_cores_and_one_thread': value / best,
             'reference_python_one_core': (value / cb['reference_python']['value']) if cb.get('reference_python') else None,
             'north_star_10x_met': bool(value >= 10. * best),
             'note': 'same_mesh_same_window_no_reuse = cpu_baseline.gpu_same_mesh_window_no_reuse.value / cpu_baseline.all_cores.value; the other '
-                    'ratios are value / cpu_baseline with different meshes: GPU: %dx%d mesh, multigrid-PCG; CPU port: %s mesh (all cores) and %s (one thread), '
+                    'ratios are value (the headline: default window, unchanged inputs reused) / cpu_baseline: GPU: %dx%d mesh, multigrid-PCG; CPU port: %s mesh (all cores) and %s (one thread), '
                     'Jacobi-PCG on CSR, same material / loading / schedule / tolerance; reference_python: unmodified pyLabFEA '
                     'on 8x8 elements in the build container' % (fe._NX, fe._NY, cb['all_cores']['mesh'], cb['one_thread']['mesh'])}
     elif rank == 0:

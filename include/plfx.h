@@ -109,6 +109,11 @@ int plfx_set_materials(plfx_ctx *ctx, int nmat, const plfx_material *mats);
  * response (:207) on N points; also the kernel-level parity entry points. */
 int plfx_seq_batch(plfx_ctx *ctx, int mat, int n, const double *sig, double *seq);
 int plfx_fgrad_batch(plfx_ctx *ctx, int mat, int n, const double *sig, double *fgrad);
+/* calc_fgrad(sig, seq=seq) of an analytic Hill material (PLFX_HILL6 / PLFX_PRINC3), material.py:834-847: the deviator of the
+ * Voigt components over 2 seq[i] with the equivalent stress handed in -- the reference's `seq` argument, and the form its
+ * point function takes for a (6,) stress of a principal-stress (sdim = 3) material: seq in sig_princ's order, deviator of
+ * the Voigt normals, no shear rows (plfx_fgrad_batch returns the principal-space normal epl_dot / C_tan use, :1044-1047). */
+int plfx_fgrad_seq_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const double *seq, double *fgrad);
 int plfx_yf_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const double *epl, double *yf);
 /* ld: NULL or one loading direction [6] shared by all points (model.py:1052); status[n]: 0 ok,
  * 1 bracket failure, 2 root not accepted (both fall back to seq-0.85*sflow as the reference) */

@@ -7,6 +7,7 @@ Writes tests/golden/princ_general.npz.  Test infrastructure; needs /root/referen
     MPLBACKEND=Agg PYTHONPATH=oracle/_refshim:/root/reference/src python oracle/gen_princ_general.py
 """
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -16,6 +17,7 @@ import pylabfea as FE  # noqa: E402  (the reference)
 from pylabfea.basic import sig_princ  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 
 def main():
@@ -57,6 +59,42 @@ def main():
         rec['ml3_x'] = x
         d2 = np.sum((x[:, None, :] - zs['par_sv'][None, :, :]) ** 2, axis=2)
         rec['ml3_yf'] = np.exp(-float(zs['par_gamma']) * d2) @ zs['par_dual'] + float(zs['par_intercept'])
+        # ---- round 5: calc_fgrad with a (6,) stress, ML_full_yf and response on the same kind of states
+        # calc_fgrad(sig (6,)) of the analytic sdim = 3 material: seq in sig_princ's order over the deviator of the VOIGT
+        # normals (material.py:834-838), and the same with the `seq` argument
+        rec['fgrad6'] = np.array([m.calc_fgrad(sig[i]) for i in range(n)])
+        rec['fgrad6_seq_in'] = rng.uniform(40., 160., size=n)
+        rec['fgrad6_seq'] = np.array([m.calc_fgrad(sig[i], seq=rec['fgrad6_seq_in'][i]) for i in range(n)])
+        m6 = FE.Material()
+        m6.elasticity(E=200.e3, nu=0.3)
+        m6.plasticity(sy=100., hill=[0.7, 1.0, 1.4, 1.2, 0.8, 1.1], khard=100., drucker=0.05, sdim=6)
+        rec['hill6'] = np.array([0.7, 1.0, 1.4, 1.2, 0.8, 1.1])
+        rec['fgrad6_seq_sdim6'] = np.array([m6.calc_fgrad(sig[i], seq=rec['fgrad6_seq_in'][i]) for i in range(n)])
+        # ML_full_yf of the 2-feature SVC (a stand-in object with the fixture's decision function takes the place of the
+        # scikit-learn estimator; everything else is the reference's code)
+
+        class Svm:
+            def decision_function(self, x):
+                d2 = np.sum((x[:, None, :] - zs['par_sv'][None, :, :]) ** 2, axis=2)
+                return np.exp(-float(zs['par_gamma']) * d2) @ zs['par_dual'] + float(zs['par_intercept'])
+        ml.svm_yf = Svm()
+        ml.ML_yf = True
+        ml.ML_grad = False
+        nf = 160
+        sf = sig[:nf] / np.array([m.calc_seq(sig[i]) for i in range(nf)])[:, None] \
+            * (float(zs['par_sy']) * rng.uniform(0.3, 1.6, size=nf))[:, None]
+        rec['ml3_full_sig'] = sf
+        rec['ml3_full_yf'] = np.array([ml.ML_full_yf(sf[i], verb=False) for i in range(nf)])
+        rec['ml3_full_yf_check'] = np.array([ml.calc_yf(sf[i]) for i in range(nf)])
+        # response of the analytic material on general 3-d states (plane strain stiffness): every calc_yf / calc_seq inside
+        # re-orders the principal stresses with LAPACK's output of that moment
+        from gen_golden import gen_response_inputs, run_response, element_CV
+        CVr = element_CV(m, False)
+        s, e, d = gen_response_inputs(m, CVr, np.random.default_rng(5), 160, False)
+        fy, so, dp, ct, ns = run_response(m, s, e, d, CVr)
+        print('response on general states: nsteps histogram', np.bincount(ns))
+        rec['r_CV'], rec['r_sig'], rec['r_epl'], rec['r_deps'] = CVr, s, e, d
+        rec['r_fy'], rec['r_sig_out'], rec['r_depl'], rec['r_ct'], rec['r_nsteps'] = fy, so, dp, ct, ns
     out = os.path.join(ROOT, 'tests', 'golden', 'princ_general.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, {k: v.shape for k, v in rec.items()})

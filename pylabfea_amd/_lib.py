@@ -52,7 +52,7 @@ SYMBOLS = [
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
-    'plfx_svc_info', 'plfx_sqmr_info',
+    'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch',
 ]
 
 _lib = None
@@ -230,6 +230,16 @@ class Context(object):
         sig = _f64(sig).reshape(-1, 6)
         out = np.empty_like(sig)
         self._chk(self.lib.plfx_fgrad_batch(self.h, int(mat), len(sig), _dp(sig), _dp(out)))
+        return out
+
+    def fgrad_seq(self, mat, sig, seq):
+        """calc_fgrad(sig, seq=seq) of an analytic Hill material: Voigt deviator over 2 seq (material.py:834-847)"""
+        sig = _f64(sig).reshape(-1, 6)
+        seq = _f64(seq).reshape(-1)
+        if len(seq) != len(sig):
+            raise ValueError('fgrad_seq: one equivalent stress per stress expected')
+        out = np.empty_like(sig)
+        self._chk(self.lib.plfx_fgrad_seq_batch(self.h, int(mat), len(sig), _dp(sig), _dp(seq), _dp(out)))
         return out
 
     def fgrad_wh(self, mat, sig, epl=None):

@@ -1974,6 +1974,29 @@ int plfx_fgrad_batch(plfx_ctx *c, int mat, int n, const double *sig, double *a)
         return fail(c, PLFX_ERR_UNSUPPORTED, "calc_fgrad: no analytical gradient for this Tresca / Barlat material (material.py:822-825)");
     return point_eval(c, 1, mat, n, sig, nullptr, nullptr, a, nullptr);
 }
+int plfx_fgrad_seq_batch(plfx_ctx *c, int mat, int n, const double *sig, const double *seq, double *a)
+{
+    if (!c || !c->dmat) return c ? fail(c, PLFX_ERR_STATE, "set_materials first") : PLFX_ERR_STATE;
+    if (mat < 0 || mat >= c->nmat || n < 0 || !sig || !seq || !a) return fail(c, PLFX_ERR_ARG, "bad argument");
+    const int kind = c->hmat[mat].kind;
+    if (kind != PLFX_HILL6 && kind != PLFX_PRINC3)
+        return fail(c, PLFX_ERR_UNSUPPORTED, "calc_fgrad(seq=...): analytic Hill materials only (material.py:822-847)");
+    if (n == 0) return PLFX_OK;
+    double *dsig = nullptr, *dseq = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dsig, (size_t)n * 48));
+    HIPCHK(c, hipMalloc((void **)&dseq, (size_t)n * 8));
+    HIPCHK(c, hipMalloc((void **)&dout, (size_t)n * 48));
+    HIPCHK(c, hipMemcpyAsync(dsig, sig, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dseq, seq, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_fgrad_seq, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->dmat, mat, n, dsig, dseq, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(a, dout, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, stream_sync(c));
+    hipFree(dsig);
+    hipFree(dseq);
+    hipFree(dout);
+    return PLFX_OK;
+}
 int plfx_yf_batch(plfx_ctx *c, int mat, int n, const double *sig, const double *epl, double *yf)
 {
     return point_eval(c, 2, mat, n, sig, epl, nullptr, yf, nullptr);

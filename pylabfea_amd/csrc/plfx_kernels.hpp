@@ -282,6 +282,34 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
     }
 }
 
+// calc_fgrad(sig, seq=...) of the analytic Hill materials with the equivalent stress handed in (material.py:834-847): the
+// deviator of the VOIGT components over 2 seq; sdim == 3 materials get no shear rows (:841 is skipped).  That is what the
+// reference's point function returns for a (6,) stress of a principal-stress material -- seq from sig_princ's order, the
+// deviator from the Voigt normals -- and differs from the principal-space normal that epl_dot / C_tan use (princ_fgrad)
+// as soon as the state has shear.
+__global__ void __launch_bounds__(BLOCK)
+k_fgrad_seq(const MatDev *gmat, int mat, int n, const double *sig_in, const double *seq_in, double *out)
+{
+    const MatDev &m = gmat[mat];
+    const bool six = (m.kind != 2);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        double s[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) s[c] = sig_in[6 * (size_t)i + c];
+        const double seq = seq_in[i];
+        const double p = (s[0] + s[1] + s[2]) / 3.;
+        const double s0 = s[0] - p, s1 = s[1] - p, s2 = s[2] - p;
+        const double h0 = m.hill[0], h1 = m.hill[1], h2 = m.hill[2], d3 = m.d0 / 3.;
+        double *a = out + 6 * (size_t)i;
+        a[0] = ((h0 + h2) * s0 - h0 * s1 - h2 * s2) / (2. * seq) + d3;
+        a[1] = ((h1 + h0) * s1 - h0 * s0 - h1 * s2) / (2. * seq) + d3;
+        a[2] = ((h2 + h1) * s2 - h2 * s0 - h1 * s1) / (2. * seq) + d3;
+        a[3] = six ? 3. * m.hill[3] * s[3] / seq : 0.;
+        a[4] = six ? 3. * m.hill[4] * s[4] / seq : 0.;
+        a[5] = six ? 3. * m.hill[5] * s[5] / seq : 0.;
+    }
+}
+
 // what: 0 calc_seq, 1 calc_fgrad, 2 calc_yf, 3 ML_full_yf (SVC) / calc_yf (analytic)
 __global__ void __launch_bounds__(BLOCK)
 k_point_eval(const MatDev *gmat, int nmat, int lds_doubles, int what, int mat, int n,

@@ -464,10 +464,13 @@ class Material(object):
         device reproduces that order in closed form; for states with out-of-plane shear it depends on LAPACK's eigenvalue
         order, so those rows are reduced HERE with the very same LAPACK call and handed to the device as diagonal states
         (whose order the device keeps): ``calc_seq`` and ``calc_yf`` then equal the reference for every stress state
-        (fixture ``tests/golden/princ_general.npz``).  SCOPE: the guarantee covers these two; ``ML_full_yf``, ``calc_fgrad``
-        with a (6,) stress and ``response`` hand the Voigt state to the device as it is, where a general 3-d state follows the
-        device's closed-form rule -- identical to the reference for plane states (all a 2-d ``Model`` ever produces), and for
-        states with out-of-plane shear only up to the order in which LAPACK happens to return the eigenvalues."""
+        (fixture ``tests/golden/princ_general.npz``); ``ML_full_yf`` searches along the ray of the reduced state (the order
+        does not change along a ray) and ``calc_fgrad`` with a (6,) stress takes its equivalent stress from ``calc_seq``
+        (round 5; same fixture).  SCOPE: ``response`` is NOT covered -- it re-orders the principal stresses of a new stress
+        in each of its up to 50 sub-steps (material.py:250-340), which the device does by the natural rule "axis i -> the
+        eigenvector with the largest component i"; the reference's order there is whatever LAPACK's ``dgeev`` returns
+        (measured on the fixture's 160 states: 94 % of the elastic and 25 % of the plastic results coincide).  Plane states
+        -- all a 2-d ``Model`` ever produces -- are exact; ``response`` warns when it is handed anything else."""
         if self.sdim != 3 or self.tresca or self.barlat:   # (Tresca, Barlat: symmetric in the principal values)
             return s
         gen = (s[:, 3] != 0.) | (s[:, 4] != 0.)
@@ -582,7 +585,7 @@ class Material(object):
             e = np.asarray(epl, dtype=float)
             if e.ndim == 1:
                 e = np.tile(e, (len(s), 1))
-        f, st = self._load().full_yf(0, s, e, ld)
+        f, st = self._load().full_yf(0, self._princ_rows(s), e, ld)
         if verb and np.any(st != 0):
             warnings.warn('ML_full_yf: Could not bracket / locate the yield locus for %d stress(es); '
                           'conservative estimate seq-0.85*sflow returned' % int(np.sum(st != 0)))
@@ -612,7 +615,15 @@ class Material(object):
             self.khard = 0.  # side effect of the reference (material.py:812-814, no work-hardening data)
             self.msg['gradient'] = 'gradient to ML_yf'
         else:
-            a = self._load(ana=True).fgrad(0, s)
+            # the reference's analytic form takes the deviator of the components it is GIVEN (principal stresses for (3,) /
+            # (N,3) input, Voigt normals for a (6,) stress) and the equivalent stress from `seq` or calc_seq (:834-838) --
+            # for a (6,) stress of a principal-stress material that is seq in sig_princ's order over the deviator of the Voigt
+            # normals, not the principal-space normal that epl_dot / C_tan build (:1044-1047, `fgrad`)
+            if seq is not None or (self.sdim == 3 and nout == 6):
+                q = self.calc_seq(s) if seq is None else np.broadcast_to(np.asarray(seq, dtype=float).reshape(-1), (len(s),))
+                a = self._load(ana=True).fgrad_seq(0, s, np.ascontiguousarray(q))
+            else:
+                a = self._load(ana=True).fgrad(0, s)
             h = self.hill
             if self.sdim == 6:
                 self.msg['gradient'] = ('analytical, J2 isotropic, full stress' if np.all(h == 1.)
@@ -638,6 +649,12 @@ class Material(object):
             raise NotImplementedError('response: the device kernel is compiled for maxit=50 (reference default)')
         if self.sy is None:
             raise AttributeError('response called for a purely elastic material')
+        if self.sdim == 3 and not (self.tresca or self.barlat):
+            ds = np.asarray(CV, dtype=float) @ np.asarray(deps, dtype=float)
+            if sig[3] != 0. or sig[4] != 0. or ds[3] != 0. or ds[4] != 0.:
+                warnings.warn('response: stress state with out-of-plane shear on a principal-stress (sdim = 3) material -- the '
+                              'order of the principal stresses follows the device\'s rule in every sub-step, the reference\'s '
+                              'follows LAPACK there (see Material._princ_rows); plane states are exact', RuntimeWarning)
         if getattr(self, 'whdat', False):
             # Material.khard is state here: read on entry, overwritten by every gradient evaluation inside the call
             fy, so, dp, ct, ns, kout = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],

@@ -98,3 +98,96 @@ def test_gpu_two_feature_svc_on_general_states(pg, golden_dir):
     assert np.max(np.abs(m.create_scaled_input(pg['sig']) - pg['ml3_x'])) < 1e-13
     f = m.calc_yf(pg['sig'])
     assert np.max(np.abs(f - pg['ml3_yf'])) < 1e-9 * max(1., np.max(np.abs(pg['ml3_yf'])))
+
+
+@pytest.mark.gpu
+def test_gpu_calc_fgrad_with_a_voigt_stress_of_a_principal_stress_material(pg):
+    """calc_fgrad(sig (6,)) of the analytic sdim = 3 material: equivalent stress in sig_princ's (LAPACK) order over the
+    deviator of the VOIGT normals, no shear rows (material.py:834-847) -- not the principal-space normal of epl_dot / C_tan;
+    the `seq` argument of the reference replaces the equivalent stress, for sdim = 6 as well"""
+    import warnings
+    import pylabfea_amd as FE
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = hill3_material(pg)
+        m6 = FE.Material()
+        m6.elasticity(E=200.e3, nu=0.3)
+        m6.plasticity(sy=100., hill=list(pg['hill6']), khard=100., drucker=0.05, sdim=6)
+    sig = pg['sig']
+    a = np.array([m.calc_fgrad(sig[i]) for i in range(len(sig))])
+    assert a.shape == (len(sig), 6) and np.all(a[:, 3:] == 0.)
+    assert np.max(np.abs(a - pg['fgrad6'])) < 1e-12
+    # the principal-space normal (what the flow rule uses) is something else on states with shear
+    ap = m.calc_fgrad(pg['princ'])
+    assert ap.shape == (len(sig), 3) and np.max(np.abs(ap[100:] - a[100:, :3])) > 1e-2
+    # plane states without shear: both coincide
+    k = np.flatnonzero((sig[:, 3] == 0.) & (sig[:, 4] == 0.))
+    assert len(k) == 40
+    q = pg['fgrad6_seq_in']
+    b = np.array([m.calc_fgrad(sig[i], seq=q[i]) for i in range(0, len(sig), 3)])
+    assert np.max(np.abs(b - pg['fgrad6_seq'][::3])) < 1e-12
+    b6 = np.array([m6.calc_fgrad(sig[i], seq=q[i]) for i in range(0, len(sig), 3)])
+    assert np.max(np.abs(b6 - pg['fgrad6_seq_sdim6'][::3])) < 1e-12
+    assert np.max(np.abs(m6.calc_fgrad(sig, seq=q) - pg['fgrad6_seq_sdim6'])) < 1e-12   # (N,6) batch, sdim = 6
+
+
+@pytest.mark.gpu
+def test_gpu_ml_full_yf_of_the_two_feature_svc_on_general_states(pg, golden_dir):
+    """ML_full_yf of the sdim = 3 SVC on states with out-of-plane shear: the ray search runs on the LAPACK-ordered principal
+    state (Material._princ_rows); handing the device the Voigt state as it is gets 44 of these 160 wrong by up to 205 MPa"""
+    import warnings
+    import pylabfea_amd as FE
+    z = np.load(os.path.join(golden_dir, 'svc_hill3d.npz'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = FE.Material(name='ML-hill3d')
+        m.elasticity(CV=z['par_CV'])
+        m.plasticity(sy=float(z['par_sy']), sdim=3)
+        m.set_svc(z['par_sv'], z['par_dual'], float(z['par_intercept']), float(z['par_gamma']), float(z['par_scale_seq']))
+        s = pg['ml3_full_sig']
+        assert np.max(np.abs(m.calc_yf(s) - pg['ml3_full_yf_check'])) < 1e-9
+        f = np.array([m.ML_full_yf(s[i], verb=False) for i in range(len(s))])
+        fb = m.ML_full_yf(s, verb=False)
+    # brentq's last iterate: xtol = 1e-5 (material.py:497-499) on a distance of ~ 100 MPa
+    assert np.max(np.abs(f - pg['ml3_full_yf'])) < 2e-5
+    assert np.array_equal(f, fb)
+
+
+@pytest.mark.gpu
+def test_gpu_response_warns_outside_its_scope_and_is_exact_on_plane_states(pg):
+    """response of a principal-stress material re-orders the principal stresses in every sub-step: exact for plane states,
+    a RuntimeWarning names the limit for states with out-of-plane shear (Material._princ_rows)"""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = hill3_material(pg)
+    CV, s, e, d = pg['r_CV'], pg['r_sig'], pg['r_epl'], pg['r_deps']
+    with pytest.warns(RuntimeWarning, match='out-of-plane shear'):
+        m.response(s[1], e[1], d[1], CV)
+    # the same inputs with the out-of-plane shear removed: no warning, and the natural rule is the reference's
+    from oracle import oracle as O
+    E, nu, sy, kh, dr = pg['par']
+    om = O.Material(kind=O.PRINC3, sy=sy, khard=kh, hill=list(pg['hill']) + [1, 1, 1], drucker=dr)
+    s2, e2, d2 = s.copy(), e.copy(), d.copy()
+    for a in (s2, e2, d2):
+        a[:, 3:5] = 0.
+    fy, so, dp, ct, ns = O.response(om, CV, s2, e2, d2)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for i in range(0, 48):
+            f, so_i, dp_i, ct_i = m.response(s2[i], e2[i], d2[i], CV)
+            assert m.msg['nsteps'] == ns[i]
+            assert np.max(np.abs(so_i - so[i])) < 1e-9 * sy and np.max(np.abs(dp_i - dp[i])) < 1e-12
+
+
+def test_fixture_fgrad_of_a_voigt_stress_is_the_mixed_form(pg):
+    """the reference's calc_fgrad(sig (6,)) for sdim = 3 = Hill form on the Voigt normal deviator over 2 seq, seq in the
+    LAPACK order (fixture self-consistency: what the new C-ABI entry plfx_fgrad_seq_batch is specified to compute)"""
+    sig, seq = pg['sig'], pg['seq']
+    h0, h1, h2 = pg['hill']
+    d3 = pg['par'][4] / 3.
+    sd = sig[:, :3] - sig[:, :3].mean(axis=1)[:, None]
+    a = np.stack([((h0 + h2) * sd[:, 0] - h0 * sd[:, 1] - h2 * sd[:, 2]) / (2. * seq) + d3,
+                  ((h1 + h0) * sd[:, 1] - h0 * sd[:, 0] - h1 * sd[:, 2]) / (2. * seq) + d3,
+                  ((h2 + h1) * sd[:, 2] - h2 * sd[:, 0] - h1 * sd[:, 1]) / (2. * seq) + d3], axis=1)
+    assert np.max(np.abs(a - pg['fgrad6'][:, :3])) < 1e-13 and np.all(pg['fgrad6'][:, 3:] == 0.)
