@@ -95,6 +95,12 @@ def main():
         print('response on general states: nsteps histogram', np.bincount(ns))
         rec['r_CV'], rec['r_sig'], rec['r_epl'], rec['r_deps'] = CVr, s, e, d
         rec['r_fy'], rec['r_sig_out'], rec['r_depl'], rec['r_ct'], rec['r_nsteps'] = fy, so, dp, ct, ns
+        # epl_dot / C_tan as point functions on the same inputs: ONE principal-stress reduction each (material.py:1044-1047,
+        # 1079-1081), the normal taken w.r.t. the principal stresses -- sdim = 3 and, for comparison, the sdim = 6 material
+        rec['ed_pdot'] = np.array([m.epl_dot(s[i], e[i], CVr, d[i]) for i in range(len(s))])
+        rec['ed_ctan'] = np.array([m.C_tan(s[i], CVr, epl=e[i]).reshape(36) for i in range(len(s))])
+        rec['ed_pdot6'] = np.array([m6.epl_dot(s[i], e[i], CVr, d[i]) for i in range(len(s))])
+        rec['ed_ctan6'] = np.array([m6.C_tan(s[i], CVr, epl=e[i]).reshape(36) for i in range(len(s))])
     out = os.path.join(ROOT, 'tests', 'golden', 'princ_general.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, {k: v.shape for k, v in rec.items()})

@@ -680,14 +680,25 @@ class Material(object):
         yfun = self.calc_yf(sig + Cel @ deps, epl=epl)
         if yfun <= yf_tolerance:
             return np.zeros(6)
-        a = self.calc_fgrad(sig, epl=np.asarray(epl, dtype=float))
+        a = self._flow_normal(sig, epl)
         hh = a @ Cel @ a + self.khard
         return (a @ Cel @ deps / hh) * a
+
+    def _flow_normal(self, sig, epl=None):
+        """Normal of the flow rule as epl_dot / C_tan take it: calc_fgrad of the Voigt stress for sdim = 6; for sdim = 3 the
+        gradient w.r.t. the PRINCIPAL stresses in the normal Voigt rows, shear rows zero (material.py:1044-1047, 1079-1081) --
+        not calc_fgrad's form for a (6,) stress of such a material (see there)."""
+        if self.sdim == 3 and not (self.tresca or self.barlat):
+            s, _ = self._voigt(sig, 'calc_fgrad')
+            if not self.ML_yf:
+                self._no_flow_rule()
+            return self._load(ana=not self.ML_yf).fgrad(0, self._princ_rows(s))[0]
+        return self.calc_fgrad(sig) if epl is None else self.calc_fgrad(sig, epl=np.asarray(epl, dtype=float))
 
     def C_tan(self, sig, Cel, epl=None):
         """Continuum tangent stiffness (material.py:1057-1086)."""
         Cel = np.asarray(Cel, dtype=float)
-        a = self.calc_fgrad(np.asarray(sig, dtype=float))
+        a = self._flow_normal(np.asarray(sig, dtype=float))
         ca = Cel @ a
         return Cel - np.outer(ca, ca) / (a @ ca + self.khard)
 

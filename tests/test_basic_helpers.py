@@ -191,3 +191,31 @@ def test_fixture_fgrad_of_a_voigt_stress_is_the_mixed_form(pg):
                   ((h1 + h0) * sd[:, 1] - h0 * sd[:, 0] - h1 * sd[:, 2]) / (2. * seq) + d3,
                   ((h2 + h1) * sd[:, 2] - h2 * sd[:, 0] - h1 * sd[:, 1]) / (2. * seq) + d3], axis=1)
     assert np.max(np.abs(a - pg['fgrad6'][:, :3])) < 1e-13 and np.all(pg['fgrad6'][:, 3:] == 0.)
+
+
+@pytest.mark.gpu
+def test_gpu_epl_dot_and_c_tan_point_functions(pg):
+    """Material.epl_dot / C_tan (material.py:1009-1086) of the sdim = 3 and an sdim = 6 Hill material on 160 general states:
+    for sdim = 3 the flow normal is the gradient w.r.t. the PRINCIPAL stresses (one LAPACK-ordered reduction per call), not
+    calc_fgrad's form for a Voigt stress"""
+    import warnings
+    import pylabfea_amd as FE
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = hill3_material(pg)
+        m6 = FE.Material()
+        m6.elasticity(E=200.e3, nu=0.3)
+        m6.plasticity(sy=100., hill=list(pg['hill6']), khard=100., drucker=0.05, sdim=6)
+    CV, s, e, d = pg['r_CV'], pg['r_sig'], pg['r_epl'], pg['r_deps']
+    for mat, kp, kc in ((m, 'ed_pdot', 'ed_ctan'), (m6, 'ed_pdot6', 'ed_ctan6')):
+        npl = 0
+        for i in range(len(s)):
+            if np.any(np.isnan(pg[kp][i])) or np.any(np.isnan(pg[kc][i])):
+                continue          # zero stress: the reference divides 0 / 0 in calc_fgrad
+            p = mat.epl_dot(s[i], e[i], CV, d[i])
+            assert np.max(np.abs(p - pg[kp][i])) < 1e-13 + 1e-9 * np.max(np.abs(pg[kp][i]))
+            npl += bool(np.any(p != 0.))
+            if i % 4 == 0 and np.linalg.norm(s[i]) > 1.:
+                ct = mat.C_tan(s[i], CV, epl=e[i])
+                assert np.max(np.abs(ct.reshape(36) - pg[kc][i])) < 1e-9 * CV[0, 0]
+        assert npl > 70
