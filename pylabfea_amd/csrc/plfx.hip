@@ -180,6 +180,8 @@ struct plfx_ctx {
     // modulus of every element, kh_out / kh_touch what its response() left, wh_carry the value each material object holds now
     int hint_nx = 0, hint_ny = 0;   // the mesh came from plfx_set_mesh_structured (numbering known, no verification scans)
     bool hint_uniform = false;
+    double *colr = nullptr;         // [gx] relative column widths of a non-proportional laminate (else null), KOp::colr
+    double colr_ratio = 1.;
     int wh_mode = 1;           // 1 = sequential carry (default on one GPU), 0 = one modulus per material point
     double wh_carry[16] = {0};
     double *kh_out = nullptr, *kh_new = nullptr, *wh_snap_el = nullptr, *wh_snap_M = nullptr;
@@ -820,6 +822,7 @@ void free_mesh(plfx_ctx *c)
     dfree(c->mg_dev);
     dfree(c->dtab);
     dfree(c->Mop);
+    dfree(c->colr);
     c->grid_ok = false;
     c->val_valid = false;
     c->mg_tail = -1;
@@ -874,7 +877,7 @@ int march_env()
     static const int v = getenv("PLFX_MARCH") ? atoi(getenv("PLFX_MARCH")) : -1;
     return v;
 }
-bool march_pcg(const plfx_ctx *c) { return matfree(c) && march_env() != 0; }
+bool march_pcg(const plfx_ctx *c) { return matfree(c) && march_env() != 0 && !c->op.colr; }   // (the marching kernels know one cell shape)
 bool march_mg(const plfx_ctx *c)
 {
     if (!matfree(c) || march_env() == 0) return false;
@@ -887,9 +890,13 @@ bool tail_mf(const plfx_ctx *c)
 }
 
 // kernels templated on the operator form: <.., 1> matrix-free grid, <.., 0> block-ELL
+// (the first kernel argument is the operator: one with per-column widths takes instantiation 2)
+template <class... T> static inline bool first_op_columns(const KOp &o, const T &...) { return o.colr != nullptr; }
 #define LAUNCH_OP1(KERN, mf, grid, ...)                                                                        \
     do {                                                                                                       \
-        if (mf)                                                                                                \
+        if ((mf) && first_op_columns(__VA_ARGS__))                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<2>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
+        else if (mf)                                                                                           \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<1>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
         else                                                                                                   \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);        \
@@ -911,7 +918,9 @@ bool tail_mf(const plfx_ctx *c)
     } while (0)
 #define LAUNCH_OP2(KERN, A, mf, grid, ...)                                                                     \
     do {                                                                                                       \
-        if (mf)                                                                                                \
+        if ((mf) && first_op_columns(__VA_ARGS__))                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 2>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
+        else if (mf)                                                                                           \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 1>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
         else                                                                                                   \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<A, 0>), grid, dim3(BLOCK), 0, c->stream, __VA_ARGS__);     \
@@ -2640,11 +2649,44 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
     // coarse re-assembly and the matrix-free operator need one element shape.  Laminate meshes compute dx = LS[i]/nes[i]
     // per section (model.py:847), so nominally uniform sections can differ by an ulp: compare with a relative tolerance and
     // use element 0's shape for the operator tables (the strain operator keeps each class's own lx, ly).
-    if (known && !c->hint_uniform) return PLFX_OK;
-    for (int e = 1; e < c->nel_total && !known; e++)
-        if (std::fabs(c->hlxy[2 * (size_t)e] - c->hlxy[0]) > 1e-12 * std::fabs(c->hlxy[0]) ||
-            std::fabs(c->hlxy[2 * (size_t)e + 1] - c->hlxy[1]) > 1e-12 * std::fabs(c->hlxy[1]))
-            return PLFX_OK;
+    // Non-proportional laminates (round 5): nes[i] = round(NX LS[i] / lenx) elements per section leave the
+    // sections with slightly different dx (relative deviation <= 1 / (2 nes[i])), constant within a column; dy is one value.
+    // The KRYLOV operator of such a mesh is exact -- the matrix-free form with the width of every column relative to column 0
+    // (KOp::colr, instantiation 2 of the kernels; or the block-ELL matrix) -- while the V-cycle is the one of the UNIFORM grid
+    // with column 0's cell shape on the same generators: a symmetric positive definite preconditioner of a spectrally
+    // equivalent operator (element matrices within [1/r, r] of each other, r = widest / narrowest column), instead of no
+    // hierarchy at all (Jacobi-PCG: ~8 NX iterations per cold solve).  r <= 1.5 is accepted (larger ratios need sections of one or two elements: meshes too small to need a hierarchy).
+    dfree(c->colr);
+    c->colr = nullptr;
+    bool uniform = known && c->hint_uniform;
+    if (!uniform) {
+        uniform = true;
+        bool columns = true;
+        std::vector<double> cr(nx, 1.);
+        const double lx0 = c->hlxy[0], ly0 = c->hlxy[1];
+        double rmin = 1., rmax = 1.;
+        for (int e = 0; e < c->nel_total && columns; e++) {
+            const double lx = c->hlxy[2 * (size_t)e], ly = c->hlxy[2 * (size_t)e + 1];
+            const int j = e / ny;
+            if (std::fabs(ly - ly0) > 1e-12 * std::fabs(ly0)) columns = false;
+            if (e % ny == 0) {
+                cr[j] = (std::fabs(lx - lx0) > 1e-12 * std::fabs(lx0)) ? lx / lx0 : 1.;
+                if (cr[j] != 1.) uniform = false;
+                rmin = std::min(rmin, cr[j]);
+                rmax = std::max(rmax, cr[j]);
+            } else if (std::fabs(lx - c->hlxy[2 * (size_t)(j * ny)]) > 1e-12 * std::fabs(lx0))
+                columns = false;
+        }
+        if (!columns) return PLFX_OK;
+        if (!uniform) {
+            if (!(rmin > 0.) || rmax / rmin > 1.5) return PLFX_OK;
+            int rc0;
+            if ((rc0 = dalloc(c, &c->colr, (size_t)nx))) return rc0;
+            HIPCHK(c, hipMemcpyAsync(c->colr, cr.data(), (size_t)8 * nx, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, stream_sync(c));
+            c->colr_ratio = rmax / rmin;
+        }
+    }
     int rc;
     {   // geometry table of grid_apply: position p = pj*2+pk <-> element (j-1+pj, k-1+pk), in which node (j,k) has the
         // local number a = (1-pj)*2 + (1-pk) (connectivity order model.py:936-948)
@@ -2665,6 +2707,7 @@ int plfx_set_grid(plfx_ctx *c, int nx, int ny)
         HIPCHK(c, stream_sync(c));
         if ((rc = dalloc(c, &c->Mop, (size_t)6 * c->nel_total))) return rc;
         c->op = make_op(c, c->nnode, c->nslot, c->dcol, c->dval, nx, ny, c->nel_total, c->Mop);
+        c->op.colr = c->colr;
         c->grid_ok = true;
     }
     if ((rc = build_hierarchy(c, nx, ny, c->hcls[0]))) return rc;
@@ -2678,6 +2721,7 @@ int plfx_set_strip(plfx_ctx *c, int own_col0, int own_col1, int global_col0, int
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh / set_grid first") : PLFX_ERR_STATE;
     if (!c->grid_ok || !c->want_matfree || c->mg.size() < 2)
         return fail(c, PLFX_ERR_UNSUPPORTED, "a strip needs the uniform structured grid (matrix-free operator + multigrid)");
+    if (c->colr) return fail(c, PLFX_ERR_UNSUPPORTED, "a strip needs element columns of one width");
     const int nx = c->gx, ny = c->gy, Ld = coarse_level;
     // material state and sweeps: either the whole local mesh (halo elements swept redundantly) or exactly the owned columns
     // (el_begin / el_end of plfx_set_mesh; the generators of the halo columns then come from the neighbours: strip_sync_M)
@@ -3366,7 +3410,10 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     if (fext) HIPCHK(c, hipMemcpyAsync(c->fext, fext, 8 * nd, hipMemcpyHostToDevice, c->stream));
     if (c->bc_nrows > 0)  // K w on the few rows where it can be non-zero
     {
-        if (matfree(c))
+        if (matfree(c) && c->op.colr)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_rows<2>), dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                               c->stream, c->bc_nrows, c->bc_rows, c->op, (const double2 *)c->wv, (double2 *)c->kw);
+        else if (matfree(c))
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_rows<1>), dim3((c->bc_nrows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
                                c->stream, c->bc_nrows, c->bc_rows, c->op, (const double2 *)c->wv, (double2 *)c->kw);
         else

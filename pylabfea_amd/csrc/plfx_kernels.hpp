@@ -1285,6 +1285,10 @@ struct KOp {
     // 10.7).  The stiffness integrals of a cell of size (rx lx, ry ly): Sxx ~ ly / lx scales with ry / rx, Syy with rx / ry,
     // Sxy does not depend on the size.
     double rx = 1., ry = 1.;
+    // width of every element COLUMN relative to the column the tables were made for (non-proportional laminates: dx = LS[i] /
+    // nes[i] per section, model.py:826-847), or null; only the Krylov operator of such a mesh carries it (instantiation 2 of the
+    // kernels) -- its V-cycle runs on the operator of the uniform grid, DESIGN 10.8
+    const double *colr = nullptr;
 };
 
 // Coarsening of one direction of a level with n cells, the last of relative size r (all others 1):
@@ -1394,7 +1398,7 @@ __device__ __forceinline__ double2 grid_apply_g(int nxn, int nyn, int nel, const
 // kernels 12-27 % and doubled the single-workgroup tail: measured, profiles/r05m)
 template <bool RAGGED = false, class MF2, class XJK>
 __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel, const double *tab, int j, int k, MF2 mf2, XJK xjk,
-                                                       double rx = 1., double ry = 1.)
+                                                       double rx = 1., double ry = 1., const double *colr = nullptr)
 {
     const int nye = nyn - 1, nxe = nxn - 1;
     double2 u[3][3];
@@ -1444,7 +1448,8 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
                 A8 = fma(syx, ub.y, A8);
             }
             if (RAGGED) {   // a cell of the last column / row: Sxx ~ ly / lx, Syy ~ lx / ly
-                const double sx = (j - 1 + pj == nxe - 1) ? rx : 1., sy = (k - 1 + pk == nye - 1) ? ry : 1.;
+                const double sx = colr ? colr[min(max(j - 1 + pj, 0), nxe - 1)] : ((j - 1 + pj == nxe - 1) ? rx : 1.);
+                const double sy = (k - 1 + pk == nye - 1) ? ry : 1.;
                 const double f = sy / sx, fi = sx / sy;
                 A1 *= f;
                 A2 *= f;
@@ -1460,20 +1465,21 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
 
 template <bool RAGGED = false, class MF2, class XF>
 __device__ __forceinline__ double2 grid_apply_pairs(int nxn, int nyn, int nel, const double *tab, int i, MF2 mf2, XF xf,
-                                                    double rx = 1., double ry = 1.)
+                                                    double rx = 1., double ry = 1., const double *colr = nullptr)
 {
     const int j = i / nyn, k = i - j * nyn;
-    return grid_apply_pairs_jk<RAGGED>(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); }, rx, ry);
+    return grid_apply_pairs_jk<RAGGED>(nxn, nyn, nel, tab, j, k, mf2, [&](int jj, int kk) { return xf(jj * nyn + kk); }, rx, ry, colr);
 }
 
 template <bool RAGGED = false, class XF>
 __device__ __forceinline__ double2 grid_apply(const KOp &g, int i, XF xf)
 {
     const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
-    return grid_apply_pairs<RAGGED>(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf, g.rx, g.ry);
+    return grid_apply_pairs<RAGGED>(g.nxn, g.nyn, g.nel, g.tab, i, [&](int q) { return M2[q]; }, xf, g.rx, g.ry, RAGGED ? g.colr : nullptr);
 }
 
-// GRID: 0 block-ELL matrix, 1 matrix-free (all cells alike), 2 matrix-free on a level whose last column / row differs (KOp::rx, ry)
+// GRID: 0 block-ELL matrix, 1 matrix-free (all cells alike), 2 matrix-free with cell shape factors: a level whose last column /
+// row differs (KOp::rx, ry) or a fine grid with per-column widths (KOp::colr)
 template <int GRID, class XF>
 __device__ __forceinline__ double2 op_apply(const KOp &o, int i, XF xf)
 {
@@ -1633,8 +1639,8 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
                 double sxx = T[0], syy = T[1];
                 const double sxy = T[2], syx = T[3];
-                if (g.rx != 1. || g.ry != 1.) {   // (uniform per level) size of this cell, KOp::rx, ry
-                    const double csx = (ej == nxe - 1) ? g.rx : 1., csy = (ek == nye - 1) ? g.ry : 1.;
+                if (g.rx != 1. || g.ry != 1. || g.colr) {   // (uniform per level) size of this cell, KOp::rx, ry / colr
+                    const double csx = g.colr ? g.colr[ej] : ((ej == nxe - 1) ? g.rx : 1.), csy = (ek == nye - 1) ? g.ry : 1.;
                     sxx *= csy / csx;
                     syy *= csx / csy;
                 }

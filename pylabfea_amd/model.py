@@ -655,8 +655,9 @@ class Model(object):
         self._e0, self._e1 = e0, e1
         if self.Nel >= 65536 and eng.precond_info()[0] != 1 and self.precond is None:
             # correct but orders of magnitude slower: say so instead of silently falling back
-            warnings.warn('mesh of {} elements without a uniform structured grid hierarchy: the solve falls back to '
-                          'Jacobi-PCG on the assembled operator'.format(self.Nel))
+            warnings.warn('mesh of {} elements without a structured grid hierarchy (explicit element sizes, column widths more '
+                          'than 1.5 apart, or a grid too irregular to coarsen): the solve falls back to Jacobi-PCG on the assembled '
+                          'operator'.format(self.Nel))
         self._dev_coll = eng.comm_info()[2]  # RCCL communicator: scalars are all-reduced inside the library
         self._engine = eng
         self._mat_versions = vers

@@ -142,6 +142,49 @@ def test_large_mesh_with_odd_dimensions_gets_a_multigrid_hierarchy():
     assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))   # (both solves stop at rtol 1e-10)
 
 
+def test_large_non_proportional_laminate_gets_a_multigrid_hierarchy():
+    """320 x 256 elements in five sections of thickness 3:1:2:1:2 -- nes = round(NX LS / lenx) leaves the sections with
+    dx = 3/106, 1/36, 2/71 ... (model.py:826-847), a mesh that ran Jacobi-PCG on the assembled operator until round 5.  Now:
+    exact matrix-free operator with per-column widths (KOp::colr) under the V-cycle of the uniform grid (DESIGN 10.8).
+    Results equal the block-ELL operator (exact class shapes) + Jacobi-PCG path, with a fraction of its iterations."""
+    import warnings
+    import pylabfea_amd as FE
+
+    def run(precond, operator):
+        ma = FE.Material(num=1)
+        ma.elasticity(E=200.e3, nu=0.3)
+        ma.plasticity(sy=150., khard=500., sdim=6)
+        mb = FE.Material(num=2)
+        mb.elasticity(E=120.e3, nu=0.33)
+        mb.plasticity(sy=90., hill=[0.8, 1.1, 1.3, 1., 0.9, 1.2], khard=300., sdim=6)
+        fe = FE.Model(dim=2, planestress=True)
+        fe.precond, fe.operator = precond, operator
+        fe.geom([3, 1, 2, 1, 2], LY=9. * 256 / 320)
+        fe.assign([ma, mb, ma, mb, ma])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.004 * fe.leny, 'disp')
+        fe.mesh(NX=320, NY=256)
+        fe._max_load_steps = 9
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=20)
+        return fe, sum(q[0] for q in fe.solver_stats)
+
+    a, ita = run(None, None)
+    dx = a._grid['dx_col']
+    assert 1.005 < np.max(dx) / np.min(dx) < 1.1 and len(np.unique(np.round(dx, 12))) == 3
+    assert a._engine.precond_info()[0] == 1 and a._engine.precond_info()[1] >= 5 and a._engine.operator_info()[0] == 1
+    b, itb = run(0, 0)
+    assert b._engine.precond_info()[0] == 0 and b._engine.operator_info()[0] == 0
+    assert a.nsteps == b.nsteps and np.max(np.abs(a._state('epl'))) > 0.
+    assert ita < 0.1 * itb
+    assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(b.sgl))
+    assert np.max(np.abs(a.u - b.u)) < 1e-7 * np.max(np.abs(b.u))
+    assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))
+
+
 def test_facade_errors():
     import pylabfea_amd as FE
     m = FE.Material()

@@ -94,9 +94,12 @@ def test_assembled_matrix_plastic_state():
         assert abs(K - K.T).max() < 1e-11 * abs(Kref).max()
 
 
-def test_nonuniform_laminate_vs_oracle():
-    """Laminate with non-proportional sections (three element classes, no multigrid hierarchy ->
-    Jacobi-PCG) and two plastic materials against the oracle's sparse direct solve."""
+@pytest.mark.parametrize('NX,NY,mg', [(13, 6, 0), (52, 8, 1), (26, 12, 1)])
+def test_nonuniform_laminate_vs_oracle(NX, NY, mg):
+    """Laminate with non-proportional sections (three element classes: dx = LS[i] / nes[i] differs from section to section,
+    model.py:826-847) and two plastic materials against the oracle's sparse direct solve.  13 x 6: odd NX, no hierarchy
+    (Jacobi-PCG); 52 x 8 (column widths within 1.17 of each other) and 26 x 12 (1.33): the exact matrix-free operator with
+    per-column widths under the V-cycle of the uniform grid (round 5)"""
     import pylabfea_amd as FE
     from oracle.solve_ref import RefSolver
 
@@ -114,13 +117,15 @@ def test_nonuniform_laminate_vs_oracle():
         fe.bcbot(0.)
         fe.bcright(0., 'force')
         fe.bctop(0.004 * fe.leny, 'disp')
-        fe.mesh(NX=13, NY=6)
+        fe.mesh(NX=NX, NY=NY)
         return fe
     fe = build()
+    dx = fe._grid['dx_col']
+    assert np.max(dx) / np.min(dx) > 1.1
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         fe.solve(min_step=5)
-    assert fe._engine.precond_info()[0] == 0
+    assert fe._engine.precond_info()[0] == mg and fe._engine.operator_info()[0] == 1   # (matrix-free with per-column widths)
     ref = RefSolver(build()).solve(min_step=5)
     assert fe.nsteps == ref.nsteps and list(fe.niter) == list(ref.niter)
     s = np.max(np.abs(ref.sig))
