@@ -168,6 +168,9 @@ int plfx_set_grid(plfx_ctx *ctx, int nx, int ny);
  * (falls back to Jacobi when no hierarchy exists); omega <= 0 / nu <= 0 keep the defaults (0.65, 2) */
 int plfx_set_precond(plfx_ctx *ctx, int kind, double omega, int nu);
 int plfx_precond_info(plfx_ctx *ctx, int *kind_in_use, int *levels);
+/* z = B r: one application of the preconditioner of plfx_solve (the multigrid V-cycle) to a host vector [ndof], for tests of
+ * its symmetry / of what it does to a given field (single GPU, after plfx_assemble + plfx_apply_bc). */
+int plfx_precond_apply(plfx_ctx *ctx, const double *r, double *z);
 /* measurement hook (bench.py: `vcycle`): `reps` applications of the multigrid preconditioner back to back on the current
  * residual vector, one pair of HIP events around them -> microseconds per V-cycle; us_coarse (may be NULL): the part of a cycle
  * below the fine level (transfers to / from level 1, the launch-latency-bound levels, the single-workgroup tail).  Only scratch

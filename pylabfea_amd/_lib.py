@@ -52,7 +52,7 @@ SYMBOLS = [
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
-    'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch',
+    'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch', 'plfx_precond_apply',
 ]
 
 _lib = None
@@ -357,6 +357,13 @@ class Context(object):
         lv = C.c_int()
         self._chk(self.lib.plfx_precond_info(self.h, C.byref(k), C.byref(lv)))
         return k.value, lv.value
+
+    def precond_apply(self, r):
+        """one V-cycle applied to a host vector (tests)"""
+        r = _f64(r).reshape(-1)
+        z = np.empty_like(r)
+        self._chk(self.lib.plfx_precond_apply(self.h, _dp(r), _dp(z)))
+        return z
 
     def precond_bench(self, reps=100):
         """(microseconds per V-cycle, microseconds of it below the fine level) from `reps` back-to-back applications"""

@@ -2424,7 +2424,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     // a zero-stiffness ghost element beyond the edge (exact behind free edges, ~10x the iterations of the homogeneous plastic
     // workload behind a Dirichlet edge); lone narrow cells only (1025 cells: r = 1/2, 1/4, 1/8 ... slivers, 795 iterations).
     // Grids whose finest level is even keep the exact-halving rule.  PLFX_MG_ODD=0: never, 1: every odd level that is large.
-    static const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 2;
+    const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 2;   // (read per hierarchy: tests switch it)
     const bool finest_odd = ((nx | ny) & 1) && (long long)(nx + 1) * (ny + 1) > 150000 && c->want_matfree;
     std::vector<std::pair<double, double>> ratio;
     ratio.push_back({1., 1.});
@@ -2507,7 +2507,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
         if ((rc = dalloc(c, &L.b, (size_t)2 * L.nnode))) return rc;
         if (L.rx != 1. || L.ry != 1.) {
             // assembled form of such a level (coarsest level: dense inverse; tail levels when the matrix-free tail is not in use):
-            // four cell shapes, class id = (last column) + 2 (last row); Sxx ~ ly / lx, Syy ~ lx / ly, Sxy independent of the size
+            // four cell shapes, class id = (odd column, mg_odd_cell) + 2 (odd row); Sxx ~ ly / lx, Syy ~ lx / ly, Sxy independent of the size
             ClassDev h4[4];
             for (int q = 0; q < 4; q++) {
                 h4[q] = geom;
@@ -2520,7 +2520,7 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
             if ((rc = dalloc(c, &L.cls4, 4))) return rc;
             HIPCHK(c, hipMemcpyAsync(L.cls4, h4, sizeof(h4), hipMemcpyHostToDevice, c->stream));
             std::vector<int32_t> hc((size_t)L.nel);
-            for (int e = 0; e < L.nel; e++) hc[e] = ((e / L.ny == L.nx - 1) ? 1 : 0) + ((e % L.ny == L.ny - 1) ? 2 : 0);
+            for (int e = 0; e < L.nel; e++) hc[e] = ((e / L.ny == mg_odd_cell(L.nx)) ? 1 : 0) + ((e % L.ny == mg_odd_cell(L.ny)) ? 2 : 0);
             HIPCHK(c, hipMemcpyAsync(L.cls0, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, stream_sync(c));
         }
@@ -3032,6 +3032,20 @@ int plfx_indefinite_info(plfx_ctx *c, int64_t *solves, int64_t *by_minres_surrog
 // measurement hook: `reps` applications of the preconditioner (z = M^-1 r on whatever r holds) back to back, timed with one
 // pair of HIP events; *us_coarse = the same with the fine level's launches left out (levels >= 1 only: the restriction to
 // level 1, the launch-latency-bound levels, the single-workgroup tail, the prolongation to level 0).
+int plfx_precond_apply(plfx_ctx *c, const double *r, double *z)
+{
+    if (!c || !mg_active(c) || c->strip.on || !c->assembled || !r || !z)
+        return c ? fail(c, PLFX_ERR_STATE, "needs the multigrid hierarchy of a single-GPU solve, assembled") : PLFX_ERR_STATE;
+    HIPCHK(c, hipMemsetAsync(&c->sc->done, 0, sizeof(int), c->stream));  // the fine-level kernels are no-ops while it is set
+    HIPCHK(c, hipMemcpyAsync(c->r, r, (size_t)8 * c->ndof, hipMemcpyHostToDevice, c->stream));
+    const int rc = mg_vcycle(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(z, c->z, (size_t)8 * c->ndof, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, stream_sync(c));
+    c->memo.valid = false;   // (the work vectors of the last solve are gone)
+    return PLFX_OK;
+}
+
 int plfx_precond_bench(plfx_ctx *c, int reps, double *us_per_cycle, double *us_coarse)
 {
     if (!c || !mg_active(c) || c->strip.on) return c ? fail(c, PLFX_ERR_STATE, "needs the multigrid hierarchy of a single-GPU solve") : PLFX_ERR_STATE;

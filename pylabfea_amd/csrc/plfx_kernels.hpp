@@ -1292,22 +1292,63 @@ struct KOp {
 };
 
 // Coarsening of one direction of a level with n cells, the last of relative size r (all others 1):
-//   n even           pairs; the last coarse cell has children (1, r)                       -> n / 2 cells,       r' = (1 + r) / 2
-//   n odd, r >= 1    pairs + the lone last cell                                            -> (n + 1) / 2 cells, r' = r / 2
-//   n odd, r <  1    pairs, the last coarse cell takes THREE children (1, 1, r)             -> (n - 1) / 2 cells, r' = (2 + r) / 2
-// so that r stays in [1/2, 3/2) on every level (a lone narrow cell halved again and again would end as a sliver: measured,
-// 1025 cells: 795 instead of ~230 PCG iterations).  The last node line of every level is the edge of the grid.
-__host__ __device__ __forceinline__ int mg_coarse_cells(int n, double r) { return (n & 1) ? (r >= 1. ? (n + 1) >> 1 : (n - 1) >> 1) : n >> 1; }
+//   n even    pairs; the last coarse cell has children (1, r)                      -> n / 2 cells,       r' = (1 + r) / 2
+//   n odd     pairs, the last coarse cell takes THREE children (1, 1, r)           -> (n - 1) / 2 cells, r' = (2 + r) / 2
+// so that r stays in [1, 2) on every level: the odd cell is never NARROWER than the others.  (Until the end of round 5 an odd
+// level with r >= 1 kept its last cell alone, r' = r / 2 in [1/2, 3/4): fewer iterations on random fields, but a cell narrower
+// than its neighbours makes the area-scaled smoothing diagonal of k_grid_setup SMALLER than the true one -- not a stable
+// Jacobi scaling -- and that diagonal is what keeps the homogeneous workload's error fields in their invariant subspace, see
+// there.  PLFX_MG_ODD_RULE=0 at compile time restores the old rule.)  The last node line of every level is the edge of the grid.
+#ifndef PLFX_MG_ODD_RULE
+#define PLFX_MG_ODD_RULE 1
+#endif
+__host__ __device__ __forceinline__ bool mg_odd_triple(int n, double r) { return (n & 1) && (PLFX_MG_ODD_RULE || r < 1.); }
+__host__ __device__ __forceinline__ int mg_coarse_cells(int n, double r) { return (n & 1) ? (mg_odd_triple(n, r) ? (n - 1) >> 1 : (n + 1) >> 1) : n >> 1; }
 __host__ __device__ __forceinline__ double mg_coarse_ratio(int n, double r)
 {
-    return (n & 1) ? (r >= 1. ? 0.5 * r : 0.5 * (2. + r)) : 0.5 * (1. + r);
+    return (n & 1) ? (mg_odd_triple(n, r) ? 0.5 * (2. + r) : 0.5 * r) : 0.5 * (1. + r);
 }
+// WHICH cell of a direction is the one of the other size: the LAST one (default), or -- PLFX_MG_RAGGED_FIRST=1 at compile
+// time -- the first, by mirroring every index (node j <-> n - j, cell e <-> n - 1 - e).  Built to test whether the odd cell
+// hurts because it lies next to the loaded edge (the reference's solve loop increments the right / top displacements only,
+// model.py:1296-1312): it does not -- 128 x 127 under tension in y costs 227 PCG iterations with the odd row at the top and 226
+// with it at the bottom (128 x 128: 28); what matters is the smoothing diagonal, see k_grid_setup.  Kept as a knob.
+#ifndef PLFX_MG_RAGGED_FIRST
+#define PLFX_MG_RAGGED_FIRST 0
+#endif
+__host__ __device__ __forceinline__ int mg_odd_cell(int n) { return PLFX_MG_RAGGED_FIRST ? 0 : n - 1; }
+__host__ __device__ __forceinline__ int mg_fine_node_last(int J, int n, double r) { return J == mg_coarse_cells(n, r) ? n : 2 * J; }
 // fine node of this level that coarse node J coincides with
-__host__ __device__ __forceinline__ int mg_fine_node(int J, int n, double r) { return J == mg_coarse_cells(n, r) ? n : 2 * J; }
+__host__ __device__ __forceinline__ int mg_fine_node(int J, int n, double r)
+{
+    if (!PLFX_MG_RAGGED_FIRST) return mg_fine_node_last(J, n, r);
+    return n - mg_fine_node_last(mg_coarse_cells(n, r) - J, n, r);
+}
+__host__ __device__ __forceinline__ void mg_tr1d_last(int j, int n, double r, int &J0, double &w0, double &w1);
 // 1-d transfer stencil (bilinear interpolation): fine node j takes w0 of coarse node J0 and w1 of J0 + 1
 __host__ __device__ __forceinline__ void mg_tr1d(int j, int n, double r, int &J0, double &w0, double &w1)
 {
-    const bool odd = n & 1, triple = odd && r < 1.;
+    if (!PLFX_MG_RAGGED_FIRST) {
+        mg_tr1d_last(j, n, r, J0, w0, w1);
+        return;
+    }
+    int Jm;
+    double a0, a1;
+    mg_tr1d_last(n - j, n, r, Jm, a0, a1);   // mirrored: coarse nodes nc - Jm (a0) and nc - Jm - 1 (a1)
+    const int nc = mg_coarse_cells(n, r);
+    if (a1 == 0.) {
+        J0 = nc - Jm;
+        w0 = 1.;
+        w1 = 0.;
+    } else {
+        J0 = nc - Jm - 1;
+        w0 = a1;
+        w1 = a0;
+    }
+}
+__host__ __device__ __forceinline__ void mg_tr1d_last(int j, int n, double r, int &J0, double &w0, double &w1)
+{
+    const bool odd = n & 1, triple = mg_odd_triple(n, r);
     if (j == n) {                       // the edge: last coarse node
         J0 = mg_coarse_cells(n, r);
         w0 = 1.;
@@ -1448,8 +1489,8 @@ __device__ __forceinline__ double2 grid_apply_pairs_jk(int nxn, int nyn, int nel
                 A8 = fma(syx, ub.y, A8);
             }
             if (RAGGED) {   // a cell of the last column / row: Sxx ~ ly / lx, Syy ~ lx / ly
-                const double sx = colr ? colr[min(max(j - 1 + pj, 0), nxe - 1)] : ((j - 1 + pj == nxe - 1) ? rx : 1.);
-                const double sy = (k - 1 + pk == nye - 1) ? ry : 1.;
+                const double sx = colr ? colr[min(max(j - 1 + pj, 0), nxe - 1)] : ((j - 1 + pj == mg_odd_cell(nxe)) ? rx : 1.);
+                const double sy = (k - 1 + pk == mg_odd_cell(nye)) ? ry : 1.;
                 const double f = sy / sx, fi = sx / sy;
                 A1 *= f;
                 A2 *= f;
@@ -1639,10 +1680,25 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
                 double sxx = T[0], syy = T[1];
                 const double sxy = T[2], syx = T[3];
-                if (g.rx != 1. || g.ry != 1. || g.colr) {   // (uniform per level) size of this cell, KOp::rx, ry / colr
-                    const double csx = g.colr ? g.colr[ej] : ((ej == nxe - 1) ? g.rx : 1.), csy = (ek == nye - 1) ? g.ry : 1.;
-                    sxx *= csy / csx;
-                    syy *= csx / csy;
+                if (g.colr) {   // per-column widths of the finest grid: the true diagonal
+                    const double csx = g.colr[ej];
+                    sxx /= csx;
+                    syy *= csx;
+                } else if (g.rx != 1. || g.ry != 1.) {
+                    // Coarse level whose last column / row has another size: NOT the true diagonal (Sxx ~ csy / csx, Syy ~ csx /
+                    // csy) but every cell's contribution scaled with its AREA.  A field that is uniform along y has the residual
+                    // h_k (A_x u)(x) at row k (h_k = tributary height), and only a scaling M_k ~ h_k keeps the damped-Jacobi
+                    // sweep u + omega M^-1 r uniform along y -- the true diagonal a h_k + b (1 / h_below + 1 / h_above) / 2 is
+                    // not.  The homogeneous workload lives on that: a tangent update changes its solution by the linear field
+                    // (beta X, 0), the whole PCG iteration stays in the fields that are uniform along y and converges in 5-7
+                    // steps; with the true diagonal on a level with an odd row the first V-cycle scatters the error over the
+                    // soft modes of the plastic tangent and the same solve takes 26-60 (measured from the host with
+                    // plfx_precond_apply, tools/probes/vcycle_pcg_host.py: 128 x 128 7, 128 x 127 60+, 127 x 128 7 iterations).
+                    // Cells are never narrower than their neighbours (mg_coarse_ratio: r in [1, 2)), so this scaling is >= the
+                    // true diagonal (stable, over-damped by <= r at the nodes of the odd cells only).
+                    const double csx = (ej == mg_odd_cell(nxe)) ? g.rx : 1., csy = (ek == mg_odd_cell(nye)) ? g.ry : 1.;
+                    sxx *= PLFX_MG_ODD_RULE ? csx * csy : csy / csx;
+                    syy *= PLFX_MG_ODD_RULE ? csx * csy : csx / csy;
                 }
                 double Mxx, Mxy, Mxs, Myy, Mys, Mss;
                 if (SRC_PAIR) {
@@ -1667,8 +1723,16 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
             }
         diag[i] = make_double2(dx, dy);
         if (dinv) {
-            // (interior node lines of a level are node lines j << level of the finest grid, its last line is the edge)
-            const int mj = (j == nxe) ? mask_nxn - 1 : min(j << shift, mask_nxn - 1), mk = (k == nye) ? mask_nyn - 1 : min(k << shift, mask_nyn - 1);
+            // (interior node lines of a level are node lines j << level of the finest grid counted from the side of the regular
+            // cells, the line beyond the odd cell is the edge)
+            int mj, mk;
+            if (PLFX_MG_RAGGED_FIRST) {
+                mj = (j == 0) ? 0 : max(mask_nxn - 1 - ((nxe - j) << shift), 0);
+                mk = (k == 0) ? 0 : max(mask_nyn - 1 - ((nye - k) << shift), 0);
+            } else {
+                mj = (j == nxe) ? mask_nxn - 1 : min(j << shift, mask_nxn - 1);
+                mk = (k == nye) ? mask_nyn - 1 : min(k << shift, mask_nyn - 1);
+            }
             const double2 df = mask_dinv[(size_t)mj * mask_nyn + mk];
             double2 o;
             o.x = (df.x != 0.) ? (fabs(dx) > 1e-300 ? 1. / fabs(dx) : 1.) : 0.;

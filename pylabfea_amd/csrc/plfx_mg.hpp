@@ -360,12 +360,15 @@ k_mg_coarsen_M(int nxc, int nyc, int nyf, int nel_f, const double *__restrict__ 
                             M_f[gen_index(pair_f, c, nel_f, e10)] + M_f[gen_index(pair_f, c, nel_f, e10 + 1)]);
             continue;
         }
-        // children columns [2J, jend) and rows [2K, kend): the last coarse cell of a direction takes what is left
-        const int jend = (J == nxc - 1) ? nxf : 2 * J + 2, kend = (K == nyc - 1) ? nyf : 2 * K + 2;
+        // children columns [2J, jend) and rows [2K, kend) counted from the side of the regular cells: the coarse cell at the
+        // other end takes what is left (mg_odd_cell)
+        const int Jm = PLFX_MG_RAGGED_FIRST ? nxc - 1 - J : J, Km = PLFX_MG_RAGGED_FIRST ? nyc - 1 - K : K;
+        const int jend = (Jm == nxc - 1) ? nxf : 2 * Jm + 2, kend = (Km == nyc - 1) ? nyf : 2 * Km + 2;
         double acc[6] = {0., 0., 0., 0., 0., 0.}, wsum = 0.;
-        for (int jf = 2 * J; jf < jend; jf++)
-            for (int kf = 2 * K; kf < kend; kf++) {
-                const double w = ((jf == nxf - 1) ? rxf : 1.) * ((kf == nyf - 1) ? ryf : 1.);
+        for (int jm = 2 * Jm; jm < jend; jm++)
+            for (int km = 2 * Km; km < kend; km++) {
+                const int jf = PLFX_MG_RAGGED_FIRST ? nxf - 1 - jm : jm, kf = PLFX_MG_RAGGED_FIRST ? nyf - 1 - km : km;
+                const double w = ((jf == mg_odd_cell(nxf)) ? rxf : 1.) * ((kf == mg_odd_cell(nyf)) ? ryf : 1.);
                 const size_t e = (size_t)jf * nyf + kf;
 #pragma unroll
                 for (int c = 0; c < 6; c++) acc[c] = fma(w, M_f[gen_index(pair_f, c, nel_f, e)], acc[c]);

@@ -105,26 +105,26 @@ def test_single_element_model_and_force_bc():
 
 
 def test_large_mesh_with_odd_dimensions_gets_a_multigrid_hierarchy():
-    """401 x 399 elements (Model.mesh accepts any NX, NY, model.py:758-952): no exact halving; since round 5 the hierarchy has
-    ceil(n / 2) elements per level with a zero-stiffness ghost element beyond the odd edge.  The preconditioner
-    only changes the iteration count: results equal the Jacobi-PCG / assembled-operator path of the same library, with a
-    fraction of its iterations."""
+    """401 x 399 elements (Model.mesh accepts any NX, NY, model.py:758-952): no exact halving; since round 5 every level covers
+    the grid with cells of one size and a wider last column / row (three children), smoothed with an area-scaled diagonal
+    (DESIGN 10.7).  The preconditioner only changes the iteration count: results equal the Jacobi-PCG / assembled-operator path
+    of the same library, with a fraction of its iterations -- and at most 1.5x those of the even neighbour 400 x 400."""
     import warnings
     import pylabfea_amd as FE
 
-    def run(precond, operator):
+    def run(precond, operator, nx=401, ny=399):
         m = FE.Material()
         m.elasticity(E=200.e3, nu=0.3)
         m.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
         fe = FE.Model(dim=2, planestress=False)
         fe.precond, fe.operator = precond, operator
-        fe.geom([4.], LY=4. * 399 / 401)
+        fe.geom([4.], LY=4. * ny / nx)
         fe.assign([m])
         fe.bcleft(0.)
         fe.bcbot(0.)
         fe.bcright(0., 'force')
         fe.bctop(0.004 * fe.leny, 'disp')
-        fe.mesh(NX=401, NY=399)
+        fe.mesh(NX=nx, NY=ny)
         fe._max_load_steps = 4
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -140,6 +140,54 @@ def test_large_mesh_with_odd_dimensions_gets_a_multigrid_hierarchy():
     assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(b.sgl))
     assert np.max(np.abs(a.u - b.u)) < 1e-7 * np.max(np.abs(b.u))
     assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))   # (both solves stop at rtol 1e-10)
+    e, ite = run(None, None, 400, 400)
+    assert e._engine.precond_info()[0] == 1 and list(e.niter) == list(a.niter)
+    assert ita <= 1.5 * ite + 4
+
+
+def test_vcycle_is_symmetric_and_keeps_uniform_fields_uniform():
+    """plfx_precond_apply (one V-cycle on a host vector) on a mesh with an odd number of rows: the cycle is a symmetric operator
+    (<a, B b> = <b, B a>), and it maps a residual that is uniform along y onto a correction that is uniform along y -- the
+    invariant subspace the homogeneous workload's solves live in; the area-scaled smoothing diagonal of the levels with a row of
+    another height keeps it (with the true diagonal the answer varies by tens of per cent from row to row)."""
+    import warnings
+    import pylabfea_amd as FE
+    nx, ny = 96, 95
+    m = FE.Material()
+    m.elasticity(E=200.e3, nu=0.3)
+    m.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+    fe = FE.Model(dim=2, planestress=False)
+    fe.geom([4.], LY=4. * ny / nx)
+    fe.assign([m])
+    fe.bcleft(0.)
+    fe.bcbot(0.)
+    fe.bcright(0., 'force')
+    fe.bctop(0.005 * fe.leny, 'disp')
+    fe.mesh(NX=nx, NY=ny)
+    fe._max_load_steps = 9
+    os.environ['PLFX_MG_ODD'] = '1'
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=50)
+    finally:
+        del os.environ['PLFX_MG_ODD']
+    eng = fe._engine
+    assert eng.precond_info()[0] == 1 and np.max(np.abs(fe._state('epl'))) > 0.
+    free = np.zeros(fe.Ndof)
+    free[np.asarray(fe.free_dofs())] = 1.
+    rng = np.random.default_rng(3)
+    a, b = free * rng.standard_normal(fe.Ndof), free * rng.standard_normal(fe.Ndof)
+    s1, s2 = a @ eng.precond_apply(b), b @ eng.precond_apply(a)
+    assert abs(s1 - s2) < 1e-12 * max(abs(s1), abs(s2))
+    g = np.zeros((nx + 1, ny + 1, 2))
+    g[:, :, 0] = np.arange(nx + 1)[:, None] / nx          # u_x = X / L, u_y = 0: what a tangent update changes
+    e = free * g.ravel()
+    r = free * eng.matvec(e)
+    z = (free * eng.precond_apply(r)).reshape(nx + 1, ny + 1, 2)
+    zx = z[:, 1:ny, 0]                                    # interior rows (the two edge rows carry the shear coupling of the edges)
+    spread = np.max(np.abs(zx - zx[:, [ny // 2]]), axis=1)
+    assert np.max(spread) < 1e-8 * np.max(np.abs(zx))     # (measured: 1.3e-10)
 
 
 def test_large_non_proportional_laminate_gets_a_multigrid_hierarchy():
