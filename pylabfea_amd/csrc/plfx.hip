@@ -2423,8 +2423,11 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     // (elastic cold solves: 11-12 PCG iterations on 512 x 511 / 511 x 512 / 512 x 512 alike).  Two earlier versions, measured:
     // a zero-stiffness ghost element beyond the edge (exact behind free edges, ~10x the iterations of the homogeneous plastic
     // workload behind a Dirichlet edge); lone narrow cells only (1025 cells: r = 1/2, 1/4, 1/8 ... slivers, 795 iterations).
-    // Grids whose finest level is even keep the exact-halving rule.  PLFX_MG_ODD=0: never, 1: every odd level that is large.
-    const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 2;   // (read per hierarchy: tests switch it)
+    // PLFX_MG_ODD=0: never (exact halving only, Chebyshev / Jacobi below an odd level), 1 (default since the area-scaled smoothing
+    // diagonal): every level that cannot be halved and is too large for the dense coarse solve is coarsened this way --
+    // also the odd coarse levels of even meshes (1000^2 -> 125^2: 6.0 -> 2.5 ms per load step of the config-3 workload instead of a
+    // Chebyshev solve there), 2: only hierarchies whose FINEST grid is odd and large (the default until then).
+    const int odd_mode = getenv("PLFX_MG_ODD") ? atoi(getenv("PLFX_MG_ODD")) : 1;   // (read per hierarchy: tests switch it)
     const bool finest_odd = ((nx | ny) & 1) && (long long)(nx + 1) * (ny + 1) > 150000 && c->want_matfree;
     std::vector<std::pair<double, double>> ratio;
     ratio.push_back({1., 1.});
