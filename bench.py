@@ -591,7 +591,7 @@ def config5_leg(FE, _lib, torch, dist, rank, world, local, host_transport, n, K=
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
-        return cpu_worker(sys.argv[2:8])
+        return cpu_worker(sys.argv[2:9])
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
