@@ -434,18 +434,20 @@ def roofline_2048(FE, _lib, device=0, n=2048, K=4, W=1):
 def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0):
     """The bench workload (config 3 material / loading / schedule) on an n x n mesh, wall-clock of the load steps
     pre+W+pre_extra .. +K, optionally with the unchanged-input reuse switched off (PLFX_REUSE is read when the engine is created)."""
-    old = os.environ.get('PLFX_REUSE')
-    if not reuse:
+    old = {k: os.environ.get(k) for k in ('PLFX_REUSE', 'PLFX_PREDICT')}
+    if not reuse:   # (and every solve from the plain warm start, whatever PLFX_PREDICT says)
         os.environ['PLFX_REUSE'] = '0'
+        os.environ['PLFX_PREDICT'] = '0'
     try:
         fe = tension_model(FE, hill_material(FE), n, 0.005, device=device)
         eng = fe._ensure_engine()
     finally:
         if not reuse:
-            if old is None:
-                del os.environ['PLFX_REUSE']
-            else:
-                os.environ['PLFX_REUSE'] = old
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
     ninc, pre = schedule(K, W + pre_extra)
     marks = {}
     first = pre + W + pre_extra
@@ -857,6 +859,9 @@ def main():
         # were therefore not recomputed (plfx_reuse_info; PLFX_REUSE=0 recomputes them) -- included in 'solves' above
         'unchanged_inputs_reused': dict(zip(('assemblies', 'bc_applications', 'solves'),
                                             [int(b - a) for a, b in zip(marks['ru0'], marks['ru1'])])),
+        # warm-started solves whose initial guess was the residual-minimising combination of the last two solutions instead of the
+        # last one alone (plfx_predict_info; an experiment that is OFF unless PLFX_PREDICT=1, DESIGN 10.9: zeros in a default run)
+        'initial_guess_from_two_solutions': dict(zip(('applied', 'skipped'), eng.predict_info())),
         'solves_completed_by_fallback_solver': int(eng.solve_fallbacks()),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),

@@ -52,7 +52,7 @@ SYMBOLS = [
     'plfx_load_step', 'plfx_set_strip', 'plfx_strip_info', 'plfx_allreduce_host',
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
-    'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch', 'plfx_precond_apply',
+    'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch', 'plfx_precond_apply', 'plfx_predict_info',
 ]
 
 _lib = None
@@ -348,6 +348,12 @@ class Context(object):
         a, b, s = C.c_int(), C.c_int(), C.c_int()
         self._chk(self.lib.plfx_reuse_info(self.h, C.byref(a), C.byref(b), C.byref(s)))
         return a.value, b.value, s.value
+
+    def predict_info(self):
+        """(applied, skipped): warm-started solves whose initial guess came from the last two solutions"""
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_predict_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_precond(self, kind, omega=0., nu=0):
         self._chk(self.lib.plfx_set_precond(self.h, int(kind), C.c_double(omega), int(nu)))

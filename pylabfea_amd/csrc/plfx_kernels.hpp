@@ -2207,6 +2207,49 @@ k_x0(size_t ndof, const double *__restrict__ du, const double *__restrict__ is_p
         x[i] = (warm && is_presc[i] == 0.) ? scale * du[i] : 0.;
 }
 
+// ---- initial guess of a warm-started solve from the last two solutions (plfx_solve)
+// d = x - xprev, xprev = x   (x = the solution of the previous solve, xprev = the one before)
+__global__ void __launch_bounds__(BLOCK)
+k_pred_diff(size_t ndof, const double *__restrict__ x, double *__restrict__ xprev, double *__restrict__ d)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        const double xi = x[i];
+        d[i] = xi - xprev[i];
+        xprev[i] = xi;
+    }
+}
+
+// the five sums of the 2 x 2 least-squares problem  min | P (b - beta K x - alpha K d) |  over the free DOFs:
+// part[0..4][block] = kx.kx, kx.kd, kd.kd, kx.b, kd.b
+__global__ void __launch_bounds__(BLOCK)
+k_pred_dots(size_t ndof, const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ kx,
+            const double *__restrict__ kd, double *__restrict__ part)
+{
+    __shared__ double sh[BLOCK / 64];
+    double a[5] = {0., 0., 0., 0., 0.};
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        if (dinv[i] == 0.) continue;
+        const double u = kx[i], v = kd[i], bi = b[i];
+        a[0] = fma(u, u, a[0]);
+        a[1] = fma(u, v, a[1]);
+        a[2] = fma(v, v, a[2]);
+        a[3] = fma(u, bi, a[3]);
+        a[4] = fma(v, bi, a[4]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double t = block_sum(a[k], sh);
+        if (threadIdx.x == 0) part[(size_t)k * MAXPART + blockIdx.x] = t;
+    }
+}
+
+// x = beta x + alpha d
+__global__ void __launch_bounds__(BLOCK)
+k_pred_combine(size_t ndof, double beta, double alpha, double *__restrict__ x, const double *__restrict__ d)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) x[i] = fma(beta, x[i], alpha * d[i]);
+}
+
 // u += du ; f += q  (q = K du)     (model.py:1383-1384)
 __global__ void __launch_bounds__(BLOCK)
 k_axpy_uf(size_t ndof, const double *__restrict__ du, const double *__restrict__ q, double *__restrict__ u, double *__restrict__ f)

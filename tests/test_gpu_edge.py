@@ -233,6 +233,42 @@ def test_large_non_proportional_laminate_gets_a_multigrid_hierarchy():
     assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))
 
 
+def test_two_solution_initial_guess_is_an_opt_in_experiment(monkeypatch):
+    """PLFX_PREDICT=1: warm-started multigrid solves start from the residual-minimal combination of the last two
+    solutions.  Off by default (plfx_predict_info reports zeros); switched on it needs fewer PCG iterations on the homogeneous
+    workload and gives the same fields to a few solver tolerances -- the reason it is not the default is the margin of the
+    sensitive traces, not this one."""
+    import warnings
+    import pylabfea_amd as FE
+
+    def run(on):
+        monkeypatch.setenv('PLFX_PREDICT', '1' if on else '0')
+        m = FE.Material()
+        m.elasticity(E=200.e3, nu=0.3)
+        m.plasticity(sy=100., hill=[0.7, 1., 1.4, 1., 1.2, 0.8], khard=100., sdim=6)
+        fe = FE.Model(dim=2, planestress=False)
+        fe.geom([4.], LY=4.)
+        fe.assign([m])
+        fe.bcleft(0.)
+        fe.bcbot(0.)
+        fe.bcright(0., 'force')
+        fe.bctop(0.005 * fe.leny, 'disp')
+        fe.mesh(NX=256, NY=256)
+        fe._max_load_steps = 16
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(min_step=50)
+        return fe, sum(q[0] for q in fe.solver_stats), fe._engine.predict_info()
+    a, ita, pa = run(False)
+    b, itb, pb = run(True)
+    monkeypatch.delenv('PLFX_PREDICT')
+    assert pa == (0, 0) and pb[0] >= 5
+    assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter)
+    assert itb < ita
+    assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(a.sgl))
+    assert np.max(np.abs(a.u - b.u)) < 1e-7 * np.max(np.abs(a.u))
+
+
 def test_facade_errors():
     import pylabfea_amd as FE
     m = FE.Material()
