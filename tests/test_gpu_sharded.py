@@ -57,6 +57,13 @@ def build(case, golden_dir):
         fe.geom([4.], LY=4.)
         fe.assign([mat])
         n, eps, ms = 12, 0.003, 8
+    elif case == 'laminate_np':     # non-proportional laminate: per-column widths, multigrid of the uniform grid
+        mb = FE.Material(num=2)
+        mb.elasticity(E=120.e3, nu=0.33)
+        mb.plasticity(sy=90., hill=[0.8, 1.1, 1.3, 1., 0.9, 1.2], khard=300., sdim=6)
+        fe.geom([2, 1, 2, 1, 2], LY=4.)
+        fe.assign([mat, mb, mat, mb, mat])
+        n, eps, ms = 52, 0.003, 6
     elif case == 'inclusion':       # heterogeneous: strips see different branches
         soft = FE.Material(num=2)
         soft.elasticity(E=1.e3, nu=0.27)
@@ -83,6 +90,8 @@ def build(case, golden_dir):
         fe.mesh(elmts=el, NX=n, NY=n)
     elif case == 'hill6_12':
         fe.mesh(NX=n, NY=n)
+    elif case == 'laminate_np':
+        fe.mesh(NX=n, NY=8)
     else:
         fe.mesh(NX=n, NY=8)
     return fe, ms
@@ -117,7 +126,7 @@ def _worker(rank, world, port, case, golden_dir, q, mode='replicated', level=Non
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case,world', [('hill6_12', 2), ('inclusion', 3), ('laminate_svc', 2)])
+@pytest.mark.parametrize('case,world', [('hill6_12', 2), ('inclusion', 3), ('laminate_svc', 2), ('laminate_np', 2)])
 def test_sharded_ranks_on_one_gpu(golden_dir, case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
@@ -137,6 +146,8 @@ def test_sharded_ranks_on_one_gpu(golden_dir, case, world):
         fe.solve(min_step=ms)
     sig1, epl1 = fe._state('sig'), fe._state('epl')
     assert np.max(epl1) > 0.
+    if case == 'laminate_np':
+        assert fe._engine.precond_info()[0] == 1 and np.ptp(fe._grid['dx_col']) > 0.01 * np.mean(fe._grid['dx_col'])
     for r in range(world):
         d = res[r]
         assert d['native']                                    # the native load step ran with device-side collectives
