@@ -860,7 +860,7 @@ def main():
         'unchanged_inputs_reused': dict(zip(('assemblies', 'bc_applications', 'solves'),
                                             [int(b - a) for a, b in zip(marks['ru0'], marks['ru1'])])),
         # warm-started solves whose initial guess was the residual-minimising combination of the last two solutions instead of the
-        # last one alone (plfx_predict_info; an experiment that is OFF unless PLFX_PREDICT=1, DESIGN 10.9: zeros in a default run)
+        # last one alone (plfx_predict_info; PLFX_PREDICT=0 switches it off; single GPU, multigrid solves); whole run
         'initial_guess_from_two_solutions': dict(zip(('applied', 'skipped'), eng.predict_info())),
         'solves_completed_by_fallback_solver': int(eng.solve_fallbacks()),
         'roofline': roof(dominant),

@@ -212,11 +212,11 @@ int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free)
  * iterations (the reference repeats the last solve of a load step as predictor and first stiffness iteration of the next,
  * model.py:1291/1335).  Counters of the three cases since plfx_create. */
 int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *solves);
-/* EXPERIMENT, off by default (environment PLFX_PREDICT=1 at plfx_create; single GPU): initial guess of a warm-started solve
- * from the last two solutions -- with x the previous solution and d its difference to the one before, plfx_solve(warm=1) starts
- * from the beta x + alpha d of smallest residual | P (b - K (beta x + alpha d)) | while solves are cheap (multigrid-PCG, previous
- * solve <= 8 iterations) and runs such a solve to rtol / 10.  -28 % per load step of the homogeneous workload, but the parity
- * margins of the sensitive traces do not survive it.  applied / skipped (degenerate 2 x 2 system) since plfx_create. */
+/* Initial guess of a warm-started solve from the last two solutions (environment PLFX_PREDICT=0 at plfx_create switches it off):
+ * with x the previous solution and d its difference to the one before, plfx_solve(warm=1) starts from x + alpha d with the alpha in
+ * [0, 1] of smallest residual | P (b - K (x + alpha d)) | -- while solves are cheap (multigrid-PCG, previous computed solve <= 8
+ * iterations), on meshes of >= 16384 nodes, single GPU.  The solution is the one of the same system to the same tolerance; x itself is
+ * never rescaled.  applied / skipped (alpha = 0) since plfx_create. */
 int plfx_predict_info(plfx_ctx *ctx, int64_t *applied, int64_t *skipped);
 /* Sweeps since plfx_create and the number of element tangents they rewrote (model.py:1346-1355: a tangent is stored, and
  * Kel refreshed, only where it changed by more than 1e-3) -- whole mesh in sharded runs.  A sweep moves 412 B per element

@@ -2219,35 +2219,36 @@ k_pred_diff(size_t ndof, const double *__restrict__ x, double *__restrict__ xpre
     }
 }
 
-// the five sums of the 2 x 2 least-squares problem  min | P (b - beta K x - alpha K d) |  over the free DOFs:
-// part[0..4][block] = kx.kx, kx.kd, kd.kd, kx.b, kd.b
+// partials of (K d) . (b - K x) and (K d) . (K d) over the free DOFs: the step alpha that minimises | P (b - K (x + alpha d)) |
 __global__ void __launch_bounds__(BLOCK)
 k_pred_dots(size_t ndof, const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ kx,
             const double *__restrict__ kd, double *__restrict__ part)
 {
     __shared__ double sh[BLOCK / 64];
-    double a[5] = {0., 0., 0., 0., 0.};
+    double a0 = 0., a1 = 0.;
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
         if (dinv[i] == 0.) continue;
-        const double u = kx[i], v = kd[i], bi = b[i];
-        a[0] = fma(u, u, a[0]);
-        a[1] = fma(u, v, a[1]);
-        a[2] = fma(v, v, a[2]);
-        a[3] = fma(u, bi, a[3]);
-        a[4] = fma(v, bi, a[4]);
+        const double v = kd[i];
+        a0 = fma(v, b[i] - kx[i], a0);
+        a1 = fma(v, v, a1);
     }
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const double t = block_sum(a[k], sh);
-        if (threadIdx.x == 0) part[(size_t)k * MAXPART + blockIdx.x] = t;
+    const double t0 = block_sum(a0, sh);
+    const double t1 = block_sum(a1, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = t0;
+        part[(size_t)MAXPART + blockIdx.x] = t1;
     }
 }
 
-// x = beta x + alpha d
+// x += alpha d, K x += alpha K d
 __global__ void __launch_bounds__(BLOCK)
-k_pred_combine(size_t ndof, double beta, double alpha, double *__restrict__ x, const double *__restrict__ d)
+k_pred_combine(size_t ndof, double alpha, double *__restrict__ x, const double *__restrict__ d, double *__restrict__ kx,
+               const double *__restrict__ kd)
 {
-    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) x[i] = fma(beta, x[i], alpha * d[i]);
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        x[i] = fma(alpha, d[i], x[i]);
+        kx[i] = fma(alpha, kd[i], kx[i]);
+    }
 }
 
 // u += du ; f += q  (q = K du)     (model.py:1383-1384)

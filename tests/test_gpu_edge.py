@@ -233,15 +233,15 @@ def test_large_non_proportional_laminate_gets_a_multigrid_hierarchy():
     assert np.max(np.abs(a._state('sig') - b._state('sig'))) < 1e-6 * np.max(np.abs(b._state('sig')))
 
 
-def test_two_solution_initial_guess_is_an_opt_in_experiment(monkeypatch):
-    """PLFX_PREDICT=1: warm-started multigrid solves start from the residual-minimal combination of the last two
-    solutions.  Off by default (plfx_predict_info reports zeros); switched on it needs fewer PCG iterations on the homogeneous
-    workload and gives the same fields to a few solver tolerances -- the reason it is not the default is the margin of the
-    sensitive traces, not this one."""
+def test_two_solution_initial_guess(monkeypatch):
+    """warm-started multigrid solves on meshes of >= 16384 nodes start from x + alpha d (d = the difference of the
+    last two solutions, 0 <= alpha <= 1 the residual-minimal step).  PLFX_PREDICT=0 restores the plain warm start: same load
+    steps / K-iterations, fields equal to a few solver tolerances, fewer PCG iterations with it; meshes below the size gate
+    never use it."""
     import warnings
     import pylabfea_amd as FE
 
-    def run(on):
+    def run(on, n=256):
         monkeypatch.setenv('PLFX_PREDICT', '1' if on else '0')
         m = FE.Material()
         m.elasticity(E=200.e3, nu=0.3)
@@ -253,7 +253,7 @@ def test_two_solution_initial_guess_is_an_opt_in_experiment(monkeypatch):
         fe.bcbot(0.)
         fe.bcright(0., 'force')
         fe.bctop(0.005 * fe.leny, 'disp')
-        fe.mesh(NX=256, NY=256)
+        fe.mesh(NX=n, NY=n)
         fe._max_load_steps = 16
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -261,8 +261,9 @@ def test_two_solution_initial_guess_is_an_opt_in_experiment(monkeypatch):
         return fe, sum(q[0] for q in fe.solver_stats), fe._engine.predict_info()
     a, ita, pa = run(False)
     b, itb, pb = run(True)
+    s, _, ps = run(True, 64)
     monkeypatch.delenv('PLFX_PREDICT')
-    assert pa == (0, 0) and pb[0] >= 5
+    assert pa == (0, 0) and pb[0] >= 5 and ps == (0, 0)
     assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter)
     assert itb < ita
     assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(a.sgl))
