@@ -4382,7 +4382,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     int rc = 0;
     // Initial guess from the last TWO solutions (round 5).  A warm start used the previous solution x as it is.  The
     // systems of consecutive solves differ by a tangent update and / or a scaled load increment, and so do their solutions, by
-    // nearly the same vector as last time: with d = x - (the solution before it), start from x + alpha d with the alpha in
+    // nearly the same vector as last time: with d = x - (the last solution that differed from it; zero on DOFs that are
+    // prescribed now), start from x + alpha d with the alpha in
     // [0, 1] that minimises | P (b - K (x + alpha d)) | -- one more operator pass and two sums.  Measured: the tangent-update solve
     // of the homogeneous workload starts 1-2 digits lower (1024^2: 24 -> 16 V-cycles in six load steps, 999^2 30 -> 10).
     // What the measurements of the free form (beta x + alpha d, both fitted: -28 % per load step) taught: beta != 1 rescales ALL
@@ -4390,39 +4391,45 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // sensitive traces; so x itself is never rescaled and the step is an interpolation (alpha <= 1).  Used while solves are cheap
     // (multigrid-PCG, previous computed solve <= 8 iterations) on meshes where a V-cycle costs more than the two extra passes and
     // the host round trip of the sums (>= 16384 nodes; the reference traces of the parity tests, <= 32 x 32 elements, run the
-    // plain warm start).  Single GPU (a strip would need the halo of d and all-reduced sums).  PLFX_PREDICT=0 at plfx_create
-    // switches it off.
-    bool predicted = false;
-    if (c->predict && x_kept && !comm_active(c) && !c->strip.on && mg_active(c) && c->nnode >= 16384 && c->last_computed_its >= 0 &&
-        c->last_computed_its <= 8) {
+    // plain warm start).  Strips: x and the solution before it are valid on the halo columns, the two sums are taken over the
+    // owned columns and all-reduced (host_sums).  PLFX_PREDICT=0 at plfx_create switches it off.
+    bool predicted = false, pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start was moved by alpha d)
+    // (every rank of a communicator takes the same decisions: the iteration count, the global node count and -- through the
+    // all-reduced sums -- alpha are the same everywhere; a replicated solve computes everything redundantly)
+    const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
+    if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= 8) {
         if (!c->pred_x && (rc = dalloc(c, &c->pred_x, nd))) return rc;
         if (!c->pred_d && (rc = dalloc(c, &c->pred_d, nd))) return rc;
         if (c->pred_valid) {
-            hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->pred_d);
+            hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->dinv, c->pred_d);
             LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->x, nullptr, nullptr, (double2 *)c->q, nullptr,
                        nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
             LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->pred_d, nullptr, nullptr, (double2 *)c->p[0],
                        nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
-            const int gp = std::min(grid_for(nd), MAXPART);
-            hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, nd, c->dinv, c->rhs, c->q, c->p[0], c->part);
+            const int gp = MAXPART;   // (one size on every rank: the all-reduce of the partial sums pairs up)
+            hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, (size_t)2 * olo, (size_t)2 * ohi, c->dinv, c->rhs, c->q, c->p[0],
+                               c->part);
             HIPCHK(c, hipGetLastError());
             double o[2];
             if ((rc = host_sums(c, c->part, 2, gp, o))) return rc;
             double alpha = (o[1] > 0.) ? o[0] / o[1] : 0.;
             if (!std::isfinite(alpha)) alpha = 0.;
             alpha = std::min(1., std::max(0., alpha));
+            if (alpha < 0.01) alpha = 0.;   // (a repeated system: x solves it already, the step is round-off)
+            pred_d_ready = true;
             if (alpha > 0.) {
                 hipLaunchKernelGGL(k_pred_combine, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, alpha, c->x, c->pred_d, c->q, c->p[0]);
                 c->n_pred++;
+                pred_moved = true;
             } else
                 c->n_pred_skipped++;
-            predicted = true;   // c->q = K x for the x that is in c->x now
+            predicted = !c->strip.on;   // c->q = K x for the x that is in c->x now (a strip takes its sums over the owned columns: k_cg_start)
         } else {
             HIPCHK(c, hipMemcpyAsync(c->pred_x, c->x, 8 * nd, hipMemcpyDeviceToDevice, c->stream));
             c->pred_valid = true;
         }
     } else
-        c->pred_valid = false;   // c->x was rebuilt (another Dirichlet set / du written from outside), a cold start, or a long solve
+        c->pred_valid = false;   // a cold start, a long solve or another solver: the history starts again
     // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1"); one pass (no q round trip)
     if (predicted)   // K x is at hand
         hipLaunchKernelGGL(k_cg_init, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->rhs, (const double2 *)c->q,
@@ -4722,6 +4729,10 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     HIPCHK(c, hipGetLastError());
     c->x_is_du = true;  // x = du on the free DOFs, 0 on the prescribed ones: the next warm start
     c->last_computed_its = (done && hs.iters >= 0) ? hs.iters : it;
+    // history of the initial guess: the solution this solve started from becomes "the one before" -- only if this solve moved
+    // away from it (the reference repeats solves of one system: such a solve ends where it started and must not erase d)
+    if (pred_d_ready && (pred_moved || c->last_computed_its > 0))
+        hipLaunchKernelGGL(k_pred_advance, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->pred_x, c->pred_d);
     if (iters) *iters = (done && hs.iters >= 0) ? hs.iters : it;
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
         c->tim.noop[1] += it - hs.iters;

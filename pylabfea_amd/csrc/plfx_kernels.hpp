@@ -2208,25 +2208,30 @@ k_x0(size_t ndof, const double *__restrict__ du, const double *__restrict__ is_p
 }
 
 // ---- initial guess of a warm-started solve from the last two solutions (plfx_solve)
-// d = x - xprev, xprev = x   (x = the solution of the previous solve, xprev = the one before)
+// d = x - xprev   (x = the solution of the previous solve, xprev = the last solution that differed from it)
 __global__ void __launch_bounds__(BLOCK)
-k_pred_diff(size_t ndof, const double *__restrict__ x, double *__restrict__ xprev, double *__restrict__ d)
+k_pred_diff(size_t ndof, const double *__restrict__ x, const double *__restrict__ xprev, const double *__restrict__ dinv,
+            double *__restrict__ d)
 {
-    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
-        const double xi = x[i];
-        d[i] = xi - xprev[i];
-        xprev[i] = xi;
-    }
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
+        d[i] = (dinv[i] != 0.) ? x[i] - xprev[i] : 0.;   // (the Dirichlet set may have changed since xprev was a solution)
+}
+
+// xprev += d: the solution this solve started from becomes "the one before" (called when the solve moved x)
+__global__ void __launch_bounds__(BLOCK)
+k_pred_advance(size_t ndof, double *__restrict__ xprev, const double *__restrict__ d)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) xprev[i] += d[i];
 }
 
 // partials of (K d) . (b - K x) and (K d) . (K d) over the free DOFs: the step alpha that minimises | P (b - K (x + alpha d)) |
 __global__ void __launch_bounds__(BLOCK)
-k_pred_dots(size_t ndof, const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ kx,
-            const double *__restrict__ kd, double *__restrict__ part)
+k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node columns) */, const double *__restrict__ dinv,
+            const double *__restrict__ b, const double *__restrict__ kx, const double *__restrict__ kd, double *__restrict__ part)
 {
     __shared__ double sh[BLOCK / 64];
     double a0 = 0., a1 = 0.;
-    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+    for (size_t i = dof_lo + blockIdx.x * (size_t)BLOCK + threadIdx.x; i < dof_hi; i += (size_t)gridDim.x * BLOCK) {
         if (dinv[i] == 0.) continue;
         const double v = kd[i];
         a0 = fma(v, b[i] - kx[i], a0);
