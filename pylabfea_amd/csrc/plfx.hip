@@ -224,6 +224,10 @@ struct plfx_ctx {
     double *pred_x = nullptr, *pred_d = nullptr;
     bool pred_valid = false;
     bool predict = true;            // PLFX_PREDICT=0 (read at plfx_create) switches the two-solution initial guess off
+    // the coarse levels are set up when a V-cycle is about to run, not when the tangents change (most tangent-update solves of
+    // a steady workload start below the tolerance, see plfx_solve): an assembly is pending; every BC application since kept the set
+    bool mg_pending = false, mg_pending_same = true;
+    long long n_mg_setup = 0, n_mg_setup_skipped = 0;
     int last_computed_its = -1;     // PCG iterations of the previous computed solve (-1: none / not a plain PCG solve)
     long long n_pred = 0, n_pred_skipped = 0;
     // Unchanged inputs are not recomputed (PLFX_REUSE=0 switches this off): the generators are re-snapshotted only when a
@@ -1413,6 +1417,23 @@ void mg_graph_drop(plfx_ctx *c)
 // The cycle in two parts so that plfx_solve can enqueue the head (fine-level pre-smoothing, residual, restriction: 60 us
 // of work whose kernels return at once if the PCG flag says "converged") BEFORE it waits for that flag: the round trip
 // to the host is hidden behind the head instead of idling the GPU.
+// Coarse levels on demand (round 5): plfx_assemble only marks them stale when the two-solution initial guess is on -- on a
+// steady workload most tangent-update solves then start below the tolerance and never apply the preconditioner, and the ~70 us of
+// the coarse set-up (8 launch-bound level passes + the coarsest assembly and its dense inverse) were spent for nothing.  Whoever
+// is about to run a V-cycle calls mg_ensure first.  Single GPU (a strip sets its child context up in lock-step with the others).
+int mg_assemble(plfx_ctx *c);
+int mg_update_dinv(plfx_ctx *c, bool same_set);
+bool mg_lazy(const plfx_ctx *c) { return c->predict && matfree(c) && !c->strip.on && !comm_active(c); }
+int mg_ensure(plfx_ctx *c)
+{
+    if (!c->mg_pending) return 0;
+    c->mg_pending = false;
+    c->n_mg_setup++;
+    int rc = mg_assemble(c);
+    if (rc) return rc;
+    return mg_update_dinv(c, c->mg_pending_same);
+}
+
 int mg_vcycle_head(plfx_ctx *c)
 {
     if (c->strip_jacobi) return 0;
@@ -1462,7 +1483,9 @@ int mg_vcycle_rest(plfx_ctx *c)
 
 int mg_vcycle(plfx_ctx *c)
 {
-    int rc = mg_vcycle_head(c);
+    int rc = mg_ensure(c);
+    if (rc) return rc;
+    rc = mg_vcycle_head(c);
     if (rc) return rc;
     return mg_vcycle_rest(c);
 }
@@ -3299,8 +3322,14 @@ int plfx_assemble(plfx_ctx *c)
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     if (mg_active(c)) {
-        int rc = mg_assemble(c);
-        if (rc) return rc;
+        if (mg_lazy(c)) {   // (an older pending set-up is superseded: only the newest generators matter)
+            if (c->mg_pending) c->n_mg_setup_skipped++;
+            else c->mg_pending_same = true;
+            c->mg_pending = true;
+        } else {
+            int rc = mg_assemble(c);
+            if (rc) return rc;
+        }
     }
     if (c->strip.on) {
         int rc = strip_child_assemble(c);
@@ -3464,8 +3493,12 @@ int apply_bc_impl(plfx_ctx *c, int n, const int32_t *idx, const double *du_presc
     if (c->sur_active)  // level 0 of the V-cycle runs on the surrogate operator: its Jacobi scaling with the new mask
         hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
     if (mg_active(c)) {
-        rc = mg_update_dinv(c, same_set && !c->sur_active);
-        if (rc) return rc;
+        if (c->mg_pending)
+            c->mg_pending_same = c->mg_pending_same && same_set && !c->sur_active;
+        else {
+            rc = mg_update_dinv(c, same_set && !c->sur_active);
+            if (rc) return rc;
+        }
     }
     if (c->strip.on && (rc = strip_child_dinv(c))) return rc;
     c->bc_set = true;
@@ -3914,6 +3947,7 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
     L0.diag = c->diag_sur;
     L0.dinv = c->dinv_sur;
     c->sur_active = true;
+    c->mg_pending = false;   // (set up right here, on the surrogate)
     if ((rc = mg_assemble(c))) return rc;
     if ((rc = mg_update_dinv(c, false))) return rc;
     c->n_sur++;
@@ -4448,9 +4482,18 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
         const unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
-        if ((rc = mg_vcycle_head(c))) return rc;  // speculative: its kernels return at once if the flag says converged
-        if ((rc = cg_check_wait(c, seq, &hs))) return rc;
-        done = hs.done;
+        if (c->mg_pending) {  // the coarse levels are stale: learn first whether a V-cycle is needed at all (mg_ensure)
+            if ((rc = cg_check_wait(c, seq, &hs))) return rc;
+            done = hs.done;
+            if (!done) {
+                if ((rc = mg_ensure(c))) return rc;
+                if ((rc = mg_vcycle_head(c))) return rc;
+            }
+        } else {
+            if ((rc = mg_vcycle_head(c))) return rc;  // speculative: its kernels return at once if the flag says converged
+            if ((rc = cg_check_wait(c, seq, &hs))) return rc;
+            done = hs.done;
+        }
     }
     static const bool fuse_dot = !(getenv("PLFX_FUSE_DOT") && atoi(getenv("PLFX_FUSE_DOT")) == 0);
     if (mg && !done) {
