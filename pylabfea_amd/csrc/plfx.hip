@@ -4418,7 +4418,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // systems of consecutive solves differ by a tangent update and / or a scaled load increment, and so do their solutions, by
     // nearly the same vector as last time: with d = x - (the last solution that differed from it; zero on DOFs that are
     // prescribed now), start from x + alpha d with the alpha in
-    // [0, 1] that minimises | P (b - K (x + alpha d)) | -- one more operator pass and two sums.  Measured: the tangent-update solve
+    // [0, 1] that minimises | P (b - K (x + alpha d)) | -- after the plain start has failed the tolerance test; one operator pass, two sums.  Measured: the tangent-update solve
     // of the homogeneous workload starts 1-2 digits lower (1024^2: 24 -> 16 V-cycles in six load steps, 999^2 30 -> 10).
     // What the measurements of the free form (beta x + alpha d, both fitted: -28 % per load step) taught: beta != 1 rescales ALL
     // of x, its converged soft components included, by ~1e-4 -- invisible to the residual test, 4e-6 in the fields of the
@@ -4427,50 +4427,25 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // the host round trip of the sums (>= 16384 nodes; the reference traces of the parity tests, <= 32 x 32 elements, run the
     // plain warm start).  Strips: x and the solution before it are valid on the halo columns, the two sums are taken over the
     // owned columns and all-reduced (host_sums).  PLFX_PREDICT=0 at plfx_create switches it off.
-    bool predicted = false, pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start was moved by alpha d)
+    bool pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start was moved by alpha d)
     // (every rank of a communicator takes the same decisions: the iteration count, the global node count and -- through the
     // all-reduced sums -- alpha are the same everywhere; a replicated solve computes everything redundantly)
     const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
+    bool pred_active = false;   // a history exists: this solve may start from x + alpha d
     if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= 8) {
         if (!c->pred_x && (rc = dalloc(c, &c->pred_x, nd))) return rc;
         if (!c->pred_d && (rc = dalloc(c, &c->pred_d, nd))) return rc;
-        if (c->pred_valid) {
-            hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->dinv, c->pred_d);
-            LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->x, nullptr, nullptr, (double2 *)c->q, nullptr,
-                       nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
-            LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->pred_d, nullptr, nullptr, (double2 *)c->p[0],
-                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
-            const int gp = MAXPART;   // (one size on every rank: the all-reduce of the partial sums pairs up)
-            hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, (size_t)2 * olo, (size_t)2 * ohi, c->dinv, c->rhs, c->q, c->p[0],
-                               c->part);
-            HIPCHK(c, hipGetLastError());
-            double o[2];
-            if ((rc = host_sums(c, c->part, 2, gp, o))) return rc;
-            double alpha = (o[1] > 0.) ? o[0] / o[1] : 0.;
-            if (!std::isfinite(alpha)) alpha = 0.;
-            alpha = std::min(1., std::max(0., alpha));
-            if (alpha < 0.01) alpha = 0.;   // (a repeated system: x solves it already, the step is round-off)
-            pred_d_ready = true;
-            if (alpha > 0.) {
-                hipLaunchKernelGGL(k_pred_combine, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, alpha, c->x, c->pred_d, c->q, c->p[0]);
-                c->n_pred++;
-                pred_moved = true;
-            } else
-                c->n_pred_skipped++;
-            predicted = !c->strip.on;   // c->q = K x for the x that is in c->x now (a strip takes its sums over the owned columns: k_cg_start)
-        } else {
+        if (c->pred_valid)
+            pred_active = true;
+        else {
             HIPCHK(c, hipMemcpyAsync(c->pred_x, c->x, 8 * nd, hipMemcpyDeviceToDevice, c->stream));
             c->pred_valid = true;
         }
     } else
         c->pred_valid = false;   // a cold start, a long solve or another solver: the history starts again
     // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1"); one pass (no q round trip)
-    if (predicted)   // K x is at hand
-        hipLaunchKernelGGL(k_cg_init, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const double2 *)c->rhs, (const double2 *)c->q,
-                           (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb);
-    else
-        LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, warm ? 1 : 0, (const double2 *)c->x, (const double2 *)c->rhs,
-                   (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb, olo, ohi);
+    LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, warm ? 1 : 0, (const double2 *)c->x, (const double2 *)c->rhs,
+               (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb, olo, ohi);
     if (c->strip.on) {  // sums of the whole grid; r valid on every local column (the V-cycle reads the halo)
         if ((rc = part_allreduce(c, P_rz[1], (size_t)3 * MAXPART))) return rc;
         if ((rc = halo_refresh(c, c->r))) return rc;
@@ -4481,10 +4456,45 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     CgScalars hs{};
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
-        const unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
-        if (c->mg_pending) {  // the coarse levels are stale: learn first whether a V-cycle is needed at all (mg_ensure)
+        unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
+        if (pred_active || c->mg_pending) {
+            // learn first whether anything is needed at all: the reference repeats solves of one system (x satisfies the
+            // tolerance as it is: nothing to interpolate, no coarse level to set up), and the coarse levels may be stale (mg_ensure)
             if ((rc = cg_check_wait(c, seq, &hs))) return rc;
             done = hs.done;
+            if (!done && pred_active) {
+                // x + alpha d, 0 <= alpha <= 1 minimising | r - alpha P K d |: one operator pass (K x = b - r is at hand), two sums
+                hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->dinv, c->pred_d);
+                LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->pred_d, nullptr, nullptr, (double2 *)c->p[0],
+                           nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
+                const int gp = MAXPART;   // (one size on every rank: the all-reduce of the partial sums pairs up)
+                hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, (size_t)2 * olo, (size_t)2 * ohi, c->dinv, c->r, c->p[0],
+                                   c->part);
+                HIPCHK(c, hipGetLastError());
+                double o[2];
+                if ((rc = host_sums(c, c->part, 2, gp, o))) return rc;
+                double alpha = (o[1] > 0.) ? o[0] / o[1] : 0.;
+                if (!std::isfinite(alpha)) alpha = 0.;
+                alpha = std::min(1., std::max(0., alpha));
+                if (alpha < 0.01) alpha = 0.;   // (round-off of a d that does not help)
+                pred_d_ready = true;
+                if (alpha > 0.) {
+                    hipLaunchKernelGGL(k_pred_apply, dim3(gn), dim3(BLOCK), 0, c->stream, nn, alpha, (double2 *)c->x, (const double2 *)c->pred_d,
+                                       (double2 *)c->r, (const double2 *)c->p[0], (const double2 *)c->dinv, (double2 *)c->z, P_rz[1], P_rr[1],
+                                       olo, ohi);
+                    HIPCHK(c, hipGetLastError());
+                    if (c->strip.on) {
+                        if ((rc = part_allreduce(c, P_rz[1], (size_t)2 * MAXPART))) return rc;   // (r.z and r.r: contiguous slots; b.b is reduced already)
+                        if ((rc = halo_refresh(c, c->r))) return rc;
+                    }
+                    c->n_pred++;
+                    pred_moved = true;
+                    seq = cg_check_post(c, P_rr[1], gn, 0);
+                    if ((rc = cg_check_wait(c, seq, &hs))) return rc;
+                    done = hs.done;
+                } else
+                    c->n_pred_skipped++;
+            }
             if (!done) {
                 if ((rc = mg_ensure(c))) return rc;
                 if ((rc = mg_vcycle_head(c))) return rc;

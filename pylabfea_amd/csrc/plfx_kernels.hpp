@@ -2224,17 +2224,17 @@ k_pred_advance(size_t ndof, double *__restrict__ xprev, const double *__restrict
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) xprev[i] += d[i];
 }
 
-// partials of (K d) . (b - K x) and (K d) . (K d) over the free DOFs: the step alpha that minimises | P (b - K (x + alpha d)) |
+// partials of (K d) . r and (K d) . (K d) over the free DOFs (r = P (b - K x)): the step alpha that minimises | r - alpha P K d |
 __global__ void __launch_bounds__(BLOCK)
 k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node columns) */, const double *__restrict__ dinv,
-            const double *__restrict__ b, const double *__restrict__ kx, const double *__restrict__ kd, double *__restrict__ part)
+            const double *__restrict__ r, const double *__restrict__ kd, double *__restrict__ part)
 {
     __shared__ double sh[BLOCK / 64];
     double a0 = 0., a1 = 0.;
     for (size_t i = dof_lo + blockIdx.x * (size_t)BLOCK + threadIdx.x; i < dof_hi; i += (size_t)gridDim.x * BLOCK) {
         if (dinv[i] == 0.) continue;
         const double v = kd[i];
-        a0 = fma(v, b[i] - kx[i], a0);
+        a0 = fma(v, r[i], a0);
         a1 = fma(v, v, a1);
     }
     const double t0 = block_sum(a0, sh);
@@ -2245,14 +2245,36 @@ k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node 
     }
 }
 
-// x += alpha d, K x += alpha K d
+// x += alpha d;  r -= alpha P K d;  z = dinv r;  partial sums of r.z and r.r over the owned nodes (as k_cg_start leaves them)
 __global__ void __launch_bounds__(BLOCK)
-k_pred_combine(size_t ndof, double alpha, double *__restrict__ x, const double *__restrict__ d, double *__restrict__ kx,
-               const double *__restrict__ kd)
+k_pred_apply(int nnode, double alpha, double2 *__restrict__ x, const double2 *__restrict__ d, double2 *__restrict__ r,
+             const double2 *__restrict__ kd, const double2 *__restrict__ dinv, double2 *__restrict__ z,
+             double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, int own_lo, int own_hi)
 {
-    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
-        x[i] = fma(alpha, d[i], x[i]);
-        kx[i] = fma(alpha, kd[i], kx[i]);
+    __shared__ double sh[BLOCK / 64];
+    double a_rz = 0., a_rr = 0.;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
+        const double2 di = d[i], ki = kd[i], dv = dinv[i];
+        double2 xi = x[i], ri = r[i], zi;
+        xi.x = fma(alpha, di.x, xi.x);
+        xi.y = fma(alpha, di.y, xi.y);
+        ri.x = (dv.x != 0.) ? fma(-alpha, ki.x, ri.x) : 0.;
+        ri.y = (dv.y != 0.) ? fma(-alpha, ki.y, ri.y) : 0.;
+        zi.x = dv.x * ri.x;
+        zi.y = dv.y * ri.y;
+        x[i] = xi;
+        r[i] = ri;
+        z[i] = zi;
+        if (i >= own_lo && i < own_hi) {
+            a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
+            a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
+        }
+    }
+    const double t1 = block_sum(a_rz, sh);
+    const double t2 = block_sum(a_rr, sh);
+    if (threadIdx.x == 0) {
+        part_rz_out[blockIdx.x] = t1;
+        part_rr_out[blockIdx.x] = t2;
     }
 }
 
