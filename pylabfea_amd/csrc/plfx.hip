@@ -4432,7 +4432,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // all-reduced sums -- alpha are the same everywhere; a replicated solve computes everything redundantly)
     const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
     bool pred_active = false;   // a history exists: this solve may start from x + alpha d
-    if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= 8) {
+    static const int pred_maxits = getenv("PLFX_PREDICT_MAXITS") ? atoi(getenv("PLFX_PREDICT_MAXITS")) : 8;
+    if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= pred_maxits) {
         if (!c->pred_x && (rc = dalloc(c, &c->pred_x, nd))) return rc;
         if (!c->pred_d && (rc = dalloc(c, &c->pred_d, nd))) return rc;
         if (c->pred_valid)
