@@ -214,8 +214,8 @@ int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free)
 int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *solves);
 /* Initial guess of a warm-started solve from the last two solutions (environment PLFX_PREDICT=0 at plfx_create switches it off):
  * with x the previous solution and d its difference to the one before, plfx_solve(warm=1) starts from x + alpha d with the alpha in
- * [0, 1] of smallest residual | P (b - K (x + alpha d)) | -- while solves are cheap (multigrid-PCG, previous computed solve <= 8
- * iterations), on meshes of >= 16384 nodes (strips: of the whole grid; the two sums are all-reduced).  d is taken to the last solution
+ * [0, 1] of smallest residual | P (b - K (x + alpha d)) | -- while solves are cheap (multigrid-PCG, previous computed solve <= 12
+ * iterations; PLFX_PREDICT_MAXITS), on meshes of >= 16384 nodes (strips: of the whole grid; the two sums are all-reduced).  d is taken to the last solution
  * that differed from x (repeated solves of one system keep the history).  The solution is the one of the same system to the same
  * tolerance; x itself is never rescaled.  applied / skipped (alpha < 0.01) since plfx_create. */
 int plfx_predict_info(plfx_ctx *ctx, int64_t *applied, int64_t *skipped);

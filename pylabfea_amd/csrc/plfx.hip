@@ -4423,7 +4423,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // What the measurements of the free form (beta x + alpha d, both fitted: -28 % per load step) taught: beta != 1 rescales ALL
     // of x, its converged soft components included, by ~1e-4 -- invisible to the residual test, 4e-6 in the fields of the
     // sensitive traces; so x itself is never rescaled and the step is an interpolation (alpha <= 1).  Used while solves are cheap
-    // (multigrid-PCG, previous computed solve <= 8 iterations) on meshes where a V-cycle costs more than the two extra passes and
+    // (multigrid-PCG, previous computed solve <= 12 iterations) on meshes where a V-cycle costs more than the two extra passes and
     // the host round trip of the sums (>= 16384 nodes; the reference traces of the parity tests, <= 32 x 32 elements, run the
     // plain warm start).  Strips: x and the solution before it are valid on the halo columns, the two sums are taken over the
     // owned columns and all-reduced (host_sums).  PLFX_PREDICT=0 at plfx_create switches it off.
@@ -4432,7 +4432,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // all-reduced sums -- alpha are the same everywhere; a replicated solve computes everything redundantly)
     const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
     bool pred_active = false;   // a history exists: this solve may start from x + alpha d
-    static const int pred_maxits = getenv("PLFX_PREDICT_MAXITS") ? atoi(getenv("PLFX_PREDICT_MAXITS")) : 8;
+    static const int pred_maxits = getenv("PLFX_PREDICT_MAXITS") ? atoi(getenv("PLFX_PREDICT_MAXITS")) : 12;
     if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= pred_maxits) {
         if (!c->pred_x && (rc = dalloc(c, &c->pred_x, nd))) return rc;
         if (!c->pred_d && (rc = dalloc(c, &c->pred_d, nd))) return rc;

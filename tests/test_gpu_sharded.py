@@ -369,7 +369,8 @@ def test_bench_two_ranks(tmp_path, mode):
     # where every rank's load step goes, and the Amdahl arithmetic that follows from it
     for r in d['per_rank']:
         b = r['time_budget_ms_per_step']
-        assert b['load_step'] > 0. and b['vcycles'] > 0. and 0. < b['divisible_by_strips'] < b['load_step']
+        # (vcycles may be 0: with the interpolated start the steady load steps of this window need no PCG iteration)
+        assert b['load_step'] > 0. and b['vcycles'] >= 0. and 0. < b['divisible_by_strips'] < b['load_step']
     assert d['amdahl']['estimated_one_gpu_ms_per_step'] > 0.
     if mode == 'strong' and nr == 2:   # the sweep-dominated leg (BASELINE config 5, here on 256 x 256 elements) in the same line
         leg = d['config5_leg']
