@@ -81,12 +81,20 @@ def committed_profile():
     sec, tab = None, {'dur': {}, 'fetch': {}, 'write': {}}
     for ln in open(path):
         if ln.startswith('=='):
-            sec = ('dur' if 'productive launches only' in ln and 'pmc' not in ln else
+            sec = ('classes' if 'launch classes' in ln else
+                   'dur' if 'productive launches only' in ln and 'pmc' not in ln else
                    'fetch' if 'FETCH_SIZE' in ln else 'write' if 'WRITE_SIZE' in ln else None)
             continue
         if sec is None or not ln.strip():
             continue
         name = ln.split()[0]
+        if sec == 'classes':
+            # "class none     n=  43  rewritten 0.000  dur 71.70 us  write 109.10 MB  fetch 160.40 MB"
+            m = re.search(r'class (\w+)\s+n=\s*(\d+)\s+rewritten ([0-9.]+)\s+dur\s+([0-9.]+) us\s+write\s+([0-9.]+) MB\s+fetch\s+([0-9.]+) MB', ln)
+            if m:
+                tab.setdefault('classes', {})[m.group(1)] = {'launches': int(m.group(2)), 'rewritten_share': float(m.group(3)),
+                                                             'dur_us': float(m.group(4)), 'write_MB': float(m.group(5)), 'fetch_MB': float(m.group(6))}
+            continue
         if sec == 'dur':
             m = re.search(r'avg\s+([0-9.]+) us', ln)
             if m:
@@ -95,7 +103,7 @@ def committed_profile():
             m = re.search(r'=\s+([0-9.]+) MB\s+\(min ([0-9.]+) MB, max ([0-9.]+) MB\)', ln)
             if m:
                 tab[sec][name] = tuple(float(v) * 1e6 for v in m.groups())
-    out = {'source': os.path.relpath(path, ROOT), 'traffic': {}, 'duration_s': {}}
+    out = {'source': os.path.relpath(path, ROOT), 'traffic': {}, 'duration_s': {}, 'sweep_classes': tab.get('classes', {})}
     for fam, k in PROFILE_KERNELS.items():
         if k not in tab['fetch'] or k not in tab['write'] or k not in tab['dur']:
             raise RuntimeError('%s: kernel %s of the bench line is not in the committed profile -- redo it (tools/profile_round.sh)'
@@ -431,7 +439,7 @@ def roofline_2048(FE, _lib, device=0, n=2048, K=4, W=1):
     return out
 
 
-def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0):
+def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0, timing=None):
     """The bench workload (config 3 material / loading / schedule) on an n x n mesh, wall-clock of the load steps
     pre+W+pre_extra .. +K, optionally with the unchanged-input reuse switched off (PLFX_REUSE is read when the engine is created)."""
     old = {k: os.environ.get(k) for k in ('PLFX_REUSE', 'PLFX_PREDICT')}
@@ -457,11 +465,19 @@ def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0):
             eng.sync()
             gc.collect()
             gc.disable()
+            if timing:   # (families, sampling stride): HIP events around every stride-th launch of these kernel families
+                eng.timing_reset()
+                eng.timing_select(timing[0])
+                eng.timing_sample(timing[1])
+                eng.timing_enable(True)
+                eng.sync()
             marks['t0'], marks['sw0'], marks['so0'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
         if il == first + K:
             eng.sync()
             marks['t1'], marks['sw1'], marks['so1'] = time.perf_counter(), fe.n_sweeps, len(fe.solver_stats)
             gc.enable()
+            if timing:
+                eng.timing_enable(False)
 
     fe._step_hook = hook
     fe._max_load_steps = first + K
@@ -471,6 +487,8 @@ def window_run(FE, n, K, W, device=0, reuse=True, pre_extra=0):
     out = {'mesh': '%dx%d' % (n, n), 'load_steps': '%d..%d of %d' % (first, first + K, ninc), 'ms_per_step': 1e3 * dt / K,
            'value': fe.Nel * (marks['sw1'] - marks['sw0']) / dt, 'unit': 'element-updates/s', 'sweeps': int(marks['sw1'] - marks['sw0']),
            'solves': len(its), 'pcg_iterations': int(np.sum(its)), 'unchanged_inputs_reused': bool(reuse)}
+    if timing:
+        out['_tim'] = {f: eng.timing_get(f) for f in timing[0]}
     fe._drop_engine()
     return out
 
@@ -796,8 +814,8 @@ def main():
 
     prof = committed_profile() if rank == 0 else None
 
-    def roof(k):
-        ms, cnt = tim[k]
+    def roof(k, tim_src=None, window=None):
+        ms, cnt = (tim_src or tim)[k]
         if cnt == 0:
             return None
         avg_s = ms * 1e-3 / cnt
@@ -826,17 +844,51 @@ def main():
                 'rocprof_avg_launch_us': (prof['duration_s'][k] * 1e6) if (same and mf and prof and k in prof['duration_s']) else None,
                 'traffic': traffic,
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, parsed from ' + (prof['source'] if mf else PMC_SOURCE_ASSEMBLED) + ' (2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)') if traffic else None,
-                'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k]}
+                'avg_launch_us': avg_s * 1e6, 'launches': cnt, 'bytes_per_launch': bytes_per[k],
+                **({'window': window} if window else {}),
+                **(sweep_classes(prof) if (k == 'sweep' and same and mf and prof and prof.get('sweep_classes')) else {})}
+
+    def sweep_classes(prof):
+        """frac_rocprof of the sweep per launch class of the committed profile (tools/prof_summary.py: no tangent rewritten /
+        all rewritten / some), each class's algorithmic bytes (412 B + 216 B x its rewritten share, per element) over ITS
+        rocprofv3 duration, and the figure for this run's window: this window's bytes per launch over the duration the
+        classes give for this window's rewritten share (linear between the 'none' and 'all' classes)."""
+        cl = prof['sweep_classes']
+        by = {}
+        for name, c in cl.items():
+            b = (412. + 216. * c['rewritten_share']) * nel_rank
+            by[name] = {'launches': c['launches'], 'rewritten_share': c['rewritten_share'], 'bytes_per_launch': b,
+                        'rocprof_avg_launch_us': c['dur_us'], 'frac_rocprof': b / (c['dur_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        'traffic': (2. * c['fetch_MB'] + c['write_MB']) * 1e6}
+        share = rewritten / max(n_sw * nel_rank, 1)
+        if 'none' in cl and 'all' in cl:
+            d_us = cl['none']['dur_us'] + share * (cl['all']['dur_us'] - cl['none']['dur_us'])
+        else:
+            tot = sum(c['launches'] for c in cl.values())
+            d_us = sum(c['launches'] * c['dur_us'] for c in cl.values()) / max(tot, 1)
+        return {'frac_rocprof': bytes_per['sweep'] / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 'rocprof_avg_launch_us': d_us,
+                'frac_rocprof_note': 'this window rewrites %.1f %% of the tangents per sweep: bytes_per_launch over the rocprofv3 duration of the '
+                                     'launch classes of the committed profile at that share (none + share x (all - none)); per class below' % (100. * share),
+                'frac_rocprof_by_class': by}
 
     out = {
         'metric': 'integration-point updates/sec (wall-clock per load step in ms_per_step)',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-        'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'none' if world == 1 else ('weak' if weak else 'strong'),
+        'ms_per_step': 1e3 * dt / K,
+        # what the same engine costs when the window is NOT answered from repeated / interpolated solutions (filled in below; null
+        # when that leg was skipped): every assembly / BC application / solve recomputed from the plain warm start; the same
+        # workload with a soft inclusion (heterogeneous fields).  pcg_iterations = PCG iterations inside the headline window.
+        'ms_per_step_reuse_off': None, 'ms_per_step_inclusion_variant': None, 'pcg_iterations': int(np.sum(its)),
+        'higher_is_better': True, 'scaling': 'none' if world == 1 else ('weak' if weak else 'strong'),
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': ('%s Q4, Hill-48 plasticity (sy=100, hill=[0.7,1,1.4,1,1.2,0.8], khard=100), '
                                 'plane strain, uniaxial tension eps=0.005, min_step=%d; timed load steps %d..%d '
-                                'of %d (after %d untimed elastic pre-roll steps)'
-                                % ('%dx%d' % (fe._NX, fe._NY), ninc, pre + W, pre + W + K, ninc, pre)) if args.config == 3 else
+                                'of %d (after %d untimed elastic pre-roll steps); %s'
+                                % ('%dx%d' % (fe._NX, fe._NY), ninc, pre + W, pre + W + K, ninc, pre,
+                                   ('0 PCG iterations in the window: every one of its %d solves is answered by the previous identical solve or by the '
+                                    'interpolation of the last two solutions, which already satisfies the tolerance (see ms_per_step_reuse_off / '
+                                    'ms_per_step_inclusion_variant for what a computed window costs)' % len(its)) if int(np.sum(its)) == 0 else
+                                   ('%d PCG iterations in the window' % int(np.sum(its))))) if args.config == 3 else
                                ('%s Q4 two-phase laminate [2,1,2,1,2] (BASELINE config 5): J2 (sy=150, khard=500) + SVC yield function '
                                 'trained on Barlat Yld2004-18p / Goss (%d support vectors), plane strain, uniaxial tension eps=0.003, '
                                 'min_step=20; timed load steps %d..%d of 20 (after %d untimed elastic pre-roll steps)'
@@ -854,14 +906,14 @@ def main():
                                     'replicated, one all-reduce of the stiffness generators per changed sweep' % world)),
                    'solver': ('multigrid V(2,2)-PCG (%d levels)' % eng.precond_info()[1] if eng.precond_info()[0] == 1
                               else 'Jacobi-PCG') + ' rtol=%g, %s operator' % (fe.cg_rtol, 'matrix-free' if mf else 'block-ELL'), 'device': devname},
-        'sweeps': sweeps, 'solves': len(its), 'pcg_iterations': int(np.sum(its)),
+        'sweeps': sweeps, 'solves': len(its),
         # solves / assemblies / BC applications of the timed steps whose inputs were bit-identical to the previous call's and
         # were therefore not recomputed (plfx_reuse_info; PLFX_REUSE=0 recomputes them) -- included in 'solves' above
         'unchanged_inputs_reused': dict(zip(('assemblies', 'bc_applications', 'solves'),
                                             [int(b - a) for a, b in zip(marks['ru0'], marks['ru1'])])),
         # warm-started solves whose initial guess was the residual-minimising combination of the last two solutions instead of the
         # last one alone (plfx_predict_info; PLFX_PREDICT=0 switches it off; single GPU, multigrid solves); whole run
-        'initial_guess_from_two_solutions': dict(zip(('applied', 'skipped'), eng.predict_info())),
+        'initial_guess_from_two_solutions': dict(zip(('accepted_as_solution', 'skipped', 'rejected_plain_warm_start'), eng.predict_info())),
         'solves_completed_by_fallback_solver': int(eng.solve_fallbacks()),
         'roofline': roof(dominant),
         'roofline_sweep': roof('sweep'),
@@ -951,14 +1003,23 @@ def main():
         out['roofline_2048'] = roofline_2048(FE, _lib, device=local)
     if rank == 0 and world == 1 and not args.no_inclusion:
         out['inclusion_variant'] = inclusion_variant(FE, n, K, W, device=local)
+        out['ms_per_step_inclusion_variant'] = out['inclusion_variant']['ms_per_step']
     if rank == 0 and world == 1 and not args.no_svc:
         out['roofline_svc'] = svc_sample(FE, _lib, args.svc_mesh, device=local)
     if rank == 0 and world == 1 and args.config == 3 and not args.no_reuse_off:
         # the same timed window with every assembly / BC application / solve recomputed (PLFX_REUSE=0): the headline answers
         # repeated identical calls of the reference's loop from the previous call (unchanged_inputs_reused above)
-        ro = window_run(FE, n, K, W, device=local, reuse=False)
+        ro = window_run(FE, n, K, W, device=local, reuse=False, timing=((_lib.T_SPMV, _lib.T_SMOOTH), args.sample))
+        rt = ro.pop('_tim')
         out['ms_per_step_reuse_off'] = ro['ms_per_step']
         out['reuse_off'] = ro
+        # north star: HBM GB/s of the return-mapping sweep AND the SpMV.  The headline window may not run a single PCG iteration
+        # (see config.workload): the operator kernels of the PCG loop are then timed in THIS window, which computes every solve
+        where = 'reuse_off window (load steps %s, %d PCG iterations, PLFX_REUSE=0 PLFX_PREDICT=0)' % (ro['load_steps'], ro['pcg_iterations'])
+        tsrc = {'spmv': rt[_lib.T_SPMV], 'mg_smooth': rt[_lib.T_SMOOTH]}
+        if out['roofline_spmv'] is None:
+            out['roofline_spmv'] = roof('spmv', tsrc, where)
+        out['roofline_mg_smooth'] = roof('mg_smooth', tsrc, where) or roof('mg_smooth')
     if rank == 0 and world == 1 and not args.no_cpu:
         # CPU window = load steps 11.. of 50 (past the ten calc_scf-scaled steps, like the GPU line's default window 8..18 mostly
         # is), nothing reused (the oracle recomputes every call): the GPU is run on the SAME mesh, window and reuse setting below

@@ -213,12 +213,13 @@ int plfx_operator_info(plfx_ctx *ctx, int *matrix_free, int *levels_matrix_free)
  * model.py:1291/1335).  Counters of the three cases since plfx_create. */
 int plfx_reuse_info(plfx_ctx *ctx, int *assemblies, int *bc_applications, int *solves);
 /* Initial guess of a warm-started solve from the last two solutions (environment PLFX_PREDICT=0 at plfx_create switches it off):
- * with x the previous solution and d its difference to the one before, plfx_solve(warm=1) starts from x + alpha d with the alpha in
- * [0, 1] of smallest residual | P (b - K (x + alpha d)) | -- while solves are cheap (multigrid-PCG, previous computed solve <= 12
- * iterations; PLFX_PREDICT_MAXITS), on meshes of >= 16384 nodes (strips: of the whole grid; the two sums are all-reduced).  d is taken to the last solution
- * that differed from x (repeated solves of one system keep the history).  The solution is the one of the same system to the same
- * tolerance; x itself is never rescaled.  applied / skipped (alpha < 0.01) since plfx_create. */
-int plfx_predict_info(plfx_ctx *ctx, int64_t *applied, int64_t *skipped);
+ * with x the previous solution, d its difference to the one before and alpha in [0, 1] of smallest residual
+ * | P (b - K (x + alpha d)) |, plfx_solve(warm=1) returns x + alpha d when -- and only when -- it satisfies the tolerance as it is
+ * (0 iterations); otherwise the solve iterates from x exactly as with PLFX_PREDICT=0 (bit-identical).  Tried on multigrid-PCG
+ * solves of meshes of >= 16384 nodes (strips: of the whole grid; the sums are all-reduced).  d is taken to the last solution that
+ * differed from x (repeated solves of one system keep the history).  x itself is never rescaled.
+ * applied (accepted as the solution) / skipped (alpha < 0.01) / rejected (failed the tolerance test) since plfx_create. */
+int plfx_predict_info(plfx_ctx *ctx, int64_t *applied, int64_t *skipped, int64_t *rejected);
 /* Sweeps since plfx_create and the number of element tangents they rewrote (model.py:1346-1355: a tangent is stored, and
  * Kel refreshed, only where it changed by more than 1e-3) -- whole mesh in sharded runs.  A sweep moves 412 B per element
  * plus 216 B per rewritten tangent. */

@@ -350,10 +350,11 @@ class Context(object):
         return a.value, b.value, s.value
 
     def predict_info(self):
-        """(applied, skipped): warm-started solves whose initial guess came from the last two solutions"""
-        a, b = C.c_int64(), C.c_int64()
-        self._chk(self.lib.plfx_predict_info(self.h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(applied, skipped, rejected): warm-started solves answered by the interpolation of the last two solutions /
+        not tried further (alpha < 0.01) / tried and iterated from the plain warm start instead"""
+        a, b, r = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.plfx_predict_info(self.h, C.byref(a), C.byref(b), C.byref(r)))
+        return a.value, b.value, r.value
 
     def set_precond(self, kind, omega=0., nu=0):
         self._chk(self.lib.plfx_set_precond(self.h, int(kind), C.c_double(omega), int(nu)))

@@ -228,8 +228,7 @@ struct plfx_ctx {
     // a steady workload start below the tolerance, see plfx_solve): an assembly is pending; every BC application since kept the set
     bool mg_pending = false, mg_pending_same = true;
     long long n_mg_setup = 0, n_mg_setup_skipped = 0;
-    int last_computed_its = -1;     // PCG iterations of the previous computed solve (-1: none / not a plain PCG solve)
-    long long n_pred = 0, n_pred_skipped = 0;
+    long long n_pred = 0, n_pred_skipped = 0, n_pred_rejected = 0;   // accepted as the solution / alpha < 0.01 / failed the tolerance test
     // Unchanged inputs are not recomputed (PLFX_REUSE=0 switches this off): the generators are re-snapshotted only when a
     // sweep reported a changed tangent (or they were written from outside) since the last plfx_assemble; a registered BC
     // plan with the same segment values on the same operator is not re-applied; and a solve of the system that the previous
@@ -801,7 +800,6 @@ void free_mesh(plfx_ctx *c)
     dfree(c->pred_x);
     dfree(c->pred_d);
     c->pred_valid = false;
-    c->last_computed_its = -1;
     dfree(c->mr_r1);
     dfree(c->mr_w);
     for (auto &b : c->gm_blk) dfree(b);
@@ -2449,8 +2447,11 @@ static int build_hierarchy(plfx_ctx *c, int nx, int ny, const ClassDev &geom)
     static const long long coarsest = getenv("PLFX_MG_COARSEST_ELEMS") ? atoll(getenv("PLFX_MG_COARSEST_ELEMS")) : 4;
     // Meshes with an odd number of elements in a direction (round 5) used to have no hierarchy at all (Jacobi-PCG, ~8 NX
     // iterations per cold solve).  Now, if the FINEST grid is odd and large, every level covers exactly the fine grid with cells
-    // of one size except the last column / row, whose relative size r stays in [1/2, 3/2): n cells are paired; an odd n leaves a
-    // lone last cell (r >= 1) or puts three children into the last coarse cell (r < 1) -- mg_coarse_cells / mg_coarse_ratio.
+    // of one size except the last column / row, whose relative size r stays in [1, 2): n cells are paired; an odd n ALWAYS puts
+    // three children (1, 1, r) into the last coarse cell -- mg_coarse_cells / mg_coarse_ratio / mg_odd_triple under the default
+    // PLFX_MG_ODD_RULE=1.  (The area-scaled smoothing diagonal of k_grid_setup is a stable Jacobi scaling only while no cell is
+    // narrower than its neighbours, i.e. r >= 1: compiling with PLFX_MG_ODD_RULE=0 restores the round-5-v3 rule r in [1/2, 3/2)
+    // with lone narrow cells AND the true-diagonal scaling that goes with it -- the two belong together.)
     // The stiffness integrals of the last cells scale with their shape (KOp::rx, ry), the transfers take the position-dependent
     // weights of bilinear interpolation (mg_tr1d), the coarse generators are area-weighted means of the children, the last node
     // line of every level is the edge of the grid (Dirichlet masks as before): the coarse spaces are nested in the fine one and
@@ -2966,11 +2967,12 @@ int plfx_reuse_info(plfx_ctx *c, int *assemblies, int *bc_applications, int *sol
     return PLFX_OK;
 }
 
-int plfx_predict_info(plfx_ctx *c, int64_t *applied, int64_t *skipped)
+int plfx_predict_info(plfx_ctx *c, int64_t *applied, int64_t *skipped, int64_t *rejected)
 {
     if (!c) return PLFX_ERR_ARG;
     if (applied) *applied = c->n_pred;
     if (skipped) *skipped = c->n_pred_skipped;
+    if (rejected) *rejected = c->n_pred_rejected;
     return PLFX_OK;
 }
 
@@ -4414,26 +4416,26 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         hipLaunchKernelGGL(k_x0, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->is_presc, warm, 1., c->x);
     c->x_is_du = false;
     int rc = 0;
-    // Initial guess from the last TWO solutions (round 5).  A warm start used the previous solution x as it is.  The
-    // systems of consecutive solves differ by a tangent update and / or a scaled load increment, and so do their solutions, by
-    // nearly the same vector as last time: with d = x - (the last solution that differed from it; zero on DOFs that are
-    // prescribed now), start from x + alpha d with the alpha in
-    // [0, 1] that minimises | P (b - K (x + alpha d)) | -- after the plain start has failed the tolerance test; one operator pass, two sums.  Measured: the tangent-update solve
-    // of the homogeneous workload starts 1-2 digits lower (1024^2: 24 -> 16 V-cycles in six load steps, 999^2 30 -> 10).
-    // What the measurements of the free form (beta x + alpha d, both fitted: -28 % per load step) taught: beta != 1 rescales ALL
-    // of x, its converged soft components included, by ~1e-4 -- invisible to the residual test, 4e-6 in the fields of the
-    // sensitive traces; so x itself is never rescaled and the step is an interpolation (alpha <= 1).  Used while solves are cheap
-    // (multigrid-PCG, previous computed solve <= 12 iterations) on meshes where a V-cycle costs more than the two extra passes and
-    // the host round trip of the sums (>= 16384 nodes; the reference traces of the parity tests, <= 32 x 32 elements, run the
-    // plain warm start).  Strips: x and the solution before it are valid on the halo columns, the two sums are taken over the
-    // owned columns and all-reduced (host_sums).  PLFX_PREDICT=0 at plfx_create switches it off.
-    bool pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start was moved by alpha d)
-    // (every rank of a communicator takes the same decisions: the iteration count, the global node count and -- through the
-    // all-reduced sums -- alpha are the same everywhere; a replicated solve computes everything redundantly)
+    // Initial guess from the last TWO solutions (round 5; acceptance rule of round 6).  A warm start uses
+    // the previous solution x as it is.  The systems of consecutive solves differ by a tangent update and / or a scaled load
+    // increment, and so do their solutions, by nearly the same vector as last time: with d = x - (the last solution that differed
+    // from it; zero on DOFs that are prescribed now) and the alpha in [0, 1] that minimises | P (b - K (x + alpha d)) | -- one
+    // operator pass, two sums, after the plain start has failed the tolerance test -- x + alpha d is taken ONLY IF IT SATISFIES THE
+    // TOLERANCE AS IT IS (k_pred_try: one more pass over r and K d that writes nothing).  Otherwise x, r and z are what the plain
+    // warm start left and the solve iterates from x: every iterating solve is bit-identical to PLFX_PREDICT=0.  Why: the error a
+    // residual tolerance leaves sits in the soft modes of the plastic tangents, and it is the iterations of a long solve after a
+    // moved start that let those components drift (round 5 guarded that with an iteration-count threshold tuned on the test set;
+    // this rule follows from the mechanism and has no constant).  x itself is never rescaled (beta != 1 rescales its converged soft
+    // components, 4e-6 in the fields of the sensitive traces).  Tried on multigrid-PCG solves of meshes where a V-cycle costs more
+    // than the extra passes and the host round trips (>= 16384 nodes; the reference traces of the parity tests, <= 32 x 32
+    // elements, run the plain warm start).  Strips: x and the solution before it are valid on the halo columns, the sums are
+    // taken over the owned columns and all-reduced (host_sums / part_allreduce).  PLFX_PREDICT=0 at plfx_create switches it off.
+    bool pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start x + alpha d was accepted as the solution)
+    // (every rank of a communicator takes the same decisions: the global node count and -- through the all-reduced sums -- alpha
+    // and the test are the same everywhere; a replicated solve computes everything redundantly)
     const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
-    bool pred_active = false;   // a history exists: this solve may start from x + alpha d
-    static const int pred_maxits = getenv("PLFX_PREDICT_MAXITS") ? atoi(getenv("PLFX_PREDICT_MAXITS")) : 12;
-    if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384 && c->last_computed_its >= 0 && c->last_computed_its <= pred_maxits) {
+    bool pred_active = false;   // a history exists: this solve may be answered by x + alpha d
+    if (c->predict && warm && !multi && mg_active(c) && nn_global >= 16384) {
         if (!c->pred_x && (rc = dalloc(c, &c->pred_x, nd))) return rc;
         if (!c->pred_d && (rc = dalloc(c, &c->pred_d, nd))) return rc;
         if (c->pred_valid)
@@ -4443,7 +4445,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
             c->pred_valid = true;
         }
     } else
-        c->pred_valid = false;   // a cold start, a long solve or another solver: the history starts again
+        c->pred_valid = false;   // a cold start or another solver: the history starts again
     // r = P(b - K x0), z = Minv r; partials -> slot 1 ("iteration -1"); one pass (no q round trip)
     LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, warm ? 1 : 0, (const double2 *)c->x, (const double2 *)c->rhs,
                (const double2 *)c->dinv, (double2 *)c->r, (double2 *)c->z, P_rz[1], P_rr[1], P_bb, olo, ohi);
@@ -4480,19 +4482,21 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 if (alpha < 0.01) alpha = 0.;   // (round-off of a d that does not help)
                 pred_d_ready = true;
                 if (alpha > 0.) {
-                    hipLaunchKernelGGL(k_pred_apply, dim3(gn), dim3(BLOCK), 0, c->stream, nn, alpha, (double2 *)c->x, (const double2 *)c->pred_d,
-                                       (double2 *)c->r, (const double2 *)c->p[0], (const double2 *)c->dinv, (double2 *)c->z, P_rz[1], P_rr[1],
-                                       olo, ohi);
+                    // would x + alpha d do?  | P (r - alpha K d) |^2 into the free slot P_rr[0]; nothing is written to x, r, z
+                    hipLaunchKernelGGL(k_pred_try, dim3(gn), dim3(BLOCK), 0, c->stream, nn, alpha, (const double2 *)c->r, (const double2 *)c->p[0],
+                                       (const double2 *)c->dinv, P_rr[0], olo, ohi);
                     HIPCHK(c, hipGetLastError());
-                    if (c->strip.on) {
-                        if ((rc = part_allreduce(c, P_rz[1], (size_t)2 * MAXPART))) return rc;   // (r.z and r.r: contiguous slots; b.b is reduced already)
-                        if ((rc = halo_refresh(c, c->r))) return rc;
-                    }
-                    c->n_pred++;
-                    pred_moved = true;
-                    seq = cg_check_post(c, P_rr[1], gn, 0);
+                    if (c->strip.on && (rc = part_allreduce(c, P_rr[0], gn))) return rc;
+                    seq = cg_check_post(c, P_rr[0], gn, 0);
                     if ((rc = cg_check_wait(c, seq, &hs))) return rc;
                     done = hs.done;
+                    if (done == 1) {   // it is the solution: commit x (r, z are not read again: the loop below is skipped)
+                        hipLaunchKernelGGL(k_pred_commit, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, alpha, c->x, c->pred_d);
+                        HIPCHK(c, hipGetLastError());
+                        c->n_pred++;
+                        pred_moved = true;
+                    } else
+                        c->n_pred_rejected++;
                 } else
                     c->n_pred_skipped++;
             }
@@ -4737,7 +4741,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         if (iters) *iters = it + itm;
         if (relres) *relres = rl;
         c->memo.valid = rcm == 0;
-        c->last_computed_its = -1;   // (not a plain PCG solve)
+        c->pred_valid = false;   // (not a plain PCG solve: the history of the initial guess starts again)
         c->memo.rtol = rtol;
         c->memo.relres = rl;
         return rcm == 0 ? PLFX_OK : 1;
@@ -4782,10 +4786,10 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
     HIPCHK(c, hipGetLastError());
     c->x_is_du = true;  // x = du on the free DOFs, 0 on the prescribed ones: the next warm start
-    c->last_computed_its = (done && hs.iters >= 0) ? hs.iters : it;
+    const int its_done = (done && hs.iters >= 0) ? hs.iters : it;
     // history of the initial guess: the solution this solve started from becomes "the one before" -- only if this solve moved
     // away from it (the reference repeats solves of one system: such a solve ends where it started and must not erase d)
-    if (pred_d_ready && (pred_moved || c->last_computed_its > 0))
+    if (pred_d_ready && (pred_moved || its_done > 0))
         hipLaunchKernelGGL(k_pred_advance, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->pred_x, c->pred_d);
     if (iters) *iters = (done && hs.iters >= 0) ? hs.iters : it;
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
@@ -4981,7 +4985,11 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
     // every pass confirms at least one more element of the chain (the first one whose entry value was wrong now runs with the
     // right one, everything before it is final), so ne + 2 passes always reach the sequential loop's sweep; two or three do
     // on every trace seen so far (the exit modulus of a call hardly depends on its entry modulus)
-    const int max_pass = (int)std::min<size_t>(ne + 2, 0x7fffffff);
+    // ... but a pass is a whole sweep + three snapshot restores + host round trips: a chain that resolves one element per pass on
+    // a large mesh would cost O(ne) sweeps without a word.  Cap (PLFX_WH_MAXPASS, default 512; never more than ne + 2): beyond it
+    // the sweep is reported unresolved (plfx_wh_info) and says so on stderr -- its tangents are those of the last pass
+    static const int wh_cap = getenv("PLFX_WH_MAXPASS") ? std::max(2, atoi(getenv("PLFX_WH_MAXPASS"))) : 512;
+    const int max_pass = (int)std::min<size_t>(ne + 2, (size_t)wh_cap);
     int pass = 0;
     for (;; pass++) {
         if (pass > 0) {
@@ -5028,8 +5036,10 @@ static int sweep_wh_sequential(plfx_ctx *c, int nit, int *changed, int *conv)
                     (long long)c->n_wh_sweeps, pass, nch, nt, imax, kmax, last[0], c->wh_carry[0]);
         }
         if (nch == 0) break;
-        if (pass + 1 >= max_pass) {  // (cannot happen, see max_pass; counted and reported by plfx_wh_info all the same)
-            c->n_wh_unresolved++;
+        if (pass + 1 >= max_pass) {  // (ne + 2 passes always resolve the chain; the cap above may end it earlier)
+            if (c->n_wh_unresolved++ == 0)
+                fprintf(stderr, "[plfx] work-hardening carry chain not resolved after %d passes (%d entry moduli still changed): "
+                                "PLFX_WH_MAXPASS raises the cap (plfx_wh_info counts such sweeps)\n", pass + 1, (int)nch);
             break;
         }
         std::swap(c->kh_el, c->kh_new);

@@ -2245,37 +2245,30 @@ k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node 
     }
 }
 
-// x += alpha d;  r -= alpha P K d;  z = dinv r;  partial sums of r.z and r.r over the owned nodes (as k_cg_start leaves them)
+// | P (r - alpha K d) |^2 over the owned free DOFs, nothing written: would x + alpha d satisfy the tolerance as it is?  (Round 6: the
+// interpolated start is taken only when it FINISHES the solve; a solve that iterates starts from x, bit for bit the plain warm start.)
 __global__ void __launch_bounds__(BLOCK)
-k_pred_apply(int nnode, double alpha, double2 *__restrict__ x, const double2 *__restrict__ d, double2 *__restrict__ r,
-             const double2 *__restrict__ kd, const double2 *__restrict__ dinv, double2 *__restrict__ z,
-             double *__restrict__ part_rz_out, double *__restrict__ part_rr_out, int own_lo, int own_hi)
+k_pred_try(int nnode, double alpha, const double2 *__restrict__ r, const double2 *__restrict__ kd, const double2 *__restrict__ dinv,
+           double *__restrict__ part_rr_out, int own_lo, int own_hi)
 {
     __shared__ double sh[BLOCK / 64];
-    double a_rz = 0., a_rr = 0.;
+    double a_rr = 0.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
-        const double2 di = d[i], ki = kd[i], dv = dinv[i];
-        double2 xi = x[i], ri = r[i], zi;
-        xi.x = fma(alpha, di.x, xi.x);
-        xi.y = fma(alpha, di.y, xi.y);
-        ri.x = (dv.x != 0.) ? fma(-alpha, ki.x, ri.x) : 0.;
-        ri.y = (dv.y != 0.) ? fma(-alpha, ki.y, ri.y) : 0.;
-        zi.x = dv.x * ri.x;
-        zi.y = dv.y * ri.y;
-        x[i] = xi;
-        r[i] = ri;
-        z[i] = zi;
-        if (i >= own_lo && i < own_hi) {
-            a_rz = fma(ri.x, zi.x, fma(ri.y, zi.y, a_rz));
-            a_rr = fma(ri.x, ri.x, fma(ri.y, ri.y, a_rr));
-        }
+        if (i < own_lo || i >= own_hi) continue;
+        const double2 ki = kd[i], dv = dinv[i], ri = r[i];
+        const double rx = (dv.x != 0.) ? fma(-alpha, ki.x, ri.x) : 0.;
+        const double ry = (dv.y != 0.) ? fma(-alpha, ki.y, ri.y) : 0.;
+        a_rr = fma(rx, rx, fma(ry, ry, a_rr));
     }
-    const double t1 = block_sum(a_rz, sh);
-    const double t2 = block_sum(a_rr, sh);
-    if (threadIdx.x == 0) {
-        part_rz_out[blockIdx.x] = t1;
-        part_rr_out[blockIdx.x] = t2;
-    }
+    const double t = block_sum(a_rr, sh);
+    if (threadIdx.x == 0) part_rr_out[blockIdx.x] = t;
+}
+
+// x += alpha d: the accepted start IS the solution (r and z of the finished solve are not read again)
+__global__ void __launch_bounds__(BLOCK)
+k_pred_commit(size_t ndof, double alpha, double *__restrict__ x, const double *__restrict__ d)
+{
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) x[i] = fma(alpha, d[i], x[i]);
 }
 
 // u += du ; f += q  (q = K du)     (model.py:1383-1384)

@@ -698,7 +698,10 @@ class Material(object):
     def C_tan(self, sig, Cel, epl=None):
         """Continuum tangent stiffness (material.py:1057-1086)."""
         Cel = np.asarray(Cel, dtype=float)
-        a = self._flow_normal(np.asarray(sig, dtype=float))
+        # the reference evaluates calc_fgrad(sig, epl=epl) with zeros when epl is None (material.py:1076-1082): for a
+        # work-hardening SVC the plastic strain is part of the feature vector and the call sets self.khard used below
+        epl = np.zeros(self.sdim) if epl is None else np.asarray(epl, dtype=float)
+        a = self._flow_normal(np.asarray(sig, dtype=float), epl)
         ca = Cel @ a
         return Cel - np.outer(ca, ca) / (a @ ca + self.khard)
 

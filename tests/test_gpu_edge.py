@@ -234,10 +234,11 @@ def test_large_non_proportional_laminate_gets_a_multigrid_hierarchy():
 
 
 def test_two_solution_initial_guess(monkeypatch):
-    """warm-started multigrid solves on meshes of >= 16384 nodes start from x + alpha d (d = the difference of the
-    last two solutions, 0 <= alpha <= 1 the residual-minimal step).  PLFX_PREDICT=0 restores the plain warm start: same load
-    steps / K-iterations, fields equal to a few solver tolerances, fewer PCG iterations with it; meshes below the size gate
-    never use it."""
+    """a warm-started multigrid solve on a mesh of >= 16384 nodes is answered by x + alpha d (d = the
+    difference of the last two solutions, 0 <= alpha <= 1 the residual-minimal step) when -- and only when -- that vector
+    satisfies the tolerance as it is; every solve that iterates starts from x exactly as with PLFX_PREDICT=0.  Same load
+    steps / K-iterations, fields equal to solver tolerance, fewer PCG iterations with it; meshes below the size gate never
+    try it."""
     import warnings
     import pylabfea_amd as FE
 
@@ -258,16 +259,71 @@ def test_two_solution_initial_guess(monkeypatch):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             fe.solve(min_step=50)
-        return fe, sum(q[0] for q in fe.solver_stats), fe._engine.predict_info()
+        return fe, [q[0] for q in fe.solver_stats], fe._engine.predict_info()
     a, ita, pa = run(False)
     b, itb, pb = run(True)
     s, _, ps = run(True, 64)
     monkeypatch.delenv('PLFX_PREDICT')
-    assert pa == (0, 0) and pb[0] >= 5 and ps == (0, 0)
-    assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter)
-    assert itb < ita
-    assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-7 * np.max(np.abs(a.sgl))
-    assert np.max(np.abs(a.u - b.u)) < 1e-7 * np.max(np.abs(a.u))
+    assert pa == (0, 0, 0) and pb[0] >= 5 and ps == (0, 0, 0)
+    assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter) and len(ita) == len(itb)
+    assert sum(itb) < sum(ita)
+    # an accepted start costs no iteration; a rejected one leaves the plain warm start
+    assert sum(1 for q in itb if q == 0) >= sum(1 for q in ita if q == 0) + pb[0] - 1
+    assert np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) < 1e-8 * np.max(np.abs(a.sgl))
+    assert np.max(np.abs(a.u - b.u)) < 1e-8 * np.max(np.abs(a.u))
+
+
+def _predict_on_off(monkeypatch, build, **kw):
+    import warnings
+    out = []
+    for on in (False, True):
+        monkeypatch.setenv('PLFX_PREDICT', '1' if on else '0')
+        fe = build()
+        for k, v in kw.items():
+            if k.startswith('_'):
+                setattr(fe, k, v)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fe.solve(**{k: v for k, v in kw.items() if not k.startswith('_')})
+        out.append((fe, [q[0] for q in fe.solver_stats], fe._engine.predict_info()))
+    monkeypatch.delenv('PLFX_PREDICT')
+    return out
+
+
+def test_interpolated_start_through_the_onset_of_yielding_1024(monkeypatch):
+    """the bench mesh (1024 x 1024 Hill) through the onset of yielding (load steps 1..12, first yield in
+    step 5), interpolated start on against off: same load steps / K-iterations, u to 1e-9 relative.  Solves whose
+    interpolated start fails the tolerance test iterate from the plain warm start (the acceptance rule has no tuned constant).
+    The stresses are derivatives of u over one element (h = L / 1024): two solutions of the same systems to the same residual
+    tolerance 1e-10 differ by ~1e-10 in u and by up to ~1e3 x that in its gradient (measured 4.5e-10 / 2.5e-8) -- the bar on
+    sig is 1e-7, an order below the parity bar of the fields (1e-6)."""
+    from test_gpu_model import make_material, tension_model
+    (a, ita, pa), (b, itb, pb) = _predict_on_off(monkeypatch, lambda: tension_model(make_material('hill6'), 1024, 0.005),
+                                                 min_step=50, _max_load_steps=12)
+    assert pa == (0, 0, 0) and pb[0] > 0
+    assert a.nsteps == b.nsteps and list(a.niter) == list(b.niter) and len(ita) == len(itb)
+    assert np.max(np.abs(a._state('epl'))) > 0.
+    du = np.max(np.abs(a.u - b.u)) / np.max(np.abs(a.u))
+    ds = np.max(np.abs(a._state('sig') - b._state('sig'))) / np.max(np.abs(a._state('sig')))
+    print('1024^2 steps 1..12, interpolated start on vs off: u %.2e sig %.2e; PCG iterations %d vs %d; accepted/skipped/rejected %s'
+          % (du, ds, sum(itb), sum(ita), pb))
+    assert du < 1e-9 and ds < 1e-7
+    assert sum(itb) <= sum(ita)
+
+
+def test_interpolated_start_config5_512x64(monkeypatch, golden_dir):
+    """... and on config 5's laminate (J2 + SVC trained on Barlat / Goss) at 512 x 64 through all 20 load steps: the long and
+    the indefinite solves of the plastic SVC phase are exactly the ones of PLFX_PREDICT=0 unless a start was accepted before them."""
+    from test_gpu_configs import laminate_cfg5
+    (a, ita, pa), (b, itb, pb) = _predict_on_off(monkeypatch, lambda: laminate_cfg5(golden_dir, 512, 64), min_step=20)
+    assert pa == (0, 0, 0)
+    assert a.nsteps == b.nsteps == 20 and list(a.niter[:8]) == list(b.niter[:8])
+    du = np.max(np.abs(a.u - b.u)) / np.max(np.abs(a.u))
+    ds = np.max(np.abs(a._state('sig') - b._state('sig'))) / np.max(np.abs(a._state('sig')))
+    dg = np.max(np.abs(np.asarray(a.sgl) - np.asarray(b.sgl))) / np.max(np.abs(a.sgl))
+    print('config 5 at 512x64, interpolated start on vs off: u %.2e sig %.2e sgl %.2e; PCG iterations %d vs %d; accepted/skipped/rejected %s; niter %s vs %s'
+          % (du, ds, dg, sum(itb), sum(ita), pb, list(b.niter), list(a.niter)))
+    assert du < 1e-9 and ds < 1e-7 and dg < 1e-9
 
 
 def test_facade_errors():

@@ -3,6 +3,7 @@ side of libplfx (built without device code) are compiled with -fsanitize=address
 already exist for them, in a child process that preloads the sanitizer runtime.  A report of either sanitizer aborts the
 child (non-zero exit)."""
 import os
+import shutil
 import subprocess
 import sys
 
@@ -19,10 +20,28 @@ def _run(env_extra, preload, args):
     return r
 
 
+def _tool(*names):
+    """first of the candidates that exists (absolute path or on PATH), else skip: a box without the toolchain skips, it does not fail"""
+    for n in names:
+        p = n if os.path.isabs(n) and os.path.exists(n) else shutil.which(n)
+        if p:
+            return p
+    pytest.skip('toolchain not found: ' + ' / '.join(names))
+
+
+def _make(path, target):
+    try:
+        subprocess.check_call(['make', '-s', '-C', path, target])
+    except (subprocess.CalledProcessError, OSError) as exc:
+        pytest.skip('sanitizer build not possible here: %s' % exc)
+
+
 def test_oracle_under_asan_ubsan():
-    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'asan'])
+    gcc = _tool('gcc')
+    _tool('make')
+    _make(os.path.join(ROOT, 'oracle'), 'asan')
     lib = os.path.join(ROOT, 'oracle', 'libplfx_oracle_asan.so')
-    asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so'], text=True).strip()
+    asan = subprocess.check_output([gcc, '-print-file-name=libasan.so'], text=True).strip()
     if not os.path.isabs(asan) or not os.path.exists(asan):
         pytest.skip('gcc has no libasan.so here')
     r = _run({'PLFO_LIB': lib}, asan, ['tests/test_oracle_golden.py'])
@@ -31,9 +50,13 @@ def test_oracle_under_asan_ubsan():
 
 
 def test_libplfx_host_code_under_asan_ubsan():
-    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'pylabfea_amd', 'csrc'), 'asan'])
+    """needs ROCm (hipcc + its clang): skipped on a box without it"""
+    _tool('/opt/rocm/bin/hipcc', 'hipcc')
+    clang = _tool('/opt/rocm/lib/llvm/bin/clang', 'amdclang', 'clang')
+    _tool('make')
+    _make(os.path.join(ROOT, 'pylabfea_amd', 'csrc'), 'asan')
     lib = os.path.join(ROOT, 'pylabfea_amd', 'libplfx_host_asan.so')
-    rt = subprocess.check_output(['/opt/rocm/lib/llvm/bin/clang', '--print-file-name=libclang_rt.asan-x86_64.so'], text=True).strip()
+    rt = subprocess.check_output([clang, '--print-file-name=libclang_rt.asan-x86_64.so'], text=True).strip()
     if not os.path.exists(rt):
         pytest.skip('no clang AddressSanitizer runtime in this image')
     # the host-only entry points and everything the binding does without a device: symbol table, structured-grid generator

@@ -241,6 +241,25 @@ def test_gpu_point_functions(z):
         m.khard = float(z['b_full_yf_khard'][i])
         f = m.ML_full_yf(z['b_sig'][i], epl=z['b_epl'][i], verb=False)
         assert abs(f - z['b_full_yf'][i]) < 1e-6 * sy
+    # C_tan(sig, Cel, epl) evaluates calc_fgrad(sig, epl=epl) -- the plastic strain is part of the feature vector and the call
+    # sets khard, which enters the denominator (material.py:1076-1085; ADVICE r5: the facade dropped epl).  Expected value: the
+    # reference's formula on the reference's own gradient and modulus of the same point (b_fgrad, b_khard)
+    CV = z['par_CV']
+    ndiff = 0
+    for i in (45, 100, 200):
+        a, kh = z['b_fgrad'][i], float(z['b_khard'][i])
+        ca = CV @ a
+        want = CV - np.outer(ca, ca) / (a @ ca + kh)
+        m.khard = 12345.
+        ct = m.C_tan(z['b_sig'][i], CV, epl=z['b_epl'][i])
+        assert np.max(np.abs(ct - want)) < 1e-8 * CV[0, 0]
+        assert abs(m.khard - kh) < 1e-7 * max(1., kh)
+        ct0 = m.C_tan(z['b_sig'][i], CV)                               # epl=None: zeros (material.py:1076-1077)
+        a0 = m.calc_fgrad(z['b_sig'][i], epl=np.zeros(6))
+        ca0 = CV @ a0
+        assert np.max(np.abs(ct0 - (CV - np.outer(ca0, ca0) / (a0 @ ca0 + m.khard)))) < 1e-8 * CV[0, 0]
+        ndiff += bool(np.max(np.abs(ct0 - ct)) > 1e-6 * CV[0, 0]) if np.any(z['b_epl'][i] != 0.) else 0
+    assert ndiff > 0                                                   # the plastic strain matters on this fixture
 
 
 @pytest.mark.gpu

@@ -12,6 +12,51 @@ def short(name):
     return m.group(1).replace(' ', '') if m else name[:40]
 
 
+def sweep_classes(d, dur, kernel='k_sweep_light<1>', nel_bytes=216.):
+    """The return-mapping sweep moves 412 B per element + 216 B per REWRITTEN tangent: its launches fall into classes (no tangent
+    rewritten / all rewritten / some), and a roofline fraction pairs the bytes of a class with the duration of THAT class.  The
+    three rocprofv3 passes run the same deterministic command, so launch i of the kernel is the same sweep in each of them:
+    WRITE_SIZE of launch i (PMC pass) classifies it, its duration comes from the kernel-trace pass (the PMC passes serialise
+    and slow the kernels)."""
+    per = {}
+    for tag, cname in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        try:
+            rows = [r for r in csv.DictReader(open('%s/%s/bench_counter_collection.csv' % (d, tag)))
+                    if r['Counter_Name'] == cname and short(r['Kernel_Name']) == kernel]
+        except IOError:
+            return []
+        rows.sort(key=lambda r: int(r['Start_Timestamp']))
+        per[tag] = [float(r['Counter_Value']) * 1024 / 1e6 for r in rows]
+    tr = [r for r in csv.DictReader(open('%s/trace/bench_kernel_trace.csv' % d)) if short(r['Kernel_Name']) == kernel]
+    tr.sort(key=lambda r: int(r['Start_Timestamp']))
+    du = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in tr]
+    n = len(du)
+    out = ['', '== %s launch classes (launch i paired across the passes: WRITE_SIZE / FETCH_SIZE of the PMC passes, duration of the kernel-trace pass) ==' % kernel]
+    if not n or len(per['pmc_write']) != n or len(per['pmc_fetch']) != n:
+        out.append('launch counts differ between the passes (trace %d, write %d, fetch %d): run the three passes with the same command'
+                   % (n, len(per.get('pmc_write', [])), len(per.get('pmc_fetch', []))))
+        return out
+    w = per['pmc_write']
+    wmin, wmax = min(w), max(w)
+    span = wmax - wmin
+    # rewritten share of a launch from its own WRITE_SIZE: 0 at the smallest write of the run; the largest write of the run is
+    # taken as "all rewritten" only when it exceeds the smallest by the 216 B per element a full rewrite adds (checked by the reader:
+    # span MB / 216 B = elements)
+    cls = {'none': [], 'some': [], 'all': []}
+    for i in range(n):
+        f = (w[i] - wmin) / span if span > 1. else 0.
+        cls['none' if f < 0.02 else 'all' if f > 0.98 else 'some'].append((f, du[i], w[i], per['pmc_fetch'][i]))
+    out.append('%d launches; WRITE_SIZE %.2f .. %.2f MB (span %.2f MB = 216 B x %.0f elements)' % (n, wmin, wmax, span, span * 1e6 / nel_bytes))
+    for k in ('none', 'some', 'all'):
+        v = cls[k]
+        if v:
+            m = len(v)
+            out.append('class %-5s n=%4d  rewritten %.3f  dur %8.2f us  write %8.2f MB  fetch %8.2f MB   (traffic 2 x fetch + write = %.2f MB)'
+                       % (k, m, sum(x[0] for x in v) / m, sum(x[1] for x in v) / m, sum(x[2] for x in v) / m, sum(x[3] for x in v) / m,
+                          (2 * sum(x[3] for x in v) + sum(x[2] for x in v)) / m))
+    return out
+
+
 def main(d, out):
     lines = []
     rows = list(csv.DictReader(open('%s/trace/bench_kernel_stats.csv' % d)))
@@ -55,6 +100,7 @@ def main(d, out):
             if v:
                 lines.append('%-28s n=%6d  avg %14.1f KiB = %10.2f MB   (min %.2f MB, max %.2f MB)'
                              % (k, len(v), sum(v) / len(v), sum(v) / len(v) * 1024 / 1e6, min(v) * 1024 / 1e6, max(v) * 1024 / 1e6))
+    lines += sweep_classes(d, dur)
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
