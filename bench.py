@@ -744,6 +744,7 @@ def main():
             marks['so0'] = len(fe.solver_stats)
             marks['ru0'] = eng.reuse_info()
             marks['si0'] = eng.sweep_info()
+            marks['st0'] = eng.strip_info() if fe._strip else None
         if il == pre + W + K:
             barrier()
             marks['t1'] = time.perf_counter()
@@ -752,6 +753,7 @@ def main():
             marks['so1'] = len(fe.solver_stats)
             marks['ru1'] = eng.reuse_info()
             marks['si1'] = eng.sweep_info()
+            marks['st1'] = eng.strip_info() if fe._strip else None
             eng.timing_enable(False)
 
     fe._step_hook = hook
@@ -952,7 +954,19 @@ def main():
         cms, cn = eng.timing_get(_lib.T_COMM)
         mine = {'rank': rank, 'owned_columns': [strip['c0'], strip['c1']] if strip else None,
                 'halo_columns': strip['W'] if strip else None, 'roofline': roof(dominant), 'roofline_sweep': roof('sweep'),
+                'roofline_spmv': roof('spmv'), 'roofline_mg_smooth': roof('mg_smooth'),
                 'collective_ms_per_step': cms / K, 'collectives_per_step': cn / K}
+        if strip and marks.get('st0'):
+            # bytes this rank SENDS per load step (the same number arrives): a halo refresh moves W node columns of (NY + 1) nodes x 16 B
+            # to each neighbour, a generator exchange 6 doubles x W x NY elements per side; the coarse right-hand side and the
+            # partial sums are all-reduced (bytes = what one rank contributes)
+            d = [b - a for a, b in zip(marks['st0'][4:8], marks['st1'][4:8])]
+            sides = (1 if rank > 0 else 0) + (1 if rank < world - 1 else 0)
+            nyn = fe._NY + 1
+            mine['collective_counts_per_step'] = {'halo_refreshes': d[0] / K, 'coarse_gathers': d[1] / K,
+                                                  'partial_sum_allreduces': d[2] / K, 'generator_exchanges': d[3] / K}
+            mine['halo_bytes_per_step'] = d[0] * sides * strip['W'] * nyn * 16. / K
+            mine['generator_exchange_bytes_per_step'] = d[3] * sides * 6 * 8. * strip['W'] * fe._NY / K
         # where this rank's load step goes (HIP events on its stream, ms per load step): what strips divide (the fine-level
         # operator passes over its own columns, its share of the sweep) and what they do not (levels >= 1 of the V-cycle --
         # launch-latency bound on the local levels, replicated below the hand-over level --, the collectives)

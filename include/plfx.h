@@ -122,6 +122,17 @@ int plfx_full_yf_batch(plfx_ctx *ctx, int mat, int n, const double *sig, const d
 int plfx_response_batch(plfx_ctx *ctx, int n, const int32_t *mat_id, const double *sig,
                         const double *epl, const double *deps, double *fy, double *sig_out,
                         double *depl, double *ct /* [n*36] */, int32_t *nsteps);
+/* The `maxit` argument of Material.response (material.py:207, 288-291: an increment whose trial step ends outside the yield
+ * locus is sub-divided into maxit sub-steps; nsteps = maxit - 1 then) for the point entries plfx_response_batch(_kh) of this
+ * context; default 50, the reference's default and what the load-step loop always uses (model.py:1346 passes none). */
+int plfx_set_response_maxit(plfx_ctx *ctx, int maxit);
+/* basic.sig_princ (basic.py:107-179) on n Voigt stresses, computed on the HOST by the routine the PRINC3 / SVC3 kernels run on
+ * states with out-of-plane shear: np.linalg.eig's eigenpair ORDER (LAPACK dgeev replayed for symmetric 3 x 3 matrices,
+ * csrc/plfx_lapack3.hpp) and the reference's row-argmax re-ordering.  No context, no GPU.  sp[n*3].  plfx_eig3_host returns the
+ * eigenvalues w[n*3] in dgeev's order and (V != NULL) the unit eigenvectors V[n*9], V[i*3+k] = component i of eigenvector k.
+ * Return 1 if a matrix did not converge / gave a complex pair (numpy would, too). */
+int plfx_sig_princ_host(int n, const double *sig, double *sp);
+int plfx_eig3_host(int n, const double *sig, double *w, double *V);
 /* Work-hardening-aware SVC materials (PLFX_SVC_WH).  The reference keeps the hardening modulus in ONE mutable attribute of
  * the Material object: every calc_fgrad call overwrites it (khard = max(0, -sum dK/dx[wh] scale_seq/scale_wh),
  * material.py:808-814), every get_sflow / epl_dot / C_tan reads it, and it is carried from call to call.  Here it is an

@@ -101,7 +101,23 @@ def main():
         rec['ed_ctan'] = np.array([m.C_tan(s[i], CVr, epl=e[i]).reshape(36) for i in range(len(s))])
         rec['ed_pdot6'] = np.array([m6.epl_dot(s[i], e[i], CVr, d[i]) for i in range(len(s))])
         rec['ed_ctan6'] = np.array([m6.C_tan(s[i], CVr, epl=e[i]).reshape(36) for i in range(len(s))])
+        # ---- round 6: Material.response(..., maxit) with maxit != 50 (material.py:207, 288-291) on the same inputs: the sdim = 3
+        # material (every sub-step re-orders the principal stresses) and the sdim = 6 one
+        for mi in (20, 7):
+            for tag, mat in (('', m), ('6', m6)):
+                fy = np.zeros(len(s)); so = np.zeros((len(s), 6)); dp = np.zeros((len(s), 6)); ct = np.zeros((len(s), 36))
+                ns = np.zeros(len(s), dtype=np.int32)
+                for i in range(len(s)):
+                    mat.msg['nsteps'] = -1
+                    f, so[i], dp[i], c = mat.response(s[i], e[i], d[i], CVr, maxit=mi)
+                    fy[i], ct[i], ns[i] = f, np.asarray(c).reshape(36), mat.msg['nsteps']
+                k = 'rm%d%s_' % (mi, tag)
+                rec[k + 'fy'], rec[k + 'sig_out'], rec[k + 'depl'], rec[k + 'ct'], rec[k + 'nsteps'] = fy, so, dp, ct, ns
+                print('response maxit=%d sdim %s: nsteps histogram' % (mi, tag or '3'), np.bincount(ns))
     out = os.path.join(ROOT, 'tests', 'golden', 'princ_general.npz')
+    old = dict(np.load(out)) if os.path.exists(out) else {}
+    for k, v in old.items():   # the keys of earlier rounds must not move (same seeds, same library)
+        assert k in rec and np.array_equal(np.asarray(rec[k]), v, equal_nan=True), k
     np.savez_compressed(out, **rec)
     print('wrote', out, {k: v.shape for k, v in rec.items()})
 

@@ -53,6 +53,7 @@ SYMBOLS = [
     'plfx_response_batch_kh', 'plfx_fgrad_batch_wh', 'plfx_timing_sample', 'plfx_solve_fallbacks', 'plfx_comm_selftest',
     'plfx_indefinite_info', 'plfx_pattern_selftest', 'plfx_precond_bench', 'plfx_set_wh_mode', 'plfx_wh_info', 'plfx_wh_carry', 'plfx_set_mesh_structured',
     'plfx_svc_info', 'plfx_sqmr_info', 'plfx_fgrad_seq_batch', 'plfx_precond_apply', 'plfx_predict_info',
+    'plfx_set_response_maxit', 'plfx_sig_princ_host', 'plfx_eig3_host',
 ]
 
 _lib = None
@@ -119,6 +120,28 @@ def gen_structured(NX, NY):
     if rc:
         raise PlfxError('plfx_gen_structured(%d, %d): error %d' % (NX, NY, rc))
     return conn, le, ri, bo, to
+
+
+def sig_princ_host(sig):
+    """basic.sig_princ's principal stresses (reference order) of (N,6) Voigt stresses from the library's host-side LAPACK replay"""
+    lib = load()
+    s = _f64(sig).reshape(-1, 6)
+    sp = np.empty((len(s), 3))
+    rc = lib.plfx_sig_princ_host(len(s), _dp(s), _dp(sp))
+    if rc < 0:
+        raise PlfxError('plfx_sig_princ_host: error %d' % rc)
+    return sp
+
+
+def eig3_host(sig):
+    """(w[N,3], V[N,3,3]): eigenvalues in LAPACK dgeev's order and unit eigenvectors (columns) of the symmetric stress tensors"""
+    lib = load()
+    s = _f64(sig).reshape(-1, 6)
+    w, V = np.empty((len(s), 3)), np.empty((len(s), 3, 3))
+    rc = lib.plfx_eig3_host(len(s), _dp(s), _dp(w), _dp(V))
+    if rc < 0:
+        raise PlfxError('plfx_eig3_host: error %d' % rc)
+    return w, V
 
 
 def pack_material(kind, CV, E=0., nu=0., sy=0., khard=0., hill=None, drucker=0., svc=None, barlat=None,
@@ -268,8 +291,18 @@ class Context(object):
                                               _dp(out), _dp(st)))
         return out, st
 
-    def response(self, sig, epl, deps, mat_id=None, khard_in=None, return_khard=False):
-        """khard_in / return_khard: entry / exit value of Material.khard per point (work-hardening SVC materials)"""
+    def set_response_maxit(self, maxit=50):
+        self._chk(self.lib.plfx_set_response_maxit(self.h, int(maxit)))
+
+    def response(self, sig, epl, deps, mat_id=None, khard_in=None, return_khard=False, maxit=50):
+        """khard_in / return_khard: entry / exit value of Material.khard per point (work-hardening SVC materials);
+        maxit: Material.response's argument (sub-steps of a sub-divided increment)"""
+        if maxit != 50:
+            self.set_response_maxit(maxit)
+            try:
+                return self.response(sig, epl, deps, mat_id, khard_in, return_khard)
+            finally:
+                self.set_response_maxit(50)
         sig = _f64(sig).reshape(-1, 6)
         n = len(sig)
         epl = _f64(epl).reshape(-1, 6)

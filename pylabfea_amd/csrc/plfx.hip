@@ -228,6 +228,7 @@ struct plfx_ctx {
     // a steady workload start below the tolerance, see plfx_solve): an assembly is pending; every BC application since kept the set
     bool mg_pending = false, mg_pending_same = true;
     long long n_mg_setup = 0, n_mg_setup_skipped = 0;
+    int resp_maxit = MAXIT;          // plfx_set_response_maxit: sub-steps of Material.response's sub-divided increment (point entry only)
     long long n_pred = 0, n_pred_skipped = 0, n_pred_rejected = 0;   // accepted as the solution / alpha < 0.01 / failed the tolerance test
     // Unchanged inputs are not recomputed (PLFX_REUSE=0 switches this off): the generators are re-snapshotted only when a
     // sweep reported a changed tangent (or they were written from outside) since the last plfx_assemble; a registered BC
@@ -278,6 +279,8 @@ struct plfx_ctx {
     double *mr_r1 = nullptr, *mr_w = nullptr;  // MINRES work vectors (allocated on first use)
     std::vector<double *> gm_blk;                // GMRES: Krylov basis in blocks of GMRES_BLK vectors, allocated as a cycle grows into them
     double *gm_part = nullptr;                   //        partial sums, on first use
+    double *gm_part2 = nullptr, *gm_red = nullptr, *gm_coef = nullptr;   // delayed re-orthogonalisation: partials of all columns, their sums, coefficients
+    long long n_gmres_its = 0;
     int n_gmres = 0, gm_m = 0;
     double *fuse_rz = nullptr;  // != null during a V-cycle of the PCG loop: the last fine-level post-smoothing launch writes the r.z partials here
     // SPD surrogate of an indefinite operator (k_make_surrogate): generators with every indefinite element's 3 x 3 generator
@@ -806,6 +809,9 @@ void free_mesh(plfx_ctx *c)
     c->gm_blk.clear();
     c->gm_m = 0;
     dfree(c->gm_part);
+    dfree(c->gm_part2);
+    dfree(c->gm_red);
+    dfree(c->gm_coef);
     dfree(c->Msur);
     dfree(c->diag_sur);
     dfree(c->dinv_sur);
@@ -2087,28 +2093,30 @@ static int response_batch_impl(plfx_ctx *c, int n, const int32_t *mat_id, const 
     EvPair *ev;
     tim_begin(c, 0, &ev);
 #define RB_ARGS(lds) c->dmat, c->nmat, lds, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns
+#define RB_TAIL (const double *)nullptr, (double *)nullptr, 0u, c->resp_maxit
     if (c->has_analytic || c->has_elastic)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<1>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<1>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0), RB_TAIL);
     if (c->has_princ)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<2>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0), RB_TAIL);
     if (c->has_barlat)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<5>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<5>), dim3(grid_for(N)), dim3(BLOCK), 0, c->stream, RB_ARGS(0), RB_TAIL);
     const bool resp_row = !(getenv("PLFX_RESPONSE_ROW") && atoi(getenv("PLFX_RESPONSE_ROW")) == 0);   // read per call: tests compare the two forms
     const unsigned rmask = (resp_row && svc_poly() == 2) ? svc_fast_mask(c) : 0u;
     if (c->has_svc && (c->svc6_mask & ~rmask))
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<3>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)nullptr, (double *)nullptr, rmask);
+                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)nullptr, (double *)nullptr, rmask, c->resp_maxit);
     for (int k = 0; k < c->nmat; k++)   // 6-feature SVC materials with tables in LDS: 16 lanes per point (the code path of the sweeps)
         if ((rmask >> k) & 1u)
             LAUNCH_ROW1(c, k, k_response_row, dim3(std::max(1, std::min((n + 31) / 32, 1024))),
-                       c->dmat, c->nmat, k, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns);
+                       c->dmat, c->nmat, k, n, d_mid, d_in, d_in + 6 * N, d_in + 12 * N, d_fy, d_so, d_dp, d_ct, d_ns, c->resp_maxit);
     if (c->has_svc3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<6>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, RB_ARGS(c->svc_lds_need));
+                           c->stream, RB_ARGS(c->svc_lds_need), RB_TAIL);
     if (c->has_svcwh)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_response_batch<7>), dim3(grid_for(N)), dim3(BLOCK), dyn_lds_bytes(c),
-                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)d_kh, d_kh + N);
+                           c->stream, RB_ARGS(c->svc_lds_need), (const double *)d_kh, d_kh + N, 0u, c->resp_maxit);
 #undef RB_ARGS
+#undef RB_TAIL
     tim_end(c, ev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fy, d_fy, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2974,6 +2982,33 @@ int plfx_predict_info(plfx_ctx *c, int64_t *applied, int64_t *skipped, int64_t *
     if (skipped) *skipped = c->n_pred_skipped;
     if (rejected) *rejected = c->n_pred_rejected;
     return PLFX_OK;
+}
+
+int plfx_set_response_maxit(plfx_ctx *c, int maxit)
+{
+    if (!c) return PLFX_ERR_ARG;
+    if (maxit < 1) return fail(c, PLFX_ERR_ARG, "maxit must be >= 1");
+    c->resp_maxit = maxit;
+    return PLFX_OK;
+}
+
+// host side of plfx_lapack3.hpp (no context, no GPU): what the device routine of the PRINC3 / SVC3 kernels computes
+int plfx_eig3_host(int n, const double *sig, double *w, double *V)
+{
+    if (n < 0 || !sig || !w) return PLFX_ERR_ARG;
+    double Vt[9];
+    for (int i = 0; i < n; i++)
+        if (lapack3::dgeev3(sig + 6 * (size_t)i, w + 3 * (size_t)i, V ? V + 9 * (size_t)i : Vt) != 0) return 1;
+    return PLFX_OK;
+}
+
+int plfx_sig_princ_host(int n, const double *sig, double *sp)
+{
+    if (n < 0 || !sig || !sp) return PLFX_ERR_ARG;
+    int rc = PLFX_OK;
+    for (int i = 0; i < n; i++)
+        if (lapack3::sig_princ_lapack3(sig + 6 * (size_t)i, sp + 3 * (size_t)i) != 0) rc = 1;
+    return rc;
 }
 
 int plfx_gen_structured(int NX, int NY, int32_t *conn, int32_t *noleft, int32_t *noright, int32_t *nobot, int32_t *notop)
@@ -4012,6 +4047,10 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
     int itn = 0, cycles = 0, poor = 0;
     double rl = 0., rr_prev = -1.;
     std::vector<double> H((size_t)(M + 1) * M), cs(M), sn(M), g(M + 1), hcol(M + 2);
+    // PLFX_GMRES_ORTH=cgs2 restores the orthogonalisation of rounds 3-5 (classical Gram-Schmidt twice: four sweeps over the basis
+    // per iteration, a host round trip per eight vectors); default: delayed re-orthogonalisation, two sweeps, two round trips
+    static const bool dcgs2 = !(getenv("PLFX_GMRES_ORTH") && !strcmp(getenv("PLFX_GMRES_ORTH"), "cgs2"));
+    std::vector<double> Hraw(dcgs2 ? (size_t)(M + 1) * M : 0);
     while (true) {
         // r0 = P (b - K x) -> c->r; beta = |r0|
         LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, 1, (const double2 *)c->x, (const double2 *)c->rhs,
@@ -4039,6 +4078,125 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
         std::fill(g.begin(), g.end(), 0.);
         g[0] = beta;
         int k = 0;  // columns built in this cycle
+        if (dcgs2) {
+            // ---- Arnoldi with delayed re-orthogonalisation (plfx_mg.hpp: k_gmres_dots2 / k_gmres_update2).
+            // State at the top of iteration j >= 1: q_0 .. q_{j-1} final in V_0 .. V_{j-1}; u = V_j the once-projected candidate
+            // for q_j (u = w_{j-1} - Q_j h1, h1 = the first-pass coefficients kept in h1p); column j-1 of the Hessenberg matrix
+            // still open.  One operator application z = A u, one dots pass (s = Q_j^T u, t = Q_j^T z, u.u, u.z), then on the host
+            //   alpha^2 = u.u - s.s                      (q_j = (u - Q_j s) / alpha: the delayed second pass of vector j)
+            //   column j-1 of H:  h1 + s  over  alpha    -> Givens, residual estimate, convergence test (one iteration late)
+            //   w_j = A q_j = (z - A Q_j s) / alpha,  A Q_j s = Q_j (H s) + q_j rho,  rho = alpha s_{j-1}     (Arnoldi relation)
+            //   first pass of w_j:  c = Q_j^T w_j = (t - H s) / alpha,   d = q_j^T w_j = ((u.z - s.t) / alpha - rho) / alpha
+            //   next candidate      w_j - Q_j c - q_j d = (z - Q_j t) / alpha - e (u - Q_j s),   e = (rho / alpha + d) / alpha
+            // and one update pass over Q_j that writes q_j into V_j and the next candidate into V_{j+1}.
+            std::vector<double> h1p, sv(M + 2), tv(M + 2), cf(2 * (size_t)M + 4), red(2 * (size_t)M + 4);
+            const int ncolmax = 2 * M + 4;
+            if (!c->gm_part2 && (rc = dalloc(c, &c->gm_part2, (size_t)ncolmax * MAXPART))) return rc;
+            if (!c->gm_red && (rc = dalloc(c, &c->gm_red, (size_t)ncolmax))) return rc;
+            if (!c->gm_coef && (rc = dalloc(c, &c->gm_coef, (size_t)ncolmax))) return rc;
+            GmBlocks GB;
+            auto fill_blocks = [&]() { for (int q = 0; q < 16; q++) GB.blk[q] = q < (int)c->gm_blk.size() ? c->gm_blk[q] : c->gm_blk[0]; };
+            // sums over the basis: columns 2k (V_k . a), 2k+1 (V_k . b), then a.a, a.b -- one reduction kernel, one host round trip
+            auto dots = [&](int j, const double *a, const double *bvec) -> int {
+                for (int b0 = 0; b0 < j; b0 += GM_CH) {
+                    const int n16 = std::min(GM_CH, j - b0);
+                    Ptr16 V16;
+                    for (int q = 0; q < GM_CH; q++) V16.p[q] = (const double2 *)Vj(b0 + std::min(q, n16 - 1));
+                    hipLaunchKernelGGL(k_gmres_dots2, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, n16, (const double2 *)a,
+                                       (const double2 *)bvec, V16, b0, b0 == 0 ? 2 * j : -1, c->gm_part2);
+                }
+                const int ncol = 2 * j + 2;
+                hipLaunchKernelGGL(k_gmres_reduce, dim3((ncol + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, c->stream, ncol, gn,
+                                   (const double *)c->gm_part2, c->gm_red);
+                HIPCHK(c, hipGetLastError());
+                int e;
+                if (comm_active(c) && c->strip.on && (e = allreduce(c, c->gm_red, (size_t)ncol, NCCL_FLOAT64, NCCL_SUM, "GMRES sums"))) return e;
+                return fetch_results(c, c->gm_red, ncol, red.data());
+            };
+            // first step: w_0 = A q_0; h1 = q_0 . w_0; candidate u_1 = w_0 - q_0 h1 -> V_1
+            itn++;
+            hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1., (const double2 *)Vj(0),
+                               (double2 *)c->r, (double2 *)nullptr);
+            if ((rc = apply_B())) return rc;
+            LAUNCH_OP1(k_minres_apply, matfree(c), dim3(gn), c->op, nn, 1., (const double2 *)c->z, (const double2 *)c->dinv,
+                       (const double2 *)c->z, (double2 *)c->p[0], (double2 *)c->q, c->gm_part, c->gm_part + MAXPART, olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = need(1))) return rc;
+            if ((rc = dots(1, c->q, nullptr))) return rc;
+            h1p.assign(1, red[0]);
+            cf[0] = red[0];
+            HIPCHK(c, hipMemcpyAsync(c->gm_coef + ncolmax / 2, cf.data(), 8, hipMemcpyHostToDevice, c->stream));
+            fill_blocks();
+            hipLaunchKernelGGL(k_gmres_update2, dim3(gn), dim3(BLOCK), 0, c->stream, nn, nd, 1, GB, (const double *)c->gm_coef,
+                               (const double *)(c->gm_coef + ncolmax / 2), 1., 0., (const double2 *)c->q, (const double2 *)nullptr,
+                               (double2 *)nullptr, (double2 *)Vj(1));
+            HIPCHK(c, hipGetLastError());
+            for (int j = 1; j <= M; j++) {
+                const bool more = j < M && itn < maxit;   // another basis vector may still be built after this one
+                // z = A u -> c->q   (the operator application of iteration j + 1, on the candidate: one ahead of the finished basis)
+                itn++;
+                hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1., (const double2 *)Vj(j),
+                                   (double2 *)c->r, (double2 *)nullptr);
+                if ((rc = apply_B())) return rc;
+                LAUNCH_OP1(k_minres_apply, matfree(c), dim3(gn), c->op, nn, 1., (const double2 *)c->z, (const double2 *)c->dinv,
+                           (const double2 *)c->z, (double2 *)c->p[0], (double2 *)c->q, c->gm_part, c->gm_part + MAXPART, olo, ohi);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = dots(j, Vj(j), c->q))) return rc;
+                double ss = 0., st = 0.;
+                for (int q = 0; q < j; q++) {
+                    sv[q] = red[2 * q];
+                    tv[q] = red[2 * q + 1];
+                    ss += sv[q] * sv[q];
+                    st += sv[q] * tv[q];
+                }
+                const double uu = red[2 * j], uz = red[2 * j + 1];
+                const double a2 = uu - ss;
+                const double alpha = (a2 > 0. && std::isfinite(a2)) ? std::sqrt(a2) : 0.;
+                // column j-1 of the Hessenberg matrix is complete: first-pass coefficients + the delayed second pass, alpha below
+                std::fill(hcol.begin(), hcol.end(), 0.);
+                for (int q = 0; q < j; q++) hcol[q] = h1p[q] + sv[q];
+                hcol[j] = alpha;
+                for (int q = 0; q <= j; q++) Hraw[(size_t)q * M + (j - 1)] = hcol[q];
+                for (int q = 0; q < j - 1; q++) {
+                    const double t = cs[q] * hcol[q] + sn[q] * hcol[q + 1];
+                    hcol[q + 1] = -sn[q] * hcol[q] + cs[q] * hcol[q + 1];
+                    hcol[q] = t;
+                }
+                const double den = std::hypot(hcol[j - 1], hcol[j]);
+                cs[j - 1] = den > 0. ? hcol[j - 1] / den : 1.;
+                sn[j - 1] = den > 0. ? hcol[j] / den : 0.;
+                hcol[j - 1] = den;
+                hcol[j] = 0.;
+                g[j] = -sn[j - 1] * g[j - 1];
+                g[j - 1] = cs[j - 1] * g[j - 1];
+                for (int q = 0; q < j; q++) H[(size_t)q * M + (j - 1)] = hcol[q];
+                k = j;
+                if (std::fabs(g[j]) <= tol || !(alpha > 0.) || !more) break;
+                // first pass of the next vector, from the sums at hand
+                const double ia = 1. / alpha;
+                const double rho = alpha * sv[j - 1];
+                const double d = ((uz - st) * ia - rho) * ia;
+                const double e = (rho * ia + d) * ia;
+                h1p.assign(j + 1, 0.);
+                for (int q = 0; q < j; q++) {
+                    double r = 0.;   // (H s)_q over the finished columns (upper Hessenberg: column p reaches row p + 1)
+                    for (int p2 = (q > 0 ? q - 1 : 0); p2 < j; p2++) r += Hraw[(size_t)q * M + p2] * sv[p2];
+                    h1p[q] = (tv[q] - r) * ia;
+                    cf[q] = sv[q];
+                    cf[ncolmax / 2 + q] = tv[q] * ia - e * sv[q];
+                }
+                h1p[j] = d;
+                if ((rc = need(j + 1))) return rc;
+                fill_blocks();
+                HIPCHK(c, hipMemcpyAsync(c->gm_coef, cf.data(), (size_t)8 * j, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->gm_coef + ncolmax / 2, cf.data() + ncolmax / 2, (size_t)8 * j, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(k_gmres_update2, dim3(gn), dim3(BLOCK), 0, c->stream, nn, nd, j, GB, (const double *)c->gm_coef,
+                                   (const double *)(c->gm_coef + ncolmax / 2), ia, e, (const double2 *)Vj(j), (const double2 *)c->q,
+                                   (double2 *)Vj(j), (double2 *)Vj(j + 1));
+                HIPCHK(c, hipGetLastError());
+            }
+            c->n_gmres_its += k;
+        } else {
         for (int j = 0; j < M && itn < maxit; j++) {
             itn++;
             // w = P K B V_j  -> c->q
@@ -4101,6 +4259,7 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
             if ((rc = need(j + 1))) return rc;
             hipLaunchKernelGGL(k_scale_copy, dim3(grid_for(nn)), dim3(BLOCK), 0, c->stream, nn, 1. / hn, (const double2 *)c->q,
                                (double2 *)Vj(j + 1), (double2 *)nullptr);
+        }
         }
         // y = H^-1 g (upper triangular); t = V y -> c->r; x += B t
         std::vector<double> y(k, 0.);

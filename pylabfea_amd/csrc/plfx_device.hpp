@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "plfx_raypoly.hpp"
+#include "plfx_lapack3.hpp"
 
 namespace plfx {
 
@@ -227,11 +228,23 @@ __device__ inline void jacobi3_dev(const double *s, double *w, double *V)
     w[2] = A[8];
 }
 
+// States with out-of-plane shear: the order of the principal stresses is the one np.linalg.eig + the reference's re-ordering
+// give, i.e. LAPACK's dgeev replayed (plfx_lapack3.hpp).  Out of line: a cold path (no state of a 2-d model takes it) that must
+// not cost the sweep kernels registers.
+__device__ __noinline__ void sig_princ_general(const double *s, double *sp)
+{
+    double q[6] = {s[0], s[1], s[2], s[3], s[4], s[5]}, o[3];
+    lapack3::sig_princ_lapack3(q, o);
+    sp[0] = o[0];
+    sp[1] = o[1];
+    sp[2] = o[2];
+}
+
 // basic.py:107-179 sig_princ: principal stresses in the reference's axis-tracking order.  Plane
 // states (s23 = s13 = 0, every stress of the 2-d FE path) have the closed form below; the larger
 // eigenvalue of the in-plane block belongs to axis 0 iff s0 >= s1 (argmax |ev|, first maximum on ties).
-// General 3-d states follow the natural rule "axis i -> eigenvector with the largest |component i|"
-// (the reference's order there depends on LAPACK's dgeev output order).
+// General 3-d states: sig_princ_general above (round 6; until then the natural rule "axis i -> eigenvector with the
+// largest |component i|", which is the reference's only when dgeev's order happens to agree).
 __device__ inline void sig_princ_dev(const double *s, double *sp)
 {
     if (s[3] == 0. && s[4] == 0.) {
@@ -251,16 +264,7 @@ __device__ inline void sig_princ_dev(const double *s, double *sp)
         sp[2] = s[2];
         return;
     }
-    double w[3], V[9];
-    jacobi3_dev(s, w, V);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        int k = 0;
-#pragma unroll
-        for (int c = 1; c < 3; c++)
-            if (fabs(V[i * 3 + c]) > fabs(V[i * 3 + k])) k = c;
-        sp[i] = w[k];
-    }
+    sig_princ_general(s, sp);
 }
 
 // 3-parameter Hill / J2 on principal stresses (material.py:662-673); I1 from the Voigt normal components
@@ -1911,16 +1915,16 @@ __device__ inline int response_light(const MatDev &m, const YF &yf, double *sig,
 template <class YF>
 __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig, const double *epl,
                                       double *deps_r, double st_scal, double &fy, double *depl,
-                                      double *Ct)
+                                      double *Ct, const int maxit = MAXIT /* the sweeps of a model: the reference's default, a constant */)
 {
     const double *CV = m.CV;
     const double toler = YF_TOL * yf.sflow_entry(epl);  // :243 (with the hardening modulus at the entry of the call)
     double a[6], ca[6], dsr[6], ddepl[6], eplt[6], tmp[6], fy1;
     // sub-divided step (:288-291): nsteps = maxit
-    const int nsteps = MAXIT;
+    const int nsteps = maxit;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        deps_r[i] /= MAXIT;
+        deps_r[i] /= maxit;
         depl[i] = 0.;
     }
     symv(CV, deps_r, dsr);
@@ -2010,13 +2014,13 @@ __device__ inline void response_heavy(const MatDev &m, const YF &yf, double *sig
 // both phases; returns msg['nsteps'] (last loop index, :345)
 template <class YF>
 __device__ inline int response_point(const MatDev &m, const YF &yf, double *sig, const double *epl,
-                                     const double *deps, double &fy, double *depl, double *Ct)
+                                     const double *deps, double &fy, double *depl, double *Ct, const int maxit = MAXIT)
 {
     double deps_r[6], st_scal;
     const int st = response_light(m, yf, sig, epl, deps, fy, depl, Ct, deps_r, st_scal);
     if (st < 2) return 0;
-    response_heavy(m, yf, sig, epl, deps_r, st_scal, fy, depl, Ct);
-    return MAXIT - 1;
+    response_heavy(m, yf, sig, epl, deps_r, st_scal, fy, depl, Ct, maxit);
+    return maxit - 1;
 }
 
 }  // namespace plfx

@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int32_t *mat_id,
                  const double *sig_in, const double *epl_in, const double *deps_in, double *fy,
                  double *sig_out, double *depl_out, double *ct_out, int32_t *nsteps,
-                 const double *kh_in = nullptr, double *kh_out = nullptr, unsigned skip_mask = 0u /* materials run by k_response_row */)
+                 const double *kh_in = nullptr, double *kh_out = nullptr, unsigned skip_mask = 0u /* materials run by k_response_row */,
+                 int maxit = MAXIT /* Material.response(..., maxit): sub-steps of a sub-divided increment (material.py:207, 288-291) */)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -265,7 +266,7 @@ k_response_batch(const MatDev *gmat, int nmat, int lds_doubles, int n, const int
             const bool staged = (mid == svc_mat);
             const typename YfOf<KIND>::type yf =
                 make_policy<KIND>(m, staged ? sv : nullptr, staged ? dual : nullptr, kh_in ? kh_in[i] : m.khard);
-            ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
+            ns = response_point(m, yf, sig, epl, deps, f, depl, Ct, maxit);
             if (KIND == 7 && kh_out) kh_out[i] = yf.kh();
         }
         fy[i] = f;
@@ -557,8 +558,10 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags,
 // [c*nel + e].  flags[0] |= changed, flags[1] |= not converged, flags[2] = length of `list`, flags[3] = tangents rewritten.
 // Material / class tables are staged in LDS (wave-uniform addresses -> broadcast reads); holding them
 // in SGPRs instead (scalar loads + waterfall over classes) was measured 35 % slower (SGPR spills).
+// (KIND 2, principal-stress Hill: two waves per SIMD as before the out-of-line LAPACK replay of sig_princ_general was
+// added -- the call must not cost the streaming path its occupancy; the spills it takes sit on the cold side of that branch)
 template <int KIND>
-__global__ void __launch_bounds__(BLOCK, PLFX_SWEEP_WAVES)
+__global__ void __launch_bounds__(BLOCK, (KIND == 2 && PLFX_SWEEP_WAVES < 2) ? 2 : PLFX_SWEEP_WAVES)
 k_sweep_light(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__restrict__ gcls, int ncls,
               int lds_doubles, int nel, int e_off, const int32_t *__restrict__ conn,
               const int32_t *__restrict__ cls, const double2 *__restrict__ du2,
@@ -853,7 +856,7 @@ __global__ void __launch_bounds__(512)
 k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const int32_t *__restrict__ mat_id,
                const double *__restrict__ sig_in, const double *__restrict__ epl_in, const double *__restrict__ deps_in,
                double *__restrict__ fy, double *__restrict__ sig_out, double *__restrict__ depl_out, double *__restrict__ ct_out,
-               int32_t *__restrict__ nsteps)
+               int32_t *__restrict__ nsteps, int maxit = MAXIT)
 {
     __shared__ MatDev smat[MAXMAT];
     stage_materials(smat, gmat, nmat);
@@ -872,7 +875,7 @@ k_response_row(const MatDev *__restrict__ gmat, int nmat, int mat, int n, const 
             deps[c] = deps_in[6 * (size_t)i + c];
         }
         const YfSvcRow<4, INLDS> yf(m, npad);
-        const int ns = response_point(m, yf, sig, epl, deps, f, depl, Ct);
+        const int ns = response_point(m, yf, sig, epl, deps, f, depl, Ct, maxit);
         if (l16 == 0) {
             fy[i] = f;
             nsteps[i] = ns;

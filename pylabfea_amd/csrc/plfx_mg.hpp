@@ -640,6 +640,122 @@ k_scale_copy(int nn, double s, const double2 *__restrict__ src, double2 *__restr
     }
 }
 
+// ---- GMRES with delayed re-orthogonalisation (round 6): the basis is read TWICE per iteration instead of four
+// times.  Classical Gram-Schmidt twice (above) makes two projection passes per new vector, each a dots pass + an update pass
+// over the j basis vectors.  Here the second pass of vector j is delayed by one iteration and shares its two sweeps over the
+// basis with the first pass of vector j + 1 (Swirydowicz, Langou, Ananthan, Yang, Thomas 2020; Bielich et al. 2022: "DCGS-2"):
+// with u = the once-projected candidate for q_j and z = A u, ONE dots pass yields s = Q^T u, t = Q^T z, u.u, u.z, and ONE update
+// pass writes q_j = (u - Q s) / alpha and the next candidate (z - Q t) / alpha - e alpha q_j (plfx.hip: gmres_solve has the
+// algebra).  Sixteen basis vectors per dots launch (32 accumulators), all of them in one update launch.
+constexpr int GM_CH = 16;
+struct Ptr16 {
+    const double2 *p[GM_CH];
+};
+struct GmBlocks {
+    const double *blk[16];   // 16 allocations of GMRES_BLK = 32 vectors hold the 401 vectors of the longest cycle
+};
+
+// partials of V_k . a (column 2 (k0 + k)) and V_k . b (column 2 (k0 + k) + 1), k < n <= 16, over [own_lo, own_hi);
+// extra >= 0: also a . a and a . b into columns extra, extra + 1.   part[column * MAXPART + block].   b == nullptr: a only.
+__global__ void __launch_bounds__(BLOCK)
+k_gmres_dots2(int own_lo, int own_hi, int n, const double2 *__restrict__ a, const double2 *__restrict__ b, Ptr16 V, int k0,
+              int extra, double *__restrict__ part)
+{
+    __shared__ double sh[BLOCK / 64];
+    double acc[2 * GM_CH];
+#pragma unroll
+    for (int k = 0; k < 2 * GM_CH; k++) acc[k] = 0.;
+    double aa = 0., ab = 0.;
+    const bool two = b != nullptr;
+    for (int i = own_lo + blockIdx.x * BLOCK + threadIdx.x; i < own_hi; i += gridDim.x * BLOCK) {
+        const double2 ai = a[i];
+        const double2 bi = two ? b[i] : make_double2(0., 0.);
+#pragma unroll
+        for (int k = 0; k < GM_CH; k++)
+            if (k < n) {
+                const double2 v = V.p[k][i];
+                acc[2 * k] = fma(ai.x, v.x, fma(ai.y, v.y, acc[2 * k]));
+                acc[2 * k + 1] = fma(bi.x, v.x, fma(bi.y, v.y, acc[2 * k + 1]));
+            }
+        if (extra >= 0) {
+            aa = fma(ai.x, ai.x, fma(ai.y, ai.y, aa));
+            ab = fma(ai.x, bi.x, fma(ai.y, bi.y, ab));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GM_CH; k++) {
+        if (k >= n) break;
+        const double t0 = block_sum(acc[2 * k], sh);
+        if (threadIdx.x == 0) part[(size_t)(2 * (k0 + k)) * MAXPART + blockIdx.x] = t0;
+        if (two) {
+            const double t1 = block_sum(acc[2 * k + 1], sh);
+            if (threadIdx.x == 0) part[(size_t)(2 * (k0 + k) + 1) * MAXPART + blockIdx.x] = t1;
+        }
+    }
+    if (extra >= 0) {
+        const double t0 = block_sum(aa, sh);
+        const double t1 = block_sum(ab, sh);
+        if (threadIdx.x == 0) {
+            part[(size_t)extra * MAXPART + blockIdx.x] = t0;
+            part[(size_t)(extra + 1) * MAXPART + blockIdx.x] = t1;
+        }
+    }
+}
+
+// out[col] = sum of the gn partials of column col, in block order (one wave per column; deterministic)
+__global__ void __launch_bounds__(BLOCK)
+k_gmres_reduce(int ncol, int gn, const double *__restrict__ part, double *__restrict__ out)
+{
+    const int col = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (col >= ncol) return;
+    double t = 0.;
+    for (int i = lane; i < gn; i += 64) t += part[(size_t)col * MAXPART + i];
+    t = wave_sum(t);
+    if (lane == 0) out[col] = t;
+}
+
+// One sweep over the j basis vectors for both vectors of an iteration (coefficients cs[0..j) and cf[0..j) in device memory,
+// read with scalar loads):   qout = (u - sum_k cs_k Q_k) * inv_alpha ;   uout = z * inv_alpha - e u - sum_k cf_k Q_k.
+// z == nullptr: first step of a cycle, uout = u - sum_k cf_k Q_k only (qout untouched).  qout may alias u.
+__global__ void __launch_bounds__(BLOCK)
+k_gmres_update2(int nn, size_t nd, int j, GmBlocks B, const double *__restrict__ cs, const double *__restrict__ cf, double inv_alpha,
+                double e, const double2 *u, const double2 *__restrict__ z, double2 *qout, double2 *__restrict__ uout)
+{
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nn; i += gridDim.x * BLOCK) {
+        const double2 ui = u[i];
+        double2 a = ui, b;
+        if (z) {
+            const double2 zi = z[i];
+            b = make_double2(fma(-e, ui.x, zi.x * inv_alpha), fma(-e, ui.y, zi.y * inv_alpha));
+        } else
+            b = ui;
+        int k = 0;
+        for (; k + 8 <= j; k += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = ((const double2 *)(B.blk[(k + q) >> 5] + (size_t)((k + q) & 31) * nd))[i];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const double s = z ? cs[k + q] : 0., f = cf[k + q];
+                a.x = fma(-s, v[q].x, a.x);
+                a.y = fma(-s, v[q].y, a.y);
+                b.x = fma(-f, v[q].x, b.x);
+                b.y = fma(-f, v[q].y, b.y);
+            }
+        }
+        for (; k < j; k++) {
+            const double2 v = ((const double2 *)(B.blk[k >> 5] + (size_t)(k & 31) * nd))[i];
+            const double s = z ? cs[k] : 0., f = cf[k];
+            a.x = fma(-s, v.x, a.x);
+            a.y = fma(-s, v.y, a.y);
+            b.x = fma(-f, v.x, b.x);
+            b.y = fma(-f, v.y, b.y);
+        }
+        if (z) qout[i] = make_double2(a.x * inv_alpha, a.y * inv_alpha);
+        uout[i] = b;
+    }
+}
+
 constexpr int MG_COARSE_MAX = 1089;  // 33 x 33 nodes
 constexpr int MG_TAIL_BLOCK = 1024;  // threads of the single-workgroup tail kernel
 constexpr int MG_TAIL_NODES = 1089;  // levels up to 33 x 33 nodes run inside the tail kernel

@@ -645,25 +645,20 @@ class Material(object):
         if sh == (3,):
             raise NotImplementedError('response: pass the Voigt stress (6,); (3,) principal input is not supported')
         self._no_flow_rule()
-        if maxit != 50:
-            raise NotImplementedError('response: the device kernel is compiled for maxit=50 (reference default)')
+        maxit = int(maxit)
+        if maxit < 1:
+            raise ValueError('response: maxit must be >= 1')
         if self.sy is None:
             raise AttributeError('response called for a purely elastic material')
-        if self.sdim == 3 and not (self.tresca or self.barlat):
-            ds = np.asarray(CV, dtype=float) @ np.asarray(deps, dtype=float)
-            if sig[3] != 0. or sig[4] != 0. or ds[3] != 0. or ds[4] != 0.:
-                warnings.warn('response: stress state with out-of-plane shear on a principal-stress (sdim = 3) material -- the '
-                              'order of the principal stresses follows the device\'s rule in every sub-step, the reference\'s '
-                              'follows LAPACK there (see Material._princ_rows); plane states are exact', RuntimeWarning)
         if getattr(self, 'whdat', False):
             # Material.khard is state here: read on entry, overwritten by every gradient evaluation inside the call
             fy, so, dp, ct, ns, kout = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
                                                                np.asarray(deps, dtype=float)[None, :],
-                                                               khard_in=[self.khard], return_khard=True)
+                                                               khard_in=[self.khard], return_khard=True, maxit=maxit)
             self.khard = float(kout[0])
         else:
             fy, so, dp, ct, ns = self._load(CV).response(sig[None, :], np.asarray(epl, dtype=float)[None, :],
-                                                         np.asarray(deps, dtype=float)[None, :])
+                                                         np.asarray(deps, dtype=float)[None, :], maxit=maxit)
         self.msg['nsteps'] = int(ns[0])
         return fy[0], so[0], dp[0], ct[0].reshape(6, 6)
 

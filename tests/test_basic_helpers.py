@@ -154,30 +154,61 @@ def test_gpu_ml_full_yf_of_the_two_feature_svc_on_general_states(pg, golden_dir)
 
 
 @pytest.mark.gpu
-def test_gpu_response_warns_outside_its_scope_and_is_exact_on_plane_states(pg):
-    """response of a principal-stress material re-orders the principal stresses in every sub-step: exact for plane states,
-    a RuntimeWarning names the limit for states with out-of-plane shear (Material._princ_rows)"""
+def test_gpu_response_on_states_with_out_of_plane_shear(pg):
+    """Material.response of a principal-stress (sdim = 3) material re-orders the principal stresses of the
+    current stress in every sub-step (material.py:250-340 through basic.py:153-175: np.linalg.eig's order + the row-argmax
+    rule).  On states with out-of-plane shear that order is LAPACK's: the device replays dgeev for 3 x 3 symmetric matrices
+    (csrc/plfx_lapack3.hpp).  All 160 response rows of the reference fixture, nsteps exact, 1e-9 sy; no warning any more."""
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         m = hill3_material(pg)
     CV, s, e, d = pg['r_CV'], pg['r_sig'], pg['r_epl'], pg['r_deps']
-    with pytest.warns(RuntimeWarning, match='out-of-plane shear'):
-        m.response(s[1], e[1], d[1], CV)
-    # the same inputs with the out-of-plane shear removed: no warning, and the natural rule is the reference's
-    from oracle import oracle as O
-    E, nu, sy, kh, dr = pg['par']
-    om = O.Material(kind=O.PRINC3, sy=sy, khard=kh, hill=list(pg['hill']) + [1, 1, 1], drucker=dr)
-    s2, e2, d2 = s.copy(), e.copy(), d.copy()
-    for a in (s2, e2, d2):
-        a[:, 3:5] = 0.
-    fy, so, dp, ct, ns = O.response(om, CV, s2, e2, d2)
+    sy = float(pg['par'][2])
+    assert np.sum((s[:, 3] != 0.) | (s[:, 4] != 0.)) > 100 and np.sum(pg['r_nsteps'] == 49) > 50
     with warnings.catch_warnings():
         warnings.simplefilter('error')
-        for i in range(0, 48):
-            f, so_i, dp_i, ct_i = m.response(s2[i], e2[i], d2[i], CV)
-            assert m.msg['nsteps'] == ns[i]
-            assert np.max(np.abs(so_i - so[i])) < 1e-9 * sy and np.max(np.abs(dp_i - dp[i])) < 1e-12
+        for i in range(len(s)):
+            f, so, dp, ct = m.response(s[i], e[i], d[i], CV)
+            assert m.msg['nsteps'] == pg['r_nsteps'][i], i
+            assert np.max(np.abs(so - pg['r_sig_out'][i])) < 1e-9 * sy, i
+            assert np.max(np.abs(dp - pg['r_depl'][i])) < 1e-12, i
+            assert abs(f - pg['r_fy'][i]) < 1e-9 * sy, i
+            assert np.max(np.abs(ct.reshape(36) - pg['r_ct'][i])) < 1e-8 * CV[0, 0], i
+    # the batch entry gives the same numbers in one launch
+    fy, so, dp, ct, ns = m.response_batch(s, e, d, CV)
+    assert np.array_equal(ns, pg['r_nsteps']) and np.max(np.abs(so - pg['r_sig_out'])) < 1e-9 * sy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('maxit', [20, 7])
+def test_gpu_response_with_maxit(pg, maxit):
+    """Material.response(..., maxit) (material.py:207, 288-291: the sub-division count of an increment whose trial step ends
+    outside the yield locus; msg['nsteps'] = maxit - 1 then) against reference vectors for maxit = 20 and 7, sdim = 3 and 6."""
+    import warnings
+    import pylabfea_amd as FE
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m3 = hill3_material(pg)
+        m6 = FE.Material()
+        m6.elasticity(E=200.e3, nu=0.3)
+        m6.plasticity(sy=100., hill=list(pg['hill6']), khard=100., drucker=0.05, sdim=6)
+    CV, s, e, d = pg['r_CV'], pg['r_sig'], pg['r_epl'], pg['r_deps']
+    sy = float(pg['par'][2])
+    for mat, tag in ((m3, ''), (m6, '6')):
+        k = 'rm%d%s_' % (maxit, tag)
+        assert np.sum(pg[k + 'nsteps'] == maxit - 1) > 50
+        for i in range(0, len(s), 2):
+            f, so, dp, ct = mat.response(s[i], e[i], d[i], CV, maxit=maxit)
+            assert mat.msg['nsteps'] == pg[k + 'nsteps'][i], (tag, i)
+            assert np.max(np.abs(so - pg[k + 'sig_out'][i])) < 1e-9 * sy, (tag, i)
+            assert np.max(np.abs(dp - pg[k + 'depl'][i])) < 1e-12, (tag, i)
+            assert np.max(np.abs(ct.reshape(36) - pg[k + 'ct'][i])) < 1e-8 * CV[0, 0], (tag, i)
+        # ... and the default is untouched by the call before
+        f, so, dp, ct = mat.response(s[0], e[0], d[0], CV)
+        assert mat.msg['nsteps'] == pg['r_nsteps'][0] if tag == '' else True
+    with pytest.raises(ValueError):
+        m6.response(s[0], e[0], d[0], CV, maxit=0)
 
 
 def test_fixture_fgrad_of_a_voigt_stress_is_the_mixed_form(pg):

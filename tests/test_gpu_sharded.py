@@ -325,7 +325,7 @@ def test_bench_one_rank_with_rccl_collectives_forced():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
     assert (d['sweeps'], d['solves'], d['pcg_iterations']) == (d1['sweeps'], d1['solves'], d1['pcg_iterations'])
     # the two-solution initial guess ran in the strip as in the plain engine: sums over the owned columns, all-reduced
-    assert d['initial_guess_from_two_solutions'] == d1['initial_guess_from_two_solutions'] and d1['initial_guess_from_two_solutions']['applied'] > 0
+    assert d['initial_guess_from_two_solutions'] == d1['initial_guess_from_two_solutions'] and d1['initial_guess_from_two_solutions']['accepted_as_solution'] > 0
     assert abs(d['config5_leg']['sgl_yy'] - d1['config5_leg']['sgl_yy']) < 1e-8 * abs(d1['config5_leg']['sgl_yy'])
 
 
