@@ -3993,8 +3993,12 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
 }
 
 constexpr int GMRES_BLK = 32;  // basis vectors per allocation
-constexpr int GMRES_M = 400;  // restart length: long enough that the solves of config 5 finish within one cycle (restarts stall on
-                            // indefinite K); halved until the basis fits into a third of the free HBM
+constexpr int GMRES_M_CGS2 = 400;  // restart length of rounds 3-5 (PLFX_GMRES_ORTH=cgs2)
+constexpr int GMRES_M = 1200;      // restart length (round 6): restarts stall on indefinite K -- a solve that needs 500 iterations took three cycles of
+                                   // 400 (1176 iterations) or none at all (residual stuck at 1e-6 after the first restart, profiles/r07e_*); with
+                                   // the basis read twice instead of four times per iteration a cycle three times as long costs what it cost,
+                                   // and the blocks are allocated as a cycle grows into them.  Reduced until the basis fits into a third of the
+                                   // free HBM (2048^2: 81 GB); PLFX_GMRES_M overrides
 int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
 {
     const size_t nd = c->ndof;
@@ -4008,8 +4012,10 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
     if (c->gm_m == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
-        c->gm_m = GMRES_M;
-        while (c->gm_m > 25 && (size_t)(c->gm_m + 1) * nd * 8 > fr / 3) c->gm_m /= 2;
+        static const bool cgs2_len = getenv("PLFX_GMRES_ORTH") && !strcmp(getenv("PLFX_GMRES_ORTH"), "cgs2");
+        c->gm_m = getenv("PLFX_GMRES_M") ? std::max(25, atoi(getenv("PLFX_GMRES_M"))) : (cgs2_len ? GMRES_M_CGS2 : GMRES_M);
+        c->gm_m = std::min(c->gm_m, 40 * GMRES_BLK - 1);
+        while (c->gm_m > 25 && (size_t)(c->gm_m + 1) * nd * 8 > fr / 3) c->gm_m = (c->gm_m * 2) / 3;
         if (comm_active(c)) {  // every rank must run the same cycle length (paired collectives of a strip; identical iterates of a replicated solve)
             double mv = c->gm_m;
             HIPCHK(c, hipMemcpyAsync(c->small, &mv, 8, hipMemcpyHostToDevice, c->stream));
@@ -4051,6 +4057,7 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
     // per iteration, a host round trip per eight vectors); default: delayed re-orthogonalisation, two sweeps, two round trips
     static const bool dcgs2 = !(getenv("PLFX_GMRES_ORTH") && !strcmp(getenv("PLFX_GMRES_ORTH"), "cgs2"));
     std::vector<double> Hraw(dcgs2 ? (size_t)(M + 1) * M : 0);
+    static const bool gm_dbg = getenv("PLFX_GMRES_DEBUG") != nullptr;
     while (true) {
         // r0 = P (b - K x) -> c->r; beta = |r0|
         LAUNCH_OP1(k_cg_start, matfree(c), dim3(gn), c->op, nn, 1, (const double2 *)c->x, (const double2 *)c->rhs,
@@ -4095,18 +4102,16 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
             if (!c->gm_red && (rc = dalloc(c, &c->gm_red, (size_t)ncolmax))) return rc;
             if (!c->gm_coef && (rc = dalloc(c, &c->gm_coef, (size_t)ncolmax))) return rc;
             GmBlocks GB;
-            auto fill_blocks = [&]() { for (int q = 0; q < 16; q++) GB.blk[q] = q < (int)c->gm_blk.size() ? c->gm_blk[q] : c->gm_blk[0]; };
+            auto fill_blocks = [&]() { for (int q = 0; q < 40; q++) GB.blk[q] = q < (int)c->gm_blk.size() ? c->gm_blk[q] : c->gm_blk[0]; };
             // sums over the basis: columns 2k (V_k . a), 2k+1 (V_k . b), then a.a, a.b -- one reduction kernel, one host round trip
             auto dots = [&](int j, const double *a, const double *bvec) -> int {
-                for (int b0 = 0; b0 < j; b0 += GM_CH) {
-                    const int n16 = std::min(GM_CH, j - b0);
-                    Ptr16 V16;
-                    for (int q = 0; q < GM_CH; q++) V16.p[q] = (const double2 *)Vj(b0 + std::min(q, n16 - 1));
-                    hipLaunchKernelGGL(k_gmres_dots2, dim3(gn), dim3(BLOCK), 0, c->stream, olo, ohi, n16, (const double2 *)a,
-                                       (const double2 *)bvec, V16, b0, b0 == 0 ? 2 * j : -1, c->gm_part2);
-                }
+                fill_blocks();
+                const int gd = std::min(gn, std::max(1, (ohi - olo + 2 * BLOCK - 1) / (2 * BLOCK)));   // tiles of 512 nodes
+                for (int b0 = 0; b0 < j; b0 += GM_KC)
+                    hipLaunchKernelGGL(k_gmres_dots3, dim3(gd), dim3(BLOCK), 0, c->stream, olo, ohi, b0, std::min(GM_KC, j - b0), GB, nd,
+                                       (const double2 *)a, (const double2 *)bvec, b0 == 0 ? 2 * j : -1, c->gm_part2);
                 const int ncol = 2 * j + 2;
-                hipLaunchKernelGGL(k_gmres_reduce, dim3((ncol + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, c->stream, ncol, gn,
+                hipLaunchKernelGGL(k_gmres_reduce, dim3((ncol + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, c->stream, ncol, gd,
                                    (const double *)c->gm_part2, c->gm_red);
                 HIPCHK(c, hipGetLastError());
                 int e;
@@ -4152,6 +4157,11 @@ int gmres_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
                 const double uu = red[2 * j], uz = red[2 * j + 1];
                 const double a2 = uu - ss;
                 const double alpha = (a2 > 0. && std::isfinite(a2)) ? std::sqrt(a2) : 0.;
+                if (gm_dbg) {
+                    double smax = 0.;
+                    for (int q = 0; q < j; q++) smax = std::max(smax, std::fabs(sv[q]));
+                    fprintf(stderr, "[gmres-d] j %d u.u %.6e s.s %.3e max|s| %.3e alpha %.6e |g| %.3e\n", j, uu, ss, smax, alpha, std::fabs(g[j - 1]));
+                }
                 // column j-1 of the Hessenberg matrix is complete: first-pass coefficients + the delayed second pass, alpha below
                 std::fill(hcol.begin(), hcol.end(), 0.);
                 for (int q = 0; q < j; q++) hcol[q] = h1p[q] + sv[q];

@@ -646,51 +646,64 @@ k_scale_copy(int nn, double s, const double2 *__restrict__ src, double2 *__restr
 // basis with the first pass of vector j + 1 (Swirydowicz, Langou, Ananthan, Yang, Thomas 2020; Bielich et al. 2022: "DCGS-2"):
 // with u = the once-projected candidate for q_j and z = A u, ONE dots pass yields s = Q^T u, t = Q^T z, u.u, u.z, and ONE update
 // pass writes q_j = (u - Q s) / alpha and the next candidate (z - Q t) / alpha - e alpha q_j (plfx.hip: gmres_solve has the
-// algebra).  Sixteen basis vectors per dots launch (32 accumulators), all of them in one update launch.
-constexpr int GM_CH = 16;
-struct Ptr16 {
-    const double2 *p[GM_CH];
-};
+// algebra).  Up to 128 basis vectors per dots launch, all of them in one update launch.
 struct GmBlocks {
-    const double *blk[16];   // 16 allocations of GMRES_BLK = 32 vectors hold the 401 vectors of the longest cycle
+    const double *blk[40];   // 40 allocations of GMRES_BLK = 32 vectors hold the 1201 vectors of the longest cycle
 };
 
-// partials of V_k . a (column 2 (k0 + k)) and V_k . b (column 2 (k0 + k) + 1), k < n <= 16, over [own_lo, own_hi);
-// extra >= 0: also a . a and a . b into columns extra, extra + 1.   part[column * MAXPART + block].   b == nullptr: a only.
+// partials of V_k . a (column 2 k) and V_k . b (column 2 k + 1) for the basis vectors k0 <= k < k0 + kn (kn <= GM_KC) over
+// [own_lo, own_hi); extra >= 0: also a . a and a . b into columns extra, extra + 1.   part[column * MAXPART + block].
+// b == nullptr: a only.  A workgroup walks tiles of 512 nodes: every thread keeps its two nodes of a and b in registers and loops
+// over the kn basis vectors (two 16-byte loads per vector), the products are summed across the wave by DPP butterflies + four
+// readlanes (no LDS crossbar) and lane 0 adds them to the wave's own accumulator row in LDS; a and b are read once per GM_KC
+// vectors (first version: 16 vectors per launch with 32 register accumulators per thread -- 3.3 TB/s and a re-read of a, b per
+// launch; profiles/r07d_config5_kernel_summary_first_dcgs2.txt).
+constexpr int GM_KC = 128;
 __global__ void __launch_bounds__(BLOCK)
-k_gmres_dots2(int own_lo, int own_hi, int n, const double2 *__restrict__ a, const double2 *__restrict__ b, Ptr16 V, int k0,
-              int extra, double *__restrict__ part)
+k_gmres_dots3(int own_lo, int own_hi, int k0, int kn, GmBlocks B, size_t nd, const double2 *__restrict__ a,
+              const double2 *__restrict__ b, int extra, double *__restrict__ part)
 {
+    __shared__ double acc[BLOCK / 64][2 * GM_KC];
     __shared__ double sh[BLOCK / 64];
-    double acc[2 * GM_CH];
-#pragma unroll
-    for (int k = 0; k < 2 * GM_CH; k++) acc[k] = 0.;
-    double aa = 0., ab = 0.;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = lane; q < 2 * GM_KC; q += 64) acc[wave][q] = 0.;   // (a wave only ever touches its own row: no barrier needed)
     const bool two = b != nullptr;
-    for (int i = own_lo + blockIdx.x * BLOCK + threadIdx.x; i < own_hi; i += gridDim.x * BLOCK) {
-        const double2 ai = a[i];
-        const double2 bi = two ? b[i] : make_double2(0., 0.);
-#pragma unroll
-        for (int k = 0; k < GM_CH; k++)
-            if (k < n) {
-                const double2 v = V.p[k][i];
-                acc[2 * k] = fma(ai.x, v.x, fma(ai.y, v.y, acc[2 * k]));
-                acc[2 * k + 1] = fma(bi.x, v.x, fma(bi.y, v.y, acc[2 * k + 1]));
-            }
+    double aa = 0., ab = 0.;
+    constexpr int TILE = 2 * BLOCK;
+    for (int base = own_lo + blockIdx.x * TILE; base < own_hi; base += gridDim.x * TILE) {
+        const int i0 = base + threadIdx.x, i1 = i0 + BLOCK;
+        const bool ok0 = i0 < own_hi, ok1 = i1 < own_hi;
+        const double2 zero = make_double2(0., 0.);
+        const double2 a0 = ok0 ? a[i0] : zero, a1 = ok1 ? a[i1] : zero;
+        const double2 b0 = (two && ok0) ? b[i0] : zero, b1 = (two && ok1) ? b[i1] : zero;
         if (extra >= 0) {
-            aa = fma(ai.x, ai.x, fma(ai.y, ai.y, aa));
-            ab = fma(ai.x, bi.x, fma(ai.y, bi.y, ab));
+            aa = fma(a0.x, a0.x, fma(a0.y, a0.y, fma(a1.x, a1.x, fma(a1.y, a1.y, aa))));
+            ab = fma(a0.x, b0.x, fma(a0.y, b0.y, fma(a1.x, b1.x, fma(a1.y, b1.y, ab))));
+        }
+#pragma unroll 4
+        for (int k = 0; k < kn; k++) {
+            const double2 *vk = (const double2 *)(B.blk[(k0 + k) >> 5] + (size_t)((k0 + k) & 31) * nd);
+            const double2 v0 = ok0 ? vk[i0] : zero, v1 = ok1 ? vk[i1] : zero;
+            double pa = fma(a0.x, v0.x, fma(a0.y, v0.y, fma(a1.x, v1.x, a1.y * v1.y)));
+            pa = wave_allsum(pa);
+            double pb = 0.;
+            if (two) {
+                pb = fma(b0.x, v0.x, fma(b0.y, v0.y, fma(b1.x, v1.x, b1.y * v1.y)));
+                pb = wave_allsum(pb);
+            }
+            if (lane == 0) {
+                acc[wave][2 * k] += pa;
+                if (two) acc[wave][2 * k + 1] += pb;
+            }
         }
     }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 2 * kn; q += BLOCK) {
+        if (!two && (q & 1)) continue;
+        double t = acc[0][q];
 #pragma unroll
-    for (int k = 0; k < GM_CH; k++) {
-        if (k >= n) break;
-        const double t0 = block_sum(acc[2 * k], sh);
-        if (threadIdx.x == 0) part[(size_t)(2 * (k0 + k)) * MAXPART + blockIdx.x] = t0;
-        if (two) {
-            const double t1 = block_sum(acc[2 * k + 1], sh);
-            if (threadIdx.x == 0) part[(size_t)(2 * (k0 + k) + 1) * MAXPART + blockIdx.x] = t1;
-        }
+        for (int w = 1; w < BLOCK / 64; w++) t += acc[w][q];
+        part[(size_t)(2 * k0 + q) * MAXPART + blockIdx.x] = t;
     }
     if (extra >= 0) {
         const double t0 = block_sum(aa, sh);
