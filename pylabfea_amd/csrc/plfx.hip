@@ -4629,46 +4629,47 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
         unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
-        if (pred_active || c->mg_pending) {
-            // learn first whether anything is needed at all: the reference repeats solves of one system (x satisfies the
-            // tolerance as it is: nothing to interpolate, no coarse level to set up), and the coarse levels may be stale (mg_ensure)
+        if (pred_active) {
+            // Everything the interpolated start needs is enqueued behind the first test and returns at once if that test passed
+            // (the reference repeats solves of one system: x satisfies the tolerance as it is); the host waits ONCE, for the second
+            // test (round 6: three round trips -> one).  d = x - (solution before), K d, the two sums, alpha on the device
+            // (k_pred_alpha), | P (r - alpha K d) |^2 into the free slot P_rr[0] without touching x, r, z, the test on it.
+            hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->dinv, c->pred_d, c->sc);
+            LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->pred_d, nullptr, nullptr, (double2 *)c->p[0],
+                       nullptr, nullptr, nullptr, 0, nullptr, c->sc, 0, 0, 0);
+            const int gp = MAXPART;   // (one size on every rank: the all-reduce of the partial sums pairs up)
+            hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, (size_t)2 * olo, (size_t)2 * ohi, c->dinv, c->r, c->p[0],
+                               c->part, c->sc);
+            HIPCHK(c, hipGetLastError());
+            if (c->strip.on && (rc = part_allreduce(c, c->part, (size_t)2 * MAXPART))) return rc;
+            hipLaunchKernelGGL(k_pred_alpha, dim3(1), dim3(BLOCK), 0, c->stream, (const double *)c->part, gp, c->sc);
+            hipLaunchKernelGGL(k_pred_try, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const CgScalars *)c->sc, (const double2 *)c->r,
+                               (const double2 *)c->p[0], (const double2 *)c->dinv, P_rr[0], olo, ohi);
+            HIPCHK(c, hipGetLastError());
+            if (c->strip.on && (rc = part_allreduce(c, P_rr[0], gn))) return rc;
+            seq = cg_check_post(c, P_rr[0], gn, -2);   // (iters = -2 marks "converged by the interpolated start")
             if ((rc = cg_check_wait(c, seq, &hs))) return rc;
             done = hs.done;
-            if (!done && pred_active) {
-                // x + alpha d, 0 <= alpha <= 1 minimising | r - alpha P K d |: one operator pass (K x = b - r is at hand), two sums
-                hipLaunchKernelGGL(k_pred_diff, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->pred_x, c->dinv, c->pred_d);
-                LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(gn), c->op, 0, nn, (const double2 *)c->pred_d, nullptr, nullptr, (double2 *)c->p[0],
-                           nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
-                const int gp = MAXPART;   // (one size on every rank: the all-reduce of the partial sums pairs up)
-                hipLaunchKernelGGL(k_pred_dots, dim3(gp), dim3(BLOCK), 0, c->stream, (size_t)2 * olo, (size_t)2 * ohi, c->dinv, c->r, c->p[0],
-                                   c->part);
+            if (done == 1 && hs.iters == -2) {   // it is the solution: commit x (r, z are not read again: the loop below is skipped)
+                hipLaunchKernelGGL(k_pred_commit, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, (const CgScalars *)c->sc, c->x, c->pred_d);
                 HIPCHK(c, hipGetLastError());
-                double o[2];
-                if ((rc = host_sums(c, c->part, 2, gp, o))) return rc;
-                double alpha = (o[1] > 0.) ? o[0] / o[1] : 0.;
-                if (!std::isfinite(alpha)) alpha = 0.;
-                alpha = std::min(1., std::max(0., alpha));
-                if (alpha < 0.01) alpha = 0.;   // (round-off of a d that does not help)
+                hs.iters = 0;
+                c->n_pred++;
                 pred_d_ready = true;
-                if (alpha > 0.) {
-                    // would x + alpha d do?  | P (r - alpha K d) |^2 into the free slot P_rr[0]; nothing is written to x, r, z
-                    hipLaunchKernelGGL(k_pred_try, dim3(gn), dim3(BLOCK), 0, c->stream, nn, alpha, (const double2 *)c->r, (const double2 *)c->p[0],
-                                       (const double2 *)c->dinv, P_rr[0], olo, ohi);
-                    HIPCHK(c, hipGetLastError());
-                    if (c->strip.on && (rc = part_allreduce(c, P_rr[0], gn))) return rc;
-                    seq = cg_check_post(c, P_rr[0], gn, 0);
-                    if ((rc = cg_check_wait(c, seq, &hs))) return rc;
-                    done = hs.done;
-                    if (done == 1) {   // it is the solution: commit x (r, z are not read again: the loop below is skipped)
-                        hipLaunchKernelGGL(k_pred_commit, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, alpha, c->x, c->pred_d);
-                        HIPCHK(c, hipGetLastError());
-                        c->n_pred++;
-                        pred_moved = true;
-                    } else
-                        c->n_pred_rejected++;
-                } else
-                    c->n_pred_skipped++;
+                pred_moved = true;
+            } else if (!done) {
+                pred_d_ready = true;
+                if (hs.aux > 0.) c->n_pred_rejected++;
+                else c->n_pred_skipped++;
             }
+            if (!done) {
+                if ((rc = mg_ensure(c))) return rc;
+                if ((rc = mg_vcycle_head(c))) return rc;
+            }
+        } else if (c->mg_pending) {
+            // the coarse levels are stale (mg_ensure): learn first whether a V-cycle is needed at all
+            if ((rc = cg_check_wait(c, seq, &hs))) return rc;
+            done = hs.done;
             if (!done) {
                 if ((rc = mg_ensure(c))) return rc;
                 if ((rc = mg_vcycle_head(c))) return rc;

@@ -1770,6 +1770,7 @@ struct CgScalars {
     int32_t done;    // sticky convergence flag
     int32_t iters;   // iteration count at convergence
     double rr_final;
+    double aux;      // step of the interpolated start (k_pred_alpha; travels to the host with the flags)
 };
 
 template <int MODE, int GRID>
@@ -1782,6 +1783,7 @@ k_spmv(KOp op, int n_begin, int n_end,
 {
     __shared__ double sh[BLOCK / 64];
     double beta = 0.;
+    if (MODE == 0 && sc != nullptr && sc->done) return;   // (speculatively enqueued K d of the interpolated start)
     if (MODE >= 1) {
         if (sc->done) return;
         double rr, rzn = 0., rzo = 1.;
@@ -2057,6 +2059,7 @@ __global__ void k_cg_setup(const double *part_bb, int npart, double rtol, CgScal
         sc->done = 0;
         sc->iters = -1;
         sc->rr_final = -1.;
+        sc->aux = 0.;
     }
 }
 
@@ -2214,8 +2217,9 @@ k_x0(size_t ndof, const double *__restrict__ du, const double *__restrict__ is_p
 // d = x - xprev   (x = the solution of the previous solve, xprev = the last solution that differed from it)
 __global__ void __launch_bounds__(BLOCK)
 k_pred_diff(size_t ndof, const double *__restrict__ x, const double *__restrict__ xprev, const double *__restrict__ dinv,
-            double *__restrict__ d)
+            double *__restrict__ d, const CgScalars *__restrict__ sc)
 {
+    if (sc->done) return;   // the plain start satisfies the tolerance: nothing to interpolate (enqueued before the host knows)
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK)
         d[i] = (dinv[i] != 0.) ? x[i] - xprev[i] : 0.;   // (the Dirichlet set may have changed since xprev was a solution)
 }
@@ -2230,9 +2234,10 @@ k_pred_advance(size_t ndof, double *__restrict__ xprev, const double *__restrict
 // partials of (K d) . r and (K d) . (K d) over the free DOFs (r = P (b - K x)): the step alpha that minimises | r - alpha P K d |
 __global__ void __launch_bounds__(BLOCK)
 k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node columns) */, const double *__restrict__ dinv,
-            const double *__restrict__ r, const double *__restrict__ kd, double *__restrict__ part)
+            const double *__restrict__ r, const double *__restrict__ kd, double *__restrict__ part, const CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
     double a0 = 0., a1 = 0.;
     for (size_t i = dof_lo + blockIdx.x * (size_t)BLOCK + threadIdx.x; i < dof_hi; i += (size_t)gridDim.x * BLOCK) {
         if (dinv[i] == 0.) continue;
@@ -2250,11 +2255,34 @@ k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node 
 
 // | P (r - alpha K d) |^2 over the owned free DOFs, nothing written: would x + alpha d satisfy the tolerance as it is?  (Round 6: the
 // interpolated start is taken only when it FINISHES the solve; a solve that iterates starts from x, bit for bit the plain warm start.)
-__global__ void __launch_bounds__(BLOCK)
-k_pred_try(int nnode, double alpha, const double2 *__restrict__ r, const double2 *__restrict__ kd, const double2 *__restrict__ dinv,
-           double *__restrict__ part_rr_out, int own_lo, int own_hi)
+// alpha = (K d . r) / (K d . K d) clamped to [0, 1], steps below 0.01 dropped (round-off of a d that does not help): one block,
+// from the partials of k_pred_dots; the step stays on the device (k_pred_try / k_pred_commit read it) and goes to the host in sc->aux
+__global__ void __launch_bounds__(BLOCK) k_pred_alpha(const double *__restrict__ part, int gp, CgScalars *__restrict__ sc)
 {
     __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    const double o0 = sum_partials(part, gp, sh);
+    const double o1 = sum_partials(part + MAXPART, gp, sh);
+    if (threadIdx.x == 0) {
+        double a = (o1 > 0.) ? o0 / o1 : 0.;
+        if (!(a == a) || a > 1.e300 || a < -1.e300) a = 0.;
+        a = fmin(1., fmax(0., a));
+        if (a < 0.01) a = 0.;
+        sc->aux = a;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_pred_try(int nnode, const CgScalars *__restrict__ sc, const double2 *__restrict__ r, const double2 *__restrict__ kd,
+           const double2 *__restrict__ dinv, double *__restrict__ part_rr_out, int own_lo, int own_hi)
+{
+    __shared__ double sh[BLOCK / 64];
+    if (sc->done) return;
+    const double alpha = sc->aux;
+    if (alpha == 0.) {   // no step: the test that follows must fail
+        if (threadIdx.x == 0) part_rr_out[blockIdx.x] = 1.e300;
+        return;
+    }
     double a_rr = 0.;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nnode; i += gridDim.x * BLOCK) {
         if (i < own_lo || i >= own_hi) continue;
@@ -2269,8 +2297,9 @@ k_pred_try(int nnode, double alpha, const double2 *__restrict__ r, const double2
 
 // x += alpha d: the accepted start IS the solution (r and z of the finished solve are not read again)
 __global__ void __launch_bounds__(BLOCK)
-k_pred_commit(size_t ndof, double alpha, double *__restrict__ x, const double *__restrict__ d)
+k_pred_commit(size_t ndof, const CgScalars *__restrict__ sc, double *__restrict__ x, const double *__restrict__ d)
 {
+    const double alpha = sc->aux;
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) x[i] = fma(alpha, d[i], x[i]);
 }
 
