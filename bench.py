@@ -635,7 +635,7 @@ def main():
                          'synchronisation in between crash rocprofv3 (ROCm 7.2); skipped automatically under the profiler')
     ap.add_argument('--no-inclusion', action='store_true', help='skip the heterogeneous (soft inclusion) variant of the workload')
     ap.add_argument('--no-svc', action='store_true', help='skip the bounded config-4 (SVC) sample behind roofline_svc')
-    ap.add_argument('--svc-mesh', type=int, default=128)
+    ap.add_argument('--svc-mesh', type=int, default=256, help='mesh of the bounded config-4 (SVC) sample: 256 = eight rounds of workgroups per CU, close to the steady state of the 512^2 configuration (128: two rounds -- the tail of each costs 10 %)')
     ap.add_argument('--no-2048', action='store_true', help='skip the 2048^2 roofline pass (kernels whose working set exceeds the Infinity Cache)')
     ap.add_argument('--all-families', action='store_true',
                     help='HIP-event timing of every kernel family (kernel_ms table) instead of only the two roofline kernels; '
@@ -922,7 +922,11 @@ def main():
         'roofline_spmv': roof('spmv'),
         'kernel_ms': {k: round(v[0], 3) for k, v in tim.items() if v[1] > 0},
     }
-    if tim['vcycle'][1] > 0 and tim['mg_smooth'][1] > 0:
+    have_sampled = tim['vcycle'][1] > 0 and tim['mg_smooth'][1] > 0
+    if not have_sampled and world == 1 and dist is None and eng.precond_info()[0] == 1 and not args.no_tight_loop:
+        out['vcycle'] = {'avg_us': None, 'cycles_timed': 0, 'fine_level_us': None, 'coarse_levels_us': None,
+                         'note': 'no V-cycle ran in the timed window (see config.workload)'}
+    if have_sampled:
         # the part of a load step that has NO roofline: levels >= 1 of the V-cycle are launch-latency bound (24 kernels of 4-7 us
         # + the single-workgroup tail) -- reported as time, not as a fraction of anything
         vc_us = 1e3 * tim['vcycle'][0] / tim['vcycle'][1]
@@ -932,6 +936,7 @@ def main():
                          'note': 'whole V(2,2) cycle (HIP events, every %d-th cycle); fine level = 4 operator passes at the rate of the '
                                  'roofline kernel; the rest (levels >= 1: transfers, 24 launch-latency-bound kernels replayed from a hipGraph, '
                                  'single-workgroup tail) is latency-bound and has no roofline' % args.sample}
+    if 'vcycle' in out:
         under_profiler = any('rocprof' in os.environ.get(v, '').lower() for v in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
         if world == 1 and dist is None and eng.precond_info()[0] == 1 and not args.no_tight_loop and not under_profiler:
             # the same cycle measured WITHOUT the solver around it: 200 applications back to back between one pair of HIP events
@@ -939,8 +944,8 @@ def main():
             # carries the sampling events and whatever the stream did before each sampled cycle
             tl = min(eng.precond_bench(200) for _ in range(3))
             v = out['vcycle']
-            v['in_run_sampled'] = {'avg_us': v['avg_us'], 'fine_level_us': v['fine_level_us'], 'coarse_levels_us': v['coarse_levels_us'],
-                                   'cycles_timed': v['cycles_timed']}
+            v['in_run_sampled'] = ({'avg_us': v['avg_us'], 'fine_level_us': v['fine_level_us'], 'coarse_levels_us': v['coarse_levels_us'],
+                                    'cycles_timed': v['cycles_timed']} if have_sampled else None)
             v['avg_us'], v['coarse_levels_us'], v['fine_level_us'] = tl[0], tl[1], tl[0] - tl[1]
             v['cycles_timed'] = 600
             v['note'] = ('whole V(2,2) cycle, 200 applications back to back between one pair of HIP events (plfx_precond_bench, best of 3); '

@@ -68,6 +68,42 @@ __device__ __forceinline__ double exp2_neg(double y)
     p = fma(p, r, 1.0);
     return __hiloint2double(__double2hiint(p) + (ni << 20), __double2loint(p));
 }
+// N of them in lock-step (the same operations per value, so the same bits): written coefficient by coefficient so that the
+// N Horner chains are issued interleaved.  The row kernels of the SVC evaluate 4 - 8 exponentials per chunk of support vectors; the
+// compiler interleaved them pairwise at best, and with a 4-cycle issue slot per wave64 FP64 instruction two dependent chains do
+// not cover the latency of v_fma_f64 (round 6: valu issue utilisation of k_sweep_svc_row<1> 0.65 -> see DESIGN 11.5).
+template <int N>
+__device__ __forceinline__ void exp2_neg_n(const double (&yin)[N], double (&out)[N])
+{
+    double r[N], p[N];
+    int ni[N];
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        const double y = fmax(yin[c], -1020.);
+        const double t = y + 6755399441055744.0;
+        const double n = t - 6755399441055744.0;
+        r[c] = y - n;
+        ni[c] = __double2loint(t);
+        p[c] = 4.4558179083360645e-10;
+    }
+#define PLFX_EXP2_STEP(COEF)                              \
+    _Pragma("unroll") for (int c = 0; c < N; c++) p[c] = fma(p[c], r[c], COEF); \
+    __builtin_amdgcn_sched_barrier(0);
+    PLFX_EXP2_STEP(7.074194297288521e-09)
+    PLFX_EXP2_STEP(1.0178057087733941e-07)
+    PLFX_EXP2_STEP(1.3215432535912375e-06)
+    PLFX_EXP2_STEP(1.5252733841556773e-05)
+    PLFX_EXP2_STEP(0.00015403530463724353)
+    PLFX_EXP2_STEP(0.001333355814640647)
+    PLFX_EXP2_STEP(0.009618129107587256)
+    PLFX_EXP2_STEP(0.055504108664821625)
+    PLFX_EXP2_STEP(0.24022650695910158)
+    PLFX_EXP2_STEP(0.6931471805599453)
+    PLFX_EXP2_STEP(1.0)
+#undef PLFX_EXP2_STEP
+#pragma unroll
+    for (int c = 0; c < N; c++) out[c] = __hiloint2double(__double2hiint(p[c]) + (ni[c] << 20), __double2loint(p[c]));
+}
 constexpr double LOG2E = 1.4426950408889634;
 
 // sum over the 64 lanes of a wave, result in every lane (and wave-uniform for the compiler: scalar branches).
@@ -982,14 +1018,20 @@ struct YfSvcT {
             for (int c = 0; c < NC; c++)
                 asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
                              "+v"(v[c][6]), "+v"(v[c][7]));
-            double w[NC], rho[NC];
+            double w[NC], rho[NC], ea[2 * NC], eo[2 * NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 double ck = 0.;
 #pragma unroll
                 for (int i = 0; i < 6; i++) ck = fma(D[i], v[c][i], ck);
-                w[c] = v[c][6] * exp2_neg(fma(g, v[c][7], fma(A1, ck, A0)));
-                rho[c] = exp2_neg(fma(R1, ck, R0));
+                ea[c] = fma(g, v[c][7], fma(A1, ck, A0));
+                ea[NC + c] = fma(R1, ck, R0);
+            }
+            exp2_neg_n<2 * NC>(ea, eo);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                w[c] = v[c][6] * eo[c];
+                rho[c] = eo[NC + c];
             }
 #pragma unroll
             for (int j = 0; j < NS; j++)
@@ -1509,8 +1551,12 @@ struct YfSvcRow {
                     const double d = x[i] - v[c][i];
                     h[c] = fma(d, d, h[c]);
                 }
+            double ea[NC], eo[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) f[c] = fma(v[c][6], exp2_neg(g * h[c]), f[c]);
+            for (int c = 0; c < NC; c++) ea[c] = g * h[c];
+            exp2_neg_n<NC>(ea, eo);
+#pragma unroll
+            for (int c = 0; c < NC; c++) f[c] = fma(v[c][6], eo[c], f[c]);
         }
         double t = f[0];
 #pragma unroll
@@ -1560,10 +1606,18 @@ struct YfSvcRow {
                     h[c] = fma(v[c][i], v[c][i], h[c]);
                     if (WITH2) h2[c] = fma(dx[i], v[c][i], h2[c]);
                 }
+            constexpr int NE = WITH2 ? 2 * NC : NC;
+            double ea[NE], eo[NE];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const double w = v[c][6] * exp2_neg(g * h[c]);
-                if (WITH2) f2[c] = fma(v[c][6], exp2_neg(g * (h[c] + h2[c])), f2[c]);
+                ea[c] = g * h[c];
+                if (WITH2) ea[NE - NC + c] = g * (h[c] + h2[c]);
+            }
+            exp2_neg_n<NE>(ea, eo);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const double w = v[c][6] * eo[c];
+                if (WITH2) f2[c] = fma(v[c][6], eo[NE - NC + c], f2[c]);
 #pragma unroll
                 for (int i = 0; i < 6; i++) acc[i] = fma(w, v[c][i], acc[i]);
             }
@@ -1649,14 +1703,20 @@ struct YfSvcRow {
             for (int c = 0; c < NC; c++)
                 asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2]), "+v"(v[c][3]), "+v"(v[c][4]), "+v"(v[c][5]),
                              "+v"(v[c][6]), "+v"(v[c][7]));
-            double w[NC], rho[NC];
+            double w[NC], rho[NC], ea[2 * NC], eo[2 * NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 double ck = 0.;
 #pragma unroll
                 for (int i = 0; i < 6; i++) ck = fma(D[i], v[c][i], ck);
-                w[c] = v[c][6] * exp2_neg(fma(g, v[c][7], fma(A1, ck, A0)));
-                rho[c] = exp2_neg(fma(R1, ck, R0));
+                ea[c] = fma(g, v[c][7], fma(A1, ck, A0));
+                ea[NC + c] = fma(R1, ck, R0);
+            }
+            exp2_neg_n<2 * NC>(ea, eo);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                w[c] = v[c][6] * eo[c];
+                rho[c] = eo[NC + c];
             }
 #pragma unroll
             for (int j = 0; j < NS; j++)

@@ -402,6 +402,22 @@ def test_bench_two_ranks(tmp_path, mode):
         its = [s[0] for s in fe.solver_stats[marks['q0']:marks['q1']]]
         assert d['sweeps'] == marks['s1'] - marks['s0'] and d['solves'] == len(its) and d['pcg_iterations'] == sum(its)
 
+def test_bench_inclusion_variant_is_reproducible():
+    """bench.py's heterogeneous leg (soft inclusion: long PCG solves, half of the matrix elements on the 50-sub-step corrector): two
+    runs of the same window in one process give the same sweeps, solves, PCG iterations and the same number of solves completed
+    by a fall-back solver (VERDICT r5: that count differed between the driver's window and the builder's -- other load steps;
+    for ONE window it is deterministic: integer atomics only, fixed-order sums)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import pylabfea_amd as FE
+    a = bench.inclusion_variant(FE, 256, 4, 1)
+    b = bench.inclusion_variant(FE, 256, 4, 1)
+    for k in ('sweeps', 'solves', 'pcg_iterations', 'solves_completed_by_fallback_solver', 'elements_on_50_substep_corrector_last_sweep'):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a['pcg_iterations'] > 100 and a['sweeps'] > 4
+
 
 def test_bench_config5_option(tmp_path):
     """bench.py --config 5 (BASELINE config 5: laminate of J2 + the Goss-Barlat-trained SVC) on a reduced mesh: one rank, and

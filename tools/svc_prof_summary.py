@@ -9,8 +9,13 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'plfx::(k_[a-zA-Z_0-9]+(<[0-9, ]+>)?)', name)
-    return m.group(1).replace(' ', '') if m else name[:40]
+    """k_sweep_svc_row<1, true> (tables in LDS) and <1, false> (tables in device memory) are one kernel family here: <1>"""
+    m = re.search(r'plfx::(k_[a-zA-Z_0-9]+)(<[0-9a-z, ]+>)?', name)
+    if not m:
+        return name[:40]
+    t = (m.group(2) or '').replace(' ', '')
+    t = re.sub(r',(true|false)>$', '>', t)
+    return m.group(1) + t
 
 
 d, nel, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
