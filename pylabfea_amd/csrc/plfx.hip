@@ -3133,6 +3133,10 @@ int plfx_precond_bench(plfx_ctx *c, int reps, double *us_per_cycle, double *us_c
 {
     if (!c || !mg_active(c) || c->strip.on) return c ? fail(c, PLFX_ERR_STATE, "needs the multigrid hierarchy of a single-GPU solve") : PLFX_ERR_STATE;
     if (reps < 1) reps = 1;
+    {   // (the coarse levels are set up on demand: a window whose solves never needed a V-cycle leaves them stale)
+        const int e = mg_ensure(c);
+        if (e) return e;
+    }
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
