@@ -3850,8 +3850,8 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     const bool direct = sl >= 0 && direct_ok && !comm_active(c);
     double *out = direct ? c->fin_pin[sl] : c->fin_dev;
     if (n > 0) {
-        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->u, out);
-        hipLaunchKernelGGL(k_gather, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, c->f, out + n);
+        hipLaunchKernelGGL(k_gather2, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n, c->fin_idx, (const double *)c->u,
+                           (const double *)c->f, out, out + n);
     }
     hipLaunchKernelGGL(k_reduce_rows, dim3(18), dim3(BLOCK), 0, c->stream, c->part_g, 18, g, out + 2 * (size_t)n);
     HIPCHK(c, hipGetLastError());
@@ -3905,6 +3905,14 @@ unsigned long long cg_check_post(plfx_ctx *c, const double *part_rr, int gn, int
     }
     const unsigned long long seq = ++c->mbox_seq;
     hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(BLOCK), 0, c->stream, part_rr, gn, c->sc, it_done, c->mbox, seq);
+    return seq;
+}
+
+// the set-up of the scalars (k_cg_setup) and the first test in one launch
+unsigned long long cg_setup_check_post(plfx_ctx *c, const double *part_bb, const double *part_rr, int gn, double rtol)
+{
+    const unsigned long long seq = c->mbox ? ++c->mbox_seq : 0ull;
+    hipLaunchKernelGGL(k_cg_setup_check, dim3(1), dim3(BLOCK), 0, c->stream, part_bb, part_rr, gn, rtol, c->sc, 0, c->mbox, seq);
     return seq;
 }
 
@@ -4604,6 +4612,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     // elements, run the plain warm start).  Strips: x and the solution before it are valid on the halo columns, the sums are
     // taken over the owned columns and all-reduced (host_sums / part_allreduce).  PLFX_PREDICT=0 at plfx_create switches it off.
     bool pred_d_ready = false, pred_moved = false;   // (d = x - pred_x is in pred_d; the start x + alpha d was accepted as the solution)
+    bool pred_finished = false;                      // (... and k_pred_finish has composed du and advanced the history already)
     // (every rank of a communicator takes the same decisions: the global node count and -- through the all-reduced sums -- alpha
     // and the test are the same everywhere; a replicated solve computes everything redundantly)
     const long long nn_global = c->strip.on ? (long long)(c->strip.gnx + 1) * (c->gy + 1) : (long long)c->nnode;
@@ -4627,12 +4636,12 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         if ((rc = halo_refresh(c, c->r))) return rc;
     }
     const double rtol_eff = rtol;
-    hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol_eff, c->sc);
     const bool mg = mg_active(c);
+    if (!mg) hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol_eff, c->sc);
     CgScalars hs{};
     int done = 0;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
-        unsigned long long seq = cg_check_post(c, P_rr[1], gn, 0);
+        unsigned long long seq = cg_setup_check_post(c, P_bb, P_rr[1], gn, rtol_eff);   // (scalars set up and first test: one launch)
         if (pred_active) {
             // Everything the interpolated start needs is enqueued behind the first test and returns at once if that test passed
             // (the reference repeats solves of one system: x satisfies the tolerance as it is); the host waits ONCE, for the second
@@ -4646,16 +4655,21 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                                c->part, c->sc);
             HIPCHK(c, hipGetLastError());
             if (c->strip.on && (rc = part_allreduce(c, c->part, (size_t)2 * MAXPART))) return rc;
-            hipLaunchKernelGGL(k_pred_alpha, dim3(1), dim3(BLOCK), 0, c->stream, (const double *)c->part, gp, c->sc);
-            hipLaunchKernelGGL(k_pred_try, dim3(gn), dim3(BLOCK), 0, c->stream, nn, (const CgScalars *)c->sc, (const double2 *)c->r,
+            hipLaunchKernelGGL(k_pred_try, dim3(gn), dim3(BLOCK), 0, c->stream, nn, c->sc, (const double *)c->part, gp, (const double2 *)c->r,
                                (const double2 *)c->p[0], (const double2 *)c->dinv, P_rr[0], olo, ohi);
             HIPCHK(c, hipGetLastError());
             if (c->strip.on && (rc = part_allreduce(c, P_rr[0], gn))) return rc;
             seq = cg_check_post(c, P_rr[0], gn, -2);   // (iters = -2 marks "converged by the interpolated start")
+            if (!c->strip.on)   // x, du and the history in one pass -- behind the test, before the host has seen it (no-op unless accepted)
+                hipLaunchKernelGGL(k_pred_finish, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, (const CgScalars *)c->sc, c->x,
+                                   (const double *)c->pred_d, c->pred_x, (const double *)c->dup, (const double *)c->is_presc, c->du);
             if ((rc = cg_check_wait(c, seq, &hs))) return rc;
             done = hs.done;
             if (done == 1 && hs.iters == -2) {   // it is the solution: commit x (r, z are not read again: the loop below is skipped)
-                hipLaunchKernelGGL(k_pred_commit, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, (const CgScalars *)c->sc, c->x, c->pred_d);
+                if (!c->strip.on)
+                    pred_finished = true;
+                else
+                    hipLaunchKernelGGL(k_pred_commit, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, (const CgScalars *)c->sc, c->x, c->pred_d);
                 HIPCHK(c, hipGetLastError());
                 hs.iters = 0;
                 c->n_pred++;
@@ -4956,14 +4970,16 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         HIPCHK(c, hipMemcpyAsync(&hs, c->sc, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, stream_sync(c));
     }
-    if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;  // x is valid on owned + 2 columns: complete the halo
-    hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
-    HIPCHK(c, hipGetLastError());
+    if (!pred_finished) {
+        if (c->strip.on && (rc = halo_refresh(c, c->x))) return rc;  // x is valid on owned + 2 columns: complete the halo
+        hipLaunchKernelGGL(k_compose_du, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->x, c->dup, c->is_presc, c->du);
+        HIPCHK(c, hipGetLastError());
+    }
     c->x_is_du = true;  // x = du on the free DOFs, 0 on the prescribed ones: the next warm start
     const int its_done = (done && hs.iters >= 0) ? hs.iters : it;
     // history of the initial guess: the solution this solve started from becomes "the one before" -- only if this solve moved
     // away from it (the reference repeats solves of one system: such a solve ends where it started and must not erase d)
-    if (pred_d_ready && (pred_moved || its_done > 0))
+    if (pred_d_ready && !pred_finished && (pred_moved || its_done > 0))
         hipLaunchKernelGGL(k_pred_advance, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->pred_x, c->pred_d);
     if (iters) *iters = (done && hs.iters >= 0) ? hs.iters : it;
     if (c->tim.on && done) {  // launches after convergence are no-ops: keep them out of the averages
@@ -5102,15 +5118,23 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
 #undef SWEEP_ARGS
 #undef WAVE_ARGS
     tim_end(c, ev);
-    hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4);
-    HIPCHK(c, hipGetLastError());
-    if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
-        // strip: the counts of rewritten tangents / sub-stepped elements stay local (halo elements are replicas)
-        const int rca = allreduce(c, c->flags + 4, c->strip.on ? 2 : 4, NCCL_INT32, NCCL_SUM, "flags");
-        if (rca) return rca;
-    }
     int h[4];
-    {
+    if (!comm_active(c) && c->mbox && c->mb_cap >= 2) {   // single GPU: the flags kernel posts its results itself
+        const unsigned long long seq = ++c->mbox_seq;
+        hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4,
+                           reinterpret_cast<int *>(c->mb_buf), c->mbox, seq);
+        HIPCHK(c, hipGetLastError());
+        const int rcw = mbox_wait(c, seq);
+        if (rcw) return rcw;
+        memcpy(h, c->mb_buf, sizeof(h));
+    } else {
+        hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4);
+        HIPCHK(c, hipGetLastError());
+        if (comm_active(c)) {  // changed / not-converged / list length of the whole mesh: no host-side collective needed
+            // strip: the counts of rewritten tangents / sub-stepped elements stay local (halo elements are replicas)
+            const int rca = allreduce(c, c->flags + 4, c->strip.on ? 2 : 4, NCCL_INT32, NCCL_SUM, "flags");
+            if (rca) return rca;
+        }
         const int rcf = fetch_results(c, reinterpret_cast<const double *>(c->flags + 4), 2, reinterpret_cast<double *>(h));
         if (rcf) return rcf;
     }

@@ -519,7 +519,12 @@ __device__ __forceinline__ void post_block_flags(int changed, int nconv, int *__
 // of the compacted list, is maintained by the kernels themselves)
 // The kernel leaves the slots and the list length zeroed for the next sweep (no memset launches between sweeps) and hands the
 // four results over in out[0..3].
-__global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags, int *__restrict__ flags, int *__restrict__ out)
+struct CgMbox;
+__device__ void mbox_publish(CgMbox *mb, unsigned long long seq);   // (defined with CgMbox below)
+// pin != nullptr (single GPU, mailbox): the four results also go to the pinned buffer and the sequence number is posted from
+// here -- no separate k_mbox_post launch before the host may read them
+__global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags, int *__restrict__ flags, int *__restrict__ out,
+                                                       int *__restrict__ pin = nullptr, CgMbox *mb = nullptr, unsigned long long seq = 0ull)
 {
     __shared__ int sc[BLOCK / 64], sn[BLOCK / 64];
     int cw = 0, nw = 0;
@@ -548,6 +553,13 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags,
         out[1] = n2;
         out[2] = flags[2];
         out[3] = c2;
+        if (pin) {
+            pin[0] = c2 ? 1 : 0;
+            pin[1] = n2;
+            pin[2] = flags[2];
+            pin[3] = c2;
+            mbox_publish(mb, seq);
+        }
         flags[2] = 0;
     }
 }
@@ -905,7 +917,10 @@ k_sweep_svc_row(const MatDev *__restrict__ gmat, int nmat, const ClassDev *__res
     __shared__ SweepTables tb;
     stage_tables(tb, gmat, nmat, gcls, ncls);
     __syncthreads();
-    constexpr int NC = 4;
+#ifndef PLFX_ROW_NC
+#define PLFX_ROW_NC 4
+#endif
+    constexpr int NC = PLFX_ROW_NC;   // (2: measured 0 % -- see DESIGN 11.5)
     const int npad = INLDS ? stage_svc_wave(tb.smat, wave_mat, 1) : tb.smat[wave_mat].rowpad;   // rows take 16 x 4 vectors per trip: padded to 64
     __syncthreads();
     const int l16 = threadIdx.x & 15;
@@ -1770,7 +1785,7 @@ struct CgScalars {
     int32_t done;    // sticky convergence flag
     int32_t iters;   // iteration count at convergence
     double rr_final;
-    double aux;      // step of the interpolated start (k_pred_alpha; travels to the host with the flags)
+    double aux;      // step of the interpolated start (k_pred_try; travels to the host with the flags)
 };
 
 template <int MODE, int GRID>
@@ -2063,6 +2078,11 @@ __global__ void k_cg_setup(const double *part_bb, int npart, double rtol, CgScal
     }
 }
 
+// k_cg_setup + k_cg_check in one launch (start of a solve)
+struct CgMbox;
+__global__ void k_cg_setup_check(const double *part_bb, const double *part_rr, int npart, double rtol, CgScalars *sc, int it_done,
+                                 CgMbox *mb, unsigned long long seq);
+
 // Pinned, host-visible copy of the PCG scalars: a kernel posts them with a sequence number and the host spins on the
 // number instead of enqueueing a device->host copy and synchronising the stream (12 instead of 19 us per round trip on
 // this system, tools/probes/sync_probe.hip).
@@ -2070,6 +2090,12 @@ struct CgMbox {
     unsigned long long seq;
     CgScalars sc;
 };
+
+__device__ void mbox_publish(CgMbox *mb, unsigned long long seq)
+{
+    __threadfence_system();
+    __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+}
 
 // convergence test on the residual partials an update kernel just wrote (one block): lets the host stop
 // BEFORE it launches the next preconditioner application (a V-cycle is the most expensive part of an iteration)
@@ -2089,6 +2115,33 @@ __global__ void k_cg_check(const double *part_rr, int npart, CgScalars *sc, int 
         mb->sc = *sc;
         __threadfence_system();
         __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+    }
+}
+
+__global__ void k_cg_setup_check(const double *part_bb, const double *part_rr, int npart, double rtol, CgScalars *sc, int it_done,
+                                 CgMbox *mb, unsigned long long seq)
+{
+    __shared__ double sh[BLOCK / 64];
+    const double bb = sum_partials(part_bb, npart, sh);
+    const double rr = sum_partials(part_rr, npart, sh);
+    if (threadIdx.x == 0) {
+        const double th = rtol * rtol * bb;
+        sc->thresh2 = th;
+        sc->aux = 0.;
+        if (rr <= th || !(rr == rr)) {
+            sc->done = (rr == rr) ? 1 : 2;
+            sc->iters = it_done;
+            sc->rr_final = rr;
+        } else {
+            sc->done = 0;
+            sc->iters = -1;
+            sc->rr_final = -1.;
+        }
+        if (mb) {
+            mb->sc = *sc;
+            __threadfence_system();
+            __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+        }
     }
 }
 
@@ -2163,6 +2216,19 @@ k_scatter_bc_plan(int n, const int32_t *__restrict__ idx, const int32_t *__restr
     y[i] = first;
     z[i] = w;
     if (flag) m[i] = 1.;
+}
+
+// va[k] = a[idx[k]], vb[k] = b[idx[k]]   (boundary values of u and f at the end of a load step: one launch)
+__global__ void __launch_bounds__(BLOCK)
+k_gather2(int n, const int32_t *__restrict__ idx, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ va,
+          double *__restrict__ vb)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) {
+        const int i = idx[k];
+        va[k] = a[i];
+        vb[k] = b[i];
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_gather(int n, const int32_t *idx, const double *y, double *v)
@@ -2255,30 +2321,21 @@ k_pred_dots(size_t dof_lo, size_t dof_hi /* owned DOFs (a strip: its owned node 
 
 // | P (r - alpha K d) |^2 over the owned free DOFs, nothing written: would x + alpha d satisfy the tolerance as it is?  (Round 6: the
 // interpolated start is taken only when it FINISHES the solve; a solve that iterates starts from x, bit for bit the plain warm start.)
-// alpha = (K d . r) / (K d . K d) clamped to [0, 1], steps below 0.01 dropped (round-off of a d that does not help): one block,
-// from the partials of k_pred_dots; the step stays on the device (k_pred_try / k_pred_commit read it) and goes to the host in sc->aux
-__global__ void __launch_bounds__(BLOCK) k_pred_alpha(const double *__restrict__ part, int gp, CgScalars *__restrict__ sc)
-{
-    __shared__ double sh[BLOCK / 64];
-    if (sc->done) return;
-    const double o0 = sum_partials(part, gp, sh);
-    const double o1 = sum_partials(part + MAXPART, gp, sh);
-    if (threadIdx.x == 0) {
-        double a = (o1 > 0.) ? o0 / o1 : 0.;
-        if (!(a == a) || a > 1.e300 || a < -1.e300) a = 0.;
-        a = fmin(1., fmax(0., a));
-        if (a < 0.01) a = 0.;
-        sc->aux = a;
-    }
-}
-
 __global__ void __launch_bounds__(BLOCK)
-k_pred_try(int nnode, const CgScalars *__restrict__ sc, const double2 *__restrict__ r, const double2 *__restrict__ kd,
-           const double2 *__restrict__ dinv, double *__restrict__ part_rr_out, int own_lo, int own_hi)
+k_pred_try(int nnode, CgScalars *__restrict__ sc, const double *__restrict__ part_dots, int gp, const double2 *__restrict__ r,
+           const double2 *__restrict__ kd, const double2 *__restrict__ dinv, double *__restrict__ part_rr_out, int own_lo, int own_hi)
 {
     __shared__ double sh[BLOCK / 64];
     if (sc->done) return;
-    const double alpha = sc->aux;
+    // alpha = (K d . r) / (K d . K d) clamped to [0, 1], steps below 0.01 dropped: every block sums the partials of k_pred_dots
+    // itself (the same loads in the same order: the same alpha everywhere); block 0 leaves it in sc->aux for the commit and the host
+    const double o0 = sum_partials(part_dots, gp, sh);
+    const double o1 = sum_partials(part_dots + MAXPART, gp, sh);
+    double alpha = (o1 > 0.) ? o0 / o1 : 0.;
+    if (!(alpha == alpha) || alpha > 1.e300 || alpha < -1.e300) alpha = 0.;
+    alpha = fmin(1., fmax(0., alpha));
+    if (alpha < 0.01) alpha = 0.;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->aux = alpha;
     if (alpha == 0.) {   // no step: the test that follows must fail
         if (threadIdx.x == 0) part_rr_out[blockIdx.x] = 1.e300;
         return;
@@ -2301,6 +2358,25 @@ k_pred_commit(size_t ndof, const CgScalars *__restrict__ sc, double *__restrict_
 {
     const double alpha = sc->aux;
     for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) x[i] = fma(alpha, d[i], x[i]);
+}
+
+// the accepted start in one pass (single GPU): x += alpha d, du = x on the free DOFs / the prescribed increment elsewhere
+// (k_compose_du), and the history of the initial guess advances (xprev += d: the solution this solve started from)
+__global__ void __launch_bounds__(BLOCK)
+k_pred_finish(size_t ndof, const CgScalars *__restrict__ sc, double *__restrict__ x, const double *__restrict__ d,
+              double *__restrict__ xprev, const double *__restrict__ dup, const double *__restrict__ is_presc, double *__restrict__ du)
+{
+    // enqueued BEFORE the host has seen the test (its round trip overlaps this pass): does nothing unless the interpolated
+    // start was accepted (k_cg_check marks that with iters = -2)
+    if (!(sc->done == 1 && sc->iters == -2)) return;
+    const double alpha = sc->aux;
+    for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < ndof; i += (size_t)gridDim.x * BLOCK) {
+        const double di = d[i];
+        const double xi = fma(alpha, di, x[i]);
+        x[i] = xi;
+        du[i] = (is_presc[i] != 0.) ? dup[i] : xi;
+        xprev[i] += di;
+    }
 }
 
 // u += du ; f += q  (q = K du)     (model.py:1383-1384)
