@@ -228,6 +228,12 @@ struct plfx_ctx {
     // a steady workload start below the tolerance, see plfx_solve): an assembly is pending; every BC application since kept the set
     bool mg_pending = false, mg_pending_same = true;
     long long n_mg_setup = 0, n_mg_setup_skipped = 0;
+    // plfx_load_step, single GPU: the set-up pass of the next stiffness iteration and the K du of the end of the load step are
+    // enqueued behind k_sweep_flags with device-side predicates, before the host has read the flags
+    bool spec_arm = false, spec_setup = false, spec_kdu = false, spec_was_clean = false;
+    int spec_h0 = 0, spec_h1 = 0;
+    CgScalars *spec_sc = nullptr;
+    long long n_spec_setup = 0, n_spec_kdu = 0;
     int resp_maxit = MAXIT;          // plfx_set_response_maxit: sub-steps of Material.response's sub-divided increment (point entry only)
     long long n_pred = 0, n_pred_skipped = 0, n_pred_rejected = 0;   // accepted as the solution / alpha < 0.01 / failed the tolerance test
     // Unchanged inputs are not recomputed (PLFX_REUSE=0 switches this off): the generators are re-snapshotted only when a
@@ -1671,7 +1677,8 @@ int plfx_create(int device, plfx_ctx **out)
     if ((rc = dalloc(c, &c->part, (size_t)8 * MAXPART))) return rc;
     if ((rc = dalloc(c, &c->part_g, (size_t)18 * SUMPART))) return rc;
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
-    if ((rc = dalloc(c, &c->flags, 8))) return rc;  // [0..3] working flags of a sweep, [4..7] its results (k_sweep_flags)
+    if ((rc = dalloc(c, &c->flags, 16))) return rc;  // [0..3] working flags of a sweep, [4..7] its results (k_sweep_flags), [8] skip flag of the speculative set-up
+    if ((rc = dalloc(c, &c->spec_sc, 1))) return rc;
     if ((rc = dalloc(c, &c->bflags, (size_t)2 * SWEEP_SLOTS))) return rc;
     if ((rc = dalloc(c, &c->small, 64))) return rc;
     HIPCHK(c, stream_sync(c));
@@ -1702,6 +1709,7 @@ void plfx_destroy(plfx_ctx *c)
     dfree(c->part_g);
     dfree(c->sc);
     dfree(c->flags);
+    dfree(c->spec_sc);
     dfree(c->bflags);
     dfree(c->small);
     dfree(c->idx_tmp);
@@ -3342,6 +3350,9 @@ int plfx_gather(plfx_ctx *c, int which, int n, const int32_t *idx, double *out)
 int plfx_assemble(plfx_ctx *c)
 {
     if (!c || !c->dval) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
+    // (the set-up pass may have run already, behind the flags of the sweep that changed the tangents: sweep_once)
+    const bool setup_done = c->spec_setup && c->spec_was_clean && c->spec_h0 != 0 && matfree(c);
+    c->spec_setup = c->spec_kdu = false;
     if (c->reuse && c->assembled && !c->M_dirty) {  // no tangent changed since the last assembly: K is what it was
         c->n_reuse_assemble++;
         return PLFX_OK;
@@ -3352,9 +3363,12 @@ int plfx_assemble(plfx_ctx *c)
     if (matfree(c)) {  // operators are applied from the generators: only the diagonal is formed
         KOp live = c->op;
         live.M = c->Mel;  // diagonal + snapshot of the generators (+ generators of multigrid level 1) in one pass
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
-                           c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
-                           (double2 *)nullptr);
+        if (setup_done)
+            c->n_spec_setup++;
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+                               c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
+                               (double2 *)nullptr);
         c->val_valid = false;
     } else {
         int rc = assemble_fine_val(c);
@@ -3769,7 +3783,11 @@ int plfx_load_step(plfx_ctx *c, plfx_step *st, double *u_at, double *f_at, doubl
             if ((rc = plfx_assemble(c))) return rc;  // updated tangent stiffness (model.py:1333)
             if ((rc = step_apply_bc(c, st, dbcr, dbct, dbcn, &st->inconsistent_entry))) return rc;
             if ((rc = step_solve(c, st, 1))) return rc;
+            // (the loop goes on after this sweep only if nit + 1 <= 15: then -- and only then -- what follows the flags is decided
+            // by the flags alone and can be enqueued behind them with device-side predicates)
+            c->spec_arm = (nit + 1 <= 15) && c->reuse && !wh_sequential(c);
             if ((rc = plfx_sweep(c, nit, &change, &conv))) return rc;  // model.py:1340-1361
+            c->spec_arm = false;
             st->nsweeps++;
             if (!conv) st->nconv++;
             nit++;
@@ -3817,8 +3835,13 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     if (!c->assembled) return fail(c, PLFX_ERR_STATE, "assemble first");
     // plfx_update_state with calc_global's element sums fused into the state-update kernel (one pass over the state)
     const size_t nd = c->ndof;
-    int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
-    if (rc) return rc;
+    int rc = 0;
+    const bool kdu_done = c->spec_kdu && c->spec_h0 == 0 && c->spec_h1 == 0 && !c->strip.on;   // (ran behind the last sweep's flags)
+    c->spec_setup = c->spec_kdu = false;
+    if (kdu_done)
+        c->n_spec_kdu++;
+    else if ((rc = plain_spmv(c, c->du, c->q)))  // K du over all DOFs (reaction forces, model.py:1384)
+        return rc;
     hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
     const int g = grid_for(c->nel, SUMPART);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<1>), dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, c->nel,
@@ -4568,6 +4591,7 @@ int sqmr_solve(plfx_ctx *c, double rtol, int maxit, int *iters, double *relres)
 int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double *relres)
 {
     if (!c || !c->bc_set) return c ? fail(c, PLFX_ERR_STATE, "apply_bc first") : PLFX_ERR_STATE;
+    c->spec_setup = c->spec_kdu = false;   // (a solve overwrites c->q: nothing enqueued behind a sweep's flags is valid beyond it)
     if (maxit < 1) maxit = 1;
     if (c->reuse && warm && c->x_is_du && c->memo.valid && c->memo.rtol == rtol) {
         // the system of the previous converged solve (no assembly, no other boundary values since): du is its solution
@@ -5119,14 +5143,32 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
 #undef WAVE_ARGS
     tim_end(c, ev);
     int h[4];
+    const bool spec = c->spec_arm && !comm_active(c) && c->mbox && c->mb_cap >= 2 && matfree(c) && !c->strip.on && c->assembled;
+    c->spec_arm = false;
     if (!comm_active(c) && c->mbox && c->mb_cap >= 2) {   // single GPU: the flags kernel posts its results itself
         const unsigned long long seq = ++c->mbox_seq;
         hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4,
-                           reinterpret_cast<int *>(c->mb_buf), c->mbox, seq);
+                           reinterpret_cast<int *>(c->mb_buf), c->mbox, seq, spec ? c->flags + 8 : (int *)nullptr,
+                           spec ? c->spec_sc : (CgScalars *)nullptr);
+        if (spec) {
+            // what the host would enqueue after reading the flags, enqueued now (the round trip overlaps it): the set-up pass of
+            // plfx_assemble if a tangent changed, else -- if every element converged as well -- the K du of plfx_finish_step
+            KOp live = c->op;
+            live.M = c->Mel;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+                               c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
+                               (double2 *)nullptr, 0x7fffffff, (const int *)(c->flags + 8));
+            LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, nullptr,
+                       (double2 *)c->q, nullptr, nullptr, nullptr, 0, nullptr, c->spec_sc, 0, 0, 0);
+            c->spec_was_clean = !c->M_dirty;
+            c->spec_setup = c->spec_kdu = true;
+        }
         HIPCHK(c, hipGetLastError());
         const int rcw = mbox_wait(c, seq);
         if (rcw) return rcw;
         memcpy(h, c->mb_buf, sizeof(h));
+        c->spec_h0 = h[0];
+        c->spec_h1 = h[1];
     } else {
         hipLaunchKernelGGL(k_sweep_flags, dim3(1), dim3(BLOCK), 0, c->stream, c->bflags, c->flags, c->flags + 4);
         HIPCHK(c, hipGetLastError());
@@ -5258,6 +5300,7 @@ int plfx_sweep(plfx_ctx *c, int nit, int *changed, int *conv)
 {
     if (!c || !c->sig) return c ? fail(c, PLFX_ERR_STATE, "set_mesh first") : PLFX_ERR_STATE;
     if (c->n_noflow) return fail(c, PLFX_ERR_UNSUPPORTED, "a Tresca / Barlat material without flow rule is loaded (material.py:822-825)");
+    c->spec_setup = c->spec_kdu = false;
     if (wh_sequential(c)) return sweep_wh_sequential(c, nit, changed, conv);
     return sweep_once(c, nit, changed, conv, false);
 }
@@ -5390,8 +5433,13 @@ int plfx_update_state(plfx_ctx *c)
 {
     if (!c || !c->assembled) return c ? fail(c, PLFX_ERR_STATE, "assemble first") : PLFX_ERR_STATE;
     const size_t nd = c->ndof;
-    int rc = plain_spmv(c, c->du, c->q);  // K du over all DOFs (reaction forces, model.py:1384)
-    if (rc) return rc;
+    int rc = 0;
+    const bool kdu_done = c->spec_kdu && c->spec_h0 == 0 && c->spec_h1 == 0 && !c->strip.on;   // (ran behind the last sweep's flags)
+    c->spec_setup = c->spec_kdu = false;
+    if (kdu_done)
+        c->n_spec_kdu++;
+    else if ((rc = plain_spmv(c, c->du, c->q)))  // K du over all DOFs (reaction forces, model.py:1384)
+        return rc;
     hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<0>), dim3(grid_for(c->nel, MAXPART)), dim3(BLOCK), 0, c->stream,
                        c->dmat, c->dcls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,

@@ -523,8 +523,14 @@ struct CgMbox;
 __device__ void mbox_publish(CgMbox *mb, unsigned long long seq);   // (defined with CgMbox below)
 // pin != nullptr (single GPU, mailbox): the four results also go to the pinned buffer and the sequence number is posted from
 // here -- no separate k_mbox_post launch before the host may read them
+// skip_setup / spec (plfx_load_step, single GPU): predicates of the two kernels enqueued BEHIND this one before the host has read
+// the flags -- the set-up pass of the next stiffness iteration runs only if a tangent changed (*skip_setup = 0), the K du of the
+// end of the load step only if the K-iteration loop ends here (spec->done = 0: nothing changed and every element converged)
+struct CgScalars;
+__device__ void spec_set(CgScalars *spec, int done);
 __global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags, int *__restrict__ flags, int *__restrict__ out,
-                                                       int *__restrict__ pin = nullptr, CgMbox *mb = nullptr, unsigned long long seq = 0ull)
+                                                       int *__restrict__ pin = nullptr, CgMbox *mb = nullptr, unsigned long long seq = 0ull,
+                                                       int *__restrict__ skip_setup = nullptr, CgScalars *spec = nullptr)
 {
     __shared__ int sc[BLOCK / 64], sn[BLOCK / 64];
     int cw = 0, nw = 0;
@@ -553,6 +559,8 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_flags(int *__restrict__ bflags,
         out[1] = n2;
         out[2] = flags[2];
         out[3] = c2;
+        if (skip_setup) *skip_setup = c2 ? 0 : 1;
+        if (spec) spec_set(spec, (c2 == 0 && n2 == 0) ? 0 : 1);
         if (pin) {
             pin[0] = c2 ? 1 : 0;
             pin[1] = n2;
@@ -1678,8 +1686,10 @@ __device__ __forceinline__ void grid_march(const KOp &g, XF xf, EM emit)
 template <int SRC_PAIR>
 __global__ void __launch_bounds__(BLOCK)
 k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, double *__restrict__ Mc,
-             const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv, int mask_nxn = 0x7fffffff)
+             const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv, int mask_nxn = 0x7fffffff,
+             const int *__restrict__ skip = nullptr /* speculative launch behind k_sweep_flags: nothing to do if no tangent changed */)
 {
+    if (skip && *skip) return;
     const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
     const int nyc = nye >> 1;
     const size_t nel_c = (size_t)(nxe >> 1) * nyc;
@@ -2090,6 +2100,8 @@ struct CgMbox {
     unsigned long long seq;
     CgScalars sc;
 };
+
+__device__ void spec_set(CgScalars *spec, int done) { spec->done = done; }
 
 __device__ void mbox_publish(CgMbox *mb, unsigned long long seq)
 {
