@@ -974,6 +974,8 @@ class Model(object):
         bc_inc = True
         pending = None   # slot of a load step whose end-of-step data are still to be collected
         defer = self._defer_finish and eng.lib_has_mailbox()
+        # (single GPU: sgl / egl / epgl / glob are filled in after the loop; with strips the boundary sums are a collective per step)
+        lazy = [] if (defer and self._strip is None and self._shard is None and not verb) else None
 
         def record_global(fin_data):
             self._calc_global_device(eng, fin_data)
@@ -1083,7 +1085,13 @@ class Model(object):
                 bc_inc = bc_inc or bool(np.any((np.abs(cur0 - tot) > 1.e-6) & (np.abs(tot) > 1.e-9)))
             if native and defer:
                 if pending is not None:
-                    record_global(eng.finish_fetch(pending))
+                    if lazy is not None:
+                        # homogenisation of the step before: its data are taken out of the pinned slot now (the slot is reused),
+                        # the numpy work on them (two bincounts over the boundary nodes, ~40 us) waits until the loop is done --
+                        # between two plfx_load_step calls the GPU only has the tail of the state update left to hide host time
+                        lazy.append(tuple(a.copy() for a in eng.finish_fetch(pending)))
+                    else:
+                        record_global(eng.finish_fetch(pending))
                 pending = (il - 1) & 1
             else:
                 record_global(fin)
@@ -1099,6 +1107,8 @@ class Model(object):
                 print('Global stress: ', np.around(self.glob['sig'], decimals=3))
                 print('Global plastic strain: ', np.around(self.glob['epl'], decimals=6))
                 print('----------------------------')
+        for fin_data in (lazy or ()):
+            record_global(fin_data)
         if pending is not None:
             record_global(eng.finish_fetch(pending))
         self.sgl, self.egl, self.epgl = np.array(sgl), np.array(egl), np.array(epgl)
