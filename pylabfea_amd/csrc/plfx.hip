@@ -1242,7 +1242,11 @@ int mg_down_level(plfx_ctx *c, int l)
     (void)ev;  // the head of the cycle is enqueued speculatively (may return at once): family 5 times the post-smoothing
                // launches of k_mg_smooth<1, .> only
     const bool march = l == 0 && mf && march_mg(c);
-    if (nu == 2) {  // both sweeps in one pass over the operator
+    // experiment (PLFX_MG_OMEGA2=w1,w2): two Chebyshev weights instead of one damping factor -- pre-smoothing w1 then w2, post-smoothing
+    // w2 then w1 (the adjoint order: the cycle stays symmetric); separate launches per sweep, for iteration counts only
+    static const char *om2s = getenv("PLFX_MG_OMEGA2");
+    static const double om2a = om2s ? atof(om2s) : 0., om2b = (om2s && strchr(om2s, ',')) ? atof(strchr(om2s, ',') + 1) : 0.;
+    if (nu == 2 && !(om2a > 0. && om2b > 0.)) {  // both sweeps in one pass over the operator
         if (march)
             hipLaunchKernelGGL(k_mg_smooth2_zero_march, dim3(L.grid), dim3(BLOCK), 0, c->stream, L.op, (const double2 *)L.dinv,
                                (const double2 *)L.b, (double2 *)L.x, om, c->sc);
@@ -1257,10 +1261,10 @@ int mg_down_level(plfx_ctx *c, int l)
         for (int k = 0; k < nu; k++) {
             if (l == 0)
                 LAUNCH_OP2(k_mg_smooth, 1, mf, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                           (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
+                           (const double2 *)src, (double2 *)dst, (om2a > 0. && om2b > 0. && nu == 2) ? (k == 0 ? om2a : om2b) : om, k == 0, c->sc);
             else
                 LAUNCH_OP2R(k_mg_smooth, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
-                           (const double2 *)src, (double2 *)dst, om, k == 0, c->sc);
+                           (const double2 *)src, (double2 *)dst, (om2a > 0. && om2b > 0. && nu == 2) ? (k == 0 ? om2a : om2b) : om, k == 0, c->sc);
             src = dst;
             dst = (dst == L.x) ? L.t : L.x;
         }
@@ -1290,7 +1294,11 @@ int mg_up_level(plfx_ctx *c, int l)
     hipLaunchKernelGGL(k_mg_prolong_add, dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.nx + 1, L.ny + 1,
                        C.ny + 1, (const double2 *)C.x, (const double2 *)L.dinv, (double2 *)L.x, L.rx, L.ry);
     double *src = L.x, *dst = L.t;
+    static const char *om2s = getenv("PLFX_MG_OMEGA2");
+    static const double om2a = om2s ? atof(om2s) : 0., om2b = (om2s && strchr(om2s, ',')) ? atof(strchr(om2s, ',') + 1) : 0.;
+    const double om_base = om;
     for (int k = 0; k < nu; k++) {
+        const double om = (om2a > 0. && om2b > 0. && nu == 2) ? (k == 0 ? om2b : om2a) : om_base;
         EvPair *ev = nullptr;
         if (l == 0) tim_begin(c, 5, &ev);  // family 5: fine-level smoother launches
         DotOut dot{};
