@@ -1123,7 +1123,7 @@ class Model(object):
             for k, m in wh:
                 m.khard = eng.wh_carry(k)
             if eng.wh_unresolved:
-                warnings.warn('{} sweep(s) ended with an unsettled hardening-modulus chain (64 passes)'.format(eng.wh_unresolved))
+                warnings.warn('{} sweep(s) ended with an unsettled hardening-modulus chain (pass cap of the library reached: PLFX_WH_MAXPASS, default 512)'.format(eng.wh_unresolved))
         # the reference's LU always returns; an iterative solve can end above its tolerance (nearly singular tangents at a
         # limit load): say so instead of continuing silently
         bad = [r for (_, r) in self.solver_stats[n_stats0:] if not r <= 10. * self.cg_rtol]
