@@ -1703,6 +1703,8 @@ void plfx_destroy(plfx_ctx *c)
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) == hipSuccess && h[7]) {
             static const char *nm[8] = {"fgrad", "plain", "ray_sample pass", "ray_sample post", "march", "brentq", "full() in corrector", "corrector loop"};
             for (int i = 0; i < 8; i++) fprintf(stderr, "[prof] %-22s %14llu ticks  %5.1f %% of the corrector loop\n", nm[i], h[i], 100. * h[i] / h[7]);
+            fprintf(stderr, "[prof] rows: ray searches %llu, direct evaluations %llu (no polynomial %llu, outside its interval %llu, inside the margin %llu), of the outside ones: below lo %llu, at brentq iterates %llu, at the start point %llu\n",
+                    h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
         }
     }
 #endif

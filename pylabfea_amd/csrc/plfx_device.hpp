@@ -30,6 +30,7 @@ extern __shared__ double dyn_lds[];
 // tools/probes/svc_scalar_share.py (time against the number of support vectors) is the measurement DESIGN 10.2 quotes.
 #ifdef PLFX_PROF_REGIONS
 __device__ unsigned long long g_prof[16];
+#define PROF_CNT(r) do { if ((threadIdx.x & 15) == 0) atomicAdd(&g_prof[r], 1ull); } while (0)   /* per row of 16 lanes */
 #define PROF_T0(t) const unsigned long long prof_##t = __builtin_readcyclecounter()
 #define PROF_ADD(r, t)                                                                                         \
     do {                                                                                                      \
@@ -38,6 +39,7 @@ __device__ unsigned long long g_prof[16];
 #else
 #define PROF_T0(t) do { } while (0)
 #define PROF_ADD(r, t) do { } while (0)
+#define PROF_CNT(r) do { } while (0)
 #endif
 
 // 2^y for the RBF kernel sums, y <= 0 (tiny positive round-off allowed); the callers fold log2(e) into -gamma.
@@ -105,6 +107,10 @@ __device__ __forceinline__ void exp2_neg_n(const double (&yin)[N], double (&out)
     for (int c = 0; c < N; c++) out[c] = __hiloint2double(__double2hiint(p[c]) + (ni[c] << 20), __double2loint(p[c]));
 }
 constexpr double LOG2E = 1.4426950408889634;
+#ifndef PLFX_RAY_BOUND
+#define PLFX_RAY_BOUND 1.e-7
+#endif
+constexpr double RAY_BOUND = PLFX_RAY_BOUND;   // rigorous bound on |f - p| the sampled-ray interval is shrunk to (see ray_sample)
 
 // sum over the 64 lanes of a wave, result in every lane (and wave-uniform for the compiler: scalar branches).
 // Four DPP butterfly steps inside each row of 16 lanes (quad xor 1, xor 2, half-row mirror, row mirror: no LDS
@@ -989,13 +995,13 @@ struct YfSvcT {
         double b = q * dl;
         b *= b; b *= b; b *= b; b *= b;
         double bound = m.svc_sabs * KN * b;
-        if (!(bound <= 1.e-7)) {
+        if (!(bound <= RAY_BOUND)) {
             if (!(bound < 1.e300)) return;
-            const double sh = sqrt(sqrt(sqrt(sqrt(1.e-7 / bound))));   // (1e-7 / bound)^(1/16)
+            const double sh = sqrt(sqrt(sqrt(sqrt(RAY_BOUND / bound))));   // (RAY_BOUND / bound)^(1/16)
             lo = x0 - (x0 - lo) * sh;
             hi = x0 + (hi - x0) * sh;
             dl = (hi - lo) * (1. / (NS - 1));
-            bound = 1.e-7;
+            bound = RAY_BOUND;
         }
         // the recurrence multiplies by rho_k up to NS - 1 times: keep its exponent range harmless
         const double sD = sqrt(DD);
@@ -1656,7 +1662,14 @@ struct YfSvcRow {
         }
     };
     __device__ __forceinline__ const double *poly_tab() const { return tabs() + 9 * npad; }
-    __device__ __forceinline__ void ray_sample(const double *su, double x0, bool halved, RowPoly &P) const
+    // xstate: ray parameter of the stress the search was called for (s = xstate su).  Inside the plastic corrector that stress lies
+    // on the yield locus to a few per cent, i.e. xstate IS where the march ends and brentq works -- and for rays along which the
+    // material is stronger than sflow by more than the default interval allows (config 4's loading direction: every search of the
+    // corrector) the end of the march and brentq's iterates fell beyond hi and cost a pass over the support vectors each
+    // (round 6, counted: 1.02 such passes per search, 13 % of the corrector).  The interval is stretched to 1.06 xstate when that is
+    // a modest extension (<= 25 %; a trial stress far outside the locus says nothing about the root); the error bound below is
+    // evaluated for the interval actually used and shrinks it as before if it has to.
+    __device__ __forceinline__ void ray_sample(const double *su, double x0, bool halved, RowPoly &P, double xstate = 0.) const
     {
         P.ok = false;
         P.ci = 0.;
@@ -1668,6 +1681,7 @@ struct YfSvcRow {
         for (int i = 0; i < 6; i++) DD = fma(D[i], D[i], DD);
         // the march starts at x0 = sflow and goes down or up, or at x0 = sflow / 2 (material.py:468-473) and goes up
         double lo = halved ? 0.94 * x0 : 0.72 * x0, hi = halved ? 2.7 * x0 : 1.30 * x0;
+        if (1.06 * xstate > hi && 1.06 * xstate <= 1.25 * hi) hi = 1.06 * xstate;
         double dl = (hi - lo) * (1. / (NS - 1));
         const double q = sqrt(2. * m.gamma * DD);
         constexpr double KN = 1.0865 * 4574143.623 / (4. * NS);   // K sqrt(16!) / (4 N)
@@ -1675,13 +1689,13 @@ struct YfSvcRow {
         double b = q * dl;
         b *= b; b *= b; b *= b; b *= b;
         double bound = m.svc_sabs * KN * b;
-        if (!(bound <= 1.e-7)) {
+        if (!(bound <= RAY_BOUND)) {
             if (!(bound < 1.e300)) return;
-            const double sh = sqrt(sqrt(sqrt(sqrt(1.e-7 / bound))));   // (1e-7 / bound)^(1/16)
+            const double sh = sqrt(sqrt(sqrt(sqrt(RAY_BOUND / bound))));   // (RAY_BOUND / bound)^(1/16)
             lo = x0 - (x0 - lo) * sh;
             hi = x0 + (hi - x0) * sh;
             dl = (hi - lo) * (1. / (NS - 1));
-            bound = 1.e-7;
+            bound = RAY_BOUND;
         }
         const double sD = sqrt(DD);
         if (!(2. * m.gamma * dl * (NS - 1) * sD * (sqrt(m.svc_vvmax) + sD * hi) < 60.) || !(hi > lo)) return;
@@ -1750,7 +1764,7 @@ struct YfSvcRow {
     }
     // f(x su): the polynomial where it decides (phase < 3: and is farther from zero than its error bound), the support-vector
     // sum otherwise
-    __device__ __forceinline__ double evalx(const double *su, const RowPoly &P, double x, bool need_sign) const
+    __device__ __forceinline__ double evalx(const double *su, const RowPoly &P, double x, bool need_sign, int site = 0) const
     {
         double f = 0.;
         bool direct = true;
@@ -1762,7 +1776,13 @@ struct YfSvcRow {
             double xs[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) xs[i] = x * su[i];
+            PROF_T0(dd);
             f = decision(xs);
+            PROF_ADD(1, dd);
+            PROF_CNT(9);
+            if (!P.ok) PROF_CNT(10);
+            else if (!(x >= P.lo && x <= P.hi)) { PROF_CNT(11); if (site == 1) PROF_CNT(15); if (site == 2) PROF_CNT(14); if (x < P.lo) PROF_CNT(13); }
+            else PROF_CNT(12);
         }
         return f;
     }
@@ -1822,10 +1842,16 @@ struct YfSvcRow {
         const bool halved = su[0] * su[1] < -1.e-5;   // material.py:468-473
         if (halved) x0 *= 0.5;
         RowPoly P;
-        ray_sample(su, x0, halved, P);
-        double f0 = evalx(su, P, x0, true), x1 = x0, f1 = f0;
+        PROF_T0(rs);
+        ray_sample(su, x0, halved, P, ld == nullptr ? seqv : 0.);
+        PROF_ADD(2, rs);
+        PROF_CNT(8);
+
+        PROF_T0(mm);
+        double f0 = evalx(su, P, x0, true, 1), x1 = x0, f1 = f0;
         if (f0 >= 0. && x0 > 0.01) march<true>(su, P, sflow, x0, f0);
         if (f1 < 0. && x1 < 5. * sflow) march<false>(su, P, sflow, x1, f1);
+        PROF_ADD(4, mm);
         if (f0 * f1 > 0.) {  // material.py:495-499
             if (status) *status = 1;
             return seqv - 0.85 * sflow;
@@ -1838,12 +1864,14 @@ struct YfSvcRow {
         double xs;
         bool conv = true;
         {
+            PROF_T0(bq);
             BrentState br;
             if (br.start(x0, x1, f0, f1)) {
-                while (br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) br.fcur = evalx(su, P, br.xcur, false);
+                while (br.next(1.e-5, 4. * 2.220446049250313e-16, 100)) br.fcur = evalx(su, P, br.xcur, false, 2);
             }
             xs = br.root;
             conv = br.converged;
+            PROF_ADD(5, bq);
         }
         if (conv && xs < 4. * sflow) return seqv - xs * seq(su);  // material.py:507
         if (status) *status = 2;
