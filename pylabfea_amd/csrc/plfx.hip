@@ -437,6 +437,29 @@ int grid_for(size_t n, int cap = MAXPART)
     return (int)g;
 }
 
+// k_grid_setup: one thread per row and group of SETUP_COLS columns, every thread exactly one walk (no partial sums: no cap)
+int setup_cols(const KOp &g)
+{
+    static const int forced = getenv("PLFX_SETUP_COLS") ? atoi(getenv("PLFX_SETUP_COLS")) : 0;   // experiments: 1, 4, 8
+    if (forced == 1 || forced == 4 || forced == 8) return forced;
+    return g.nnode >= (1 << 19) ? 4 : 1;   // (level 1 of 1024^2, 513^2 nodes: 12.4 us with 1, 13.6 with 4)
+}
+int setup_grid(const KOp &g)
+{
+    return (int)((grid_setup_tasks(g.nxn, g.nyn, setup_cols(g)) + BLOCK - 1) / BLOCK);
+}
+// k_grid_setup<SRC, COLS> with the column walk of the level's size
+#define LAUNCH_SETUP(SRC, G, ...)                                                                                             \
+    do {                                                                                                                       \
+        const int cols_ = setup_cols(G);                                                                                       \
+        if (cols_ == 8)                                                                                                        \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<SRC, 8>), dim3(setup_grid(G)), dim3(BLOCK), 0, c->stream, G, __VA_ARGS__); \
+        else if (cols_ == 4)                                                                                                   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<SRC, 4>), dim3(setup_grid(G)), dim3(BLOCK), 0, c->stream, G, __VA_ARGS__); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<SRC, 1>), dim3(setup_grid(G)), dim3(BLOCK), 0, c->stream, G, __VA_ARGS__); \
+    } while (0)
+
 // round the grid to a multiple of 8 (XCD count) when large enough, for xcd_tile()
 int grid_xcd(size_t n)
 {
@@ -1184,7 +1207,7 @@ int mg_assemble(plfx_ctx *c)
                                // layout on every level >= 1 and in the snapshot of level 0 (the live array of level 0 is SoA)
         const bool setup_mf = mf && (L.matfree || (tail_mf(c) && l < nl - 1));  // coarsest: assembled for the dense inverse
         if (setup_mf)  // only the diagonal (Jacobi smoother) is needed
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(L.nnode)), dim3(BLOCK), 0, c->stream, L.op, (double2 *)L.diag,
+            LAUNCH_SETUP(1, L.op, (double2 *)L.diag,
                                (double *)nullptr, (l + 1 < nl && level_plain(L)) ? c->mg[l + 1].Mel : (double *)nullptr,
                                (const double2 *)c->dinv, c->mg[0].ny + 1, l,
                                c->mg_dinv_current ? (double2 *)L.dinv : (double2 *)nullptr, c->mg[0].nx + 1);
@@ -1576,7 +1599,7 @@ int strip_child_assemble(plfx_ctx *c)
     }
     KOp live = k->op;
     live.M = k->Mel;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(k->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)k->diag, k->Mop,
+    LAUNCH_SETUP(1, live, (double2 *)k->diag, k->Mop,
                        k->mg[1].Mel, (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
     HIPCHK(c, hipGetLastError());
     k->bc_valid = false;  // its Jacobi scalings / Dirichlet masks follow in strip_child_dinv (after the parent's calc_BC)
@@ -3376,7 +3399,7 @@ int plfx_assemble(plfx_ctx *c)
         if (setup_done)
             c->n_spec_setup++;
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+            LAUNCH_SETUP(0, live, (double2 *)c->diag,
                                c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
                                (double2 *)nullptr);
         c->val_valid = false;
@@ -4020,7 +4043,7 @@ int surrogate_build(plfx_ctx *c, long long *replaced)
     KOp sop = c->op;
     sop.M = c->Msur;
     // diagonal of the surrogate + generators of level 1, then the coarser levels, Jacobi scalings and the coarse inverse
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<1>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, sop,
+    LAUNCH_SETUP(1, sop,
                        (double2 *)c->diag_sur, (double *)nullptr, level_plain(c->mg[0]) ? c->mg[1].Mel : (double *)nullptr,
                        (const double2 *)nullptr, 0, 0, (double2 *)nullptr);
     hipLaunchKernelGGL(k_dinv_masked, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->diag_sur, c->dinv, c->dinv_sur);
@@ -5165,7 +5188,7 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
             // plfx_assemble if a tangent changed, else -- if every element converged as well -- the K du of plfx_finish_step
             KOp live = c->op;
             live.M = c->Mel;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_setup<0>), dim3(grid_for(c->nnode)), dim3(BLOCK), 0, c->stream, live, (double2 *)c->diag,
+            LAUNCH_SETUP(0, live, (double2 *)c->diag,
                                c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
                                (double2 *)nullptr, 0x7fffffff, (const int *)(c->flags + 8));
             LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, nullptr,

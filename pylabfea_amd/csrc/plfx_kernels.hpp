@@ -1683,7 +1683,15 @@ __device__ __forceinline__ void grid_march(const KOp &g, XF xf, EM emit)
 //          (node (j << shift, k << shift) of the grid with mask_nyn nodes per column)
 // SRC_PAIR: layout of g.M (0: the live SoA array of the finest level; 1: pair layout, every other level); Msnap and Mc are
 // written in pair layout.
-template <int SRC_PAIR>
+// Loads: a thread walks SETUP_COLS consecutive columns at one row k.  A node's four elements are the pair (j-1,k), (j,k) of
+// its own row -- the second one loaded, the first one kept from the column before -- and the same pair of the node BELOW it,
+// which is the neighbouring lane (lane 0 of a wave fetches it itself): 7.5 loads per node instead of 24, and the coarse
+// generators are formed where all four children are already in registers -- at the odd/odd node (2J+1, 2K+1) -- instead of 18
+// more loads at the even/even one.  Sums in the order of the node loop they replace: bit-identical (tools/probes/lib_ab.py).
+// SETUP_COLS = 1 on the small levels (a walk of four columns is four dependent rounds of loads where the launch is all
+// there is: 5.5 -> 8.5 us), 4 from 2^19 nodes (1024^2: 48.8 -> 35 us; 8 columns leave two waves per SIMD: not faster).
+__host__ __device__ inline size_t grid_setup_tasks(int nxn, int nyn, int cols) { return (size_t)((nxn + cols - 1) / cols) * nyn; }
+template <int SRC_PAIR, int SETUP_COLS = 1>
 __global__ void __launch_bounds__(BLOCK)
 k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, double *__restrict__ Mc,
              const double2 *__restrict__ mask_dinv, int mask_nyn, int shift, double2 *__restrict__ dinv, int mask_nxn = 0x7fffffff,
@@ -1693,17 +1701,47 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
     const int nyn = g.nyn, nye = nyn - 1, nxe = g.nxn - 1;
     const int nyc = nye >> 1;
     const size_t nel_c = (size_t)(nxe >> 1) * nyc;
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < g.nnode; i += gridDim.x * BLOCK) {
-        const int j = i / nyn, k = i - j * nyn;
+    const int lane = threadIdx.x & 63;
+    auto load6 = [&](size_t e, double(&o)[6]) {
+        if (SRC_PAIR) {
+            const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
+            const double2 a01 = M2[e], a23 = M2[(size_t)g.nel + e], a45 = M2[(size_t)2 * g.nel + e];
+            o[0] = a01.x, o[1] = a01.y, o[2] = a23.x, o[3] = a23.y, o[4] = a45.x, o[5] = a45.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) o[c] = g.M[(size_t)c * g.nel + e];
+        }
+    };
+    const int ntask = (int)grid_setup_tasks(g.nxn, nyn, SETUP_COLS);
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < ntask; t += gridDim.x * BLOCK) {
+      const int jg = t / nyn, k = t - jg * nyn;
+      const bool okk[2] = {k >= 1, k < nye};
+      double el[2][2][6];   // el[pj][pk] = generators of element (j-1+pj, k-1+pk), zero where it does not exist
+      const int jlo = jg * SETUP_COLS, jhi = min(jlo + SETUP_COLS, g.nxn);
+      for (int j = jlo; j < jhi; j++) {
+        const int i = j * nyn + k;
         double dx = 0., dy = 0.;
-        double own[6] = {0., 0., 0., 0., 0., 0.};
+        const bool okj[2] = {j >= 1, j < nxe};
+#pragma unroll
+        for (int pj = 0; pj < 2; pj++) {
+            if (SETUP_COLS > 1 && pj == 0 && j > jlo) continue;   // the pair of column j-1 is the one kept from the step before
+#pragma unroll
+            for (int c = 0; c < 6; c++) el[pj][1][c] = 0.;
+            if (okj[pj] && okk[1]) load6((size_t)(j - 1 + pj) * nye + k, el[pj][1]);
+        }
+#pragma unroll
+        for (int pj = 0; pj < 2; pj++) {
+            if (SETUP_COLS > 1 && pj == 0 && j > jlo) continue;
+#pragma unroll
+            for (int c = 0; c < 6; c++) el[pj][0][c] = __shfl_up(el[pj][1][c], 1);   // lane - 1 is node (j, k-1) when k >= 1
+            if (lane == 0 && okk[0] && okj[pj]) load6((size_t)(j - 1 + pj) * nye + k - 1, el[pj][0]);
+        }
 #pragma unroll
         for (int pj = 0; pj < 2; pj++)
 #pragma unroll
             for (int pk = 0; pk < 2; pk++) {
+                if (!(okj[pj] && okk[pk])) continue;
                 const int ej = j - 1 + pj, ek = k - 1 + pk;
-                if (ej < 0 || ej >= nxe || ek < 0 || ek >= nye) continue;
-                const size_t e = (size_t)ej * nye + ek;
                 const int a = (1 - pj) * 2 + (1 - pk);
                 const double *T = g.tab + (pj * 2 + pk) * 16 + a * 4;   // b = a
                 double sxx = T[0], syy = T[1];
@@ -1728,27 +1766,17 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
                     sxx *= PLFX_MG_ODD_RULE ? csx * csy : csy / csx;
                     syy *= PLFX_MG_ODD_RULE ? csx * csy : csx / csy;
                 }
-                double Mxx, Mxy, Mxs, Myy, Mys, Mss;
-                if (SRC_PAIR) {
-                    const double2 *M2 = reinterpret_cast<const double2 *>(g.M);
-                    const double2 a01 = M2[e], a23 = M2[(size_t)g.nel + e], a45 = M2[(size_t)2 * g.nel + e];
-                    Mxx = a01.x, Mxy = a01.y, Mxs = a23.x, Myy = a23.y, Mys = a45.x, Mss = a45.y;
-                } else {
-                    Mxx = g.M[e], Mxy = g.M[(size_t)g.nel + e], Mxs = g.M[(size_t)2 * g.nel + e];
-                    Myy = g.M[(size_t)3 * g.nel + e], Mys = g.M[(size_t)4 * g.nel + e], Mss = g.M[(size_t)5 * g.nel + e];
-                }
+                const double Mxx = el[pj][pk][0], Mxs = el[pj][pk][2], Myy = el[pj][pk][3], Mys = el[pj][pk][4], Mss = el[pj][pk][5];
                 dx += Mxx * sxx + Mxs * (sxy + syx) + Mss * syy;
                 dy += Myy * syy + Mys * (syx + sxy) + Mss * sxx;
-                if (pj == 1 && pk == 1) {  // node (j,k) "owns" element (j,k)
-                    own[0] = Mxx; own[1] = Mxy; own[2] = Mxs; own[3] = Myy; own[4] = Mys; own[5] = Mss;
-                    if (Msnap) {
-                        double2 *S2 = reinterpret_cast<double2 *>(Msnap);
-                        S2[e] = make_double2(own[0], own[1]);
-                        S2[(size_t)g.nel + e] = make_double2(own[2], own[3]);
-                        S2[(size_t)2 * g.nel + e] = make_double2(own[4], own[5]);
-                    }
-                }
             }
+        if (Msnap && okj[1] && okk[1]) {   // node (j,k) "owns" element (j,k)
+            const size_t e = (size_t)j * nye + k;
+            double2 *S2 = reinterpret_cast<double2 *>(Msnap);
+            S2[e] = make_double2(el[1][1][0], el[1][1][1]);
+            S2[(size_t)g.nel + e] = make_double2(el[1][1][2], el[1][1][3]);
+            S2[(size_t)2 * g.nel + e] = make_double2(el[1][1][4], el[1][1][5]);
+        }
         diag[i] = make_double2(dx, dy);
         if (dinv) {
             // (interior node lines of a level are node lines j << level of the finest grid counted from the side of the regular
@@ -1767,19 +1795,25 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
             o.y = (df.y != 0.) ? (fabs(dy) > 1e-300 ? 1. / fabs(dy) : 1.) : 0.;
             dinv[i] = o;
         }
-        if (Mc && !(j & 1) && !(k & 1) && j < nxe && k < nye) {  // (levels that halve exactly; otherwise the host runs k_mg_coarsen_M)
-            const size_t e00 = (size_t)j * nye + k, e10 = e00 + nye;
+        // (levels that halve exactly; otherwise the host runs k_mg_coarsen_M): coarse element (J,K) has the children
+        // (2J,2K) (2J,2K+1) (2J+1,2K) (2J+1,2K+1) = the four elements of node (2J+1, 2K+1), summed in that order
+        if (Mc && (j & 1) && (k & 1) && okj[1] && okk[1]) {
             const size_t ec = (size_t)(j >> 1) * nyc + (k >> 1);
             double mc[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++)
-                mc[c] = 0.25 * (own[c] + g.M[gen_index(SRC_PAIR, c, g.nel, e00 + 1)] + g.M[gen_index(SRC_PAIR, c, g.nel, e10)] +
-                                g.M[gen_index(SRC_PAIR, c, g.nel, e10 + 1)]);
+            for (int c = 0; c < 6; c++) mc[c] = 0.25 * (el[0][0][c] + el[0][1][c] + el[1][0][c] + el[1][1][c]);
             double2 *C2 = reinterpret_cast<double2 *>(Mc);
             C2[ec] = make_double2(mc[0], mc[1]);
             C2[nel_c + ec] = make_double2(mc[2], mc[3]);
             C2[2 * nel_c + ec] = make_double2(mc[4], mc[5]);
         }
+        if (SETUP_COLS > 1) {
+#pragma unroll
+            for (int pk = 0; pk < 2; pk++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) el[0][pk][c] = el[1][pk][c];
+        }
+      }
     }
 }
 
