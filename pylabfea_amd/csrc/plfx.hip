@@ -3871,11 +3871,15 @@ int plfx_finish_step(plfx_ctx *c, double *u_at, double *f_at, double *sums18)
     int rc = 0;
     const bool kdu_done = c->spec_kdu && c->spec_h0 == 0 && c->spec_h1 == 0 && !c->strip.on;   // (ran behind the last sweep's flags)
     c->spec_setup = c->spec_kdu = false;
-    if (kdu_done)
+    if (kdu_done)   // u += du, f += K du happened in that pass
         c->n_spec_kdu++;
-    else if ((rc = plain_spmv(c, c->du, c->q)))  // K du over all DOFs (reaction forces, model.py:1384)
-        return rc;
-    hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    else if (!comm_active(c) && !c->strip.on)   // K du over all DOFs (reaction forces, model.py:1384) with the two updates in its epilogue
+        LAUNCH_OP2(k_spmv, 3, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, (double2 *)c->u,
+                   (double2 *)c->f, nullptr, nullptr, nullptr, 0, nullptr, (CgScalars *)nullptr, 0, 0, 0);
+    else {
+        if ((rc = plain_spmv(c, c->du, c->q))) return rc;
+        hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    }
     const int g = grid_for(c->nel, SUMPART);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<1>), dim3(g), dim3(BLOCK), 0, c->stream, c->dmat, c->dcls, c->nel,
                        c->e0, c->dconn, c->dcls_id, (const double2 *)c->du, (const double2 *)c->u, c->sig, c->epl,
@@ -5191,8 +5195,9 @@ static int sweep_once(plfx_ctx *c, int nit, int *changed, int *conv, bool wh_seq
             LAUNCH_SETUP(0, live, (double2 *)c->diag,
                                c->Mop, (mg_active(c) && level_plain(c->mg[0])) ? c->mg[1].Mel : (double *)nullptr, (const double2 *)nullptr, 0, 0,
                                (double2 *)nullptr, 0x7fffffff, (const int *)(c->flags + 8));
-            LAUNCH_OP2(k_spmv, 0, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, nullptr,
-                       (double2 *)c->q, nullptr, nullptr, nullptr, 0, nullptr, c->spec_sc, 0, 0, 0);
+            // (u += du and f += K du in the same pass, MODE 3: the predicate is exactly "plfx_finish_step comes next")
+            LAUNCH_OP2(k_spmv, 3, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, (double2 *)c->u,
+                       (double2 *)c->f, nullptr, nullptr, nullptr, 0, nullptr, c->spec_sc, 0, 0, 0);
             c->spec_was_clean = !c->M_dirty;
             c->spec_setup = c->spec_kdu = true;
         }
@@ -5469,11 +5474,15 @@ int plfx_update_state(plfx_ctx *c)
     int rc = 0;
     const bool kdu_done = c->spec_kdu && c->spec_h0 == 0 && c->spec_h1 == 0 && !c->strip.on;   // (ran behind the last sweep's flags)
     c->spec_setup = c->spec_kdu = false;
-    if (kdu_done)
+    if (kdu_done)   // u += du, f += K du happened in that pass
         c->n_spec_kdu++;
-    else if ((rc = plain_spmv(c, c->du, c->q)))  // K du over all DOFs (reaction forces, model.py:1384)
-        return rc;
-    hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    else if (!comm_active(c) && !c->strip.on)   // K du over all DOFs (reaction forces, model.py:1384) with the two updates in its epilogue
+        LAUNCH_OP2(k_spmv, 3, matfree(c), dim3(c->grid_nodes), c->op, 0, c->nnode, (const double2 *)c->du, nullptr, (double2 *)c->u,
+                   (double2 *)c->f, nullptr, nullptr, nullptr, 0, nullptr, (CgScalars *)nullptr, 0, 0, 0);
+    else {
+        if ((rc = plain_spmv(c, c->du, c->q))) return rc;
+        hipLaunchKernelGGL(k_axpy_uf, dim3(grid_for(nd)), dim3(BLOCK), 0, c->stream, nd, c->du, c->q, c->u, c->f);
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_state<0>), dim3(grid_for(c->nel, MAXPART)), dim3(BLOCK), 0, c->stream,
                        c->dmat, c->dcls, c->nel, c->e0, c->dconn, c->dcls_id, (const double2 *)c->du,
                        (const double2 *)c->u, c->sig, c->epl, c->eps, c->elstiff, c->res_sig,

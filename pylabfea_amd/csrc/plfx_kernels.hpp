@@ -1824,6 +1824,7 @@ k_grid_setup(KOp g, double2 *__restrict__ diag, double *__restrict__ Msnap, doub
 // MODE 1: PCG step: beta = rz_new/rz_old from the partial sums of the previous update kernel,
 //         p_new = z + beta p_old (written to pnew), q = K p_new, partial sums of p_new . q.
 // MODE 2: first PCG step: p_new = z, q = K z, partial sums of z . q (p_old is neither initialised nor read)
+// MODE 3: end of a load step (model.py:1383-1384): u += du, f += K du in one pass -- p = du, pnew = u, q = f; K du itself is not stored
 struct CgScalars {
     double thresh2;  // (rtol * |b|)^2
     int32_t done;    // sticky convergence flag
@@ -1842,8 +1843,8 @@ k_spmv(KOp op, int n_begin, int n_end,
 {
     __shared__ double sh[BLOCK / 64];
     double beta = 0.;
-    if (MODE == 0 && sc != nullptr && sc->done) return;   // (speculatively enqueued K d of the interpolated start)
-    if (MODE >= 1) {
+    if ((MODE == 0 || MODE == 3) && sc != nullptr && sc->done) return;   // (speculatively enqueued K d of the interpolated start / K du of the end of a load step)
+    if (MODE == 1 || MODE == 2) {
         if (sc->done) return;
         double rr, rzn = 0., rzo = 1.;
         if (MODE == 1) {  // MODE 2 = first iteration: p = z (beta = 0, p_old is not initialised and never read)
@@ -1884,7 +1885,17 @@ k_spmv(KOp op, int n_begin, int n_end,
         else
             qv = op_apply<GRID>(op, i, [&](int j) { return p[j]; });
         const double qx = qv.x, qy = qv.y;
-        q[i] = make_double2(qx, qy);
+        if (MODE == 3) {   // pnew = u, q = f: u += du, f += K du in the pass that forms K du (k_axpy_uf's two additions)
+            const double2 d = p[i];
+            double2 uu = pnew[i], ff = q[i];
+            uu.x += d.x;
+            uu.y += d.y;
+            ff.x += qx;
+            ff.y += qy;
+            pnew[i] = uu;
+            q[i] = ff;
+        } else
+            q[i] = make_double2(qx, qy);
         if (MODE == 1) {
             const double2 zi = z[i], po = p[i];
             double2 pn;
@@ -1898,7 +1909,7 @@ k_spmv(KOp op, int n_begin, int n_end,
             if (i >= own_lo && i < own_hi) acc_pq = fma(zi.x, qx, fma(zi.y, qy, acc_pq));
         }
     }
-    if (MODE >= 1) {
+    if (MODE == 1 || MODE == 2) {
         const double t = block_sum(acc_pq, sh);
         if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
     }
