@@ -231,6 +231,11 @@ struct plfx_ctx {
     // plfx_load_step, single GPU: the set-up pass of the next stiffness iteration and the K du of the end of the load step are
     // enqueued behind k_sweep_flags with device-side predicates, before the host has read the flags
     bool spec_arm = false, spec_setup = false, spec_kdu = false, spec_was_clean = false;
+    // plfx_load_step tells plfx_solve which of its two solves this is (0 predictor of the load step, 1 stiffness iteration;
+    // -1 any other caller); first_test_hint[site]: the last solve of that kind was answered by the test of the plain warm start
+    // -- the next one waits for that test before it enqueues the six launches of the interpolated start behind it
+    int solve_site = -1;
+    bool first_test_hint[2] = {false, false};
     int spec_h0 = 0, spec_h1 = 0;
     CgScalars *spec_sc = nullptr;
     long long n_spec_setup = 0, n_spec_kdu = 0;
@@ -1302,7 +1307,8 @@ int mg_down_level(plfx_ctx *c, int l)
         LAUNCH_OP2R(k_mg_residual, 0, mf, L.op, dim3(L.grid), L.op, (const double2 *)L.dinv, (const double2 *)L.b,
                    (const double2 *)L.x, (double2 *)L.res, c->sc);
     hipLaunchKernelGGL(k_mg_restrict, dim3(grid_for(C.nnode)), dim3(BLOCK), 0, c->stream, C.nx + 1, C.ny + 1,
-                       L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b, L.rx, L.ry);
+                       L.nx + 1, L.ny + 1, (const double2 *)L.res, (const double2 *)C.dinv, (double2 *)C.b, L.rx, L.ry,
+                       l == 0 ? (const CgScalars *)c->sc : (const CgScalars *)nullptr);
     return 0;
 }
 
@@ -3777,6 +3783,7 @@ int plfx_load_step(plfx_ctx *c, plfx_step *st, double *u_at, double *f_at, doubl
     double *dbcn = st->max_dbcn;  // the reference's dbcn IS max_dbcn (alias, model.py:1285)
     // elastic predictor with the stiffness of the previous step (model.py:1290-1291)
     if ((rc = step_apply_bc(c, st, dbcr, dbct, dbcn, &st->inconsistent_entry))) return rc;
+    c->solve_site = 0;
     if ((rc = step_solve(c, st, st->warm))) return rc;
     if (st->nonlin) {
         if (st->il < 10) {  // calc_scf (model.py:1036-1067, 1296)
@@ -3815,6 +3822,7 @@ int plfx_load_step(plfx_ctx *c, plfx_step *st, double *u_at, double *f_at, doubl
             }
             if ((rc = plfx_assemble(c))) return rc;  // updated tangent stiffness (model.py:1333)
             if ((rc = step_apply_bc(c, st, dbcr, dbct, dbcn, &st->inconsistent_entry))) return rc;
+            c->solve_site = 1;
             if ((rc = step_solve(c, st, 1))) return rc;
             // (the loop goes on after this sweep only if nit + 1 <= 15: then -- and only then -- what follows the flags is decided
             // by the flags alone and can be enqueued behind them with device-side predicates)
@@ -4629,6 +4637,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
 {
     if (!c || !c->bc_set) return c ? fail(c, PLFX_ERR_STATE, "apply_bc first") : PLFX_ERR_STATE;
     c->spec_setup = c->spec_kdu = false;   // (a solve overwrites c->q: nothing enqueued behind a sweep's flags is valid beyond it)
+    const int solve_site_in = c->solve_site;
+    c->solve_site = -1;
     if (maxit < 1) maxit = 1;
     if (c->reuse && warm && c->x_is_du && c->memo.valid && c->memo.rtol == rtol) {
         // the system of the previous converged solve (no assembly, no other boundary values since): du is its solution
@@ -4701,9 +4711,22 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
     if (!mg) hipLaunchKernelGGL(k_cg_setup, dim3(1), dim3(BLOCK), 0, c->stream, P_bb, gn, rtol_eff, c->sc);
     CgScalars hs{};
     int done = 0;
+    int pred_site = -1;
+    bool pred_first_passed = false;
     if (mg) {  // z0 = V-cycle(r0) replaces the Jacobi z of k_cg_init -- unless x0 already satisfies the tolerance
         unsigned long long seq = cg_setup_check_post(c, P_bb, P_rr[1], gn, rtol_eff);   // (scalars set up and first test: one launch)
-        if (pred_active) {
+        const int site = pred_site = solve_site_in;
+        bool first_passed = false;
+        if (pred_active && site >= 0 && c->first_test_hint[site] && !c->strip.on) {
+            // the predictor solve of a load step repeats the system of the solve before it up to the last bits of its boundary
+            // values: x passes the first test.  Learn that before enqueuing what would return at once (six launches, 28 us)
+            if ((rc = cg_check_wait(c, seq, &hs))) return rc;
+            done = hs.done;
+            first_passed = done != 0;
+        }
+        if (first_passed) {
+            pred_first_passed = true;   // (nothing to do: done, hs as the chain below would have left them)
+        } else if (pred_active) {
             // Everything the interpolated start needs is enqueued behind the first test and returns at once if that test passed
             // (the reference repeats solves of one system: x satisfies the tolerance as it is); the host waits ONCE, for the second
             // test (round 6: three round trips -> one).  d = x - (solution before), K d, the two sums, alpha on the device
@@ -4745,6 +4768,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
                 if ((rc = mg_ensure(c))) return rc;
                 if ((rc = mg_vcycle_head(c))) return rc;
             }
+            pred_first_passed = done == 1 && !pred_moved;
         } else if (c->mg_pending) {
             // the coarse levels are stale (mg_ensure): learn first whether a V-cycle is needed at all
             if ((rc = cg_check_wait(c, seq, &hs))) return rc;
@@ -4760,6 +4784,7 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         }
     }
     static const bool fuse_dot = !(getenv("PLFX_FUSE_DOT") && atoi(getenv("PLFX_FUSE_DOT")) == 0);
+    if (mg && pred_site >= 0 && pred_active) c->first_test_hint[pred_site] = pred_first_passed;
     if (mg && !done) {
         c->fuse_rz = fuse_dot ? P_rz[1] : nullptr;  // r.z partials from the last post-smoothing launch of the cycle
         rc = mg_vcycle_rest(c);

@@ -267,8 +267,10 @@ __device__ __forceinline__ double2 mg_restrict_at(int J, int K, int nfx, int nfy
 // relative size of the fine level's last cell
 __global__ void __launch_bounds__(BLOCK)
 k_mg_restrict(int nxc_nodes, int nyc, int nxf_nodes, int nyf, const double2 *__restrict__ res_f,
-              const double2 *__restrict__ dinv_c, double2 *__restrict__ b_c, double rxf = 1., double ryf = 1.)
+              const double2 *__restrict__ dinv_c, double2 *__restrict__ b_c, double rxf = 1., double ryf = 1.,
+              const CgScalars *__restrict__ sc = nullptr /* finest level: the head of a cycle is enqueued behind the convergence test */)
 {
+    if (sc && sc->done) return;
     const int nc = nxc_nodes * nyc;
     const int nfx = nxf_nodes - 1, nfy = nyf - 1;   // cells of the fine level
     const bool plain = !(nfx & 1) && !(nfy & 1) && rxf == 1. && ryf == 1.;
