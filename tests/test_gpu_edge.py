@@ -389,3 +389,23 @@ def test_structured_mesh_description_equals_explicit_index_arrays():
         assert s.nsteps == e.nsteps and list(s.niter) == list(e.niter)
         assert np.array_equal(s.u, e.u) and np.array_equal(s.f, e.f) and np.array_equal(s._state('sig'), e._state('sig'))
         assert s._engine.precond_info() == e._engine.precond_info() and s._engine.operator_info() == e._engine.operator_info()
+
+
+def test_setup_pass_column_walk_variants_are_bit_identical():
+    """k_grid_setup<SRC, COLS>: one column per thread on small levels, a four-column walk from 2^19 nodes.  Both
+    forms (and the eight-column one kept as a knob) must give the same bits -- diagonal, operator snapshot, level-1 generators --
+    on every kind of level: plain, odd-size (area-scaled diagonal) and per-column widths.  PLFX_SETUP_COLS is read once per process:
+    tools/probes/lib_ab.py's child runs the three solves under each setting; its line per case carries a digest of u, sig, epl,
+    sgl, egl and the PCG iteration count of every solve."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, 'tools', 'probes', 'lib_ab.py')
+    res = {}
+    for cols in ('1', '4', '8'):
+        env = dict(os.environ, PLFX_SETUP_COLS=cols)
+        out = subprocess.run([sys.executable, script, '--child'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[cols] = [ln for ln in out.stdout.splitlines() if ln.count('|') == 2]
+        assert len(res[cols]) == 3
+    assert res['1'] == res['4'] == res['8']
