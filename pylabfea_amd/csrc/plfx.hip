@@ -4717,7 +4717,8 @@ int plfx_solve(plfx_ctx *c, double rtol, int maxit, int warm, int *iters, double
         unsigned long long seq = cg_setup_check_post(c, P_bb, P_rr[1], gn, rtol_eff);   // (scalars set up and first test: one launch)
         const int site = pred_site = solve_site_in;
         bool first_passed = false;
-        if (pred_active && site >= 0 && c->first_test_hint[site] && !c->strip.on) {
+        static const bool wait_first = !(getenv("PLFX_WAIT_FIRST") && atoi(getenv("PLFX_WAIT_FIRST")) == 0);   // (0: always speculate, as before)
+        if (wait_first && pred_active && site >= 0 && c->first_test_hint[site] && !c->strip.on) {
             // the predictor solve of a load step repeats the system of the solve before it up to the last bits of its boundary
             // values: x passes the first test.  Learn that before enqueuing what would return at once (six launches, 28 us)
             if ((rc = cg_check_wait(c, seq, &hs))) return rc;

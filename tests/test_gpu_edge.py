@@ -409,3 +409,8 @@ def test_setup_pass_column_walk_variants_are_bit_identical():
         res[cols] = [ln for ln in out.stdout.splitlines() if ln.count('|') == 2]
         assert len(res[cols]) == 3
     assert res['1'] == res['4'] == res['8']
+    # the predictor solve that waits for its first test before it speculates changes the order of launches only
+    out = subprocess.run([sys.executable, script, '--child'], env=dict(os.environ, PLFX_WAIT_FIRST='0'), capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert [ln for ln in out.stdout.splitlines() if ln.count('|') == 2] == res['1']
