@@ -36,6 +36,27 @@ def record(rec, p, ref, dt):
     rec[p + '_seconds'] = np.array(dt)
 
 
+def larger(which):
+    """One octave up (round 6, end): config 4 on 128 x 128 and config 5 on 256 x 128 -> tests/golden/mid_configs_128.npz
+    (about 20 and 40 minutes of the oracle on 8 cores); fields in float32 steps would lose the comparison: float64, compressed."""
+    out = os.path.join(GOLD, 'mid_configs_128.npz')
+    rec = dict(np.load(out)) if os.path.exists(out) else {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if 4 in which:
+            t = time.time()
+            ref = RefSolver(tension_model(svc_material(GOLD, 'hill'), 128, 0.001)).solve(min_step=10)
+            record(rec, 'cfg4_128', ref, time.time() - t)
+            print('config 4 on 128 x 128: %.0f s, %d load steps, niter %s, sgl_yy %.6f' % (time.time() - t, ref.nsteps, list(ref.niter), ref.sgl[-1][1]), flush=True)
+            np.savez_compressed(out, **rec)
+        if 5 in which:
+            t = time.time()
+            ref = RefSolver(laminate_cfg5(GOLD, 256, 128)).solve(min_step=20)
+            record(rec, 'cfg5_256x128', ref, time.time() - t)
+            print('config 5 on 256 x 128: %.0f s, %d load steps, niter %s, sgl_yy %.6f' % (time.time() - t, ref.nsteps, list(ref.niter), ref.sgl[-1][1]), flush=True)
+            np.savez_compressed(out, **rec)
+
+
 def main(which):
     rec = dict(np.load(OUT)) if os.path.exists(OUT) else {}
     with warnings.catch_warnings():
@@ -55,4 +76,7 @@ def main(which):
 
 
 if __name__ == '__main__':
-    main([int(a) for a in sys.argv[1:]] or [4, 5])
+    if len(sys.argv) > 1 and sys.argv[1] == '--larger':
+        larger([int(a) for a in sys.argv[2:]] or [4, 5])
+    else:
+        main([int(a) for a in sys.argv[1:]] or [4, 5])

@@ -177,6 +177,32 @@ def test_config4_schedule_64x64_vs_oracle_fixture(mid, golden_dir):
     assert np.max(fe._state('max_steps')) == 49
 
 
+@pytest.fixture(scope='module')
+def mid128(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mid_configs_128.npz'))
+
+
+def test_config4_schedule_128x128_vs_oracle_fixture(mid128, golden_dir):
+    """One octave above the 64 x 64 comparison: config 4 on 128 x 128 elements, all 11 load steps, against the oracle's sparse
+    direct solve (fixture: 21 minutes of the oracle on 8 cores, oracle/gen_mid_configs.py --larger 4), same bars."""
+    mid, p = mid128, 'cfg4_128'
+    fe = tension_model(svc_material(golden_dir, 'hill'), 128, 0.001)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=10)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+    assert fe.nsteps == int(mid[p + '_nsteps']) == 11
+    assert list(fe.niter) == list(mid[p + '_niter']) and list(fe.co_nconv) == list(mid[p + '_co_nconv'])
+    s = np.max(np.abs(mid[p + '_sig']))
+    err = {'u': np.max(np.abs(fe.u - mid[p + '_u'])) / np.max(np.abs(mid[p + '_u'])),
+           'sig': np.max(np.abs(fe._state('sig') - mid[p + '_sig'])) / s,
+           'epl': np.max(np.abs(fe._state('epl') - mid[p + '_epl'])) / np.max(np.abs(mid[p + '_eps'])),
+           'sgl': np.max(np.abs(np.asarray(fe.sgl) - mid[p + '_sgl'])) / s}
+    print('config 4 on 128 x 128 against the oracle fixture:', {k: float('%.2e' % v) for k, v in err.items()})
+    assert max(err.values()) < 5e-6, err
+    assert np.max(fe._state('max_steps')) == 49
+
+
 # ------------------------------------------------------------------ config 5: J2 + Goss-Barlat-trained SVC laminate
 def laminate_cfg5(golden_dir, NX, NY):
     ma = make_material('j2')
