@@ -302,6 +302,56 @@ def test_config5_real_materials_128x64_vs_oracle_fixture_all_load_steps(mid, gol
     assert np.max(np.abs(mid[p + '_epl'][fe._mat_id == 1])) > 1e-3
 
 
+def test_config5_real_materials_256x128_vs_oracle_fixture_all_load_steps(mid128, golden_dir):
+    """One octave above the 128 x 64 comparison: config 5's laminate on 256 x 128 elements through all 20 load steps against the
+    oracle's sparse direct solve (fixture: 40 minutes of the oracle on 8 cores, oracle/gen_mid_configs.py --larger 5).
+    Global stress history and displacements at the bars of the smaller meshes (measured: sgl 2e-9, u 8e-7).  The element fields
+    agree in the mean (RMS 1e-7 .. 7e-7) -- but NOT everywhere at 2e-5: in the last load steps the SVC tangents are indefinite
+    (material.py:317-338), four of them end after 12-13 stiffness iterations here and after 14-15 in the oracle (the end test is a
+    maximum over all elements of a non-smooth quantity, model.py:1346-1355), and a cluster of about 15 elements of one SVC
+    section (element columns 171-179) carries the difference: up to 1e-4 of the largest strain (tools/probes/cfg5_256_diag.py).
+    The bars say that: mean at 5e-6, at most 0.2 % of the elements beyond 2e-5, none beyond 5e-4.  That the cluster is the 1e-10
+    of the iterative solves carried through those steps, and nothing else, is shown by the second run: with the solves at 1e-12
+    (Model.cg_rtol) every element field agrees with the direct solve to 1e-6 (measured: sig 9.9e-7, epl 8.3e-7; bar 5e-6)."""
+    mid, p = mid128, 'cfg5_256x128'
+    if p + '_nsteps' not in mid.files:
+        pytest.skip('fixture not generated (oracle/gen_mid_configs.py --larger 5)')
+    fe = laminate_cfg5(golden_dir, 256, 128)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fe.solve(min_step=20)
+    assert fe._engine.precond_info()[0] == 1 and fe._engine.operator_info()[0] == 1
+    assert fe.nsteps == int(mid[p + '_nsteps']) == 20
+    rn = mid[p + '_niter']
+    assert list(fe.niter[:10]) == list(rn[:10])      # (see the 128 x 64 test for why the later counts may differ by an iteration)
+    assert np.max(np.abs(np.asarray(fe.niter) - rn)) <= 2
+    s = np.max(np.abs(mid[p + '_sig']))
+    d_sgl = np.max(np.abs(np.asarray(fe.sgl) - mid[p + '_sgl'])) / s
+    d_u = np.max(np.abs(fe.u - mid[p + '_u'])) / np.max(np.abs(mid[p + '_u']))
+    e_sig = np.abs(fe._state('sig') - mid[p + '_sig']) / s
+    e_epl = np.abs(fe._state('epl') - mid[p + '_epl']) / np.max(np.abs(mid[p + '_eps']))
+    beyond = int(np.sum(np.maximum(e_sig.max(axis=1), e_epl.max(axis=1)) > 2e-5))
+    print('config 5 on 256 x 128 vs the oracle fixture: sgl %.1e u %.1e sig max %.1e rms %.1e epl max %.1e rms %.1e, %d of %d elements beyond '
+          '2e-5; niter %s vs %s; fall-back solves %d'
+          % (d_sgl, d_u, e_sig.max(), np.sqrt(np.mean(e_sig ** 2)), e_epl.max(), np.sqrt(np.mean(e_epl ** 2)), beyond, len(e_sig),
+             list(fe.niter), [int(v) for v in rn], fe._engine.solve_fallbacks()))
+    assert d_sgl < 5e-6 and d_u < 2e-5
+    assert np.sqrt(np.mean(e_sig ** 2)) < 5e-6 and np.sqrt(np.mean(e_epl ** 2)) < 5e-6
+    assert beyond <= 0.002 * len(e_sig) and max(e_sig.max(), e_epl.max()) < 5e-4
+    assert np.max(np.abs(mid[p + '_epl'][fe._mat_id == 1])) > 1e-3
+    ft = laminate_cfg5(golden_dir, 256, 128)
+    ft.cg_rtol = 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ft.solve(min_step=20)
+    t_sig = np.max(np.abs(ft._state('sig') - mid[p + '_sig'])) / s
+    t_epl = np.max(np.abs(ft._state('epl') - mid[p + '_epl'])) / np.max(np.abs(mid[p + '_eps']))
+    t_u = np.max(np.abs(ft.u - mid[p + '_u'])) / np.max(np.abs(mid[p + '_u']))
+    print('   with the solves at 1e-12: u %.1e sig max %.1e epl max %.1e; niter %s' % (t_u, t_sig, t_epl, list(ft.niter)))
+    assert ft.nsteps == 20 and np.max(np.abs(np.asarray(ft.niter) - rn)) <= 2
+    assert t_u < 5e-6 and t_sig < 5e-6 and t_epl < 5e-6
+
+
 def test_config5_sgl_does_not_depend_on_the_mesh(golden_dir):
     """Size-independent property of BASELINE config 5 (laminate [2,1,2,1,2] along y, J2 + the SVC trained on Barlat
     Yld2004-18p, eps = 0.003, min_step = 20): the fields are uniform along y and piecewise constant per section, so the
